@@ -1,0 +1,196 @@
+/* x265gpu: C-ABI over hand-written gfx950 (MI355X) HIP kernels for x265's
+ * lowres lookahead: half-res downscale with half-pel planes, the 8x8 intra
+ * estimate, and per-8x8-block motion search / bidir cost estimation.
+ *
+ * The boundary sits one level above x265's per-block EncoderPrimitives slots
+ * (source/common/primitives.h:239-432): a device round trip per 8x8 call is
+ * impossible, so each entry point replaces one of the batch points x265's own
+ * lookahead already has.  The host keeps x265's decision logic, request order,
+ * float math (MV-cost table, AQ, weight guessing) and the Lowres bookkeeping;
+ * this library owns a device-side mirror of the per-frame Lowres arrays
+ * (source/common/lowres.h:164-258) in "slots".
+ *
+ * Conventions: every function returns X265GPU_OK (0) or a negative error
+ * code; nothing throws; all host buffers are caller-owned; strides are in
+ * PIXELS as in x265; `pixel` is uint8_t when bitDepth == 8 and uint16_t
+ * otherwise (source/common/common.h:127-141).  A context is bound to one
+ * device and one HIP stream; calls on one context must not overlap.
+ * There is no CPU fallback: if no gfx950 device or no kernel image is
+ * available, x265gpu_open fails.
+ */
+#ifndef X265GPU_H
+#define X265GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X265GPU_OK            0
+#define X265GPU_ERR_ARG      -1   /* bad argument / out-of-range slot, distance or size */
+#define X265GPU_ERR_DEVICE   -2   /* HIP runtime error (see x265gpu_last_error) */
+#define X265GPU_ERR_NOMEM    -3
+#define X265GPU_ERR_STATE    -4   /* call order violated (e.g. search before MV-cost table upload) */
+#define X265GPU_ERR_UNSUPPORTED -5
+
+#define X265GPU_BFRAME_MAX 16      /* X265_BFRAME_MAX, source/x265.h:599 */
+
+/* numbering of X265_*_SEARCH in source/x265.h */
+#define X265GPU_DIA_SEARCH  0
+#define X265GPU_HEX_SEARCH  1
+#define X265GPU_UMH_SEARCH  2
+#define X265GPU_STAR_SEARCH 3
+
+/* where a caller-supplied buffer lives */
+#define X265GPU_MEM_HOST   0
+#define X265GPU_MEM_DEVICE 1
+
+typedef struct x265gpu_ctx x265gpu_ctx;
+
+/* The subset of x265_param the path reads (source/x265.h; defaults
+ * source/common/param.cpp:197-260,310-315). */
+typedef struct x265gpu_config
+{
+    int32_t sourceWidth;
+    int32_t sourceHeight;
+    int32_t internalBitDepth;     /* 8, 10 or 12 */
+    int32_t maxCUSize;            /* CTU size; margins are maxCUSize+32 / maxCUSize+16 */
+    int32_t bframes;              /* sizes the [bframes+2] result arrays */
+    int32_t numSlots;             /* device-resident Lowres mirrors to allocate */
+    int32_t searchMethod;         /* lowres search; x265 hard-wires HEX (slicetype.cpp:4402-4404) */
+    int32_t merange;              /* Lookahead::s_merange = 16 (slicetype.h:337) */
+    int32_t bEnableHME;
+    int32_t hmeSearchMethod[3];
+    int32_t hmeRange[3];
+    int32_t bFrameBias;
+    int32_t maxSlices;
+    int32_t lookaheadLambda;      /* (int)x265_lambda_tab[X265_LOOKAHEAD_QP]: 1, 16 or 256 */
+    int32_t deviceId;
+    void*   stream;               /* hipStream_t to run on, or NULL for the library's own */
+} x265gpu_config;
+
+/* Geometry derived exactly as Lowres::create does (source/common/lowres.cpp:84-103). */
+typedef struct x265gpu_geometry
+{
+    int32_t width, lines;         /* lowres size rounded up to multiples of 8 */
+    int32_t stride;               /* lumaStride, pixels */
+    int32_t marginX, marginY;
+    int32_t widthInCU, heightInCU, cuCount;
+    int32_t widthInCU4, heightInCU4;   /* quarter-res (HME level 0) block grid, 0 if HME is off */
+    int64_t planeSize;            /* pixels per padded plane */
+    int64_t padOffset;            /* pixels from buffer start to pixel (0,0) */
+} x265gpu_geometry;
+
+/* One cost-estimation request = one CostEstimateGroup::estimateFrameCost body
+ * (source/encoder/slicetype.cpp:4284-4376) with the cache check and the
+ * bDoSearch decision already taken by the caller. */
+typedef struct x265gpu_request
+{
+    int32_t slotP0, slotB, slotP1;    /* slotP1 == slotB for a P request */
+    int32_t p0, b, p1;                /* frame indices: distances are b-p0 and p1-b */
+    int32_t doSearch[2];              /* run the L0 / L1 motion search for this request */
+    int32_t weightedL0;               /* L0 search reads the weighted planes set with x265gpu_weight_planes */
+} x265gpu_request;
+
+/* per-request scalars, as stored by x265 in Lowres::costEst/costEstAq/intraMbs */
+typedef struct x265gpu_frame_cost
+{
+    int64_t costEst;      /* after the B-frame *100/(130+bFrameBias) scaling */
+    int64_t costEstAq;
+    int32_t intraMbs;     /* blocks that chose intra in a P request (added onto the slot's running count) */
+    int32_t reserved;
+} x265gpu_frame_cost;
+
+/* ---- lifetime --------------------------------------------------------- */
+
+/* Replaces Lookahead::create + LookaheadTLD setup for the device side
+ * (source/encoder/slicetype.cpp:1061-1066, 1213-1216). */
+int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out);
+void x265gpu_close(x265gpu_ctx* ctx);
+int x265gpu_get_geometry(const x265gpu_ctx* ctx, x265gpu_geometry* out);
+const char* x265gpu_last_error(const x265gpu_ctx* ctx);
+/* Waits for all work queued by this context. */
+int x265gpu_sync(x265gpu_ctx* ctx);
+
+/* Uploads the host-built BitCost table (source/encoder/bitcost.cpp:31-56):
+ * `centre` points at the MVD-0 entry, valid for [-maxMvd, +maxMvd]. */
+int x265gpu_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd);
+
+/* ---- pre-lookahead: PreLookaheadGroup::processTasks (slicetype.cpp:1836-1861) */
+
+/* Lowres::init (source/common/lowres.cpp:344-402): resets the slot's
+ * sentinels and cost caches, runs the half-res downscale to four planes,
+ * extends their borders, and with HME the quarter-res set.  `luma` points at
+ * pixel (0,0) of the full-res luma plane; columns/rows beyond the picture are
+ * taken as edge replicas, which is what PicYuv::copyFromPicture stores there
+ * (source/common/picyuv.cpp:291-300,572-583). */
+int x265gpu_lowres_init(x265gpu_ctx* ctx, int32_t slot, const void* luma, intptr_t stride,
+                        int32_t memKind, int32_t poc);
+/* Batched form: n frames in one launch sequence. */
+int x265gpu_lowres_init_batch(x265gpu_ctx* ctx, int32_t n, const int32_t* slots, const void* const* lumas,
+                              const intptr_t* strides, int32_t memKind, const int32_t* pocs);
+
+/* invQscaleFactor from the host's calcAdaptiveQuantFrame (slicetype.cpp:454-704),
+ * one int per 8x8 lowres block; NULL clears it (costEstAq == costEst). */
+int x265gpu_lowres_set_aq(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQscaleFactor);
+
+/* LookaheadTLD::lowresIntraEstimate (slicetype.cpp:706-815) for n slots. */
+int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots);
+
+/* ---- cost estimation: CostEstimateGroup::add/finishBatch/singleCost
+ *      (slicetype.cpp:4148-4196) -> estimateFrameCost -> estimateCUCost ---- */
+
+/* Executes n requests.  All motion searches of the batch run first (each one
+ * a bottom-right to top-left wavefront over the 8x8 blocks), then all
+ * per-block cost evaluations; a request may therefore use vectors searched by
+ * any request of the same batch, and requests of one batch must not search
+ * the same (frame, list, distance) twice. */
+int x265gpu_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs);
+
+/* ---- weighted prediction analysis: LookaheadTLD::weightsAnalyse
+ *      (slicetype.cpp:870-971); the float guessing stays with the caller ---- */
+
+/* weightCostLuma (slicetype.cpp:817-850): sum over 8x8 blocks of
+ * min(SATD(ref [weighted], fenc), intraCost).  wtPresent == 0 measures the
+ * unweighted reference.  The result is written to *cost after a sync. */
+int x265gpu_weight_cost(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t wtPresent,
+                        int32_t scale, int32_t log2Denom, int32_t offset, uint32_t* cost);
+/* weight_pp over all four padded planes of slotRef (slicetype.cpp:957-969);
+ * the result becomes the L0 reference of requests with weightedL0 set, for
+ * (slotFenc, dist) until replaced. */
+int x265gpu_weight_planes(x265gpu_ctx* ctx, int32_t slotFenc, int32_t dist, int32_t slotRef,
+                          int32_t scale, int32_t log2Denom, int32_t offset);
+
+/* ---- results ---------------------------------------------------------- */
+
+/* Each getter syncs the context's stream and copies into caller memory; any
+ * output pointer may be NULL. */
+int x265gpu_get_plane(x265gpu_ctx* ctx, int32_t slot, int32_t planeIdx /*0..3, 4..7 quarter-res*/,
+                      void* paddedBuffer);
+int x265gpu_get_intra(x265gpu_ctx* ctx, int32_t slot, int32_t* intraCost, uint8_t* intraMode);
+int x265gpu_get_mvs(x265gpu_ctx* ctx, int32_t slot, int32_t list, int32_t dist,
+                    int32_t* mvsXY /* cuCount x {x,y} */, int32_t* mvCosts);
+int x265gpu_get_hme_mvs(x265gpu_ctx* ctx, int32_t slot, int32_t list, int32_t dist,
+                        int32_t* mvsXY, int32_t* mvCosts);
+int x265gpu_get_costs(x265gpu_ctx* ctx, int32_t slot, int32_t d0, int32_t d1,
+                      uint16_t* lowresCosts, int32_t* rowSatds, x265gpu_frame_cost* frameCost);
+
+/* ---- instrumentation --------------------------------------------------- */
+
+#define X265GPU_PHASE_LOWRES 0
+#define X265GPU_PHASE_INTRA  1
+#define X265GPU_PHASE_SEARCH 2
+#define X265GPU_PHASE_COST   3
+#define X265GPU_PHASE_COUNT  4
+
+/* When enabled, every kernel group is bracketed by HIP events on the
+ * context's stream; totals are read back (and optionally reset) here. */
+int x265gpu_profile_enable(x265gpu_ctx* ctx, int32_t on);
+int x265gpu_profile_read(x265gpu_ctx* ctx, int32_t phase, double* ms, int64_t* launches, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X265GPU_H */

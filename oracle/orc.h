@@ -1,0 +1,191 @@
+/* CPU oracle for the x265 lowres-lookahead / motion-search hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference's
+ * algorithm, used by tests/, __graft_entry__.smoke() and the cpu_baseline leg of
+ * bench.py as the checker.  Nothing in the product path may call into it.
+ *
+ * PARITY UNPINNED: the reference tree cannot be compiled in this container from
+ * its own sources alone (every translation unit includes the cmake-generated
+ * x265_config.h), and its own tests hold no golden vectors for this path
+ * (source/test/pixelharness.cpp compares C against SIMD on time-seeded random
+ * buffers).  The restatement is therefore checked only against independent
+ * numpy formulations of the same arithmetic (tests/test_oracle_*.py) and the
+ * constants recorded from the reference's headers.
+ *
+ * Compiled once per bit depth (ORC_DEPTH = 8, 10 or 12), mirroring the way the
+ * reference fixes `pixel` at compile time (source/common/common.h:127-141).
+ */
+#ifndef ORC_H
+#define ORC_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef ORC_DEPTH
+#define ORC_DEPTH 8
+#endif
+
+#if ORC_DEPTH > 8
+typedef uint16_t pixel;
+#else
+typedef uint8_t pixel;
+#endif
+
+#define ORC_PIXEL_MAX ((1 << ORC_DEPTH) - 1)
+#define ORC_FENC_STRIDE 64           /* source/common/common.h:71 */
+#define ORC_CU 8                     /* X265_LOWRES_CU_SIZE, source/common/common.h:225 */
+#define ORC_BFRAME_MAX 16            /* X265_BFRAME_MAX, source/x265.h:599 */
+#define ORC_COST_MAX (1 << 28)       /* MotionEstimate::COST_MAX, source/encoder/motion.h:65 */
+#define ORC_LOWRES_COST_MASK ((1 << 14) - 1)  /* source/encoder/slicetype.h:42 */
+#define ORC_LOWRES_COST_SHIFT 14
+#define ORC_BC_MAX_MV (1 << 15)      /* source/encoder/bitcost.h:92 */
+
+/* search methods, numbering of source/x265.h X265_*_SEARCH */
+enum { ORC_DIA = 0, ORC_HEX = 1, ORC_UMH = 2, ORC_STAR = 3, ORC_SEA = 4, ORC_FULL = 5 };
+
+typedef struct { int32_t x, y; } orc_mv;   /* source/common/mv.h:37-45: x then y, 8 bytes */
+
+/* ---- primitives (orc_pixel.c, orc_intra.c, orc_ipfilter.c) ---- */
+int  orc_depth(void);
+int  orc_sad(int w, int h, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+void orc_sad_x3(int w, int h, const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2,
+                intptr_t rstride, int32_t* res);
+void orc_sad_x4(int w, int h, const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2,
+                const pixel* r3, intptr_t rstride, int32_t* res);
+int  orc_satd(int w, int h, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+int  orc_sa8d(int size, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+void orc_pixelavg_pp(int w, int h, pixel* dst, intptr_t ds, const pixel* s0, intptr_t ss0,
+                     const pixel* s1, intptr_t ss1);
+void orc_frame_init_lowres_core(const pixel* src0, pixel* dst0, pixel* dsth, pixel* dstv, pixel* dstc,
+                                intptr_t src_stride, intptr_t dst_stride, int width, int height);
+void orc_extend_pic_border(pixel* pic, intptr_t stride, int width, int height, int marginX, int marginY);
+void orc_weight_pp(const pixel* src, pixel* dst, intptr_t stride, int width, int height,
+                   int w0, int round, int shift, int offset);
+uint64_t orc_pixel_var(int size, const pixel* pix, intptr_t stride);
+
+void orc_intra_filter(int tuSize, const pixel* samples, pixel* filtered);
+void orc_intra_pred(int size, int mode, pixel* dst, intptr_t dstStride, const pixel* srcPix, int bFilter);
+int  orc_intra_filter_flag(int mode, int size);
+
+void orc_luma_hpp(int w, int h, const pixel* src, intptr_t ss, pixel* dst, intptr_t ds, int coeffIdx);
+void orc_luma_vpp(int w, int h, const pixel* src, intptr_t ss, pixel* dst, intptr_t ds, int coeffIdx);
+void orc_luma_hvpp(int w, int h, const pixel* src, intptr_t ss, pixel* dst, intptr_t ds, int idxX, int idxY);
+
+/* ---- MV cost table (orc_bitcost.c) ---- */
+/* out has 4*ORC_BC_MAX_MV+1 entries; element [2*ORC_BC_MAX_MV] is MVD 0 */
+void   orc_bitcost_table(double lambda, uint16_t* out);
+double orc_lookahead_lambda(void);   /* x265_lambda_tab[X265_LOOKAHEAD_QP] for this depth */
+
+/* ---- reference planes + motion search (orc_motion.c) ---- */
+typedef struct orc_refplanes {
+    pixel*   plane[4];        /* lowresPlane[0..3] (origin pointers); plane[0] doubles as fpelPlane[0] */
+    pixel*   lowerPlane[4];   /* lowerResPlane[0..3] (HME level 0), or NULL */
+    intptr_t stride;          /* lumaStride */
+    int      isLowres;
+    int      isHMELowres;
+} orc_refplanes;
+
+typedef struct orc_me {
+    pixel     fenc[ORC_FENC_STRIDE * 64];
+    int       bw, bh;
+    intptr_t  blockOffset;
+    const uint16_t* cost;     /* centred MV cost table */
+    orc_mv    mvp;
+    int       searchMethod, searchMethodL0, searchMethodL1, subpelRefine;
+    /* executed-compare counters (for the algorithmic-op denominators) */
+    uint64_t  nSad, nSatd;
+} orc_me;
+
+void orc_me_init(orc_me* me, const uint16_t* centredCost);
+void orc_me_set_source(orc_me* me, const pixel* fencY, intptr_t stride, intptr_t offset, int w, int h,
+                       int method, int searchL0, int searchL1, int refine);
+int  orc_me_buf_satd(orc_me* me, const pixel* ref, intptr_t stride);
+/* hmePlane: 0 = search the half-res plane set, 1 = search the quarter-res (HME level-0) plane set */
+int  orc_motion_estimate(orc_me* me, const orc_refplanes* ref, orc_mv mvmin, orc_mv mvmax, orc_mv qmvp,
+                         int numCandidates, const orc_mv* mvc, int merange, orc_mv* outQMv,
+                         uint32_t maxSlices, int hmePlane);
+const pixel* orc_lowres_mc(const orc_refplanes* ref, intptr_t blockOffset, orc_mv qmv, pixel* buf,
+                           intptr_t* outstride, int hme);
+int  orc_lowres_qpel_cost(orc_me* me, const orc_refplanes* ref, intptr_t blockOffset, orc_mv qmv,
+                          int useSatd, int hme);
+
+/* ---- lookahead frame state and cost estimation (orc_lookahead.c) ---- */
+typedef struct orc_param {
+    int sourceWidth, sourceHeight;
+    int maxCUSize;            /* 64 */
+    int bframes;
+    int bEnableHME;
+    int hmeSearchMethod[3];
+    int hmeRange[3];
+    int qgSize;               /* 32 */
+    int bFrameBias;
+    int bEnableWeightedPred;
+    int maxSlices;
+    int lookaheadSearchMethod;/* x265 hard-wires ORC_HEX (source/encoder/slicetype.cpp:4402-4404) */
+} orc_param;
+
+typedef struct orc_lowres {
+    orc_refplanes rp;         /* must be first */
+    pixel*   buffer[4];
+    pixel*   lowerResBuffer[4];
+    int      frameNum;
+    int      width, lines;    /* rounded up to multiples of 8 */
+    int      marginX, marginY;
+    int      bframes;
+    int      widthInCU, heightInCU, cuCount;
+    size_t   planesize, padoffset;
+    int64_t  costEst[ORC_BFRAME_MAX + 2][ORC_BFRAME_MAX + 2];
+    int64_t  costEstAq[ORC_BFRAME_MAX + 2][ORC_BFRAME_MAX + 2];
+    int32_t* rowSatds[ORC_BFRAME_MAX + 2][ORC_BFRAME_MAX + 2];
+    int      intraMbs[ORC_BFRAME_MAX + 2];
+    int32_t* intraCost;
+    uint8_t* intraMode;
+    uint16_t* lowresCosts[ORC_BFRAME_MAX + 2][ORC_BFRAME_MAX + 2];
+    int32_t* lowresMvCosts[2][ORC_BFRAME_MAX + 2];
+    orc_mv*  lowresMvs[2][ORC_BFRAME_MAX + 2];
+    int32_t* lowerResMvCosts[2][ORC_BFRAME_MAX + 2];
+    orc_mv*  lowerResMvs[2][ORC_BFRAME_MAX + 2];
+    int      widthInCU4, heightInCU4;
+    int*     invQscaleFactor; /* NULL when AQ/weightp are all off */
+    uint64_t wp_ssd[3], wp_sum[3];
+    orc_refplanes weightedRef[ORC_BFRAME_MAX + 2];
+    int      weightedRefIsWeighted[ORC_BFRAME_MAX + 2];
+    double   weightedCostDelta[ORC_BFRAME_MAX + 2];
+} orc_lowres;
+
+typedef struct orc_tld {
+    orc_me   me;
+    pixel*   wbuffer[4];
+    int      paddedLines;
+    int      widthInCU, heightInCU, ncu;
+} orc_tld;
+
+orc_lowres* orc_lowres_create(const orc_param* p, int withAq);
+void orc_lowres_destroy(orc_lowres* lr);
+/* luma: pointer to pixel (0,0) of a source plane whose row/col padding follows
+ * PicYuv::copyFromPicture (source/common/picyuv.cpp:291-300,572-583) */
+void orc_lowres_init(orc_lowres* lr, const orc_param* p, const pixel* luma, intptr_t stride, int poc);
+/* pads a tight w x h plane the way PicYuv does; returns malloc'd buffer, *origin = pixel (0,0) */
+pixel* orc_picyuv_pad(const orc_param* p, const pixel* tight, pixel** origin, intptr_t* stride);
+
+orc_tld* orc_tld_create(const orc_param* p, const uint16_t* centredCost);
+void orc_tld_destroy(orc_tld* t);
+void orc_intra_estimate(orc_tld* t, orc_lowres* fenc, const orc_param* p);
+int64_t orc_estimate_frame_cost(orc_tld* t, const orc_param* p, orc_lowres** frames,
+                                int p0, int p1, int b, int bIntraPenalty);
+uint32_t orc_weight_cost_luma(orc_tld* t, orc_lowres* fenc, orc_lowres* ref,
+                              int wtPresent, int scale, int denom, int offset);
+void orc_weights_analyse(orc_tld* t, orc_lowres* fenc, orc_lowres* ref);
+
+/* field accessors for ctypes */
+void* orc_lowres_ptr(orc_lowres* lr, const char* field, int i, int j);
+int64_t orc_lowres_i64(orc_lowres* lr, const char* field, int i, int j);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,237 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liborc{8,10,12}.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package (x265_amd) never imports it.
+Parity of the oracle itself is unpinned (see oracle/orc.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+
+BC_MAX_MV = 1 << 15
+BFRAME_MAX = 16
+DIA, HEX, UMH, STAR, SEA, FULL = range(6)
+
+
+class MV(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32)]
+
+
+class Param(C.Structure):
+    _fields_ = [
+        ("sourceWidth", C.c_int), ("sourceHeight", C.c_int), ("maxCUSize", C.c_int), ("bframes", C.c_int),
+        ("bEnableHME", C.c_int), ("hmeSearchMethod", C.c_int * 3), ("hmeRange", C.c_int * 3),
+        ("qgSize", C.c_int), ("bFrameBias", C.c_int), ("bEnableWeightedPred", C.c_int), ("maxSlices", C.c_int),
+        ("lookaheadSearchMethod", C.c_int),
+    ]
+
+
+class RefPlanes(C.Structure):
+    _fields_ = [("plane", C.c_void_p * 4), ("lowerPlane", C.c_void_p * 4), ("stride", C.c_ssize_t),
+                ("isLowres", C.c_int), ("isHMELowres", C.c_int)]
+
+
+def build(force=False):
+    """Compile the oracle for all depths (gcc, a few seconds)."""
+    if force or not all(os.path.exists(os.path.join(_BUILD, "liborc%d.so" % d)) for d in (8, 10, 12)):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-j4"])
+
+
+_libs = {}
+
+
+def lib(depth=8):
+    if depth in _libs:
+        return _libs[depth]
+    path = os.path.join(_BUILD, "liborc%d.so" % depth)
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    vp, i, ip = C.c_void_p, C.c_int, C.c_ssize_t
+    L.orc_depth.restype = i
+    L.orc_sad.argtypes = [i, i, vp, ip, vp, ip]
+    L.orc_sad_x3.argtypes = [i, i, vp, vp, vp, vp, ip, vp]
+    L.orc_sad_x4.argtypes = [i, i, vp, vp, vp, vp, vp, ip, vp]
+    L.orc_satd.argtypes = [i, i, vp, ip, vp, ip]
+    L.orc_sa8d.argtypes = [i, vp, ip, vp, ip]
+    L.orc_pixelavg_pp.argtypes = [i, i, vp, ip, vp, ip, vp, ip]
+    L.orc_frame_init_lowres_core.argtypes = [vp, vp, vp, vp, vp, ip, ip, i, i]
+    L.orc_extend_pic_border.argtypes = [vp, ip, i, i, i, i]
+    L.orc_weight_pp.argtypes = [vp, vp, ip, i, i, i, i, i, i]
+    L.orc_pixel_var.argtypes = [i, vp, ip]
+    L.orc_pixel_var.restype = C.c_uint64
+    L.orc_intra_filter.argtypes = [i, vp, vp]
+    L.orc_intra_pred.argtypes = [i, i, vp, ip, vp, i]
+    L.orc_intra_filter_flag.argtypes = [i, i]
+    for f in (L.orc_luma_hpp, L.orc_luma_vpp):
+        f.argtypes = [i, i, vp, ip, vp, ip, i]
+    L.orc_luma_hvpp.argtypes = [i, i, vp, ip, vp, ip, i, i]
+    L.orc_bitcost_table.argtypes = [C.c_double, vp]
+    L.orc_lookahead_lambda.restype = C.c_double
+    L.orc_lowres_create.argtypes = [C.POINTER(Param), i]
+    L.orc_lowres_create.restype = vp
+    L.orc_lowres_destroy.argtypes = [vp]
+    L.orc_lowres_init.argtypes = [vp, C.POINTER(Param), vp, ip, i]
+    L.orc_picyuv_pad.argtypes = [C.POINTER(Param), vp, C.POINTER(vp), C.POINTER(ip)]
+    L.orc_picyuv_pad.restype = vp
+    L.orc_tld_create.argtypes = [C.POINTER(Param), vp]
+    L.orc_tld_create.restype = vp
+    L.orc_tld_destroy.argtypes = [vp]
+    L.orc_intra_estimate.argtypes = [vp, vp, C.POINTER(Param)]
+    L.orc_estimate_frame_cost.argtypes = [vp, C.POINTER(Param), C.POINTER(vp), i, i, i, i]
+    L.orc_estimate_frame_cost.restype = C.c_int64
+    L.orc_weight_cost_luma.argtypes = [vp, vp, vp, i, i, i, i]
+    L.orc_weight_cost_luma.restype = C.c_uint32
+    L.orc_weights_analyse.argtypes = [vp, vp, vp]
+    L.orc_lowres_ptr.argtypes = [vp, C.c_char_p, i, i]
+    L.orc_lowres_ptr.restype = vp
+    L.orc_lowres_i64.argtypes = [vp, C.c_char_p, i, i]
+    L.orc_lowres_i64.restype = C.c_int64
+    L.orc_me_init.argtypes = [vp, vp]
+    L.orc_me_set_source.argtypes = [vp, vp, ip, ip, i, i, i, i, i, i]
+    L.orc_motion_estimate.argtypes = [vp, C.POINTER(RefPlanes), MV, MV, MV, i, vp, i, C.POINTER(MV), C.c_uint32, i]
+    L.orc_motion_estimate.restype = i
+    L.libc_free = C.CDLL(None).free
+    L.libc_free.argtypes = [vp]
+    _libs[depth] = L
+    return L
+
+
+def pixel_dtype(depth):
+    return np.uint8 if depth == 8 else np.uint16
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_param(width, height, bframes=4, hme=False, weightp=False, ctu=64, search=HEX,
+               hme_methods=(HEX, UMH, UMH), hme_range=(16, 32, 48), bframe_bias=0):
+    p = Param()
+    p.sourceWidth, p.sourceHeight, p.maxCUSize, p.bframes = width, height, ctu, bframes
+    p.bEnableHME = int(hme)
+    for k in range(3):
+        p.hmeSearchMethod[k] = hme_methods[k]
+        p.hmeRange[k] = hme_range[k]
+    p.qgSize = 32
+    p.bFrameBias = bframe_bias
+    p.bEnableWeightedPred = int(weightp)
+    p.maxSlices = 1
+    p.lookaheadSearchMethod = search
+    return p
+
+
+def bitcost_table(depth, lam=None):
+    """(table, centre index): uint16[4*BC_MAX_MV+1] for the lookahead lambda."""
+    L = lib(depth)
+    t = np.zeros(4 * BC_MAX_MV + 1, np.uint16)
+    L.orc_bitcost_table(L.orc_lookahead_lambda() if lam is None else lam, ptr(t))
+    return t, 2 * BC_MAX_MV
+
+
+class Lowres:
+    """One reference-side Lowres (oracle) with numpy views on its arrays."""
+
+    def __init__(self, L, depth, param, with_aq=False):
+        self.L, self.depth, self.param = L, depth, param
+        self.h = L.orc_lowres_create(C.byref(param), int(with_aq))
+        self.with_aq = with_aq
+
+    def close(self):
+        if self.h:
+            self.L.orc_lowres_destroy(self.h)
+            self.h = None
+
+    def i64(self, field, i=0, j=0):
+        return self.L.orc_lowres_i64(self.h, field.encode(), i, j)
+
+    def _view(self, field, i, j, count, dtype):
+        p = self.L.orc_lowres_ptr(self.h, field.encode(), i, j)
+        if not p:
+            return None
+        buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=dtype, count=count)
+
+    @property
+    def geometry(self):
+        return {k: self.i64(k) for k in ("width", "lines", "stride", "marginX", "marginY", "widthInCU",
+                                          "heightInCU", "planesize", "padoffset", "widthInCU4", "heightInCU4")}
+
+    def init(self, tight_luma, poc):
+        """tight_luma: (H, W) array; padded the way PicYuv::copyFromPicture does."""
+        org, st = C.c_void_p(), C.c_ssize_t()
+        tight = np.ascontiguousarray(tight_luma, dtype=pixel_dtype(self.depth))
+        buf = self.L.orc_picyuv_pad(C.byref(self.param), ptr(tight), C.byref(org), C.byref(st))
+        self.L.orc_lowres_init(self.h, C.byref(self.param), org, st, poc)
+        self.L.libc_free(buf)
+
+    def buffer(self, i):
+        return self._view("buffer", i, 0, self.i64("planesize"), pixel_dtype(self.depth))
+
+    def lower_buffer(self, i):
+        return self._view("lowerBuffer", i, 0, self.i64("planesize") // 2, pixel_dtype(self.depth))
+
+    def ncu(self):
+        return self.i64("widthInCU") * self.i64("heightInCU")
+
+    def intra_cost(self):
+        return self._view("intraCost", 0, 0, self.ncu(), np.int32)
+
+    def intra_mode(self):
+        return self._view("intraMode", 0, 0, self.ncu(), np.uint8)
+
+    def inv_qscale(self):
+        return self._view("invQscaleFactor", 0, 0, self.ncu(), np.int32)
+
+    def mvs(self, lst, dist):
+        return self._view("lowresMvs", lst, dist, 2 * self.ncu(), np.int32).reshape(-1, 2)
+
+    def mv_costs(self, lst, dist):
+        return self._view("lowresMvCosts", lst, dist, self.ncu(), np.int32)
+
+    def lowres_costs(self, d0, d1):
+        return self._view("lowresCosts", d0, d1, self.ncu(), np.uint16)
+
+    def row_satds(self, d0, d1):
+        return self._view("rowSatds", d0, d1, self.i64("heightInCU"), np.int32)
+
+    def wp(self):
+        return self._view("wp_sum", 0, 0, 3, np.uint64), self._view("wp_ssd", 0, 0, 3, np.uint64)
+
+
+class Lookahead:
+    """Drives the oracle's estimateFrameCost over a list of frames."""
+
+    def __init__(self, depth, param, with_aq=False):
+        self.depth, self.param = depth, param
+        self.L = lib(depth)
+        self.table, self.centre = bitcost_table(depth)
+        self.tld = self.L.orc_tld_create(C.byref(param), C.c_void_p(self.table.ctypes.data + 2 * self.centre))
+        self.frames = []
+        self.with_aq = with_aq
+
+    def add_frame(self, tight_luma, inv_qscale=None):
+        lr = Lowres(self.L, self.depth, self.param, self.with_aq)
+        lr.init(tight_luma, len(self.frames))
+        if inv_qscale is not None:
+            lr.inv_qscale()[:] = inv_qscale
+        self.L.orc_intra_estimate(self.tld, lr.h, C.byref(self.param))
+        self.frames.append(lr)
+        return lr
+
+    def frame_cost(self, p0, p1, b, intra_penalty=False):
+        arr = (C.c_void_p * len(self.frames))(*[f.h for f in self.frames])
+        return self.L.orc_estimate_frame_cost(self.tld, C.byref(self.param), arr, p0, p1, b, int(intra_penalty))
+
+    def close(self):
+        for f in self.frames:
+            f.close()
+        self.frames = []
+        if self.tld:
+            self.L.orc_tld_destroy(self.tld)
+            self.tld = None

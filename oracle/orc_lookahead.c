@@ -1,0 +1,641 @@
+/* CPU oracle (test infrastructure only; parity unpinned, see orc.h).
+ * Per-frame lookahead state, the 8x8 intra estimate and the per-block
+ * inter/bidir cost estimation, restated from source/common/lowres.cpp:78-422
+ * and source/encoder/slicetype.cpp:706-971, 4284-4557 (whole-frame mode,
+ * i.e. no cooperative slices). */
+#include "orc.h"
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+/* ---------------------------------------------------------------- frames */
+
+/* source/common/lowres.cpp:78-219 (sizes, strides, array shapes) */
+orc_lowres* orc_lowres_create(const orc_param* p, int withAq)
+{
+    orc_lowres* lr = (orc_lowres*)calloc(1, sizeof(orc_lowres));
+    lr->rp.isLowres = 1;
+    lr->rp.isHMELowres = p->bEnableHME ? 1 : 0;
+    lr->bframes = p->bframes;
+    lr->marginX = p->maxCUSize + 32;    /* source/common/picyuv.cpp:91-92 */
+    lr->marginY = p->maxCUSize + 16;
+    int width = p->sourceWidth / 2, lines = p->sourceHeight / 2;
+    intptr_t stride = width + 2 * lr->marginX;
+    if (stride & 31)
+        stride += 32 - (stride & 31);
+    lr->rp.stride = stride;
+    lr->widthInCU = (width + ORC_CU - 1) >> 3;
+    lr->heightInCU = (lines + ORC_CU - 1) >> 3;
+    lr->cuCount = lr->widthInCU * lr->heightInCU;
+    lr->width = lr->widthInCU * ORC_CU;
+    lr->lines = lr->heightInCU * ORC_CU;
+    lr->planesize = (size_t)stride * (lr->lines + 2 * lr->marginY);
+    lr->padoffset = (size_t)stride * lr->marginY + lr->marginX;
+
+    lr->buffer[0] = (pixel*)calloc(4 * lr->planesize, sizeof(pixel));
+    for (int i = 0; i < 4; i++)
+    {
+        lr->buffer[i] = lr->buffer[0] + i * lr->planesize;
+        lr->rp.plane[i] = lr->buffer[i] + lr->padoffset;
+    }
+    if (p->bEnableHME)
+    {
+        size_t half = lr->planesize / 2, padHalf = lr->padoffset / 2;
+        lr->lowerResBuffer[0] = (pixel*)calloc(4 * half, sizeof(pixel));
+        for (int i = 0; i < 4; i++)
+        {
+            lr->lowerResBuffer[i] = lr->lowerResBuffer[0] + i * half;
+            lr->rp.lowerPlane[i] = lr->lowerResBuffer[i] + padHalf;
+        }
+        /* loop bounds follow Lookahead::m_4x4Width/Height
+         * (source/encoder/slicetype.cpp:1063-1064); the arrays are sized for
+         * the larger of that and the allocation formula of
+         * source/common/lowres.cpp:211-213 */
+        lr->widthInCU4 = ((p->sourceWidth / 4) + ORC_CU - 1) >> 3;
+        lr->heightInCU4 = ((p->sourceHeight / 4) + ORC_CU - 1) >> 3;
+    }
+    if (withAq)
+        lr->invQscaleFactor = (int*)calloc(lr->cuCount, sizeof(int));
+    lr->intraCost = (int32_t*)malloc(sizeof(int32_t) * lr->cuCount);
+    lr->intraMode = (uint8_t*)malloc(lr->cuCount);
+    for (int i = 0; i < p->bframes + 2; i++)
+    {
+        for (int j = 0; j < p->bframes + 2; j++)
+        {
+            lr->rowSatds[i][j] = (int32_t*)malloc(sizeof(int32_t) * lr->heightInCU);
+            lr->lowresCosts[i][j] = (uint16_t*)malloc(sizeof(uint16_t) * lr->cuCount);
+        }
+        for (int l = 0; l < 2; l++)
+        {
+            lr->lowresMvs[l][i] = (orc_mv*)malloc(sizeof(orc_mv) * lr->cuCount);
+            lr->lowresMvCosts[l][i] = (int32_t*)malloc(sizeof(int32_t) * lr->cuCount);
+            if (p->bEnableHME)
+            {
+                int aw = ((lr->width / 2) + ORC_CU - 1) >> 3, ah = ((lr->lines / 2) + ORC_CU - 1) >> 3;
+                int n4 = imax(aw, lr->widthInCU4) * imax(ah, lr->heightInCU4);
+                lr->lowerResMvs[l][i] = (orc_mv*)malloc(sizeof(orc_mv) * n4);
+                lr->lowerResMvCosts[l][i] = (int32_t*)malloc(sizeof(int32_t) * n4);
+            }
+        }
+    }
+    return lr;
+}
+
+void orc_lowres_destroy(orc_lowres* lr)
+{
+    if (!lr)
+        return;
+    free(lr->buffer[0]);
+    free(lr->lowerResBuffer[0]);
+    free(lr->invQscaleFactor);
+    free(lr->intraCost);
+    free(lr->intraMode);
+    for (int i = 0; i < ORC_BFRAME_MAX + 2; i++)
+    {
+        for (int j = 0; j < ORC_BFRAME_MAX + 2; j++)
+        {
+            free(lr->rowSatds[i][j]);
+            free(lr->lowresCosts[i][j]);
+        }
+        for (int l = 0; l < 2; l++)
+        {
+            free(lr->lowresMvs[l][i]);
+            free(lr->lowresMvCosts[l][i]);
+            free(lr->lowerResMvs[l][i]);
+            free(lr->lowerResMvCosts[l][i]);
+        }
+    }
+    free(lr);
+}
+
+/* Lay a tight w x h plane out like PicYuv: CTU-rounded stride with margins,
+ * right/bottom replication out to a multiple of 16 plus one extra row/column
+ * (source/common/picyuv.cpp:88-103, 291-300, 572-583). */
+pixel* orc_picyuv_pad(const orc_param* p, const pixel* tight, pixel** origin, intptr_t* strideOut)
+{
+    int w = p->sourceWidth, h = p->sourceHeight, ctu = p->maxCUSize;
+    int marginX = ctu + 32, marginY = ctu + 16;
+    intptr_t stride = ((w + ctu - 1) / ctu) * ctu + 2 * marginX;
+    int maxH = ((h + ctu - 1) / ctu) * ctu;
+    pixel* buf = (pixel*)calloc((size_t)stride * (maxH + 2 * marginY), sizeof(pixel));
+    pixel* Y = buf + marginY * stride + marginX;
+    int padx = (w & 15) ? 16 - (w & 15) : 0;
+    int pady = (h & 15) ? 16 - (h & 15) : 0;
+    padx++;
+    pady++;
+    for (int r = 0; r < h; r++)
+    {
+        memcpy(Y + r * stride, tight + (size_t)r * w, w * sizeof(pixel));
+        for (int x = 0; x < padx; x++)
+            Y[r * stride + w + x] = Y[r * stride + w - 1];
+    }
+    for (int i = 1; i <= pady; i++)
+        memcpy(Y + (h - 1 + i) * stride, Y + (h - 1) * stride, (w + padx) * sizeof(pixel));
+    *origin = Y;
+    *strideOut = stride;
+    return buf;
+}
+
+/* source/common/lowres.cpp:344-402 */
+void orc_lowres_init(orc_lowres* lr, const orc_param* p, const pixel* luma, intptr_t stride, int poc)
+{
+    lr->frameNum = poc;
+    memset(lr->costEst, -1, sizeof(lr->costEst));
+    memset(lr->weightedCostDelta, 0, sizeof(lr->weightedCostDelta));
+    if (lr->invQscaleFactor)
+        memset(lr->costEstAq, -1, sizeof(lr->costEstAq));
+    for (int y = 0; y < lr->bframes + 2; y++)
+        for (int x = 0; x < lr->bframes + 2; x++)
+            lr->rowSatds[y][x][0] = -1;
+    for (int i = 0; i < lr->bframes + 2; i++)
+    {
+        lr->lowresMvs[0][i][0].x = 0x7FFF;
+        lr->lowresMvs[1][i][0].x = 0x7FFF;
+        lr->intraMbs[i] = 0;
+    }
+
+    intptr_t ls = lr->rp.stride;
+    orc_frame_init_lowres_core(luma, lr->rp.plane[0], lr->rp.plane[1], lr->rp.plane[2], lr->rp.plane[3],
+                               stride, ls, lr->width, lr->lines);
+    for (int i = 0; i < 4; i++)
+        orc_extend_pic_border(lr->rp.plane[i], ls, lr->width, lr->lines, lr->marginX, lr->marginY);
+
+    if (p->bEnableHME)
+    {
+        orc_frame_init_lowres_core(lr->rp.plane[0], lr->rp.lowerPlane[0], lr->rp.lowerPlane[1],
+                                   lr->rp.lowerPlane[2], lr->rp.lowerPlane[3], ls, ls / 2,
+                                   lr->width / 2, lr->lines / 2);
+        for (int i = 0; i < 4; i++)
+            orc_extend_pic_border(lr->rp.lowerPlane[i], ls / 2, lr->width / 2, lr->lines / 2,
+                                  lr->marginX / 2, lr->marginY / 2);
+    }
+}
+
+/* ---------------------------------------------------------------- thread-local state */
+
+orc_tld* orc_tld_create(const orc_param* p, const uint16_t* centredCost)
+{
+    orc_tld* t = (orc_tld*)calloc(1, sizeof(orc_tld));
+    orc_me_init(&t->me, centredCost);
+    t->widthInCU = ((p->sourceWidth / 2) + ORC_CU - 1) >> 3;
+    t->heightInCU = ((p->sourceHeight / 2) + ORC_CU - 1) >> 3;
+    /* m_8x8Blocks: interior blocks only (source/encoder/slicetype.cpp:1065-1066) */
+    int n = t->widthInCU * t->heightInCU;
+    t->ncu = (t->widthInCU > 2 && t->heightInCU > 2) ? n + 4 - 2 * (t->widthInCU + t->heightInCU) : n;
+    return t;
+}
+
+void orc_tld_destroy(orc_tld* t)
+{
+    if (t)
+    {
+        free(t->wbuffer[0]);
+        free(t);
+    }
+}
+
+/* ---------------------------------------------------------------- intra */
+
+/* source/encoder/slicetype.cpp:706-815 */
+void orc_intra_estimate(orc_tld* t, orc_lowres* fenc, const orc_param* p)
+{
+    pixel pred[64], cur[64], nbr[2][33];
+    const int lambda = (int)orc_lookahead_lambda();
+    const int intraPenalty = 5 * lambda, lowresPenalty = 4;
+    const int W = t->widthInCU, H = t->heightInCU;
+    const intptr_t ls = fenc->rp.stride;
+    int costEst = 0, costEstAq = 0;
+    (void)p;
+
+    for (int cuY = 0; cuY < H; cuY++)
+    {
+        fenc->rowSatds[0][0][cuY] = 0;
+        for (int cuX = 0; cuX < W; cuX++)
+        {
+            const int cuXY = cuX + cuY * W;
+            const pixel* pix = fenc->rp.plane[0] + 8 * cuX + 8 * cuY * ls;
+            for (int y = 0; y < 8; y++)
+                memcpy(cur + 8 * y, pix + y * ls, 8 * sizeof(pixel));
+
+            const pixel* tl = pix - ls - 1;
+            memcpy(nbr[0], tl, 17 * sizeof(pixel));
+            for (int i = 1; i <= 16; i++)
+                nbr[0][16 + i] = tl[i * ls];
+            orc_intra_filter(8, nbr[0], nbr[1]);
+
+            int cost, icost = ORC_COST_MAX;
+            uint32_t ilowmode = 0;
+
+            orc_intra_pred(8, 1, pred, 8, nbr[0], 1);
+            cost = orc_satd(8, 8, cur, 8, pred, 8);
+            if (cost < icost) { icost = cost; ilowmode = 1; }
+
+            orc_intra_pred(8, 0, pred, 8, nbr[1], 0);
+            cost = orc_satd(8, 8, cur, 8, pred, 8);
+            if (cost < icost) { icost = cost; ilowmode = 0; }
+
+            int acost = ORC_COST_MAX;
+            uint32_t alowmode = 4;
+            for (uint32_t mode = 5; mode < 35; mode += 5)
+            {
+                orc_intra_pred(8, mode, pred, 8, nbr[orc_intra_filter_flag(mode, 8)], 1);
+                cost = orc_satd(8, 8, cur, 8, pred, 8);
+                if (cost < acost) { acost = cost; alowmode = mode; }
+            }
+            for (uint32_t dist = 2; dist >= 1; dist--)
+            {
+                uint32_t two[2] = { alowmode - dist, alowmode + dist };
+                for (int k = 0; k < 2; k++)
+                {
+                    uint32_t mode = two[k];
+                    orc_intra_pred(8, mode, pred, 8, nbr[orc_intra_filter_flag(mode, 8)], 1);
+                    cost = orc_satd(8, 8, cur, 8, pred, 8);
+                    if (cost < acost) { acost = cost; alowmode = mode; }
+                }
+            }
+            if (acost < icost) { icost = acost; ilowmode = alowmode; }
+
+            icost += intraPenalty + lowresPenalty;
+            fenc->lowresCosts[0][0][cuXY] = (uint16_t)imin(icost, ORC_LOWRES_COST_MASK);
+            fenc->intraCost[cuXY] = icost;
+            fenc->intraMode[cuXY] = (uint8_t)ilowmode;
+
+            const int scored = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
+            int icostAq = (scored && fenc->invQscaleFactor)
+                              ? ((icost * fenc->invQscaleFactor[cuXY] + 128) >> 8) : icost;
+            if (scored)
+            {
+                costEst += icost;
+                costEstAq += icostAq;
+            }
+            fenc->rowSatds[0][0][cuY] += icostAq;
+        }
+    }
+    fenc->costEst[0][0] = costEst;
+    fenc->costEstAq[0][0] = costEstAq;
+}
+
+/* ---------------------------------------------------------------- weighted prediction */
+
+/* source/encoder/slicetype.cpp:817-850 */
+uint32_t orc_weight_cost_luma(orc_tld* t, orc_lowres* fenc, orc_lowres* ref,
+                              int wtPresent, int scale, int denom, int offsetIn)
+{
+    const pixel* src = ref->rp.plane[0];
+    intptr_t stride = fenc->rp.stride;
+    if (wtPresent)
+    {
+        int offset = offsetIn * (1 << (ORC_DEPTH - 8));
+        int round = denom ? 1 << (denom - 1) : 0;
+        int correction = 14 - ORC_DEPTH;
+        orc_weight_pp(ref->buffer[0], t->wbuffer[0], stride, (int)stride, t->paddedLines,
+                      scale, round << correction, denom + correction, offset);
+        src = t->wbuffer[0] + fenc->padoffset;
+    }
+    uint32_t cost = 0;
+    int mb = 0;
+    for (int y = 0; y < fenc->lines; y += 8)
+        for (int x = 0; x < fenc->width; x += 8, mb++)
+        {
+            intptr_t off = y * stride + x;
+            int satd = orc_satd(8, 8, src + off, stride, fenc->rp.plane[0] + off, stride);
+            cost += imin(satd, fenc->intraCost[mb]);
+        }
+    return cost;
+}
+
+/* WeightParam::setFromWeightAndOffset (source/common/slice.h): reduce the
+ * weight to at most 7 bits by dropping denominator bits */
+static void wp_set(int* inputWeight, int* log2Denom, int* inputOffset, int w, int o, int denom, int bNormalize)
+{
+    *inputOffset = o;
+    *log2Denom = denom;
+    *inputWeight = w;
+    while (bNormalize && *log2Denom > 0 && (*inputWeight > 127))
+    {
+        (*log2Denom)--;
+        *inputWeight >>= 1;
+    }
+    *inputWeight = imin(*inputWeight, 127);
+}
+
+/* source/encoder/slicetype.cpp:870-971; float scalar logic as in the reference */
+void orc_weights_analyse(orc_tld* t, orc_lowres* fenc, orc_lowres* ref)
+{
+    static const float epsilon = 1.f / 128.f;
+    int deltaIndex = fenc->frameNum - ref->frameNum;
+
+    if (!t->wbuffer[0])
+    {
+        t->paddedLines = (int)(fenc->planesize / fenc->rp.stride);
+        t->wbuffer[0] = (pixel*)malloc(4 * fenc->planesize * sizeof(pixel));
+        for (int i = 1; i < 4; i++)
+            t->wbuffer[i] = t->wbuffer[0] + i * fenc->planesize;
+    }
+    orc_refplanes* wr = &fenc->weightedRef[deltaIndex];
+    memset(wr, 0, sizeof(*wr));
+    for (int i = 0; i < 4; i++)
+        wr->plane[i] = t->wbuffer[i] + fenc->padoffset;
+    wr->stride = fenc->rp.stride;
+    wr->isLowres = 1;
+    wr->isHMELowres = ref->rp.isHMELowres;
+    fenc->weightedRefIsWeighted[deltaIndex] = 0;
+
+    float guessScale, fencMean, refMean;
+    if (fenc->wp_ssd[0] && ref->wp_ssd[0])
+        guessScale = sqrtf((float)fenc->wp_ssd[0] / ref->wp_ssd[0]);
+    else
+        guessScale = 1.0f;
+    fencMean = (float)fenc->wp_sum[0] / (fenc->lines * fenc->width) / (1 << (ORC_DEPTH - 8));
+    refMean = (float)ref->wp_sum[0] / (fenc->lines * fenc->width) / (1 << (ORC_DEPTH - 8));
+
+    if (fabsf(refMean - fencMean) < 0.5f && fabsf(1.f - guessScale) < epsilon)
+        return;
+
+    int minoff = 0, minscale, mindenom;
+    unsigned int minscore = 0, origscore = 1;
+    int found = 0;
+    int wW, wD, wO;
+
+    wp_set(&wW, &wD, &wO, (int)(guessScale * 128 + 0.5f), 0, 7, 1);
+    mindenom = wD;
+    minscale = wW;
+
+    origscore = minscore = orc_weight_cost_luma(t, fenc, ref, 0, 0, 0, 0);
+    if (!minscore)
+        return;
+
+    unsigned int s = 0;
+    int curScale = minscale;
+    int curOffset = (int)(fencMean - refMean * curScale / (1 << mindenom) + 0.5f);
+    if (curOffset < -128 || curOffset > 127)
+    {
+        curOffset = imax(-128, imin(127, curOffset));
+        curScale = (int)((1 << mindenom) * (fencMean - curOffset) / refMean + 0.5f);
+        curScale = imax(0, imin(127, curScale));
+    }
+    s = orc_weight_cost_luma(t, fenc, ref, 1, curScale, mindenom, curOffset);
+    if (s < minscore) { minscore = s; minscale = curScale; minoff = curOffset; found = 1; }
+
+    if (mindenom > 0 && minscale && !(minscale & 1))
+    {
+        int idx = __builtin_ctz((unsigned)minscale);
+        int shift = imin(idx, mindenom);
+        mindenom -= shift;
+        minscale >>= shift;
+    }
+
+    if (!found || (minscale == 1 << mindenom && minoff == 0) || (float)minscore / origscore > 0.998f)
+        return;
+
+    /* integer division, as in the reference (source/encoder/slicetype.cpp:955) */
+    fenc->weightedCostDelta[deltaIndex] = minscore / origscore;
+
+    int offset = minoff * (1 << (ORC_DEPTH - 8));
+    int round = mindenom ? 1 << (mindenom - 1) : 0;
+    int correction = 14 - ORC_DEPTH;
+    intptr_t stride = ref->rp.stride;
+    for (int i = 0; i < 4; i++)
+        orc_weight_pp(ref->buffer[i], t->wbuffer[i], stride, (int)stride, t->paddedLines,
+                      minscale, round << correction, mindenom + correction, offset);
+    fenc->weightedRefIsWeighted[deltaIndex] = 1;
+}
+
+/* ---------------------------------------------------------------- inter / bidir */
+
+/* source/encoder/slicetype.cpp:4385-4557 */
+static void estimate_cu(orc_tld* t, const orc_param* p, orc_lowres** frames, int cuX, int cuY,
+                        int p0, int p1, int b, const int bDoSearch[2], int lastRow, int hme)
+{
+    orc_lowres* fref0 = frames[p0];
+    orc_lowres* fref1 = frames[p1];
+    orc_lowres* fenc = frames[b];
+    const orc_refplanes* wfref0 =
+        (fenc->weightedRefIsWeighted[b - p0] && !hme) ? &fenc->weightedRef[b - p0] : &fref0->rp;
+
+    const int W = hme ? fenc->widthInCU4 : fenc->widthInCU;
+    const int H = hme ? fenc->heightInCU4 : fenc->heightInCU;
+    const int bBidir = b < p1;
+    const int cuXY = cuX + cuY * W;
+    const int cuXY4 = (cuX / 2) + (cuY / 2) * W / 2;
+    const intptr_t ls = fenc->rp.stride;
+    const intptr_t pelOffset = 8 * cuX + 8 * cuY * (hme ? ls / 2 : ls);
+
+    if (bBidir || bDoSearch[0] || bDoSearch[1])
+        orc_me_set_source(&t->me, hme ? fenc->rp.lowerPlane[0] : fenc->rp.plane[0], hme ? ls / 2 : ls,
+                          pelOffset, 8, 8, p->lookaheadSearchMethod, p->hmeSearchMethod[0],
+                          p->hmeSearchMethod[1], 1);
+
+    const int lowresPenalty = 4;
+    const int listDist[2] = { b - p0, p1 - b };
+    int bcost = ORC_COST_MAX;
+    int listused = 0;
+
+    orc_mv mvmin = { -cuX * 8 - 8, -cuY * 8 - 8 };
+    orc_mv mvmax = { (W - cuX - 1) * 8 + 8, (H - cuY - 1) * 8 + 8 };
+
+    for (int i = 0; i < 1 + bBidir; i++)
+    {
+        int32_t* fencCost = hme ? &fenc->lowerResMvCosts[i][listDist[i]][cuXY]
+                                : &fenc->lowresMvCosts[i][listDist[i]][cuXY];
+        int skipCost = INT_MAX;
+
+        if (!bDoSearch[i])
+        {
+            if (*fencCost < bcost) { bcost = *fencCost; listused = i + 1; }
+            continue;
+        }
+
+        int numc = 0;
+        orc_mv mvc[5], mvp = { 0, 0 };
+        orc_mv* fencMV = hme ? &fenc->lowerResMvs[i][listDist[i]][cuXY] : &fenc->lowresMvs[i][listDist[i]][cuXY];
+        const orc_refplanes* fref = i ? &fref1->rp : wfref0;
+
+        /* predictors from blocks already visited (right, below, below-left, below-right) */
+        if (cuX < W - 1)
+            mvc[numc++] = fencMV[1];
+        if (!lastRow)
+        {
+            mvc[numc++] = fencMV[W];
+            if (cuX > 0)
+                mvc[numc++] = fencMV[W - 1];
+            if (cuX < W - 1)
+                mvc[numc++] = fencMV[W + 1];
+        }
+        if (fenc->lowerResMvs[0][0] && !hme && fenc->lowerResMvCosts[i][listDist[i]][cuXY4] > 0)
+        {
+            orc_mv m = fenc->lowerResMvs[i][listDist[i]][cuXY4];
+            m.x *= 2;
+            m.y *= 2;
+            mvc[numc++] = m;
+        }
+
+        if (numc)
+        {
+            pixel subpelbuf[64];
+            int mvpcost = ORC_COST_MAX;
+            for (int idx = 0; idx < numc; idx++)
+            {
+                intptr_t stride = 8;
+                const pixel* src = orc_lowres_mc(fref, pelOffset, mvc[idx], subpelbuf, &stride, hme);
+                int cost = orc_me_buf_satd(&t->me, src, stride);
+                if (cost < mvpcost) { mvpcost = cost; mvp = mvc[idx]; }
+                /* evaluated after every candidate: tracks the cost of the latest
+                 * candidate while the running best is still the zero vector */
+                if (!(mvp.x | mvp.y) && bBidir)
+                    skipCost = cost;
+            }
+        }
+
+        int searchRange = p->bEnableHME ? (hme ? p->hmeRange[0] : p->hmeRange[1]) : 16;
+        *fencCost = orc_motion_estimate(&t->me, fref, mvmin, mvmax, mvp, 0, NULL, searchRange, fencMV,
+                                        (uint32_t)p->maxSlices, hme);
+        if (skipCost < 64 && skipCost < *fencCost && bBidir)
+        {
+            *fencCost = skipCost;
+            fencMV->x = 0;
+            fencMV->y = 0;
+        }
+        if (*fencCost < bcost) { bcost = *fencCost; listused = i + 1; }
+    }
+    if (hme)
+        return;
+
+    if (bBidir)
+    {
+        pixel buf0[64], buf1[64], avg[64];
+        intptr_t s0 = 8, s1 = 8;
+        const pixel* src0 = orc_lowres_mc(&fref0->rp, pelOffset, fenc->lowresMvs[0][listDist[0]][cuXY], buf0, &s0, 0);
+        const pixel* src1 = orc_lowres_mc(&fref1->rp, pelOffset, fenc->lowresMvs[1][listDist[1]][cuXY], buf1, &s1, 0);
+        orc_pixelavg_pp(8, 8, avg, 8, src0, s0, src1, s1);
+        int bicost = orc_me_buf_satd(&t->me, avg, 8);
+        if (bicost < bcost) { bcost = bicost; listused = 3; }
+        orc_pixelavg_pp(8, 8, avg, 8, fref0->rp.plane[0] + pelOffset, fref0->rp.stride,
+                        fref1->rp.plane[0] + pelOffset, fref1->rp.stride);
+        bicost = orc_me_buf_satd(&t->me, avg, 8);
+        if (bicost < bcost) { bcost = bicost; listused = 3; }
+        bcost += lowresPenalty;
+    }
+    else
+    {
+        bcost += lowresPenalty;
+        if (fenc->intraCost[cuXY] < bcost)
+        {
+            bcost = fenc->intraCost[cuXY];
+            listused = 0;
+        }
+    }
+
+    const int scored = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
+    int bcostAq = (scored && fenc->invQscaleFactor) ? ((bcost * fenc->invQscaleFactor[cuXY] + 128) >> 8) : bcost;
+    if (scored)
+    {
+        fenc->costEst[b - p0][p1 - b] += bcost;
+        fenc->costEstAq[b - p0][p1 - b] += bcostAq;
+        if (!listused && !bBidir)
+            fenc->intraMbs[b - p0]++;
+    }
+    fenc->rowSatds[b - p0][p1 - b][cuY] += bcostAq;
+    fenc->lowresCosts[b - p0][p1 - b][cuXY] =
+        (uint16_t)(imin(bcost, ORC_LOWRES_COST_MASK) | (listused << ORC_LOWRES_COST_SHIFT));
+}
+
+/* source/encoder/slicetype.cpp:4284-4383, whole-frame branch */
+int64_t orc_estimate_frame_cost(orc_tld* t, const orc_param* p, orc_lowres** frames,
+                                int p0, int p1, int b, int bIntraPenalty)
+{
+    orc_lowres* fenc = frames[b];
+    int64_t score;
+
+    if (fenc->costEst[b - p0][p1 - b] >= 0 && fenc->rowSatds[b - p0][p1 - b][0] != -1)
+        score = fenc->costEst[b - p0][p1 - b];
+    else
+    {
+        int bDoSearch[2];
+        bDoSearch[0] = fenc->lowresMvs[0][b - p0][0].x == 0x7FFF;
+        bDoSearch[1] = p1 > b && fenc->lowresMvs[1][p1 - b][0].x == 0x7FFF;
+
+        fenc->weightedRefIsWeighted[b - p0] = 0;
+        if (p->bEnableWeightedPred && bDoSearch[0])
+            orc_weights_analyse(t, frames[b], frames[p0]);
+
+        fenc->costEst[b - p0][p1 - b] = 0;
+        fenc->costEstAq[b - p0][p1 - b] = 0;
+
+        if (p->bEnableHME)
+        {
+            int lastRow = 1;
+            for (int cuY = fenc->heightInCU4 - 1; cuY >= 0; cuY--)
+            {
+                for (int cuX = fenc->widthInCU4 - 1; cuX >= 0; cuX--)
+                    estimate_cu(t, p, frames, cuX, cuY, p0, p1, b, bDoSearch, lastRow, 1);
+                lastRow = 0;
+            }
+        }
+        int lastRow = 1;
+        for (int cuY = fenc->heightInCU - 1; cuY >= 0; cuY--)
+        {
+            fenc->rowSatds[b - p0][p1 - b][cuY] = 0;
+            for (int cuX = fenc->widthInCU - 1; cuX >= 0; cuX--)
+                estimate_cu(t, p, frames, cuX, cuY, p0, p1, b, bDoSearch, lastRow, 0);
+            lastRow = 0;
+        }
+
+        score = fenc->costEst[b - p0][p1 - b];
+        if (b != p1)
+            score = score * 100 / (130 + p->bFrameBias);
+        fenc->costEst[b - p0][p1 - b] = score;
+    }
+
+    if (bIntraPenalty)
+        score += score * fenc->intraMbs[b - p0] / (t->ncu * 8);
+    return score;
+}
+
+/* ---------------------------------------------------------------- ctypes accessors */
+
+void* orc_lowres_ptr(orc_lowres* lr, const char* f, int i, int j)
+{
+    if (!strcmp(f, "plane")) return lr->rp.plane[i];
+    if (!strcmp(f, "buffer")) return lr->buffer[i];
+    if (!strcmp(f, "lowerPlane")) return lr->rp.lowerPlane[i];
+    if (!strcmp(f, "lowerBuffer")) return lr->lowerResBuffer[i];
+    if (!strcmp(f, "intraCost")) return lr->intraCost;
+    if (!strcmp(f, "intraMode")) return lr->intraMode;
+    if (!strcmp(f, "invQscaleFactor")) return lr->invQscaleFactor;
+    if (!strcmp(f, "rowSatds")) return lr->rowSatds[i][j];
+    if (!strcmp(f, "lowresCosts")) return lr->lowresCosts[i][j];
+    if (!strcmp(f, "lowresMvs")) return lr->lowresMvs[i][j];
+    if (!strcmp(f, "lowresMvCosts")) return lr->lowresMvCosts[i][j];
+    if (!strcmp(f, "lowerResMvs")) return lr->lowerResMvs[i][j];
+    if (!strcmp(f, "lowerResMvCosts")) return lr->lowerResMvCosts[i][j];
+    if (!strcmp(f, "wp_sum")) return lr->wp_sum;
+    if (!strcmp(f, "wp_ssd")) return lr->wp_ssd;
+    if (!strcmp(f, "weightedPlane")) return lr->weightedRef[i].plane[j];
+    return NULL;
+}
+
+int64_t orc_lowres_i64(orc_lowres* lr, const char* f, int i, int j)
+{
+    if (!strcmp(f, "costEst")) return lr->costEst[i][j];
+    if (!strcmp(f, "costEstAq")) return lr->costEstAq[i][j];
+    if (!strcmp(f, "intraMbs")) return lr->intraMbs[i];
+    if (!strcmp(f, "width")) return lr->width;
+    if (!strcmp(f, "lines")) return lr->lines;
+    if (!strcmp(f, "stride")) return lr->rp.stride;
+    if (!strcmp(f, "marginX")) return lr->marginX;
+    if (!strcmp(f, "marginY")) return lr->marginY;
+    if (!strcmp(f, "widthInCU")) return lr->widthInCU;
+    if (!strcmp(f, "heightInCU")) return lr->heightInCU;
+    if (!strcmp(f, "widthInCU4")) return lr->widthInCU4;
+    if (!strcmp(f, "heightInCU4")) return lr->heightInCU4;
+    if (!strcmp(f, "planesize")) return (int64_t)lr->planesize;
+    if (!strcmp(f, "padoffset")) return (int64_t)lr->padoffset;
+    if (!strcmp(f, "isWeighted")) return lr->weightedRefIsWeighted[i];
+    if (!strcmp(f, "frameNum")) return lr->frameNum;
+    return -1;
+}

@@ -1,0 +1,134 @@
+"""GPU parity: the HIP path through the C-ABI against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from x265_amd import api, synth
+from x265_amd.lookahead import CostEstimateGroup, LowresState, PreLookaheadGroup
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(width, height, nframes, depth, with_aq=False, seed=1234, bframes=4):
+    clip = synth.luma_clip(width, height, nframes, depth, seed=seed)
+    param = orc.make_param(width, height, bframes=bframes)
+    ref = orc.Lookahead(depth, param, with_aq=with_aq)
+    aq = None
+    if with_aq:
+        rng = np.random.default_rng(seed + 1)
+    for f in clip:
+        q = None
+        if with_aq:
+            tmp = orc.Lowres(ref.L, depth, param)
+            n = tmp.ncu()
+            tmp.close()
+            q = rng.integers(128, 513, size=n).astype(np.int32)
+            aq = (aq or []) + [q]
+        ref.add_frame(f, q)
+    ctx = api.Context(width, height, depth=depth, bframes=bframes, num_slots=nframes)
+    ctx.set_mvcost(ref.table, ref.centre)
+    frames = [LowresState(i, i, ctx.D) for i in range(nframes)]
+    PreLookaheadGroup(ctx).process_tasks(frames, clip, aq)
+    return clip, ref, ctx, frames
+
+
+def _check_request(ref, ctx, frames, p0, p1, b):
+    d0, d1 = b - p0, p1 - b
+    fr = ref.frames[b]
+    lc, rs, (ce, ceaq, _) = ctx.get_costs(frames[b].slot, d0, d1)
+    mv0, c0 = ctx.get_mvs(frames[b].slot, 0, d0)
+    np.testing.assert_array_equal(mv0, fr.mvs(0, d0), err_msg="L0 mvs %s" % ((p0, p1, b),))
+    np.testing.assert_array_equal(c0, fr.mv_costs(0, d0), err_msg="L0 mv costs %s" % ((p0, p1, b),))
+    if d1:
+        mv1, c1 = ctx.get_mvs(frames[b].slot, 1, d1)
+        np.testing.assert_array_equal(mv1, fr.mvs(1, d1), err_msg="L1 mvs %s" % ((p0, p1, b),))
+        np.testing.assert_array_equal(c1, fr.mv_costs(1, d1), err_msg="L1 mv costs %s" % ((p0, p1, b),))
+    np.testing.assert_array_equal(lc, fr.lowres_costs(d0, d1), err_msg="lowresCosts %s" % ((p0, p1, b),))
+    np.testing.assert_array_equal(rs, fr.row_satds(d0, d1), err_msg="rowSatds %s" % ((p0, p1, b),))
+    assert ce == fr.i64("costEst", d0, d1)
+    assert ceaq == fr.i64("costEstAq", d0, d1)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size", [(320, 192), (424, 242)])
+def test_lowres_planes_and_intra(depth, size):
+    W, H = size
+    clip, ref, ctx, frames = _setup(W, H, 3, depth)
+    try:
+        for i in range(3):
+            for p in range(4):
+                np.testing.assert_array_equal(ctx.get_plane(i, p), ref.frames[i].buffer(p),
+                                              err_msg="frame %d plane %d" % (i, p))
+            cost, mode = ctx.get_intra(i)
+            np.testing.assert_array_equal(cost, ref.frames[i].intra_cost())
+            np.testing.assert_array_equal(mode, ref.frames[i].intra_mode())
+            lc, rs, (ce, ceaq, _) = ctx.get_costs(i, 0, 0)
+            np.testing.assert_array_equal(lc, ref.frames[i].lowres_costs(0, 0))
+            np.testing.assert_array_equal(rs, ref.frames[i].row_satds(0, 0))
+            assert ce == ref.frames[i].i64("costEst", 0, 0)
+            assert ceaq == ref.frames[i].i64("costEstAq", 0, 0)
+    finally:
+        ctx.close()
+        ref.close()
+
+
+@pytest.mark.parametrize("depth,with_aq", [(8, False), (8, True), (10, True)])
+def test_single_cost_sequence(depth, with_aq):
+    """Lazy request order (no pool): every singleCost is its own batch."""
+    W, H, N = 384, 208, 8
+    clip, ref, ctx, frames = _setup(W, H, N, depth, with_aq=with_aq)
+    try:
+        est = CostEstimateGroup(ctx, frames)
+        seq = [(0, 1, 1), (0, 2, 2), (0, 2, 1), (1, 2, 2), (0, 3, 3), (0, 3, 1), (0, 3, 2), (1, 3, 2),
+               (3, 4, 4), (3, 5, 4), (3, 7, 5), (4, 7, 7), (2, 7, 7), (3, 4, 4), (0, 2, 1)]
+        for (p0, p1, b) in seq:
+            for pen in (False, True):
+                assert est.single_cost(p0, p1, b, pen) == ref.frame_cost(p0, p1, b, pen), (p0, p1, b, pen)
+            _check_request(ref, ctx, frames, p0, p1, b)
+            assert frames[b].intra_mbs[b - p0] == ref.frames[b].i64("intraMbs", b - p0)
+    finally:
+        ctx.close()
+        ref.close()
+
+
+def test_batch_order_matches_sequential():
+    """slicetypeAnalyse batch 1 + batch 2 (slicetype.cpp:2925-2988) issued as two device batches."""
+    W, H, N = 320, 192, 8
+    clip, ref, ctx, frames = _setup(W, H, N, 8)
+    try:
+        est = CostEstimateGroup(ctx, frames)
+        bframes = 4
+        batch1 = []
+        for b in range(2, N):
+            for i in range(1, bframes + 2):
+                p0 = b - i
+                if p0 < 0:
+                    continue
+                p1 = b + i
+                if p1 >= N:
+                    p1 = b
+                batch1.append((p0, p1, b))
+        for r in batch1:
+            est.add(*r)
+        est.finish_batch()
+        for (p0, p1, b) in batch1:          # the oracle runs them one after another in the same order
+            ref.frame_cost(p0, p1, b)
+        batch2 = []
+        for b in range(2, N):
+            for i in range(1, bframes + 2):
+                if b < i:
+                    continue
+                for j in range(0, bframes + 1):
+                    if b + j >= N:
+                        break
+                    batch2.append((b - i, b + j, b))
+        for r in batch2:
+            est.add(*r)
+        est.finish_batch()
+        for (p0, p1, b) in batch2:
+            want = ref.frame_cost(p0, p1, b)
+            assert frames[b].cost_est[(b - p0, p1 - b)] == want, (p0, p1, b)
+            _check_request(ref, ctx, frames, p0, p1, b)
+    finally:
+        ctx.close()
+        ref.close()

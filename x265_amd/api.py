@@ -1,0 +1,247 @@
+"""ctypes binding of libx265gpu.so (the C-ABI declared in include/x265gpu.h).
+
+This is plumbing for tests and the benchmark; the product is the shared
+library.  There is no CPU fallback: a missing library, a missing GPU or any
+non-zero status raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libx265gpu.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+DIA_SEARCH, HEX_SEARCH, UMH_SEARCH, STAR_SEARCH = 0, 1, 2, 3
+PHASES = ("lowres", "intra", "search", "cost")
+
+EXPORTS = (
+    "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
+    "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
+    "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_weight_cost", "x265gpu_weight_planes",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs",
+    "x265gpu_profile_enable", "x265gpu_profile_read",
+)
+
+
+class X265GpuError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("sourceWidth", C.c_int32), ("sourceHeight", C.c_int32), ("internalBitDepth", C.c_int32),
+        ("maxCUSize", C.c_int32), ("bframes", C.c_int32), ("numSlots", C.c_int32),
+        ("searchMethod", C.c_int32), ("merange", C.c_int32), ("bEnableHME", C.c_int32),
+        ("hmeSearchMethod", C.c_int32 * 3), ("hmeRange", C.c_int32 * 3), ("bFrameBias", C.c_int32),
+        ("maxSlices", C.c_int32), ("lookaheadLambda", C.c_int32), ("deviceId", C.c_int32),
+        ("stream", C.c_void_p),
+    ]
+
+
+class Geometry(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("lines", C.c_int32), ("stride", C.c_int32), ("marginX", C.c_int32),
+        ("marginY", C.c_int32), ("widthInCU", C.c_int32), ("heightInCU", C.c_int32), ("cuCount", C.c_int32),
+        ("widthInCU4", C.c_int32), ("heightInCU4", C.c_int32), ("planeSize", C.c_int64), ("padOffset", C.c_int64),
+    ]
+
+
+class Request(C.Structure):
+    _fields_ = [
+        ("slotP0", C.c_int32), ("slotB", C.c_int32), ("slotP1", C.c_int32),
+        ("p0", C.c_int32), ("b", C.c_int32), ("p1", C.c_int32),
+        ("doSearch", C.c_int32 * 2), ("weightedL0", C.c_int32),
+    ]
+
+
+class FrameCost(C.Structure):
+    _fields_ = [("costEst", C.c_int64), ("costEstAq", C.c_int64), ("intraMbs", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libx265gpu.so; raises if it has not been built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise X265GpuError("%s not found: build the HIP library first (python -c 'import __graft_entry__ as g; "
+                           "g.build()')" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, ip = C.c_void_p, C.c_int32, C.c_ssize_t
+    L.x265gpu_open.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.x265gpu_close.argtypes = [vp]
+    L.x265gpu_close.restype = None
+    L.x265gpu_get_geometry.argtypes = [vp, C.POINTER(Geometry)]
+    L.x265gpu_last_error.argtypes = [vp]
+    L.x265gpu_last_error.restype = C.c_char_p
+    L.x265gpu_sync.argtypes = [vp]
+    L.x265gpu_set_mvcost.argtypes = [vp, vp, i32]
+    L.x265gpu_lowres_init.argtypes = [vp, i32, vp, ip, i32, i32]
+    L.x265gpu_lowres_init_batch.argtypes = [vp, i32, vp, vp, vp, i32, vp]
+    L.x265gpu_lowres_set_aq.argtypes = [vp, i32, vp]
+    L.x265gpu_intra_estimate.argtypes = [vp, i32, vp]
+    L.x265gpu_estimate.argtypes = [vp, i32, vp]
+    L.x265gpu_weight_cost.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint32)]
+    L.x265gpu_weight_planes.argtypes = [vp, i32, i32, i32, i32, i32, i32]
+    L.x265gpu_get_plane.argtypes = [vp, i32, i32, vp]
+    L.x265gpu_get_intra.argtypes = [vp, i32, vp, vp]
+    L.x265gpu_get_mvs.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.x265gpu_get_hme_mvs.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.x265gpu_get_costs.argtypes = [vp, i32, i32, i32, vp, vp, C.POINTER(FrameCost)]
+    L.x265gpu_profile_enable.argtypes = [vp, i32]
+    L.x265gpu_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One x265gpu context (one device, one stream)."""
+
+    def __init__(self, width, height, depth=8, bframes=4, num_slots=8, search=HEX_SEARCH, merange=16,
+                 ctu=64, hme=False, hme_methods=(HEX_SEARCH, UMH_SEARCH, UMH_SEARCH), hme_range=(16, 32, 48),
+                 bframe_bias=0, device=0, stream=None):
+        self.L = load_library()
+        cfg = Config()
+        cfg.sourceWidth, cfg.sourceHeight, cfg.internalBitDepth = width, height, depth
+        cfg.maxCUSize, cfg.bframes, cfg.numSlots = ctu, bframes, num_slots
+        cfg.searchMethod, cfg.merange, cfg.bEnableHME = search, merange, int(hme)
+        for k in range(3):
+            cfg.hmeSearchMethod[k] = hme_methods[k]
+            cfg.hmeRange[k] = hme_range[k]
+        cfg.bFrameBias, cfg.maxSlices = bframe_bias, 1
+        cfg.lookaheadLambda = {8: 1, 10: 16, 12: 256}[depth]
+        cfg.deviceId = device
+        cfg.stream = stream
+        self.cfg = cfg
+        self.depth = depth
+        self.pix = np.uint8 if depth == 8 else np.uint16
+        h = C.c_void_p()
+        rc = self.L.x265gpu_open(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise X265GpuError("x265gpu_open failed with status %d" % rc)
+        self.h = h
+        g = Geometry()
+        self._chk(self.L.x265gpu_get_geometry(self.h, C.byref(g)))
+        self.geom = g
+        self.D = bframes + 2
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise X265GpuError("x265gpu status %d: %s" % (rc, self.L.x265gpu_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.x265gpu_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- inputs ----
+    def set_mvcost(self, table, centre):
+        t = np.ascontiguousarray(table, np.uint16)
+        max_mvd = min(centre, len(t) - 1 - centre)
+        self._chk(self.L.x265gpu_set_mvcost(self.h, C.c_void_p(t.ctypes.data + 2 * centre), max_mvd))
+
+    def lowres_init(self, slot, luma, poc=0):
+        a = np.ascontiguousarray(luma, self.pix)
+        self._chk(self.L.x265gpu_lowres_init(self.h, slot, _ptr(a), a.shape[1], MEM_HOST, poc))
+
+    def lowres_init_device(self, slots, dev_ptrs, strides, pocs=None):
+        n = len(slots)
+        s = (C.c_int32 * n)(*slots)
+        p = (C.c_void_p * n)(*dev_ptrs)
+        st = (C.c_ssize_t * n)(*strides)
+        pc = (C.c_int32 * n)(*(pocs if pocs is not None else [0] * n))
+        self._chk(self.L.x265gpu_lowres_init_batch(self.h, n, s, p, st, MEM_DEVICE, pc))
+
+    def set_aq(self, slot, inv_qscale):
+        if inv_qscale is None:
+            self._chk(self.L.x265gpu_lowres_set_aq(self.h, slot, None))
+        else:
+            a = np.ascontiguousarray(inv_qscale, np.int32)
+            assert a.size == self.geom.cuCount
+            self._chk(self.L.x265gpu_lowres_set_aq(self.h, slot, _ptr(a)))
+
+    # ---- work ----
+    def intra_estimate(self, slots):
+        s = (C.c_int32 * len(slots))(*slots)
+        self._chk(self.L.x265gpu_intra_estimate(self.h, len(slots), s))
+
+    def estimate(self, requests):
+        """requests: iterable of (slotP0, slotB, slotP1, p0, b, p1, doSearch0, doSearch1[, weightedL0])."""
+        reqs = list(requests)
+        arr = (Request * len(reqs))()
+        for k, r in enumerate(reqs):
+            arr[k].slotP0, arr[k].slotB, arr[k].slotP1 = r[0], r[1], r[2]
+            arr[k].p0, arr[k].b, arr[k].p1 = r[3], r[4], r[5]
+            arr[k].doSearch[0], arr[k].doSearch[1] = int(r[6]), int(r[7])
+            arr[k].weightedL0 = int(r[8]) if len(r) > 8 else 0
+        self._chk(self.L.x265gpu_estimate(self.h, len(reqs), arr))
+
+    def weight_cost(self, slot_fenc, slot_ref, wt_present=0, scale=0, denom=0, offset=0):
+        out = C.c_uint32()
+        self._chk(self.L.x265gpu_weight_cost(self.h, slot_fenc, slot_ref, wt_present, scale, denom, offset,
+                                             C.byref(out)))
+        return out.value
+
+    def weight_planes(self, slot_fenc, dist, slot_ref, scale, denom, offset):
+        self._chk(self.L.x265gpu_weight_planes(self.h, slot_fenc, dist, slot_ref, scale, denom, offset))
+
+    def sync(self):
+        self._chk(self.L.x265gpu_sync(self.h))
+
+    # ---- results ----
+    def get_plane(self, slot, idx):
+        n = self.geom.planeSize if idx < 4 else self.geom.planeSize // 2
+        out = np.empty(n, self.pix)
+        self._chk(self.L.x265gpu_get_plane(self.h, slot, idx, _ptr(out)))
+        return out
+
+    def get_intra(self, slot):
+        cost = np.empty(self.geom.cuCount, np.int32)
+        mode = np.empty(self.geom.cuCount, np.uint8)
+        self._chk(self.L.x265gpu_get_intra(self.h, slot, _ptr(cost), _ptr(mode)))
+        return cost, mode
+
+    def get_mvs(self, slot, lst, dist):
+        mv = np.empty((self.geom.cuCount, 2), np.int32)
+        cost = np.empty(self.geom.cuCount, np.int32)
+        self._chk(self.L.x265gpu_get_mvs(self.h, slot, lst, dist, _ptr(mv), _ptr(cost)))
+        return mv, cost
+
+    def get_costs(self, slot, d0, d1):
+        lc = np.empty(self.geom.cuCount, np.uint16)
+        rs = np.empty(self.geom.heightInCU, np.int32)
+        fc = FrameCost()
+        self._chk(self.L.x265gpu_get_costs(self.h, slot, d0, d1, _ptr(lc), _ptr(rs), C.byref(fc)))
+        return lc, rs, (fc.costEst, fc.costEstAq, fc.intraMbs)
+
+    def get_frame_cost(self, slot, d0, d1):
+        fc = FrameCost()
+        self._chk(self.L.x265gpu_get_costs(self.h, slot, d0, d1, None, None, C.byref(fc)))
+        return fc.costEst, fc.costEstAq, fc.intraMbs
+
+    # ---- instrumentation ----
+    def profile_enable(self, on=True):
+        self._chk(self.L.x265gpu_profile_enable(self.h, int(on)))
+
+    def profile_read(self, reset=True):
+        out = {}
+        for k, name in enumerate(PHASES):
+            ms, n = C.c_double(), C.c_int64()
+            self._chk(self.L.x265gpu_profile_read(self.h, k, C.byref(ms), C.byref(n), int(reset)))
+            out[name] = (ms.value, n.value)
+        return out

@@ -1,0 +1,240 @@
+// Per-block cost decision with stored vectors, weighted-prediction helpers.
+//
+// cost_rows_kernel replaces the decision half of
+// CostEstimateGroup::estimateCUCost (source/encoder/slicetype.cpp:4427-4431,
+// 4495-4556): pick the cheaper list from the stored search costs, for B
+// requests also measure the two bidirectional candidates (average of the two
+// motion-compensated blocks, average of the co-located blocks), for P requests
+// compare against the intra cost; apply the AQ scale; emit lowresCosts and the
+// row / frame sums.  No block depends on another here, so every 8-lane group
+// of a wave takes its own block (lane = row) and a workgroup owns one block
+// row, whose total it reduces in LDS -- sums are exact integers, independent
+// of scheduling, with no atomics.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace xg {
+
+template <typename P>
+__global__ void __launch_bounds__(256) cost_rows_kernel(const CostJob* jobs, Geometry g)
+{
+    __shared__ long long red[4][4];
+
+    const CostJob job = jobs[blockIdx.y];
+    const int cuY = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 3, r = lane & 7;
+    const int W = g.W, H = g.H;
+    const int by = 8 * cuY;
+
+    PlaneSet<P> ps0, ps1;
+    ps0.origin = (const P*)job.ref0Origin;
+    ps0.planeSize = g.planeSize;
+    ps0.stride = g.stride;
+    ps0.minX = -g.marginX;
+    ps0.maxX = g.width + g.marginX - 8;
+    ps0.minY = -g.marginY;
+    ps0.maxY = g.lines + g.marginY - 8;
+    ps1 = ps0;
+    ps1.origin = (const P*)job.ref1Origin;
+
+    long long accRow = 0, accEst = 0, accAq = 0, accIntra = 0;
+    const int chunks = (W + 7) / 8;
+    for (int chunk = wave; chunk < chunks; chunk += 4)
+    {
+        const int cuXraw = chunk * 8 + grp;
+        const bool live = cuXraw < W;
+        const int cuX = min(cuXraw, W - 1);
+        const int cuXY = cuX + cuY * W;
+        const int bx = 8 * cuX;
+
+        int bcost = COST_MAX, listused = 0;
+        const int fc0 = job.mvCosts0[cuXY];
+        if (fc0 < bcost) { bcost = fc0; listused = 1; }
+        if (job.bBidir)
+        {
+            const int fc1 = job.mvCosts1[cuXY];
+            if (fc1 < bcost) { bcost = fc1; listused = 2; }
+
+            int f[8];
+            unpack_row<P>(load_row<P>((const P*)job.fencPlane0 + (long long)(by + r) * g.stride + bx), f);
+            const int m0x = job.mvs0[2 * cuXY], m0y = job.mvs0[2 * cuXY + 1];
+            const int m1x = job.mvs1[2 * cuXY], m1y = job.mvs1[2 * cuXY + 1];
+            const bool odd = __any((m0x | m0y | m1x | m1y) & 1) != 0;
+            // average of the two motion-compensated predictions
+            Row<P> a = mc_row<P>(ps0, bx, by, r, m0x, m0y, odd);
+            Row<P> b = mc_row<P>(ps1, bx, by, r, m1x, m1y, odd);
+            int bicost = satd8x8<P>(f, avg_row<P>(a, b), r);
+            if (bicost < bcost) { bcost = bicost; listused = 3; }
+            // average of the co-located blocks
+            a = fetch_row<P>(ps0, bx, by, r, 0, 0);
+            b = fetch_row<P>(ps1, bx, by, r, 0, 0);
+            bicost = satd8x8<P>(f, avg_row<P>(a, b), r);
+            if (bicost < bcost) { bcost = bicost; listused = 3; }
+            bcost += 4;   // lowresPenalty
+        }
+        else
+        {
+            bcost += 4;
+            const int ic = job.intraCost[cuXY];
+            if (ic < bcost) { bcost = ic; listused = 0; }
+        }
+
+        const bool scored = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
+        int bcostAq = bcost;
+        if (scored && job.invQscale)
+            bcostAq = (bcost * job.invQscale[cuXY] + 128) >> 8;
+        if (live && r == 0)
+        {
+            job.lowresCosts[cuXY] = (uint16_t)(min(bcost, LOWRES_COST_MASK) | (listused << LOWRES_COST_SHIFT));
+            accRow += bcostAq;
+            if (scored)
+            {
+                accEst += bcost;
+                accAq += bcostAq;
+                if (!listused && !job.bBidir)
+                    accIntra++;
+            }
+        }
+    }
+
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        accRow += __shfl_down(accRow, o);
+        accEst += __shfl_down(accEst, o);
+        accAq += __shfl_down(accAq, o);
+        accIntra += __shfl_down(accIntra, o);
+    }
+    if (lane == 0)
+    {
+        red[wave][0] = accRow;
+        red[wave][1] = accEst;
+        red[wave][2] = accAq;
+        red[wave][3] = accIntra;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        job.rowSatds[cuY] = (int32_t)(red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+        job.rowPartials[3 * cuY + 0] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        job.rowPartials[3 * cuY + 1] = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+        job.rowPartials[3 * cuY + 2] = red[0][3] + red[1][3] + red[2][3] + red[3][3];
+    }
+}
+
+// frame totals of one request: costEst, costEstAq, intraMbs (slicetype.cpp:4541-4544)
+__global__ void cost_finalize_kernel(const CostJob* jobs, int H)
+{
+    const CostJob job = jobs[blockIdx.x];
+    long long a = 0, b = 0, c = 0;
+    for (int y = threadIdx.x; y < H; y += 64)
+    {
+        a += job.rowPartials[3 * y];
+        b += job.rowPartials[3 * y + 1];
+        c += job.rowPartials[3 * y + 2];
+    }
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        a += __shfl_down(a, o);
+        b += __shfl_down(b, o);
+        c += __shfl_down(c, o);
+    }
+    if (threadIdx.x == 0)
+    {
+        job.sums[0] = a;
+        job.sums[1] = b;
+        job.sums[2] = c;
+    }
+}
+
+hipError_t launch_cost(hipStream_t s, const Geometry& g, int bpp, const CostJob* dJobs, int n)
+{
+    if (n <= 0)
+        return hipSuccess;
+    dim3 grid(g.H, n);
+    if (bpp == 1)
+        hipLaunchKernelGGL(cost_rows_kernel<uint8_t>, grid, dim3(256), 0, s, dJobs, g);
+    else
+        hipLaunchKernelGGL(cost_rows_kernel<uint16_t>, grid, dim3(256), 0, s, dJobs, g);
+    hipLaunchKernelGGL(cost_finalize_kernel, dim3(n), dim3(64), 0, s, dJobs, g.H);
+    return hipGetLastError();
+}
+
+// LookaheadTLD::weightCostLuma (slicetype.cpp:836-849): sum over all 8x8 blocks
+// of min(SATD(ref, fenc), intraCost).  The uint32 total wraps like the
+// reference's accumulator; one atomic per workgroup.
+template <typename P>
+__global__ void __launch_bounds__(256) weight_cost_kernel(WeightCostJob job, Geometry g)
+{
+    __shared__ unsigned int red[4];
+    const int cuY = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 3, r = lane & 7;
+    const int W = g.W;
+    unsigned int acc = 0;
+    const int chunks = (W + 7) / 8;
+    for (int chunk = wave; chunk < chunks; chunk += 4)
+    {
+        const int cuXraw = chunk * 8 + grp;
+        const int cuX = min(cuXraw, W - 1);
+        const long long off = (long long)(8 * cuY + r) * g.stride + 8 * cuX;
+        int f[8];
+        unpack_row<P>(load_row<P>((const P*)job.fencPlane0 + off), f);
+        const int satd = satd8x8<P>(f, load_row<P>((const P*)job.refPlane0 + off), r);
+        if (cuXraw < W && r == 0)
+            acc += (unsigned int)min(satd, job.intraCost[cuX + cuY * W]);
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        acc += __shfl_down(acc, o);
+    if (lane == 0)
+        red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicAdd(job.out, red[0] + red[1] + red[2] + red[3]);
+}
+
+hipError_t launch_weight_cost(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* job)
+{
+    dim3 grid(g.H);
+    if (bpp == 1)
+        hipLaunchKernelGGL(weight_cost_kernel<uint8_t>, grid, dim3(256), 0, s, *job, g);
+    else
+        hipLaunchKernelGGL(weight_cost_kernel<uint16_t>, grid, dim3(256), 0, s, *job, g);
+    return hipGetLastError();
+}
+
+// weight_pp over `count` pixels (source/common/pixel.cpp:510-535):
+// clip(((w0 * (pix << (14 - depth)) + round) >> shift) + offset)
+template <typename P>
+__global__ void __launch_bounds__(256) weight_pp_kernel(const P* src, P* dst, long long spans, int correction,
+                                                        int pixelMax, int w0, int round, int shift, int offset)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= spans)
+        return;
+    int v[8];
+    unpack_row<P>(load_row<P>(src + 8 * i), v);
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+    {
+        const int val = (int)(short)(v[k] << correction);
+        v[k] = clampi(((w0 * val + round) >> shift) + offset, 0, pixelMax);
+    }
+    store_row<P>(dst + 8 * i, pack_row<P>(v));
+}
+
+hipError_t launch_weight_planes(hipStream_t s, const Geometry& g, int bpp, int depth, int nPlanes, const void* src,
+                                void* dst, int w0, int round, int shift, int offset)
+{
+    const long long spans = nPlanes * g.planeSize / 8;
+    dim3 grid((unsigned)((spans + 255) / 256));
+    if (bpp == 1)
+        hipLaunchKernelGGL(weight_pp_kernel<uint8_t>, grid, dim3(256), 0, s, (const uint8_t*)src, (uint8_t*)dst, spans,
+                           14 - depth, (1 << depth) - 1, w0, round, shift, offset);
+    else
+        hipLaunchKernelGGL(weight_pp_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst,
+                           spans, 14 - depth, (1 << depth) - 1, w0, round, shift, offset);
+    return hipGetLastError();
+}
+
+} // namespace xg

@@ -1,0 +1,212 @@
+// Device-side building blocks shared by the gfx950 kernels.
+//
+// Lane mapping used throughout: a 64-lane wave is split into eight 8-lane
+// groups.  Lane (g = lane >> 3, r = lane & 7) owns ROW r of the 8x8 block that
+// group g is working on, held as packed dwords (two for 8-bit pixels, four for
+// 16-bit).  One wave therefore measures up to eight candidate blocks per pass,
+// which is the shape of x265's sad_x3 / sad_x4 / square-refine call sites
+// (source/encoder/motion.cpp:271-353).  Row sums are combined with DPP
+// (quad_perm + row_half_mirror), so no LDS is spent on reductions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xg {
+
+constexpr int COST_MAX = 1 << 28;             // source/encoder/motion.h:65
+constexpr int LOWRES_COST_MASK = (1 << 14) - 1;  // source/encoder/slicetype.h:42-43
+constexpr int LOWRES_COST_SHIFT = 14;
+
+template <typename P> struct PixT;
+template <> struct PixT<uint8_t>  { static constexpr int NW = 2; static constexpr uint32_t HALF = 0x7f7f7f7fu; };
+template <> struct PixT<uint16_t> { static constexpr int NW = 4; static constexpr uint32_t HALF = 0x7fff7fffu; };
+
+// eight pixels of one row, packed little-endian
+template <typename P> struct Row { uint32_t w[PixT<P>::NW]; };
+
+// Row load from an arbitrarily aligned address.  gfx950 under HSA runs with
+// unaligned global access enabled, so this lowers to one dwordx2 / dwordx4.
+template <typename P> __device__ __forceinline__ Row<P> load_row(const P* p)
+{
+    Row<P> r;
+    __builtin_memcpy(r.w, p, 8 * sizeof(P));
+    return r;
+}
+
+template <typename P> __device__ __forceinline__ void store_row(P* p, const Row<P>& r)
+{
+    __builtin_memcpy(p, r.w, 8 * sizeof(P));
+}
+
+// per-element (a + b + 1) >> 1 on packed lanes: pixelavg_pp, source/common/pixel.cpp:537-549
+template <typename P> __device__ __forceinline__ Row<P> avg_row(const Row<P>& a, const Row<P>& b)
+{
+    Row<P> o;
+#pragma unroll
+    for (int i = 0; i < PixT<P>::NW; i++)
+        o.w[i] = (a.w[i] | b.w[i]) - (((a.w[i] ^ b.w[i]) >> 1) & PixT<P>::HALF);
+    return o;
+}
+
+template <typename P> __device__ __forceinline__ void unpack_row(const Row<P>& r, int v[8]);
+template <> __device__ __forceinline__ void unpack_row<uint8_t>(const Row<uint8_t>& r, int v[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        v[i] = (int)((r.w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+}
+template <> __device__ __forceinline__ void unpack_row<uint16_t>(const Row<uint16_t>& r, int v[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        v[i] = (int)((r.w[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+}
+
+template <typename P> __device__ __forceinline__ Row<P> pack_row(const int v[8]);
+template <> __device__ __forceinline__ Row<uint8_t> pack_row<uint8_t>(const int v[8])
+{
+    Row<uint8_t> r;
+    r.w[0] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+    r.w[1] = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
+    return r;
+}
+template <> __device__ __forceinline__ Row<uint16_t> pack_row<uint16_t>(const int v[8])
+{
+    Row<uint16_t> r;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        r.w[i] = (uint32_t)v[2 * i] | ((uint32_t)v[2 * i + 1] << 16);
+    return r;
+}
+
+// ---- cross-lane moves (DPP; all 64 lanes must be active) -------------------
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7 - i inside each 8-lane half row
+
+template <int CTRL> __device__ __forceinline__ int dpp(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+// sum over the 8 lanes of a group, result in every lane of the group
+__device__ __forceinline__ int group_sum8(int v)
+{
+    v += dpp<DPP_XOR1>(v);
+    v += dpp<DPP_XOR2>(v);
+    v += dpp<DPP_HALF_MIRROR>(v);
+    return v;
+}
+
+// value held by lane 8*g, as a wave-uniform scalar
+template <int G> __device__ __forceinline__ int group_value(int v)
+{
+    return __builtin_amdgcn_readlane(v, 8 * G);
+}
+
+// ---- block compares -----------------------------------------------------------
+
+// row SAD on packed pixels (v_sad_u8 / v_sad_u16): source/common/pixel.cpp:40-55
+template <typename P> __device__ __forceinline__ int sad_row(const Row<P>& a, const Row<P>& b);
+template <> __device__ __forceinline__ int sad_row<uint8_t>(const Row<uint8_t>& a, const Row<uint8_t>& b)
+{
+    uint32_t s = __builtin_amdgcn_sad_u8(a.w[0], b.w[0], 0u);
+    return (int)__builtin_amdgcn_sad_u8(a.w[1], b.w[1], s);
+}
+template <> __device__ __forceinline__ int sad_row<uint16_t>(const Row<uint16_t>& a, const Row<uint16_t>& b)
+{
+    uint32_t s = __builtin_amdgcn_sad_u16(a.w[0], b.w[0], 0u);
+    s = __builtin_amdgcn_sad_u16(a.w[1], b.w[1], s);
+    s = __builtin_amdgcn_sad_u16(a.w[2], b.w[2], s);
+    return (int)__builtin_amdgcn_sad_u16(a.w[3], b.w[3], s);
+}
+
+// 8x8 SAD of the group's block; every lane of the group gets the total
+template <typename P> __device__ __forceinline__ int sad8x8(const Row<P>& fenc, const Row<P>& ref)
+{
+    return group_sum8(sad_row<P>(fenc, ref));
+}
+
+// 8x8 SATD = two 8x4 halves, each (sum of |4x4 Hadamard| over its two 4x4
+// blocks) >> 1: source/common/pixel.cpp:239-261, 277-289.  `f` is this lane's
+// unpacked encode row, `r` its lane index inside the group (row number).
+// Horizontal transform in registers, vertical transform across the four lanes
+// of a quad.
+template <typename P> __device__ __forceinline__ int satd8x8(const int f[8], const Row<P>& ref, int r)
+{
+    int d[8];
+    unpack_row<P>(ref, d);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        d[i] = f[i] - d[i];
+#pragma unroll
+    for (int h = 0; h < 8; h += 4)
+    {
+        int a0 = d[h] + d[h + 1], a1 = d[h] - d[h + 1];
+        int a2 = d[h + 2] + d[h + 3], a3 = d[h + 2] - d[h + 3];
+        d[h] = a0 + a2;
+        d[h + 1] = a1 + a3;
+        d[h + 2] = a0 - a2;
+        d[h + 3] = a1 - a3;
+    }
+    const int m1 = -(r & 1), m2 = -((r >> 1) & 1);   // 0 or -1: negate own value on odd partner
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        d[i] = ((d[i] ^ m1) - m1) + dpp<DPP_XOR1>(d[i]);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        d[i] = ((d[i] ^ m2) - m2) + dpp<DPP_XOR2>(d[i]);
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        s += abs(d[i]);
+    s += dpp<DPP_XOR1>(s);
+    s += dpp<DPP_XOR2>(s);
+    s >>= 1;
+    s += dpp<DPP_HALF_MIRROR>(s);
+    return s;
+}
+
+// signed 4-bit table packed in a dword, biased by 8
+__device__ __forceinline__ int nib(uint32_t pack, int i) { return (int)((pack >> (4 * i)) & 15u) - 8; }
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// One set of four half-pel planes (full, H, V, HV) laid out back to back, the
+// way Lowres::buffer[0..3] is (source/common/lowres.cpp:160-169).
+template <typename P> struct PlaneSet
+{
+    const P* origin;      // pixel (0,0) of plane 0
+    long long planeSize;  // pixels between consecutive planes
+    int stride;
+    int minX, maxX, minY, maxY;  // legal block origins (inside the padded buffer)
+};
+
+// Row r of the 8x8 block at quarter-pel displacement (qx,qy) from block origin
+// (bx,by): ReferencePlanes::lowresMC, source/common/lowres.h:72-93.  `anyOdd`
+// is wave-uniform: when no lane has a quarter-pel component the second fetch
+// and the average are skipped.  Block origins are clamped into the padded
+// buffer; for vectors the reference itself would produce this is a no-op.
+template <typename P>
+__device__ __forceinline__ Row<P> fetch_row(const PlaneSet<P>& ps, int bx, int by, int r, int qx, int qy)
+{
+    const int hp = (qy & 2) | ((qx & 2) >> 1);
+    const int X = clampi(bx + (qx >> 2), ps.minX, ps.maxX);
+    const int Y = clampi(by + (qy >> 2), ps.minY, ps.maxY) + r;
+    return load_row<P>(ps.origin + hp * ps.planeSize + (long long)Y * ps.stride + X);
+}
+
+template <typename P>
+__device__ __forceinline__ Row<P> mc_row(const PlaneSet<P>& ps, int bx, int by, int r, int qx, int qy, bool anyOdd)
+{
+    Row<P> a = fetch_row<P>(ps, bx, by, r, qx, qy);
+    if (anyOdd)
+    {
+        Row<P> b = fetch_row<P>(ps, bx, by, r, qx + (qx & 1), qy + (qy & 1));
+        a = avg_row<P>(a, b);
+    }
+    return a;
+}
+
+} // namespace xg

@@ -1,0 +1,296 @@
+// 8x8 intra cost estimate of the half-res plane.
+//
+// Replaces LookaheadTLD::lowresIntraEstimate (source/encoder/slicetype.cpp:
+// 706-815) and the primitives it calls for BLOCK_8x8: intra_filter, intra_pred
+// DC / planar / angular (source/common/intrapred.cpp:31-204) and satd 8x8.
+//
+// One wave per 8x8 block.  The 33 neighbour samples and their 1:2:1 smoothed
+// copy sit in LDS; each 8-lane group predicts one mode (lane = row), so the
+// eight first-pass modes (DC, planar, 5,10,..,30) are measured in one pass,
+// then best-2/best+2, then best-1/best+1 -- the reference's order and strict
+// '<' tie-breaks, taken on wave-uniform scalars.  Block rows are independent
+// workgroups; row totals are reduced in LDS, frame totals in a second tiny
+// kernel, so results do not depend on scheduling.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace xg {
+
+// SATD core on a ready difference row (see satd8x8 in device_common.h)
+__device__ __forceinline__ int satd8x8_diff(int d[8], int r)
+{
+#pragma unroll
+    for (int h = 0; h < 8; h += 4)
+    {
+        int a0 = d[h] + d[h + 1], a1 = d[h] - d[h + 1];
+        int a2 = d[h + 2] + d[h + 3], a3 = d[h + 2] - d[h + 3];
+        d[h] = a0 + a2;
+        d[h + 1] = a1 + a3;
+        d[h + 2] = a0 - a2;
+        d[h + 3] = a1 - a3;
+    }
+    const int m1 = -(r & 1), m2 = -((r >> 1) & 1);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        d[i] = ((d[i] ^ m1) - m1) + dpp<DPP_XOR1>(d[i]);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        d[i] = ((d[i] ^ m2) - m2) + dpp<DPP_XOR2>(d[i]);
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        s += abs(d[i]);
+    s += dpp<DPP_XOR1>(s);
+    s += dpp<DPP_XOR2>(s);
+    s >>= 1;
+    s += dpp<DPP_HALF_MIRROR>(s);
+    return s;
+}
+
+// g_intraFilterFlags[mode] & 8 (source/common/constants.cpp:561-567): for 8x8
+// blocks only planar and the three diagonal modes read the smoothed samples
+__device__ __forceinline__ bool uses_filtered(int mode) { return mode == 0 || mode == 2 || mode == 18 || mode == 34; }
+
+// Row r of the 8x8 prediction for `mode` (0 planar, 1 DC, 2..34 angular).
+// nb[0..32] raw neighbours, nb[40..72] smoothed; layout [0] corner,
+// [1..16] top + top-right, [17..32] left + bottom-left.
+__device__ void predict_row(const int* nb, int mode, int r, int pixelMax, int p[8])
+{
+    const int* raw = nb;
+    if (mode == 1)
+    {
+        // intra_pred_dc_c with the edge filter on (bFilter = size <= 16)
+        int dc = 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            dc += raw[1 + i] + raw[17 + i];
+        dc >>= 4;
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+            p[x] = (r == 0) ? ((raw[1 + x] + 3 * dc + 2) >> 2) : dc;
+        p[0] = (r == 0) ? ((raw[1] + raw[17] + 2 * dc + 2) >> 2) : ((raw[17 + r] + 3 * dc + 2) >> 2);
+        return;
+    }
+    const int* s = uses_filtered(mode) ? nb + 40 : nb;
+    if (mode == 0)
+    {
+        const int tr = s[9], bl = s[25], lf = s[17 + r];
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+            p[x] = ((7 - x) * lf + (7 - r) * s[1 + x] + (x + 1) * tr + (r + 1) * bl + 8) >> 4;
+        return;
+    }
+
+    // angular: horizontal modes are the vertical formula on swapped neighbours,
+    // transposed; sw(k) maps an index of the swapped array back to `s`
+    const bool hor = mode < 18;
+    const int angOff = hor ? 10 - mode : mode - 26;
+    // angleTable[8 + angOff], invAngleTable[-angOff - 1]
+    const int aabs = angOff < 0 ? -angOff : angOff;
+    // |angle| for offsets 0..8: 0,2,5,9,13,17,21,26,32
+    const int angMag = (aabs == 0) ? 0 : (aabs == 1) ? 2 : (aabs == 2) ? 5 : (aabs == 3) ? 9 : (aabs == 4) ? 13
+                     : (aabs == 5) ? 17 : (aabs == 6) ? 21 : (aabs == 7) ? 26 : 32;
+    const int angle = angOff < 0 ? -angMag : angMag;
+    // inverse angles for offsets -1..-8: 4096,1638,910,630,482,390,315,256
+    const int inv = (aabs == 1) ? 4096 : (aabs == 2) ? 1638 : (aabs == 3) ? 910 : (aabs == 4) ? 630
+                  : (aabs == 5) ? 482 : (aabs == 6) ? 390 : (aabs == 7) ? 315 : 256;
+
+#define SW(k) (hor ? (((k) == 0) ? 0 : (((k) <= 16) ? (k) + 16 : (k) - 16)) : (k))
+#pragma unroll
+    for (int x = 0; x < 8; x++)
+    {
+        // (yy, xx): position in the un-transposed prediction
+        const int yy = hor ? x : r;
+        const int xx = hor ? r : x;
+        int v;
+        if (angle == 0)
+        {
+            v = s[SW(1 + xx)];
+            if (xx == 0)
+            {
+                int t = s[SW(1)] + ((s[SW(17 + yy)] - s[SW(0)]) >> 1);
+                v = clampi((int)(short)t, 0, pixelMax);
+            }
+        }
+        else
+        {
+            const int angSum = (yy + 1) * angle;
+            const int off = angSum >> 5, frac = angSum & 31;
+            // ref[i]: i >= -1 -> swapped[i + 1]; i < -1 -> projected side sample
+            int i0 = off + xx, i1 = i0 + 1;
+            int k0 = (i0 >= -1) ? i0 + 1 : 16 + ((128 + (-1 - i0) * inv) >> 8);
+            int k1 = (i1 >= -1) ? i1 + 1 : 16 + ((128 + (-1 - i1) * inv) >> 8);
+            const int a = s[SW(k0)], b = s[SW(k1)];
+            v = frac ? (((32 - frac) * a + frac * b + 16) >> 5) : a;
+        }
+        p[x] = v;
+    }
+#undef SW
+}
+
+template <typename P>
+__global__ void __launch_bounds__(256) intra_kernel(const IntraJob* jobs, Geometry g, int lambda, int pixelMax)
+{
+    __shared__ int nbr[4][80];
+    __shared__ long long red[4][3];
+
+    const IntraJob job = jobs[blockIdx.y];
+    const int cuY = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 3, r = lane & 7;
+    const int W = g.W, H = g.H;
+    const P* plane = (const P*)job.plane0;
+    int* nb = nbr[wave];
+
+    long long accRow = 0, accEst = 0, accAq = 0;
+    const int iters = (W + 3) / 4;
+    for (int it = 0; it < iters; it++)
+    {
+        const int cuX = it * 4 + wave;
+        const bool live = cuX < W;          // wave-uniform
+        const int bx = 8 * min(cuX, W - 1), by = 8 * cuY;
+        const P* tl = plane + (long long)(by - 1) * g.stride + bx - 1;
+        if (lane < 33)
+            nb[lane] = (lane < 17) ? (int)tl[lane] : (int)tl[(long long)(lane - 16) * g.stride];
+        __syncthreads();
+        if (lane < 33)
+        {
+            // intraFilter<8>: source/common/intrapred.cpp:31-51
+            int f;
+            if (lane == 0)
+                f = (2 * nb[0] + nb[1] + nb[17] + 2) >> 2;
+            else if (lane == 16 || lane == 32)
+                f = nb[lane];
+            else if (lane == 17)
+                f = (2 * nb[17] + nb[0] + nb[18] + 2) >> 2;
+            else
+                f = (2 * nb[lane] + nb[lane - 1] + nb[lane + 1] + 2) >> 2;
+            nb[40 + lane] = f;
+        }
+        __syncthreads();
+
+        int f[8];
+        unpack_row<P>(load_row<P>(plane + (long long)(by + r) * g.stride + bx), f);
+
+        int p[8], d[8];
+        // pass 1: DC, planar, 5, 10, ..., 30
+        {
+            const int mode = (grp == 0) ? 1 : (grp == 1) ? 0 : 5 * (grp - 1);
+            predict_row(nb, mode, r, pixelMax, p);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                d[i] = f[i] - p[i];
+        }
+        int c = satd8x8_diff(d, r);
+        int icost = COST_MAX, ilow = 0;
+        {
+            const int cDC = group_value<0>(c), cPl = group_value<1>(c);
+            if (cDC < icost) { icost = cDC; ilow = 1; }
+            if (cPl < icost) { icost = cPl; ilow = 0; }
+        }
+        int acost = COST_MAX, alow = 4;
+        {
+            const int c5 = group_value<2>(c), c10 = group_value<3>(c), c15 = group_value<4>(c);
+            const int c20 = group_value<5>(c), c25 = group_value<6>(c), c30 = group_value<7>(c);
+            if (c5 < acost) { acost = c5; alow = 5; }
+            if (c10 < acost) { acost = c10; alow = 10; }
+            if (c15 < acost) { acost = c15; alow = 15; }
+            if (c20 < acost) { acost = c20; alow = 20; }
+            if (c25 < acost) { acost = c25; alow = 25; }
+            if (c30 < acost) { acost = c30; alow = 30; }
+        }
+        // passes 2 and 3: best-dist, best+dist with the best updated in between
+#pragma unroll
+        for (int dist = 2; dist >= 1; dist--)
+        {
+            const int minus = alow - dist, plus = alow + dist;
+            const int mode = (grp == 1) ? plus : minus;
+            predict_row(nb, mode, r, pixelMax, p);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                d[i] = f[i] - p[i];
+            c = satd8x8_diff(d, r);
+            const int cm = group_value<0>(c), cp = group_value<1>(c);
+            if (cm < acost) { acost = cm; alow = minus; }
+            if (cp < acost) { acost = cp; alow = plus; }
+        }
+        if (acost < icost) { icost = acost; ilow = alow; }
+
+        icost += 5 * lambda + 4;   // intraPenalty + lowresPenalty
+
+        if (live)
+        {
+            const int cuXY = cuX + cuY * W;
+            const bool scored = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
+            int icostAq = icost;
+            if (scored && job.invQscale)
+                icostAq = (icost * job.invQscale[cuXY] + 128) >> 8;
+            if (lane == 0)
+            {
+                job.lowresCosts[cuXY] = (uint16_t)min(icost, LOWRES_COST_MASK);
+                job.intraCost[cuXY] = icost;
+                job.intraMode[cuXY] = (uint8_t)ilow;
+            }
+            accRow += icostAq;
+            if (scored)
+            {
+                accEst += icost;
+                accAq += icostAq;
+            }
+        }
+        __syncthreads();   // neighbour buffer is rewritten next iteration
+    }
+
+    if (lane == 0)
+    {
+        red[wave][0] = accRow;
+        red[wave][1] = accEst;
+        red[wave][2] = accAq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        job.rowSatds[cuY] = (int32_t)(red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+        job.rowPartials[2 * cuY + 0] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        job.rowPartials[2 * cuY + 1] = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+    }
+}
+
+// frame totals: costEst[0][0], costEstAq[0][0] (slicetype.cpp:813-814)
+__global__ void intra_finalize_kernel(const IntraJob* jobs, long long* sums, int H)
+{
+    const IntraJob job = jobs[blockIdx.x];
+    long long a = 0, b = 0;
+    for (int y = threadIdx.x; y < H; y += 64)
+    {
+        a += job.rowPartials[2 * y];
+        b += job.rowPartials[2 * y + 1];
+    }
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        a += __shfl_down(a, o);
+        b += __shfl_down(b, o);
+    }
+    if (threadIdx.x == 0)
+    {
+        sums[2 * blockIdx.x] = a;
+        sums[2 * blockIdx.x + 1] = b;
+    }
+}
+
+hipError_t launch_intra(hipStream_t s, const Geometry& g, int bpp, int depth, int lambda, const IntraJob* dJobs,
+                        long long* dSums, int n)
+{
+    if (n <= 0)
+        return hipSuccess;
+    dim3 grid(g.H, n);
+    const int pixelMax = (1 << depth) - 1;
+    if (bpp == 1)
+        hipLaunchKernelGGL(intra_kernel<uint8_t>, grid, dim3(256), 0, s, dJobs, g, lambda, pixelMax);
+    else
+        hipLaunchKernelGGL(intra_kernel<uint16_t>, grid, dim3(256), 0, s, dJobs, g, lambda, pixelMax);
+    hipLaunchKernelGGL(intra_finalize_kernel, dim3(n), dim3(64), 0, s, dJobs, dSums, g.H);
+    return hipGetLastError();
+}
+
+} // namespace xg

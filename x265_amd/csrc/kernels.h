@@ -1,0 +1,96 @@
+// Job descriptors passed from the host-side C-ABI to the kernels, and the
+// launch entry points each .hip file exports.  Pointers in a job are already
+// resolved to device addresses of one slot's arrays, so kernels never chase a
+// slot table.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xg {
+
+struct Geometry
+{
+    int srcWidth, srcHeight;
+    int width, lines, stride;       // lowres, rounded to 8; stride in pixels
+    int marginX, marginY;
+    int W, H, cuCount;              // 8x8 block grid of the half-res planes
+    int W4, H4, cuCount4;           // block grid of the quarter-res planes (HME level 0)
+    long long planeSize, padOffset; // pixels
+    long long planeSize4, padOffset4;
+    int stride4, width4, lines4, marginX4, marginY4;
+};
+
+struct LowresJob
+{
+    const void* src;      // full-res luma, pixel (0,0)
+    long long srcStride;  // pixels
+    void* planes;         // buffer start of the 4 half-res planes
+    void* planes4;        // buffer start of the 4 quarter-res planes or null
+};
+
+struct IntraJob
+{
+    const void* plane0;       // origin of half-res plane 0
+    const int32_t* invQscale; // or null
+    int32_t* intraCost;
+    uint8_t* intraMode;
+    uint16_t* lowresCosts;    // lowresCosts[0][0]
+    int32_t* rowSatds;        // rowSatds[0][0]
+    long long* rowPartials;   // [H][2]: costEst, costEstAq partial per block row
+};
+
+struct SearchJob
+{
+    const void* fencPlane0;   // origin of the encode frame's plane 0 (of the searched resolution)
+    const void* refOrigin;    // origin of plane 0 of the 4-plane reference set that is searched
+    const void* zeroRef;      // origin of the plane the closing zero-vector check reads
+    int zeroStride;           // and its stride
+    int32_t* mvs;             // {x,y} per block, this (frame, list, distance)
+    int32_t* mvCosts;
+    const int32_t* hmeMvs;    // quarter-res vectors used as an extra predictor, or null
+    const int32_t* hmeMvCosts;
+    int bBidir;
+    int level0;               // 1: this job searches the quarter-res planes
+    int method;
+    int merange;
+};
+
+struct CostJob
+{
+    const void* fencPlane0;
+    const void* ref0Origin;
+    const void* ref1Origin;
+    const int32_t* mvs0;
+    const int32_t* mvs1;
+    const int32_t* mvCosts0;
+    const int32_t* mvCosts1;
+    const int32_t* intraCost;
+    const int32_t* invQscale;   // or null
+    uint16_t* lowresCosts;
+    int32_t* rowSatds;
+    long long* rowPartials;     // [H][3]: costEst, costEstAq, intraMbs per block row
+    long long* sums;            // [3] frame totals written by the finalize pass
+    int bBidir;
+};
+
+struct WeightCostJob
+{
+    const void* fencPlane0;
+    const void* refPlane0;      // origin of (possibly weighted) plane 0
+    const int32_t* intraCost;
+    unsigned int* out;          // single accumulator, zeroed by the host beforehand
+};
+
+// launchers (defined in the .hip files); bytesPerPixel is 1 or 2
+hipError_t launch_lowres_init(hipStream_t s, const Geometry& g, int bpp, const LowresJob* dJobs, int n);
+hipError_t launch_intra(hipStream_t s, const Geometry& g, int bpp, int depth, int lambda, const IntraJob* dJobs,
+                        long long* dSums /* [n][2] */, int n);
+hipError_t launch_search(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0,
+                         const uint16_t* costTab, int maxMvd, int maxSlices, int* launches);
+hipError_t launch_cost(hipStream_t s, const Geometry& g, int bpp, const CostJob* dJobs, int n);
+hipError_t launch_weight_cost(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJob);
+hipError_t launch_weight_planes(hipStream_t s, const Geometry& g, int bpp, int depth, int nPlanes, const void* src,
+                                void* dst, int w0, int round, int shift, int offset);
+
+} // namespace xg

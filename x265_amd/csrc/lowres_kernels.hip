@@ -1,0 +1,181 @@
+// Half-resolution downscale with the H / V / HV half-pel planes and their
+// replicated borders, in one pass over the PADDED output domain.
+//
+// Replaces primitives.frameInitLowres + 4x extendPicBorder as called from
+// Lowres::init (source/common/lowres.cpp:380-386; arithmetic
+// source/common/pixel.cpp:596-620, borders source/common/pixel.cpp:1044-1058).
+// A border sample equals the nearest picture sample, so every output position
+// is computed straight from the source at its clamped picture coordinate: no
+// second pass, no dependency between threads, fully coalesced row stores.
+// HBM-bound: algorithmic traffic is one read of the source plus one write of
+// four quarter-size planes.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace xg {
+
+__device__ __forceinline__ int ravg(int a, int b) { return (a + b + 1) >> 1; }
+
+template <typename P>
+struct DownscaleArgs
+{
+    const P* src;
+    long long srcStride;
+    int srcWidth, srcHeight;   // valid source extent; beyond it the edge sample repeats
+    P* dst0;                   // origin (pixel 0,0) of output plane 0
+    long long planeSize;
+    int dstStride;
+    int width, lines;          // output picture size
+    int marginX, marginY;
+};
+
+// One thread: 8 consecutive output positions of one padded row, all 4 planes.
+template <typename P>
+__device__ void downscale_span(const DownscaleArgs<P>& a, int span, int prow)
+{
+    const int px0 = span * 8 - a.marginX;      // first output x of the span (may be negative)
+    const int py = prow - a.marginY;
+    const int y = clampi(py, 0, a.lines - 1);
+    const int r0 = min(2 * y, a.srcHeight - 1), r1 = min(2 * y + 1, a.srcHeight - 1),
+              r2 = min(2 * y + 2, a.srcHeight - 1);
+    const P* s0 = a.src + (long long)r0 * a.srcStride;
+    const P* s1 = a.src + (long long)r1 * a.srcStride;
+    const P* s2 = a.src + (long long)r2 * a.srcStride;
+
+    int o0[8], oh[8], ov[8], oc[8];
+    const bool interior = px0 >= 0 && px0 + 8 <= a.width;
+    if (interior && 2 * px0 + 23 < a.srcWidth)
+    {
+        // 18 source columns per row, fetched as three 8-pixel rows
+        int t0[24], t1[24], t2[24];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+            unpack_row<P>(load_row<P>(s0 + 2 * px0 + 8 * k), t0 + 8 * k);
+            unpack_row<P>(load_row<P>(s1 + 2 * px0 + 8 * k), t1 + 8 * k);
+            unpack_row<P>(load_row<P>(s2 + 2 * px0 + 8 * k), t2 + 8 * k);
+        }
+        int v01[18], v12[18];
+#pragma unroll
+        for (int k = 0; k < 18; k++)
+        {
+            v01[k] = ravg(t0[k], t1[k]);
+            v12[k] = ravg(t1[k], t2[k]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+        {
+            o0[i] = ravg(v01[2 * i], v01[2 * i + 1]);
+            oh[i] = ravg(v01[2 * i + 1], v01[2 * i + 2]);
+            ov[i] = ravg(v12[2 * i], v12[2 * i + 1]);
+            oc[i] = ravg(v12[2 * i + 1], v12[2 * i + 2]);
+        }
+    }
+    else
+    {
+        const int slackStart = a.width + a.marginX;   // first x right of the right margin
+        int prevx = -1;
+        int l0 = 0, lh = 0, lv = 0, lc = 0;   // values at prevx
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+        {
+            const int px = px0 + i;
+            const int x = clampi(px, 0, a.width - 1);
+            if (x != prevx)
+            {
+                const int c0 = min(2 * x, a.srcWidth - 1), c1 = min(2 * x + 1, a.srcWidth - 1),
+                          c2 = min(2 * x + 2, a.srcWidth - 1);
+                const int a0 = ravg(s0[c0], s1[c0]), a1 = ravg(s0[c1], s1[c1]), a2 = ravg(s0[c2], s1[c2]);
+                const int b0 = ravg(s1[c0], s2[c0]), b1 = ravg(s1[c1], s2[c1]), b2 = ravg(s1[c2], s2[c2]);
+                l0 = ravg(a0, a1);
+                lh = ravg(a1, a2);
+                lv = ravg(b0, b1);
+                lc = ravg(b1, b2);
+                prevx = x;
+            }
+            // stride-rounding slack right of the margin stays zero, as calloc leaves it
+            const bool slack = px >= slackStart;
+            o0[i] = slack ? 0 : l0;
+            oh[i] = slack ? 0 : lh;
+            ov[i] = slack ? 0 : lv;
+            oc[i] = slack ? 0 : lc;
+        }
+    }
+
+    P* d = a.dst0 + (long long)py * a.dstStride + px0;
+    store_row<P>(d, pack_row<P>(o0));
+    store_row<P>(d + a.planeSize, pack_row<P>(oh));
+    store_row<P>(d + 2 * a.planeSize, pack_row<P>(ov));
+    store_row<P>(d + 3 * a.planeSize, pack_row<P>(oc));
+}
+
+// grid: (ceil(spans*rows / 256), n jobs).  `level` 0: full-res -> half-res,
+// 1: half-res plane 0 -> quarter-res (frameInitLowerRes, lowres.cpp:393-398).
+template <typename P>
+__global__ void __launch_bounds__(256) lowres_init_kernel(const LowresJob* jobs, Geometry g, int level)
+{
+    const LowresJob job = jobs[blockIdx.y];
+    DownscaleArgs<P> a;
+    if (level == 0)
+    {
+        a.src = (const P*)job.src;
+        a.srcStride = job.srcStride;
+        a.srcWidth = g.srcWidth;
+        a.srcHeight = g.srcHeight;
+        a.dst0 = (P*)job.planes + g.padOffset;
+        a.planeSize = g.planeSize;
+        a.dstStride = g.stride;
+        a.width = g.width;
+        a.lines = g.lines;
+        a.marginX = g.marginX;
+        a.marginY = g.marginY;
+    }
+    else
+    {
+        // the half-res plane is read through its own replicated border, which
+        // equals clamping at its picture edge
+        a.src = (const P*)job.planes + g.padOffset;
+        a.srcStride = g.stride;
+        a.srcWidth = g.width;
+        a.srcHeight = g.lines;
+        a.dst0 = (P*)job.planes4 + g.padOffset4;
+        a.planeSize = g.planeSize4;
+        a.dstStride = g.stride4;
+        a.width = g.width4;
+        a.lines = g.lines4;
+        a.marginX = g.marginX4;
+        a.marginY = g.marginY4;
+    }
+    const int spans = a.dstStride / 8;
+    const int rows = a.lines + 2 * a.marginY;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= spans * rows)
+        return;
+    downscale_span<P>(a, idx % spans, idx / spans);
+}
+
+hipError_t launch_lowres_init(hipStream_t s, const Geometry& g, int bpp, const LowresJob* dJobs, int n)
+{
+    if (n <= 0)
+        return hipSuccess;
+    {
+        const int work = (g.stride / 8) * (g.lines + 2 * g.marginY);
+        dim3 grid((work + 255) / 256, n);
+        if (bpp == 1)
+            hipLaunchKernelGGL(lowres_init_kernel<uint8_t>, grid, dim3(256), 0, s, dJobs, g, 0);
+        else
+            hipLaunchKernelGGL(lowres_init_kernel<uint16_t>, grid, dim3(256), 0, s, dJobs, g, 0);
+    }
+    if (g.W4 > 0)
+    {
+        const int work = (g.stride4 / 8) * (g.lines4 + 2 * g.marginY4);
+        dim3 grid((work + 255) / 256, n);
+        if (bpp == 1)
+            hipLaunchKernelGGL(lowres_init_kernel<uint8_t>, grid, dim3(256), 0, s, dJobs, g, 1);
+        else
+            hipLaunchKernelGGL(lowres_init_kernel<uint16_t>, grid, dim3(256), 0, s, dJobs, g, 1);
+    }
+    return hipGetLastError();
+}
+
+} // namespace xg

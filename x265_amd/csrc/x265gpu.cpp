@@ -1,0 +1,800 @@
+// C-ABI layer: context, device-side Lowres mirrors ("slots"), request batching.
+// See include/x265gpu.h for the contract of each entry point.
+#include "../../include/x265gpu.h"
+#include "kernels.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace xg;
+
+namespace {
+
+struct Slot
+{
+    char* base = nullptr;          // one allocation per slot
+    char* planes = nullptr;        // 4 half-res planes
+    char* planes4 = nullptr;       // 4 quarter-res planes (HME)
+    int32_t* intraCost = nullptr;
+    uint8_t* intraMode = nullptr;
+    int32_t* invQscale = nullptr;
+    bool hasAq = false;
+    int32_t* mvs = nullptr;        // [2][D][n][2]
+    int32_t* mvCosts = nullptr;    // [2][D][n]
+    int32_t* mvs4 = nullptr;       // [2][D][n4][2]
+    int32_t* mvCosts4 = nullptr;   // [2][D][n4]
+    uint16_t* lowresCosts = nullptr; // [D*D][n]
+    int32_t* rowSatds = nullptr;     // [D*D][H]
+    long long* rowPartials = nullptr;// [D*D][H][3]
+    long long* sums = nullptr;       // [D*D][3]   ([0] holds the intra totals in its first two entries)
+    std::vector<char*> weighted;     // [D] weighted plane sets, allocated on first use
+    int poc = 0;
+};
+
+} // namespace
+
+struct x265gpu_ctx
+{
+    x265gpu_config cfg;
+    Geometry g;
+    int bpp = 1;
+    int D = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    std::vector<Slot> slots;
+    uint16_t* costBuf = nullptr;
+    uint16_t* costCentre = nullptr;
+    int maxMvd = 0;
+    // staging for job descriptors and host-supplied source planes
+    char* jobBuf = nullptr;
+    size_t jobBufSize = 0;
+    char* jobHost = nullptr;          // pinned mirror of jobBuf
+    hipEvent_t jobCopied = nullptr;   // last upload out of jobHost has finished
+    char* srcStage = nullptr;
+    size_t srcStageSize = 0;
+    unsigned int* scalar = nullptr;   // small device scratch for weight_cost
+    std::string err;
+    // profiling
+    bool prof = false;
+    double profMs[X265GPU_PHASE_COUNT] = { 0, 0, 0, 0 };
+    int64_t profLaunches[X265GPU_PHASE_COUNT] = { 0, 0, 0, 0 };
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int fail(x265gpu_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (c)
+    {
+        c->err = what;
+        if (e != hipSuccess)
+        {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define HIPCHK(call)                                                     \
+    do                                                                   \
+    {                                                                    \
+        hipError_t e_ = (call);                                          \
+        if (e_ != hipSuccess)                                            \
+            return fail(ctx, X265GPU_ERR_DEVICE, #call, e_);             \
+    } while (0)
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Lowres::create, source/common/lowres.cpp:84-103 and :171-177, :211-213
+void compute_geometry(const x265gpu_config& cfg, Geometry& g)
+{
+    memset(&g, 0, sizeof(g));
+    g.srcWidth = cfg.sourceWidth;
+    g.srcHeight = cfg.sourceHeight;
+    g.marginX = cfg.maxCUSize + 32;
+    g.marginY = cfg.maxCUSize + 16;
+    int width = cfg.sourceWidth / 2, lines = cfg.sourceHeight / 2;
+    int stride = width + 2 * g.marginX;
+    if (stride & 31)
+        stride += 32 - (stride & 31);
+    g.stride = stride;
+    g.W = (width + 7) >> 3;
+    g.H = (lines + 7) >> 3;
+    g.cuCount = g.W * g.H;
+    g.width = g.W * 8;
+    g.lines = g.H * 8;
+    g.planeSize = (long long)stride * (g.lines + 2 * g.marginY);
+    g.padOffset = (long long)stride * g.marginY + g.marginX;
+    if (cfg.bEnableHME)
+    {
+        g.stride4 = stride / 2;
+        g.width4 = g.width / 2;
+        g.lines4 = g.lines / 2;
+        g.marginX4 = g.marginX / 2;
+        g.marginY4 = g.marginY / 2;
+        g.planeSize4 = g.planeSize / 2;
+        g.padOffset4 = g.padOffset / 2;
+        // loop bounds: Lookahead::m_4x4Width/Height, source/encoder/slicetype.cpp:1063-1064
+        g.W4 = ((cfg.sourceWidth / 4) + 7) >> 3;
+        g.H4 = ((cfg.sourceHeight / 4) + 7) >> 3;
+        int aw = ((g.width / 2) + 7) >> 3, ah = ((g.lines / 2) + 7) >> 3;
+        g.cuCount4 = (aw > g.W4 ? aw : g.W4) * (ah > g.H4 ? ah : g.H4);
+    }
+}
+
+int alloc_slot(x265gpu_ctx* ctx, Slot& s)
+{
+    const Geometry& g = ctx->g;
+    const int D = ctx->D, n = g.cuCount, n4 = g.cuCount4;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
+    const size_t oPlanes = take((size_t)4 * g.planeSize * ctx->bpp);
+    const size_t oPlanes4 = take((size_t)4 * g.planeSize4 * ctx->bpp);
+    const size_t oIntraCost = take(sizeof(int32_t) * n);
+    const size_t oIntraMode = take(n);
+    const size_t oInvQ = take(sizeof(int32_t) * n);
+    const size_t oMvs = take(sizeof(int32_t) * 2 * (size_t)2 * D * n);
+    const size_t oMvCosts = take(sizeof(int32_t) * (size_t)2 * D * n);
+    const size_t oMvs4 = take(sizeof(int32_t) * 2 * (size_t)2 * D * n4);
+    const size_t oMvCosts4 = take(sizeof(int32_t) * (size_t)2 * D * n4);
+    const size_t oLowresCosts = take(sizeof(uint16_t) * (size_t)D * D * n);
+    const size_t oRowSatds = take(sizeof(int32_t) * (size_t)D * D * g.H);
+    const size_t oRowPartials = take(sizeof(long long) * (size_t)D * D * g.H * 3);
+    const size_t oSums = take(sizeof(long long) * (size_t)D * D * 3);
+    HIPCHK(hipMalloc((void**)&s.base, off));
+    HIPCHK(hipMemsetAsync(s.base, 0, off, ctx->stream));
+    s.planes = s.base + oPlanes;
+    s.planes4 = g.planeSize4 ? s.base + oPlanes4 : nullptr;
+    s.intraCost = (int32_t*)(s.base + oIntraCost);
+    s.intraMode = (uint8_t*)(s.base + oIntraMode);
+    s.invQscale = (int32_t*)(s.base + oInvQ);
+    s.mvs = (int32_t*)(s.base + oMvs);
+    s.mvCosts = (int32_t*)(s.base + oMvCosts);
+    s.mvs4 = (int32_t*)(s.base + oMvs4);
+    s.mvCosts4 = (int32_t*)(s.base + oMvCosts4);
+    s.lowresCosts = (uint16_t*)(s.base + oLowresCosts);
+    s.rowSatds = (int32_t*)(s.base + oRowSatds);
+    s.rowPartials = (long long*)(s.base + oRowPartials);
+    s.sums = (long long*)(s.base + oSums);
+    s.weighted.assign(D, nullptr);
+    return X265GPU_OK;
+}
+
+int ensure_job_buf(x265gpu_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->jobBufSize)
+        return X265GPU_OK;
+    if (ctx->jobBuf)
+    {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(ctx->jobBuf));
+        ctx->jobBuf = nullptr;
+    }
+    if (ctx->jobHost)
+    {
+        HIPCHK(hipHostFree(ctx->jobHost));
+        ctx->jobHost = nullptr;
+    }
+    size_t sz = align256(bytes * 2);
+    HIPCHK(hipMalloc((void**)&ctx->jobBuf, sz));
+    HIPCHK(hipHostMalloc((void**)&ctx->jobHost, sz, hipHostMallocDefault));
+    ctx->jobBufSize = sz;
+    return X265GPU_OK;
+}
+
+// Stage `bytes` of descriptors at jobBuf + offset through the pinned mirror.
+// The mirror is reused by every call, so wait until the previous upload has
+// drained it (kernels of earlier calls are ordered by the stream itself).
+int upload_jobs(x265gpu_ctx* ctx, size_t offset, const void* src, size_t bytes, bool first)
+{
+    if (first)
+        HIPCHK(hipEventSynchronize(ctx->jobCopied));
+    memcpy(ctx->jobHost + offset, src, bytes);
+    HIPCHK(hipMemcpyAsync(ctx->jobBuf + offset, ctx->jobHost + offset, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->jobCopied, ctx->stream));
+    return X265GPU_OK;
+}
+
+int ensure_src_stage(x265gpu_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->srcStageSize)
+        return X265GPU_OK;
+    if (ctx->srcStage)
+    {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(ctx->srcStage));
+        ctx->srcStage = nullptr;
+    }
+    HIPCHK(hipMalloc((void**)&ctx->srcStage, bytes));
+    ctx->srcStageSize = bytes;
+    return X265GPU_OK;
+}
+
+struct PhaseTimer
+{
+    x265gpu_ctx* c;
+    int phase;
+    PhaseTimer(x265gpu_ctx* ctx, int ph) : c(ctx), phase(ph)
+    {
+        if (c->prof)
+            hipEventRecord(c->ev0, c->stream);
+    }
+    void stop(int64_t launches)
+    {
+        if (!c->prof)
+            return;
+        hipEventRecord(c->ev1, c->stream);
+        hipEventSynchronize(c->ev1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        c->profMs[phase] += ms;
+        c->profLaunches[phase] += launches;
+    }
+};
+
+inline char* plane_origin(const x265gpu_ctx* ctx, char* planes)
+{
+    return planes + ctx->g.padOffset * ctx->bpp;
+}
+inline char* plane4_origin(const x265gpu_ctx* ctx, char* planes4)
+{
+    return planes4 + ctx->g.padOffset4 * ctx->bpp;
+}
+
+bool slot_ok(const x265gpu_ctx* ctx, int s) { return s >= 0 && s < (int)ctx->slots.size(); }
+
+} // namespace
+
+extern "C" {
+
+int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
+{
+    if (!cfg || !out)
+        return X265GPU_ERR_ARG;
+    *out = nullptr;
+    if (cfg->sourceWidth < 16 || cfg->sourceHeight < 16 || cfg->numSlots < 1 || cfg->bframes < 0 ||
+        cfg->bframes > X265GPU_BFRAME_MAX ||
+        (cfg->internalBitDepth != 8 && cfg->internalBitDepth != 10 && cfg->internalBitDepth != 12) ||
+        (cfg->maxCUSize != 16 && cfg->maxCUSize != 32 && cfg->maxCUSize != 64))
+        return X265GPU_ERR_ARG;
+    if (cfg->searchMethod != X265GPU_HEX_SEARCH && cfg->searchMethod != X265GPU_DIA_SEARCH)
+        return X265GPU_ERR_UNSUPPORTED;
+    if (cfg->bEnableHME || cfg->maxSlices > 1)
+        return X265GPU_ERR_UNSUPPORTED;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->deviceId < 0 || cfg->deviceId >= ndev)
+        return X265GPU_ERR_DEVICE;
+    if (hipSetDevice(cfg->deviceId) != hipSuccess)
+        return X265GPU_ERR_DEVICE;
+
+    x265gpu_ctx* ctx = new (std::nothrow) x265gpu_ctx();
+    if (!ctx)
+        return X265GPU_ERR_NOMEM;
+    ctx->cfg = *cfg;
+    ctx->bpp = cfg->internalBitDepth > 8 ? 2 : 1;
+    ctx->D = cfg->bframes + 2;
+    compute_geometry(*cfg, ctx->g);
+
+    int rc = X265GPU_OK;
+    do
+    {
+        if (cfg->stream)
+            ctx->stream = (hipStream_t)cfg->stream;
+        else
+        {
+            if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+            {
+                rc = X265GPU_ERR_DEVICE;
+                break;
+            }
+            ctx->ownStream = true;
+        }
+        if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->jobCopied, hipEventDisableTiming) != hipSuccess ||
+            hipEventRecord(ctx->jobCopied, ctx->stream) != hipSuccess)
+        {
+            rc = X265GPU_ERR_DEVICE;
+            break;
+        }
+        if (hipMalloc((void**)&ctx->scalar, 256) != hipSuccess)
+        {
+            rc = X265GPU_ERR_NOMEM;
+            break;
+        }
+        ctx->slots.resize(cfg->numSlots);
+        for (auto& s : ctx->slots)
+        {
+            rc = alloc_slot(ctx, s);
+            if (rc != X265GPU_OK)
+                break;
+        }
+        if (rc == X265GPU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = X265GPU_ERR_DEVICE;
+    } while (0);
+
+    if (rc != X265GPU_OK)
+    {
+        x265gpu_close(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return X265GPU_OK;
+}
+
+void x265gpu_close(x265gpu_ctx* ctx)
+{
+    if (!ctx)
+        return;
+    if (ctx->stream)
+        hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->slots)
+    {
+        if (s.base)
+            hipFree(s.base);
+        for (char* w : s.weighted)
+            if (w)
+                hipFree(w);
+    }
+    if (ctx->costBuf) hipFree(ctx->costBuf);
+    if (ctx->jobBuf) hipFree(ctx->jobBuf);
+    if (ctx->jobHost) hipHostFree(ctx->jobHost);
+    if (ctx->jobCopied) hipEventDestroy(ctx->jobCopied);
+    if (ctx->srcStage) hipFree(ctx->srcStage);
+    if (ctx->scalar) hipFree(ctx->scalar);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->ownStream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int x265gpu_get_geometry(const x265gpu_ctx* ctx, x265gpu_geometry* o)
+{
+    if (!ctx || !o)
+        return X265GPU_ERR_ARG;
+    const Geometry& g = ctx->g;
+    o->width = g.width;
+    o->lines = g.lines;
+    o->stride = g.stride;
+    o->marginX = g.marginX;
+    o->marginY = g.marginY;
+    o->widthInCU = g.W;
+    o->heightInCU = g.H;
+    o->cuCount = g.cuCount;
+    o->widthInCU4 = g.W4;
+    o->heightInCU4 = g.H4;
+    o->planeSize = g.planeSize;
+    o->padOffset = g.padOffset;
+    return X265GPU_OK;
+}
+
+const char* x265gpu_last_error(const x265gpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int x265gpu_sync(x265gpu_ctx* ctx)
+{
+    if (!ctx)
+        return X265GPU_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
+int x265gpu_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd)
+{
+    if (!ctx || !centre || maxMvd < 1024)
+        return X265GPU_ERR_ARG;
+    if (ctx->costBuf)
+    {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(ctx->costBuf));
+        ctx->costBuf = nullptr;
+    }
+    const size_t count = 2 * (size_t)maxMvd + 1;
+    HIPCHK(hipMalloc((void**)&ctx->costBuf, count * sizeof(uint16_t)));
+    HIPCHK(hipMemcpyAsync(ctx->costBuf, centre - maxMvd, count * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->costCentre = ctx->costBuf + maxMvd;
+    ctx->maxMvd = maxMvd;
+    return X265GPU_OK;
+}
+
+int x265gpu_lowres_init_batch(x265gpu_ctx* ctx, int32_t n, const int32_t* slots, const void* const* lumas,
+                              const intptr_t* strides, int32_t memKind, const int32_t* pocs)
+{
+    if (!ctx || n < 0 || (n && (!slots || !lumas || !strides)))
+        return X265GPU_ERR_ARG;
+    if (!n)
+        return X265GPU_OK;
+    const Geometry& g = ctx->g;
+    for (int i = 0; i < n; i++)
+        if (!slot_ok(ctx, slots[i]) || !lumas[i] || strides[i] < g.srcWidth)
+            return fail(ctx, X265GPU_ERR_ARG, "lowres_init: bad slot, plane or stride");
+
+    std::vector<LowresJob> jobs(n);
+    const size_t frameBytes = (size_t)g.srcWidth * g.srcHeight * ctx->bpp;
+    if (memKind == X265GPU_MEM_HOST)
+    {
+        int rc = ensure_src_stage(ctx, frameBytes * n);
+        if (rc)
+            return rc;
+    }
+    for (int i = 0; i < n; i++)
+    {
+        Slot& s = ctx->slots[slots[i]];
+        s.poc = pocs ? pocs[i] : 0;
+        if (memKind == X265GPU_MEM_HOST)
+        {
+            char* dst = ctx->srcStage + frameBytes * i;
+            HIPCHK(hipMemcpy2DAsync(dst, (size_t)g.srcWidth * ctx->bpp, lumas[i], (size_t)strides[i] * ctx->bpp,
+                                    (size_t)g.srcWidth * ctx->bpp, g.srcHeight, hipMemcpyHostToDevice, ctx->stream));
+            jobs[i].src = dst;
+            jobs[i].srcStride = g.srcWidth;
+        }
+        else
+        {
+            jobs[i].src = lumas[i];
+            jobs[i].srcStride = strides[i];
+        }
+        jobs[i].planes = s.planes;
+        jobs[i].planes4 = s.planes4;
+    }
+    int rc = ensure_job_buf(ctx, sizeof(LowresJob) * n);
+    if (rc)
+        return rc;
+    rc = upload_jobs(ctx, 0, jobs.data(), sizeof(LowresJob) * n, true);
+    if (rc)
+        return rc;
+    PhaseTimer pt(ctx, X265GPU_PHASE_LOWRES);
+    HIPCHK(launch_lowres_init(ctx->stream, g, ctx->bpp, (const LowresJob*)ctx->jobBuf, n));
+    pt.stop(g.W4 > 0 ? 2 : 1);
+    return X265GPU_OK;
+}
+
+int x265gpu_lowres_init(x265gpu_ctx* ctx, int32_t slot, const void* luma, intptr_t stride, int32_t memKind,
+                        int32_t poc)
+{
+    return x265gpu_lowres_init_batch(ctx, 1, &slot, &luma, &stride, memKind, &poc);
+}
+
+int x265gpu_lowres_set_aq(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQscaleFactor)
+{
+    if (!ctx || !slot_ok(ctx, slot))
+        return X265GPU_ERR_ARG;
+    Slot& s = ctx->slots[slot];
+    if (!invQscaleFactor)
+    {
+        s.hasAq = false;
+        return X265GPU_OK;
+    }
+    HIPCHK(hipMemcpyAsync(s.invQscale, invQscaleFactor, sizeof(int32_t) * ctx->g.cuCount, hipMemcpyHostToDevice,
+                          ctx->stream));
+    s.hasAq = true;
+    return X265GPU_OK;
+}
+
+int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots)
+{
+    if (!ctx || n < 0 || (n && !slots))
+        return X265GPU_ERR_ARG;
+    if (!n)
+        return X265GPU_OK;
+    for (int i = 0; i < n; i++)
+        if (!slot_ok(ctx, slots[i]))
+            return fail(ctx, X265GPU_ERR_ARG, "intra_estimate: bad slot");
+    std::vector<IntraJob> jobs(n);
+    for (int i = 0; i < n; i++)
+    {
+        Slot& s = ctx->slots[slots[i]];
+        jobs[i].plane0 = plane_origin(ctx, s.planes);
+        jobs[i].invQscale = s.hasAq ? s.invQscale : nullptr;
+        jobs[i].intraCost = s.intraCost;
+        jobs[i].intraMode = s.intraMode;
+        jobs[i].lowresCosts = s.lowresCosts;   // [0][0]
+        jobs[i].rowSatds = s.rowSatds;         // [0][0]
+        jobs[i].rowPartials = s.rowPartials;   // scratch of request (0,0)
+    }
+    // per-job frame totals land in a scratch array behind the jobs, then are copied into each slot
+    const size_t jobsBytes = align256(sizeof(IntraJob) * n);
+    int rc = ensure_job_buf(ctx, jobsBytes + sizeof(long long) * 2 * n);
+    if (rc)
+        return rc;
+    long long* dSums = (long long*)(ctx->jobBuf + jobsBytes);
+    rc = upload_jobs(ctx, 0, jobs.data(), sizeof(IntraJob) * n, true);
+    if (rc)
+        return rc;
+    PhaseTimer pt(ctx, X265GPU_PHASE_INTRA);
+    HIPCHK(launch_intra(ctx->stream, ctx->g, ctx->bpp, ctx->cfg.internalBitDepth, ctx->cfg.lookaheadLambda,
+                        (const IntraJob*)ctx->jobBuf, dSums, n));
+    pt.stop(2);
+    for (int i = 0; i < n; i++)
+        HIPCHK(hipMemcpyAsync(ctx->slots[slots[i]].sums, dSums + 2 * i, sizeof(long long) * 2,
+                              hipMemcpyDeviceToDevice, ctx->stream));
+    return X265GPU_OK;
+}
+
+int x265gpu_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs)
+{
+    if (!ctx || n < 0 || (n && !reqs))
+        return X265GPU_ERR_ARG;
+    if (!n)
+        return X265GPU_OK;
+    const Geometry& g = ctx->g;
+    const int D = ctx->D, nb = g.cuCount;
+    std::vector<SearchJob> sj;
+    std::vector<CostJob> cj(n);
+    for (int i = 0; i < n; i++)
+    {
+        const x265gpu_request& r = reqs[i];
+        const int d0 = r.b - r.p0, d1 = r.p1 - r.b;
+        if (!slot_ok(ctx, r.slotP0) || !slot_ok(ctx, r.slotB) || !slot_ok(ctx, r.slotP1) || d0 < 1 || d0 >= D ||
+            d1 < 0 || d1 >= D || (d1 == 0 && r.slotP1 != r.slotB) || (r.doSearch[1] && d1 == 0))
+            return fail(ctx, X265GPU_ERR_ARG, "estimate: bad request");
+        if ((r.doSearch[0] || r.doSearch[1]) && !ctx->costCentre)
+            return fail(ctx, X265GPU_ERR_STATE, "estimate: MV cost table not set");
+        Slot& sb = ctx->slots[r.slotB];
+        Slot& s0 = ctx->slots[r.slotP0];
+        Slot& s1 = ctx->slots[r.slotP1];
+        const int bBidir = d1 > 0;
+        int32_t* mvs0 = sb.mvs + ((size_t)(0 * D + d0) * nb) * 2;
+        int32_t* mvs1 = sb.mvs + ((size_t)(1 * D + d1) * nb) * 2;
+        int32_t* mc0 = sb.mvCosts + (size_t)(0 * D + d0) * nb;
+        int32_t* mc1 = sb.mvCosts + (size_t)(1 * D + d1) * nb;
+        if (r.doSearch[0])
+        {
+            SearchJob j;
+            memset(&j, 0, sizeof(j));
+            j.fencPlane0 = plane_origin(ctx, sb.planes);
+            char* ref = s0.planes;
+            if (r.weightedL0)
+            {
+                if (!sb.weighted[d0])
+                    return fail(ctx, X265GPU_ERR_STATE, "estimate: weighted planes not prepared");
+                ref = sb.weighted[d0];
+            }
+            j.refOrigin = plane_origin(ctx, ref);
+            j.zeroRef = j.refOrigin;
+            j.zeroStride = g.stride;
+            j.mvs = mvs0;
+            j.mvCosts = mc0;
+            j.bBidir = bBidir;
+            j.method = ctx->cfg.searchMethod;
+            j.merange = ctx->cfg.merange;
+            sj.push_back(j);
+        }
+        if (r.doSearch[1])
+        {
+            SearchJob j;
+            memset(&j, 0, sizeof(j));
+            j.fencPlane0 = plane_origin(ctx, sb.planes);
+            j.refOrigin = plane_origin(ctx, s1.planes);
+            j.zeroRef = j.refOrigin;
+            j.zeroStride = g.stride;
+            j.mvs = mvs1;
+            j.mvCosts = mc1;
+            j.bBidir = bBidir;
+            j.method = ctx->cfg.searchMethod;
+            j.merange = ctx->cfg.merange;
+            sj.push_back(j);
+        }
+        CostJob& c = cj[i];
+        memset(&c, 0, sizeof(c));
+        const size_t q = (size_t)d0 * D + d1;
+        c.fencPlane0 = plane_origin(ctx, sb.planes);
+        c.ref0Origin = plane_origin(ctx, s0.planes);
+        c.ref1Origin = plane_origin(ctx, s1.planes);
+        c.mvs0 = mvs0;
+        c.mvs1 = mvs1;
+        c.mvCosts0 = mc0;
+        c.mvCosts1 = mc1;
+        c.intraCost = sb.intraCost;
+        c.invQscale = sb.hasAq ? sb.invQscale : nullptr;
+        c.lowresCosts = sb.lowresCosts + q * nb;
+        c.rowSatds = sb.rowSatds + q * g.H;
+        c.rowPartials = sb.rowPartials + q * g.H * 3;
+        c.sums = sb.sums + q * 3;
+        c.bBidir = bBidir;
+    }
+
+    const size_t sBytes = align256(sizeof(SearchJob) * sj.size());
+    const size_t cBytes = sizeof(CostJob) * cj.size();
+    int rc = ensure_job_buf(ctx, sBytes + cBytes);
+    if (rc)
+        return rc;
+    if (!sj.empty())
+    {
+        rc = upload_jobs(ctx, 0, sj.data(), sizeof(SearchJob) * sj.size(), true);
+        if (rc)
+            return rc;
+    }
+    rc = upload_jobs(ctx, sBytes, cj.data(), cBytes, sj.empty());
+    if (rc)
+        return rc;
+
+    if (!sj.empty())
+    {
+        PhaseTimer pt(ctx, X265GPU_PHASE_SEARCH);
+        int launches = 0;
+        HIPCHK(launch_search(ctx->stream, g, ctx->bpp, (const SearchJob*)ctx->jobBuf, (int)sj.size(), 0,
+                             ctx->costCentre, ctx->maxMvd, ctx->cfg.maxSlices, &launches));
+        pt.stop(launches);
+    }
+    {
+        PhaseTimer pt(ctx, X265GPU_PHASE_COST);
+        HIPCHK(launch_cost(ctx->stream, g, ctx->bpp, (const CostJob*)(ctx->jobBuf + sBytes), n));
+        pt.stop(2);
+    }
+    return X265GPU_OK;
+}
+
+int x265gpu_weight_cost(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t wtPresent, int32_t scale,
+                        int32_t log2Denom, int32_t offset, uint32_t* cost)
+{
+    if (!ctx || !slot_ok(ctx, slotFenc) || !slot_ok(ctx, slotRef) || !cost)
+        return X265GPU_ERR_ARG;
+    const Geometry& g = ctx->g;
+    Slot& sf = ctx->slots[slotFenc];
+    Slot& sr = ctx->slots[slotRef];
+    const int depth = ctx->cfg.internalBitDepth;
+    WeightCostJob job;
+    job.fencPlane0 = plane_origin(ctx, sf.planes);
+    job.refPlane0 = plane_origin(ctx, sr.planes);
+    job.intraCost = sf.intraCost;
+    job.out = ctx->scalar;
+    if (wtPresent)
+    {
+        // weight plane 0 of the reference into the staging buffer (slicetype.cpp:822-834)
+        int rc = ensure_src_stage(ctx, (size_t)g.planeSize * ctx->bpp);
+        if (rc)
+            return rc;
+        const int corr = 14 - depth;
+        const int round = log2Denom ? 1 << (log2Denom - 1) : 0;
+        HIPCHK(launch_weight_planes(ctx->stream, g, ctx->bpp, depth, 1, sr.planes, ctx->srcStage, scale,
+                                    round << corr, log2Denom + corr, offset * (1 << (depth - 8))));
+        job.refPlane0 = plane_origin(ctx, ctx->srcStage);
+    }
+    HIPCHK(hipMemsetAsync(ctx->scalar, 0, sizeof(unsigned int), ctx->stream));
+    HIPCHK(launch_weight_cost(ctx->stream, g, ctx->bpp, &job));
+    HIPCHK(hipMemcpyAsync(cost, ctx->scalar, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
+int x265gpu_weight_planes(x265gpu_ctx* ctx, int32_t slotFenc, int32_t dist, int32_t slotRef, int32_t scale,
+                          int32_t log2Denom, int32_t offset)
+{
+    if (!ctx || !slot_ok(ctx, slotFenc) || !slot_ok(ctx, slotRef) || dist < 1 || dist >= ctx->D)
+        return X265GPU_ERR_ARG;
+    const Geometry& g = ctx->g;
+    Slot& sf = ctx->slots[slotFenc];
+    Slot& sr = ctx->slots[slotRef];
+    if (!sf.weighted[dist])
+        HIPCHK(hipMalloc((void**)&sf.weighted[dist], (size_t)4 * g.planeSize * ctx->bpp));
+    const int depth = ctx->cfg.internalBitDepth;
+    const int corr = 14 - depth;
+    const int round = log2Denom ? 1 << (log2Denom - 1) : 0;
+    HIPCHK(launch_weight_planes(ctx->stream, g, ctx->bpp, depth, 4, sr.planes, sf.weighted[dist], scale, round << corr,
+                                log2Denom + corr, offset * (1 << (depth - 8))));
+    return X265GPU_OK;
+}
+
+int x265gpu_get_plane(x265gpu_ctx* ctx, int32_t slot, int32_t planeIdx, void* paddedBuffer)
+{
+    if (!ctx || !slot_ok(ctx, slot) || planeIdx < 0 || planeIdx > 7 || !paddedBuffer)
+        return X265GPU_ERR_ARG;
+    const Geometry& g = ctx->g;
+    Slot& s = ctx->slots[slot];
+    if (planeIdx < 4)
+        HIPCHK(hipMemcpyAsync(paddedBuffer, s.planes + (size_t)planeIdx * g.planeSize * ctx->bpp,
+                              (size_t)g.planeSize * ctx->bpp, hipMemcpyDeviceToHost, ctx->stream));
+    else
+    {
+        if (!s.planes4)
+            return X265GPU_ERR_ARG;
+        HIPCHK(hipMemcpyAsync(paddedBuffer, s.planes4 + (size_t)(planeIdx - 4) * g.planeSize4 * ctx->bpp,
+                              (size_t)g.planeSize4 * ctx->bpp, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
+int x265gpu_get_intra(x265gpu_ctx* ctx, int32_t slot, int32_t* intraCost, uint8_t* intraMode)
+{
+    if (!ctx || !slot_ok(ctx, slot))
+        return X265GPU_ERR_ARG;
+    Slot& s = ctx->slots[slot];
+    if (intraCost)
+        HIPCHK(hipMemcpyAsync(intraCost, s.intraCost, sizeof(int32_t) * ctx->g.cuCount, hipMemcpyDeviceToHost, ctx->stream));
+    if (intraMode)
+        HIPCHK(hipMemcpyAsync(intraMode, s.intraMode, ctx->g.cuCount, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
+int x265gpu_get_mvs(x265gpu_ctx* ctx, int32_t slot, int32_t list, int32_t dist, int32_t* mvsXY, int32_t* mvCosts)
+{
+    if (!ctx || !slot_ok(ctx, slot) || list < 0 || list > 1 || dist < 0 || dist >= ctx->D)
+        return X265GPU_ERR_ARG;
+    Slot& s = ctx->slots[slot];
+    const size_t nb = ctx->g.cuCount, idx = (size_t)list * ctx->D + dist;
+    if (mvsXY)
+        HIPCHK(hipMemcpyAsync(mvsXY, s.mvs + idx * nb * 2, sizeof(int32_t) * 2 * nb, hipMemcpyDeviceToHost, ctx->stream));
+    if (mvCosts)
+        HIPCHK(hipMemcpyAsync(mvCosts, s.mvCosts + idx * nb, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
+int x265gpu_get_hme_mvs(x265gpu_ctx* ctx, int32_t slot, int32_t list, int32_t dist, int32_t* mvsXY, int32_t* mvCosts)
+{
+    if (!ctx || !slot_ok(ctx, slot) || list < 0 || list > 1 || dist < 0 || dist >= ctx->D || !ctx->g.cuCount4)
+        return X265GPU_ERR_ARG;
+    Slot& s = ctx->slots[slot];
+    const size_t nb = ctx->g.cuCount4, idx = (size_t)list * ctx->D + dist;
+    if (mvsXY)
+        HIPCHK(hipMemcpyAsync(mvsXY, s.mvs4 + idx * nb * 2, sizeof(int32_t) * 2 * nb, hipMemcpyDeviceToHost, ctx->stream));
+    if (mvCosts)
+        HIPCHK(hipMemcpyAsync(mvCosts, s.mvCosts4 + idx * nb, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
+int x265gpu_get_costs(x265gpu_ctx* ctx, int32_t slot, int32_t d0, int32_t d1, uint16_t* lowresCosts,
+                      int32_t* rowSatds, x265gpu_frame_cost* fc)
+{
+    if (!ctx || !slot_ok(ctx, slot) || d0 < 0 || d0 >= ctx->D || d1 < 0 || d1 >= ctx->D)
+        return X265GPU_ERR_ARG;
+    Slot& s = ctx->slots[slot];
+    const Geometry& g = ctx->g;
+    const size_t q = (size_t)d0 * ctx->D + d1;
+    long long sums[3] = { 0, 0, 0 };
+    if (lowresCosts)
+        HIPCHK(hipMemcpyAsync(lowresCosts, s.lowresCosts + q * g.cuCount, sizeof(uint16_t) * g.cuCount,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    if (rowSatds)
+        HIPCHK(hipMemcpyAsync(rowSatds, s.rowSatds + q * g.H, sizeof(int32_t) * g.H, hipMemcpyDeviceToHost, ctx->stream));
+    if (fc)
+        HIPCHK(hipMemcpyAsync(sums, s.sums + q * 3, sizeof(sums), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (fc)
+    {
+        long long score = sums[0];
+        // B-frame bias, source/encoder/slicetype.cpp:4372-4373
+        if (d1 != 0)
+            score = score * 100 / (130 + ctx->cfg.bFrameBias);
+        fc->costEst = score;
+        fc->costEstAq = sums[1];
+        fc->intraMbs = (d0 == 0 && d1 == 0) ? 0 : (int32_t)sums[2];
+        fc->reserved = 0;
+    }
+    return X265GPU_OK;
+}
+
+int x265gpu_profile_enable(x265gpu_ctx* ctx, int32_t on)
+{
+    if (!ctx)
+        return X265GPU_ERR_ARG;
+    ctx->prof = on != 0;
+    return X265GPU_OK;
+}
+
+int x265gpu_profile_read(x265gpu_ctx* ctx, int32_t phase, double* ms, int64_t* launches, int32_t reset)
+{
+    if (!ctx || phase < 0 || phase >= X265GPU_PHASE_COUNT)
+        return X265GPU_ERR_ARG;
+    if (ms)
+        *ms = ctx->profMs[phase];
+    if (launches)
+        *launches = ctx->profLaunches[phase];
+    if (reset)
+    {
+        ctx->profMs[phase] = 0;
+        ctx->profLaunches[phase] = 0;
+    }
+    return X265GPU_OK;
+}
+
+} // extern "C"

@@ -148,6 +148,11 @@ int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots);
  * any request of the same batch, and requests of one batch must not search
  * the same (frame, list, distance) twice. */
 int x265gpu_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs);
+/* Same, then waits and returns the n per-request scalars in one transfer; the
+ * per-block arrays stay on the device until a getter asks for them.  This is
+ * what CostEstimateGroup::finishBatch's caller consumes (slicetype.cpp:2947,
+ * 2987: only costEst/intraMbs are read before the next decision). */
+int x265gpu_estimate_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, x265gpu_frame_cost* out);
 
 /* ---- weighted prediction analysis: LookaheadTLD::weightsAnalyse
  *      (slicetype.cpp:870-971); the float guessing stays with the caller ---- */

@@ -19,7 +19,7 @@ PHASES = ("lowres", "intra", "search", "cost")
 EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
-    "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_weight_cost", "x265gpu_weight_planes",
+    "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_weight_cost", "x265gpu_weight_planes",
     "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs",
     "x265gpu_profile_enable", "x265gpu_profile_read",
 )
@@ -86,6 +86,7 @@ def load_library():
     L.x265gpu_lowres_set_aq.argtypes = [vp, i32, vp]
     L.x265gpu_intra_estimate.argtypes = [vp, i32, vp]
     L.x265gpu_estimate.argtypes = [vp, i32, vp]
+    L.x265gpu_estimate_costs.argtypes = [vp, i32, vp, vp]
     L.x265gpu_weight_cost.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint32)]
     L.x265gpu_weight_planes.argtypes = [vp, i32, i32, i32, i32, i32, i32]
     L.x265gpu_get_plane.argtypes = [vp, i32, i32, vp]
@@ -180,8 +181,8 @@ class Context:
         s = (C.c_int32 * len(slots))(*slots)
         self._chk(self.L.x265gpu_intra_estimate(self.h, len(slots), s))
 
-    def estimate(self, requests):
-        """requests: iterable of (slotP0, slotB, slotP1, p0, b, p1, doSearch0, doSearch1[, weightedL0])."""
+    @staticmethod
+    def _pack(requests):
         reqs = list(requests)
         arr = (Request * len(reqs))()
         for k, r in enumerate(reqs):
@@ -189,7 +190,19 @@ class Context:
             arr[k].p0, arr[k].b, arr[k].p1 = r[3], r[4], r[5]
             arr[k].doSearch[0], arr[k].doSearch[1] = int(r[6]), int(r[7])
             arr[k].weightedL0 = int(r[8]) if len(r) > 8 else 0
-        self._chk(self.L.x265gpu_estimate(self.h, len(reqs), arr))
+        return arr
+
+    def estimate(self, requests):
+        """requests: iterable of (slotP0, slotB, slotP1, p0, b, p1, doSearch0, doSearch1[, weightedL0])."""
+        arr = self._pack(requests)
+        self._chk(self.L.x265gpu_estimate(self.h, len(arr), arr))
+
+    def estimate_costs(self, requests):
+        """estimate() plus one transfer of the per-request (costEst, costEstAq, intraMbs)."""
+        arr = self._pack(requests)
+        out = (FrameCost * len(arr))()
+        self._chk(self.L.x265gpu_estimate_costs(self.h, len(arr), arr, out))
+        return [(o.costEst, o.costEstAq, o.intraMbs) for o in out]
 
     def weight_cost(self, slot_fenc, slot_ref, wt_present=0, scale=0, denom=0, offset=0):
         out = C.c_uint32()

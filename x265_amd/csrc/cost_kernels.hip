@@ -144,6 +144,12 @@ __global__ void cost_finalize_kernel(const CostJob* jobs, int H)
         job.sums[0] = a;
         job.sums[1] = b;
         job.sums[2] = c;
+        if (job.batchOut)
+        {
+            job.batchOut[0] = a;
+            job.batchOut[1] = b;
+            job.batchOut[2] = c;
+        }
     }
 }
 

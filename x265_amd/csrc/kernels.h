@@ -71,6 +71,7 @@ struct CostJob
     int32_t* rowSatds;
     long long* rowPartials;     // [H][3]: costEst, costEstAq, intraMbs per block row
     long long* sums;            // [3] frame totals written by the finalize pass
+    long long* batchOut;        // [3] second copy in a per-batch contiguous array, or null
     int bBidir;
 };
 

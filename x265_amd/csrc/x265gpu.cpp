@@ -56,6 +56,9 @@ struct x265gpu_ctx
     char* srcStage = nullptr;
     size_t srcStageSize = 0;
     unsigned int* scalar = nullptr;   // small device scratch for weight_cost
+    long long* batchSums = nullptr;   // [n][3] frame totals of the latest batch (device)
+    long long* batchSumsHost = nullptr;
+    size_t batchSumsCap = 0;
     std::string err;
     // profiling
     bool prof = false;
@@ -222,16 +225,16 @@ struct PhaseTimer
     PhaseTimer(x265gpu_ctx* ctx, int ph) : c(ctx), phase(ph)
     {
         if (c->prof)
-            hipEventRecord(c->ev0, c->stream);
+            (void)hipEventRecord(c->ev0, c->stream);
     }
     void stop(int64_t launches)
     {
         if (!c->prof)
             return;
-        hipEventRecord(c->ev1, c->stream);
-        hipEventSynchronize(c->ev1);
+        (void)hipEventRecord(c->ev1, c->stream);
+        (void)hipEventSynchronize(c->ev1);
         float ms = 0;
-        hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
         c->profMs[phase] += ms;
         c->profLaunches[phase] += launches;
     }
@@ -332,24 +335,26 @@ void x265gpu_close(x265gpu_ctx* ctx)
     if (!ctx)
         return;
     if (ctx->stream)
-        hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
     for (auto& s : ctx->slots)
     {
         if (s.base)
-            hipFree(s.base);
+            (void)hipFree(s.base);
         for (char* w : s.weighted)
             if (w)
-                hipFree(w);
+                (void)hipFree(w);
     }
-    if (ctx->costBuf) hipFree(ctx->costBuf);
-    if (ctx->jobBuf) hipFree(ctx->jobBuf);
-    if (ctx->jobHost) hipHostFree(ctx->jobHost);
-    if (ctx->jobCopied) hipEventDestroy(ctx->jobCopied);
-    if (ctx->srcStage) hipFree(ctx->srcStage);
-    if (ctx->scalar) hipFree(ctx->scalar);
-    if (ctx->ev0) hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) hipEventDestroy(ctx->ev1);
-    if (ctx->ownStream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->costBuf) (void)hipFree(ctx->costBuf);
+    if (ctx->jobBuf) (void)hipFree(ctx->jobBuf);
+    if (ctx->jobHost) (void)hipHostFree(ctx->jobHost);
+    if (ctx->jobCopied) (void)hipEventDestroy(ctx->jobCopied);
+    if (ctx->srcStage) (void)hipFree(ctx->srcStage);
+    if (ctx->scalar) (void)hipFree(ctx->scalar);
+    if (ctx->batchSums) (void)hipFree(ctx->batchSums);
+    if (ctx->batchSumsHost) (void)hipHostFree(ctx->batchSumsHost);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -516,13 +521,26 @@ int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots)
     return X265GPU_OK;
 }
 
-int x265gpu_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs)
+static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, bool wantBatchOut)
 {
     if (!ctx || n < 0 || (n && !reqs))
         return X265GPU_ERR_ARG;
     if (!n)
         return X265GPU_OK;
     const Geometry& g = ctx->g;
+    if (wantBatchOut && (size_t)n > ctx->batchSumsCap)
+    {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ctx->batchSums) HIPCHK(hipFree(ctx->batchSums));
+        if (ctx->batchSumsHost) HIPCHK(hipHostFree(ctx->batchSumsHost));
+        ctx->batchSums = nullptr;
+        ctx->batchSumsHost = nullptr;
+        ctx->batchSumsCap = 0;
+        const size_t cap = (size_t)n * 2;
+        HIPCHK(hipMalloc((void**)&ctx->batchSums, cap * 3 * sizeof(long long)));
+        HIPCHK(hipHostMalloc((void**)&ctx->batchSumsHost, cap * 3 * sizeof(long long), hipHostMallocDefault));
+        ctx->batchSumsCap = cap;
+    }
     const int D = ctx->D, nb = g.cuCount;
     std::vector<SearchJob> sj;
     std::vector<CostJob> cj(n);
@@ -596,6 +614,7 @@ int x265gpu_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs)
         c.rowSatds = sb.rowSatds + q * g.H;
         c.rowPartials = sb.rowPartials + q * g.H * 3;
         c.sums = sb.sums + q * 3;
+        c.batchOut = wantBatchOut ? ctx->batchSums + (size_t)i * 3 : nullptr;
         c.bBidir = bBidir;
     }
 
@@ -626,6 +645,34 @@ int x265gpu_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs)
         PhaseTimer pt(ctx, X265GPU_PHASE_COST);
         HIPCHK(launch_cost(ctx->stream, g, ctx->bpp, (const CostJob*)(ctx->jobBuf + sBytes), n));
         pt.stop(2);
+    }
+    return X265GPU_OK;
+}
+
+int x265gpu_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs)
+{
+    return run_estimate(ctx, n, reqs, false);
+}
+
+int x265gpu_estimate_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, x265gpu_frame_cost* out)
+{
+    if (!out && n)
+        return X265GPU_ERR_ARG;
+    int rc = run_estimate(ctx, n, reqs, true);
+    if (rc || !n)
+        return rc;
+    HIPCHK(hipMemcpyAsync(ctx->batchSumsHost, ctx->batchSums, (size_t)n * 3 * sizeof(long long),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; i++)
+    {
+        long long score = ctx->batchSumsHost[3 * i];
+        if (reqs[i].p1 != reqs[i].b)
+            score = score * 100 / (130 + ctx->cfg.bFrameBias);   // slicetype.cpp:4372-4373
+        out[i].costEst = score;
+        out[i].costEstAq = ctx->batchSumsHost[3 * i + 1];
+        out[i].intraMbs = (int32_t)ctx->batchSumsHost[3 * i + 2];
+        out[i].reserved = 0;
     }
     return X265GPU_OK;
 }

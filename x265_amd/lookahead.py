@@ -73,9 +73,9 @@ class CostEstimateGroup:
         fenc.pending.add((d0, d1))
         return (self.frames[p0].slot, fenc.slot, self.frames[p1].slot, p0, b, p1, do0, do1, 0)
 
-    def _collect(self, b, d0, d1):
+    def _collect(self, b, d0, d1, res=None):
         fenc = self.frames[b]
-        ce, ceaq, imb = self.ctx.get_frame_cost(fenc.slot, d0, d1)
+        ce, ceaq, imb = res if res is not None else self.ctx.get_frame_cost(fenc.slot, d0, d1)
         fenc.cost_est[(d0, d1)] = ce
         fenc.cost_est_aq[(d0, d1)] = ceaq
         if d1 == 0:
@@ -87,8 +87,7 @@ class CostEstimateGroup:
         fenc = self.frames[b]
         d0, d1 = b - p0, p1 - b
         if r is not None:
-            self.ctx.estimate([r])
-            self._collect(b, d0, d1)
+            self._collect(b, d0, d1, self.ctx.estimate_costs([r])[0])
         score = fenc.cost_est[(d0, d1)]
         if intra_penalty:
             # C integer division truncates toward zero; operands are non-negative here
@@ -103,7 +102,7 @@ class CostEstimateGroup:
     def finish_batch(self):
         if not self.batch:
             return
-        self.ctx.estimate([r for r, _, _, _ in self.batch])
-        for _, b, d0, d1 in self.batch:
-            self._collect(b, d0, d1)
+        res = self.ctx.estimate_costs([r for r, _, _, _ in self.batch])
+        for (_, b, d0, d1), rc in zip(self.batch, res):
+            self._collect(b, d0, d1, rc)
         self.batch = []

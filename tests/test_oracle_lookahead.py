@@ -1,0 +1,171 @@
+"""CPU: the oracle's lookahead (Lowres::init, intra estimate, motion search, frame
+costs) against the committed golden vectors, domain properties, and the host-side
+mirror of CostEstimateGroup driven with the oracle standing in for the device."""
+import importlib.util
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from x265_amd import synth
+from x265_amd.lookahead import CostEstimateGroup, LowresState
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _golden_module():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("name", ["lookahead_8bit", "lookahead_10bit"])
+def test_oracle_matches_golden(oracle_built, name):
+    mg = _golden_module()
+    want = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    got = mg.generate(name)
+    assert sorted(got.keys()) == sorted(want.files)
+    for k in want.files:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+
+
+def test_lowres_planes_are_edge_extended(oracle_built):
+    W, H = 200, 120   # lowres 100x60 -> rounded to 104x64: rows/cols beyond the picture are replicas
+    clip = synth.luma_clip(W, H, 1, 8, seed=3)
+    param = orc.make_param(W, H)
+    la = orc.Lookahead(8, param)
+    lr = la.add_frame(clip[0])
+    g = lr.geometry
+    assert (g["width"], g["lines"], g["widthInCU"], g["heightInCU"]) == (104, 64, 13, 8)
+    assert g["stride"] % 32 == 0 and g["marginX"] == 96 and g["marginY"] == 80
+    rows = g["lines"] + 2 * g["marginY"]
+    for p in range(4):
+        buf = lr.buffer(p).reshape(rows, g["stride"])
+        inner = buf[g["marginY"]:g["marginY"] + g["lines"], g["marginX"]:g["marginX"] + g["width"]]
+        full = np.pad(inner, ((g["marginY"],) * 2, (g["marginX"],) * 2), mode="edge")
+        np.testing.assert_array_equal(buf[:, :g["width"] + 2 * g["marginX"]], full)
+    la.close()
+
+
+def test_static_clip_gives_zero_vectors_and_flat_costs(oracle_built):
+    W, H = 192, 128
+    frame = synth.luma_clip(W, H, 1, 8, seed=5, scene_cut=False)[0]
+    param = orc.make_param(W, H)
+    la = orc.Lookahead(8, param)
+    for _ in range(3):
+        la.add_frame(frame)
+    la.frame_cost(0, 2, 1)
+    mv0, c0 = la.frames[1].mvs(0, 1), la.frames[1].mv_costs(0, 1)
+    assert not mv0.any()
+    # identical reference, zero residual.  The first visited block (bottom-right) has no
+    # predictor candidates and returns the MV cost of (0,0); every later block has a zero-cost
+    # zero-vector candidate, so the bidir skip shortcut stores cost 0 (slicetype.cpp:4485-4489)
+    t, c = la.table, la.centre
+    assert c0[-1] == 2 * int(t[c]) and not c0[:-1].any()
+    # the bidirectional average has SATD 0 everywhere: every block costs lowresPenalty, lists = 3 or 1
+    assert (la.frames[1].lowres_costs(1, 1) & 0x3FFF == 4).all()
+    # as a P request the search has no skip shortcut: MV cost of (0,0) everywhere
+    la.frame_cost(1, 2, 2)
+    assert (la.frames[2].mv_costs(0, 1) == 2 * int(t[c])).all()
+    la.close()
+
+
+def test_global_translation_is_recovered(oracle_built):
+    """A pure pan by (+6,+4) half-res quarter-pels shows up as the dominant vector."""
+    W, H = 320, 192
+    clip = synth.luma_clip(W, H, 4, 8, seed=11, scene_cut=False)
+    param = orc.make_param(W, H)
+    la = orc.Lookahead(8, param)
+    for f in clip:
+        la.add_frame(f)
+    la.frame_cost(0, 1, 1)
+    mv = la.frames[1].mvs(0, 1)
+    vals, counts = np.unique(mv, axis=0, return_counts=True)
+    assert tuple(vals[counts.argmax()]) == (6, 4)
+    assert counts.max() > 0.6 * len(mv)
+    la.close()
+
+
+def test_cost_cache_and_bias(oracle_built):
+    W, H = 192, 128
+    clip = synth.luma_clip(W, H, 4, 8, seed=2)
+    la = orc.Lookahead(8, orc.make_param(W, H, bframe_bias=0))
+    lb = orc.Lookahead(8, orc.make_param(W, H, bframe_bias=20))
+    for f in clip:
+        la.add_frame(f)
+        lb.add_frame(f)
+    a = la.frame_cost(0, 2, 1)
+    assert la.frame_cost(0, 2, 1) == a                       # cached
+    b = lb.frame_cost(0, 2, 1)
+    # both are the same raw sum scaled by 100/(130 + bias), truncating
+    lo = a * 130 // 100
+    raw = [r for r in range(lo, lo + 3) if r * 100 // 130 == a]
+    assert any(r * 100 // 150 == b for r in raw)
+    assert la.frame_cost(0, 1, 1) == la.frames[1].i64("costEst", 1, 0)   # P requests are not scaled
+    la.close()
+    lb.close()
+
+
+class OracleBackedCtx:
+    """Stands in for the device context: executes requests with the oracle and checks the
+    doSearch flags the host mirror decided against the oracle's own 0x7FFF sentinels."""
+
+    class _G:
+        pass
+
+    def __init__(self, la):
+        self.la = la
+        g = la.frames[0].geometry
+        self.geom = self._G()
+        self.geom.widthInCU, self.geom.heightInCU = g["widthInCU"], g["heightInCU"]
+        self.D = la.param.bframes + 2
+        self.searches = 0
+
+    def estimate_costs(self, requests):
+        out = []
+        for (s0, sb, s1, p0, b, p1, do0, do1, _w) in requests:
+            fr = self.la.frames[b]
+            assert bool(do0) == (int(fr.mvs(0, b - p0)[0, 0]) == 0x7FFF)
+            assert bool(do1) == (p1 > b and int(fr.mvs(1, p1 - b)[0, 0]) == 0x7FFF)
+            self.searches += int(do0) + int(do1)
+            before = fr.i64("intraMbs", b - p0)
+            self.la.frame_cost(p0, p1, b)
+            out.append((fr.i64("costEst", b - p0, p1 - b), fr.i64("costEstAq", b - p0, p1 - b),
+                        fr.i64("intraMbs", b - p0) - before))
+        return out
+
+
+def test_host_mirror_decisions_match_oracle(oracle_built):
+    import bench
+    W, H, N = 192, 128, 9
+    clip = synth.luma_clip(W, H, N, 8, seed=21)
+    param = orc.make_param(W, H)
+    la = orc.Lookahead(8, param)      # executes the mirror's requests
+    lb = orc.Lookahead(8, param)      # straight sequential reference
+    for f in clip:
+        la.add_frame(f)
+        lb.add_frame(f)
+    ctx = OracleBackedCtx(la)
+    frames = [LowresState(i, i, ctx.D) for i in range(N)]
+    est = CostEstimateGroup(ctx, frames)
+    # lazy order with penalties and repeats
+    for (p0, p1, b) in [(0, 2, 2), (0, 2, 1), (0, 1, 1), (1, 2, 2), (0, 2, 2), (3, 6, 6), (3, 6, 4), (3, 6, 5)]:
+        for pen in (True, False):
+            assert est.single_cost(p0, p1, b, pen) == lb.frame_cost(p0, p1, b, pen)
+    # the two batch loops: batch 2 must not need any search
+    b1, b2 = bench.batch_requests(N, 4)
+    for r in b1:
+        est.add(*r)
+    est.finish_batch()
+    n_after_b1 = ctx.searches
+    for r in b2:
+        est.add(*r)
+    est.finish_batch()
+    assert ctx.searches == n_after_b1
+    for (p0, p1, b) in b1 + b2:
+        assert frames[b].cost_est[(b - p0, p1 - b)] == lb.frame_cost(p0, p1, b)
+    la.close()
+    lb.close()

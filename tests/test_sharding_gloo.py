@@ -1,0 +1,86 @@
+"""CPU, world_size 2 over gloo: frame-segment sharding and the cost gather.
+
+Each rank runs the request pattern on its own frame segment (with the oracle
+standing in for the device, since this box has no GPU) and the per-request
+scalars are gathered; rank 0 must see exactly what a single process computes
+for both segments.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, TOTAL, BFRAMES = 192, 128, 13, 3
+
+
+def _segment_costs(start, end):
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import orc
+    from x265_amd import synth
+    clip = synth.luma_clip(W, H, TOTAL, 8, seed=7)[start:end]
+    param = orc.make_param(W, H, bframes=BFRAMES)
+    ref = orc.Lookahead(8, param)
+    for f in clip:
+        ref.add_frame(f)
+    b1, b2 = bench.batch_requests(end - start, BFRAMES)
+    rows = []
+    for (p0, p1, b) in b1 + b2:
+        ref.frame_cost(p0, p1, b)
+        fr = ref.frames[b]
+        rows.append((fr.i64("costEst", b - p0, p1 - b), fr.i64("costEstAq", b - p0, p1 - b),
+                     fr.i64("intraMbs", b - p0)))
+    ref.close()
+    return np.array(rows, np.int64).reshape(-1, 3)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from x265_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    start, end = sharding.segment_bounds(TOTAL, world, rank)
+    local = _segment_costs(start, end)
+    parts = sharding.gather_costs(local)
+    if rank == 0:
+        q.put([p.tolist() for p in parts])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_segment_bounds_cover_everything():
+    sys.path.insert(0, ROOT)
+    from x265_amd import sharding
+    for total in (1, 7, 8, 13, 60):
+        for world in (1, 2, 4, 8):
+            edges = [sharding.segment_bounds(total, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            for a, b in zip(edges, edges[1:]):
+                assert a[1] == b[0]
+            sizes = [e - s for s, e in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gather_matches_single_process(oracle_built):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    parts = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from x265_amd import sharding
+    assert len(parts) == 2
+    for r in range(2):
+        s, e = sharding.segment_bounds(TOTAL, 2, r)
+        np.testing.assert_array_equal(np.array(parts[r], np.int64).reshape(-1, 3), _segment_costs(s, e))

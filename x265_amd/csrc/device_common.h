@@ -34,6 +34,38 @@ template <typename P> __device__ __forceinline__ Row<P> load_row(const P* p)
     return r;
 }
 
+// Same, through a pointer known to be global memory (pointers read out of a
+// job descriptor are generic otherwise and would use flat loads): one
+// global_load_dwordx2/x4 with a scalar base and a 32-bit lane offset.
+#define XG_GLOBAL __attribute__((address_space(1)))
+typedef uint32_t u32x2_unaligned __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+
+template <typename P> __device__ __forceinline__ Row<P> load_row_g(const XG_GLOBAL P* base, int offsetPixels);
+template <> __device__ __forceinline__ Row<uint8_t> load_row_g<uint8_t>(const XG_GLOBAL uint8_t* base, int offsetPixels)
+{
+    const u32x2_unaligned v = *(const XG_GLOBAL u32x2_unaligned*)(base + offsetPixels);
+    Row<uint8_t> r;
+    r.w[0] = v.x;
+    r.w[1] = v.y;
+    return r;
+}
+template <> __device__ __forceinline__ Row<uint16_t> load_row_g<uint16_t>(const XG_GLOBAL uint16_t* base, int offsetPixels)
+{
+    const u32x4_unaligned v = *(const XG_GLOBAL u32x4_unaligned*)(base + offsetPixels);
+    Row<uint16_t> r;
+    r.w[0] = v.x;
+    r.w[1] = v.y;
+    r.w[2] = v.z;
+    r.w[3] = v.w;
+    return r;
+}
+
+template <typename T> __device__ __forceinline__ const XG_GLOBAL T* as_global(const void* p)
+{
+    return (const XG_GLOBAL T*)p;
+}
+
 template <typename P> __device__ __forceinline__ void store_row(P* p, const Row<P>& r)
 {
     __builtin_memcpy(p, r.w, 8 * sizeof(P));

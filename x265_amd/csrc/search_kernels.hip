@@ -19,6 +19,12 @@
 // strict-'<' tie-breaks on wave-uniform scalars, but measures the candidates
 // of one step (sad_x3 / sad_x4 / square refine / four sub-pel points) in
 // parallel, one per 8-lane group.
+//
+// The kernel is bound by vector-L1 accesses (every lane's 8-pixel row is its
+// own cache access), so groups without a candidate issue no loads, the second
+// half-pel plane is only fetched by lanes whose vector has a quarter-pel part,
+// and the two MV-cost table reads of a candidate ride on lanes 0 and 1 of its
+// group and are folded into the row reduction.
 #include "device_common.h"
 #include "kernels.h"
 
@@ -36,33 +42,71 @@ constexpr uint32_t MOD6M1 = 0x05432105u;   // mod6m1[8] = 5,0,1,2,3,4,5,0 (unbia
 template <typename P>
 struct BlockCtx
 {
-    PlaneSet<P> ps;        // reference plane set being searched
-    Row<P> fr;             // this lane's encode row, packed
-    int f[8];              // and unpacked
-    int bx, by;            // block origin in pixels
-    int g, r;              // candidate group and row of this lane
-    int minx, miny, maxx, maxy;   // full-pel search bounds (mvmin / mvmax)
-    int mvpx, mvpy;        // quarter-pel predictor the MV cost is centred on
-    const uint16_t* cost;  // centred MV-cost table
+    const XG_GLOBAL P* base;       // start of the buffer holding the 4 searched planes
+    int padOffset;                 // pixels from `base` to pixel (0,0) of plane 0
+    int planeSize;                 // pixels between consecutive planes
+    int stride;
+    int minX, maxX, minY, maxY;    // legal block origins (inside the padded buffer)
+    Row<P> fr;                     // this lane's encode row, packed
+    int f[8];                      // and unpacked
+    int bx, by;                    // block origin in pixels (wave-uniform)
+    int g, r;                      // candidate group and row of this lane
+    int minx, miny, maxx, maxy;    // full-pel search bounds mvmin / mvmax (wave-uniform)
+    int mvpx, mvpy;                // quarter-pel predictor the MV cost is centred on
+    const XG_GLOBAL uint16_t* costBase;   // MV-cost table, entry [maxMvd] is MVD 0
     int maxMvd;
 };
 
-// BitCost::mvcost (source/encoder/bitcost.h:56): uint16 sum of two table reads
-template <typename P> __device__ __forceinline__ int mvcost_q(const BlockCtx<P>& c, int qx, int qy)
+// Row r of the block displaced by the quarter-pel vector (qx,qy), from the
+// half-pel plane that vector selects: ReferencePlanes::lowresMC,
+// source/common/lowres.h:72-93.  Block origins are clamped into the padded
+// buffer; for vectors the reference itself can produce this is a no-op.
+template <typename P> __device__ __forceinline__ Row<P> fetch_plane_row(const BlockCtx<P>& c, int qx, int qy)
 {
-    const int ix = clampi(qx - c.mvpx, -c.maxMvd, c.maxMvd);
-    const int iy = clampi(qy - c.mvpy, -c.maxMvd, c.maxMvd);
-    return ((int)c.cost[ix] + (int)c.cost[iy]) & 0xffff;
+    const int hp = (qy & 2) | ((qx & 2) >> 1);
+    const int X = clampi(c.bx + (qx >> 2), c.minX, c.maxX);
+    const int Y = clampi(c.by + (qy >> 2), c.minY, c.maxY) + c.r;
+    return load_row_g<P>(c.base, c.padOffset + hp * c.planeSize + Y * c.stride + X);
 }
 
-template <typename P> __device__ __forceinline__ int cand_sad(const BlockCtx<P>& c, int qx, int qy, bool anyOdd)
+constexpr int EV_SAD = 0, EV_SATD = 1;
+
+// Cost of this lane's group candidate at quarter-pel (qx,qy).  `active`: the
+// group has a candidate in this step (others issue no loads); `priced`: add
+// BitCost::mvcost (source/encoder/bitcost.h:56).  The result is valid in lane
+// 0 of every active group.  All 64 lanes must call this together.
+template <typename P, int KIND>
+__device__ __forceinline__ int eval(const BlockCtx<P>& c, int qx, int qy, bool active, bool priced)
 {
-    return sad8x8<P>(c.fr, mc_row<P>(c.ps, c.bx, c.by, c.r, qx, qy, anyOdd));
+    Row<P> ref;
+#pragma unroll
+    for (int i = 0; i < PixT<P>::NW; i++)
+        ref.w[i] = 0;
+    int t = 0;
+    if (active)
+    {
+        ref = fetch_plane_row<P>(c, qx, qy);
+        if ((qx | qy) & 1)
+            ref = avg_row<P>(ref, fetch_plane_row<P>(c, qx + (qx & 1), qy + (qy & 1)));
+        if (priced && c.r < 2)
+        {
+            const int d = (c.r == 0) ? qx - c.mvpx : qy - c.mvpy;
+            t = (int)c.costBase[(unsigned)(clampi(d, -c.maxMvd, c.maxMvd) + c.maxMvd)];
+        }
+    }
+    if (KIND == EV_SAD)
+        return group_sum8(sad_row<P>(c.fr, ref) + t);
+    const int s = satd8x8<P>(c.f, ref, c.r);
+    t += dpp<DPP_XOR1>(t);
+    return s + t;
 }
 
-template <typename P> __device__ __forceinline__ int cand_satd(const BlockCtx<P>& c, int qx, int qy, bool anyOdd)
+// mvcost of a wave-uniform vector (two scalar-address table reads)
+template <typename P> __device__ __forceinline__ int mvcost_u(const BlockCtx<P>& c, int qx, int qy)
 {
-    return satd8x8<P>(c.f, mc_row<P>(c.ps, c.bx, c.by, c.r, qx, qy, anyOdd), c.r);
+    const int ix = clampi(qx - c.mvpx, -c.maxMvd, c.maxMvd) + c.maxMvd;
+    const int iy = clampi(qy - c.mvpy, -c.maxMvd, c.maxMvd) + c.maxMvd;
+    return ((int)c.costBase[(unsigned)ix] + (int)c.costBase[(unsigned)iy]) & 0xffff;
 }
 
 template <typename P> __device__ __forceinline__ bool y_ok(const BlockCtx<P>& c, int y) { return y >= c.miny && y <= c.maxy; }
@@ -72,15 +116,15 @@ template <typename P> __device__ __forceinline__ bool in_range(const BlockCtx<P>
 }
 
 // full-pel cost of this lane's group candidate: SAD + mvcost(mv << 2)
-template <typename P> __device__ __forceinline__ int fpel_cost(const BlockCtx<P>& c, int mx, int my)
+template <typename P> __device__ __forceinline__ int fpel_cost(const BlockCtx<P>& c, int mx, int my, bool active)
 {
-    return cand_sad<P>(c, mx * 4, my * 4, false) + mvcost_q<P>(c, mx * 4, my * 4);
+    return eval<P, EV_SAD>(c, mx * 4, my * 4, active, true);
 }
 
 // 8-point square refinement around (bmx,bmy): motion.cpp:1120-1138
-template <typename P> __device__ void square_refine(const BlockCtx<P>& c, int& bmx, int& bmy, int& bcost)
+template <typename P> __device__ __forceinline__ void square_refine(const BlockCtx<P>& c, int& bmx, int& bmy, int& bcost)
 {
-    const int cost = fpel_cost<P>(c, bmx + nib(SQ1_X, c.g), bmy + nib(SQ1_Y, c.g));
+    const int cost = fpel_cost<P>(c, bmx + nib(SQ1_X, c.g), bmy + nib(SQ1_Y, c.g), true);
     const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost),
               c3 = group_value<3>(cost), c4 = group_value<4>(cost), c5 = group_value<5>(cost),
               c6 = group_value<6>(cost), c7 = group_value<7>(cost);
@@ -103,11 +147,11 @@ template <typename P> __device__ void square_refine(const BlockCtx<P>& c, int& b
 
 // radius-2 hexagon walk, direction carried in the low 3 bits of the cost:
 // motion.cpp:1041-1118, followed by the square refinement
-template <typename P> __device__ void hex_search(const BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost)
+template <typename P> __device__ __forceinline__ void hex_search(const BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost)
 {
     int bc;
     {
-        const int cost = fpel_cost<P>(c, bmx + nib(HEX6_X, c.g), bmy + nib(HEX6_Y, c.g));
+        const int cost = fpel_cost<P>(c, bmx + nib(HEX6_X, c.g), bmy + nib(HEX6_Y, c.g), c.g < 6);
         const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost),
                   c3 = group_value<3>(cost), c4 = group_value<4>(cost), c5 = group_value<5>(cost);
         bc = bcost << 3;
@@ -128,7 +172,7 @@ template <typename P> __device__ void hex_search(const BlockCtx<P>& c, int meran
             for (int i = (merange >> 1) - 1; i > 0 && in_range<P>(c, bmx, bmy); i--)
             {
                 const int idx = dir + (c.g < 3 ? c.g : 0);
-                const int cost = fpel_cost<P>(c, bmx + nib(HEX2_X, idx), bmy + nib(HEX2_Y, idx));
+                const int cost = fpel_cost<P>(c, bmx + nib(HEX2_X, idx), bmy + nib(HEX2_Y, idx), c.g < 3);
                 const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost);
                 bc &= ~7;
                 if (y_ok<P>(c, bmy + nib(HEX2_Y, dir + 0))) bc = min(bc, (c0 << 3) + 1);
@@ -148,7 +192,7 @@ template <typename P> __device__ void hex_search(const BlockCtx<P>& c, int meran
 }
 
 // radius-1 diamond, step packed in the low 4 bits of the cost: motion.cpp:1016-1039
-template <typename P> __device__ void dia_search(const BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost)
+template <typename P> __device__ __forceinline__ void dia_search(const BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost)
 {
     int bc = bcost << 4;
     int i = merange;
@@ -156,7 +200,7 @@ template <typename P> __device__ void dia_search(const BlockCtx<P>& c, int meran
     {
         // points (0,-1) (0,1) (-1,0) (1,0) = square1[1..4]
         const int gi = c.g & 3;
-        const int cost = fpel_cost<P>(c, bmx + nib(SQ1_X, gi), bmy + nib(SQ1_Y, gi));
+        const int cost = fpel_cost<P>(c, bmx + nib(SQ1_X, gi), bmy + nib(SQ1_Y, gi), c.g < 4);
         const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost),
                   c3 = group_value<3>(cost);
         if (y_ok<P>(c, bmy - 1)) bc = min(bc, (c0 << 4) + 1);
@@ -177,8 +221,8 @@ template <typename P> __device__ void dia_search(const BlockCtx<P>& c, int meran
 // candidates, subpelRefine 1).  Returns the cost; the quarter-pel vector comes
 // back in (outx, outy).  Everything returned is wave-uniform.
 template <typename P>
-__device__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, int mvpy, int method, int merange,
-                                      const P* zeroRef, int zeroStride, int& outx, int& outy)
+__device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, int mvpy, int method, int merange,
+                                                      const XG_GLOBAL P* zeroRef, int zeroStride, int& outx, int& outy)
 {
     c.mvpx = mvpx;
     c.mvpy = mvpy;
@@ -191,14 +235,13 @@ __device__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, int mvpy, int me
         // group 1: predictor rounded to full pel; group 2: zero vector
         const int qx = (c.g == 0) ? pmvx : (c.g == 1) ? bmx * 4 : 0;
         const int qy = (c.g == 0) ? pmvy : (c.g == 1) ? bmy * 4 : 0;
-        const bool odd = ((pmvx | pmvy) & 1) != 0;
-        int cost = cand_sad<P>(c, qx, qy, odd);
-        if (c.g != 0)
-            cost += mvcost_q<P>(c, qx, qy);
+        const bool sub = ((pmvx | pmvy) & 3) != 0, nz = (pmvx | pmvy) != 0;
+        const bool active = c.g == 0 || (c.g == 1 && sub) || (c.g == 2 && nz);
+        const int cost = eval<P, EV_SAD>(c, qx, qy, active, c.g != 0);
         const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost);
         bprecost = c0;
-        bcost = ((pmvx | pmvy) & 3) ? c1 : c0;
-        if ((pmvx | pmvy) && c2 < bcost)
+        bcost = sub ? c1 : c0;
+        if (nz && c2 < bcost)
         {
             bcost = c2;
             bmx = 0;
@@ -209,7 +252,7 @@ __device__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, int mvpy, int me
     {
         outx = bmx * 4;
         outy = bmy * 4;
-        return mvcost_q<P>(c, bmx * 4, bmy * 4);
+        return mvcost_u<P>(c, bmx * 4, bmy * 4);
     }
 
     if (method == 0)
@@ -231,7 +274,7 @@ __device__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, int mvpy, int me
     }
 
     if (!bcost)
-        bcost = mvcost_q<P>(c, bqx, bqy);
+        bcost = mvcost_u<P>(c, bqx, bqy);
     else
     {
         // workload[1]: four half-pel SADs, SATD at the winner, four quarter-pel
@@ -239,8 +282,7 @@ __device__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, int mvpy, int me
         const int gi = c.g & 3;
         {
             const int qx = bqx + 2 * nib(SQ1_X, gi), qy = bqy + 2 * nib(SQ1_Y, gi);
-            const bool odd = ((bqx | bqy) & 1) != 0;
-            const int cost = cand_sad<P>(c, qx, qy, odd) + mvcost_q<P>(c, qx, qy);
+            const int cost = eval<P, EV_SAD>(c, qx, qy, c.g < 4, true);
             const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost),
                       c3 = group_value<3>(cost);
             const bool up = (bqy - 2 >= qminy) && (bqy - 2 <= qmaxy), dn = (bqy + 2 >= qminy) && (bqy + 2 <= qmaxy);
@@ -256,16 +298,14 @@ __device__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, int mvpy, int me
                 bqy += 2 * nib(SQ1_Y, bdir - 1);
             }
         }
+        // groups 0..3: the four quarter-pel neighbours; group 4: the centre itself,
+        // whose SATD replaces the running cost before the neighbours are compared
         {
-            const bool odd = ((bqx | bqy) & 1) != 0;
-            const int cost = cand_satd<P>(c, bqx, bqy, odd) + mvcost_q<P>(c, bqx, bqy);
-            bcost = group_value<0>(cost);
-        }
-        {
-            const int qx = bqx + nib(SQ1_X, gi), qy = bqy + nib(SQ1_Y, gi);
-            const int cost = cand_satd<P>(c, qx, qy, true) + mvcost_q<P>(c, qx, qy);
+            const int qx = bqx + ((c.g < 4) ? nib(SQ1_X, gi) : 0), qy = bqy + ((c.g < 4) ? nib(SQ1_Y, gi) : 0);
+            const int cost = eval<P, EV_SATD>(c, qx, qy, c.g < 5, true);
             const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost),
                       c3 = group_value<3>(cost);
+            bcost = group_value<4>(cost);
             const bool up = (bqy - 1 >= qminy) && (bqy - 1 <= qmaxy), dn = (bqy + 1 >= qminy) && (bqy + 1 <= qmaxy);
             const bool mid = (bqy >= qminy) && (bqy <= qmaxy);
             int bdir = 0;
@@ -286,8 +326,13 @@ __device__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, int mvpy, int me
     // fpelPlane[0] with the full lumaStride whatever plane set was searched.
     if (bqx | bqy)
     {
-        const P* p = zeroRef + (long long)c.by * c.ps.stride + c.bx + (long long)c.r * zeroStride;
-        const int cost = group_value<0>(satd8x8<P>(c.f, load_row<P>(p), c.r)) + mvcost_q<P>(c, 0, 0);
+        Row<P> z;
+#pragma unroll
+        for (int i = 0; i < PixT<P>::NW; i++)
+            z.w[i] = 0;
+        if (c.g == 0)
+            z = load_row_g<P>(zeroRef, c.by * c.stride + c.bx + c.r * zeroStride);
+        const int cost = group_value<0>(satd8x8<P>(c.f, z, c.r)) + mvcost_u<P>(c, 0, 0);
         if (cost <= bcost)
             bqx = bqy = 0;
     }
@@ -297,28 +342,30 @@ __device__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, int mvpy, int me
 }
 
 template <typename P>
-__device__ void search_block(const SearchJob& job, const Geometry& g, int level0, int cuX, int cuY, int lane,
-                             const uint16_t* costTab, int maxMvd)
+__device__ __forceinline__ void search_block(const SearchJob& job, const Geometry& g, int level0, int cuX, int cuY,
+                                             int lane, const uint16_t* costTab, int maxMvd)
 {
     const int W = level0 ? g.W4 : g.W, H = level0 ? g.H4 : g.H;
     const int stride = level0 ? g.stride4 : g.stride;
     const int width = level0 ? g.width4 : g.width, lines = level0 ? g.lines4 : g.lines;
     const int marginX = level0 ? g.marginX4 : g.marginX, marginY = level0 ? g.marginY4 : g.marginY;
+    const int padOffset = (int)(level0 ? g.padOffset4 : g.padOffset);
     const int cuXY = cuX + cuY * W;
 
     BlockCtx<P> c;
-    c.ps.origin = (const P*)job.refOrigin;
-    c.ps.planeSize = level0 ? g.planeSize4 : g.planeSize;
-    c.ps.stride = stride;
-    c.ps.minX = -marginX;
-    c.ps.maxX = width + marginX - 8;
-    c.ps.minY = -marginY;
-    c.ps.maxY = lines + marginY - 8;
+    c.base = as_global<P>(job.refOrigin) - padOffset;
+    c.padOffset = padOffset;
+    c.planeSize = (int)(level0 ? g.planeSize4 : g.planeSize);
+    c.stride = stride;
+    c.minX = -marginX;
+    c.maxX = width + marginX - 8;
+    c.minY = -marginY;
+    c.maxY = lines + marginY - 8;
     c.g = lane >> 3;
     c.r = lane & 7;
     c.bx = 8 * cuX;
     c.by = 8 * cuY;
-    c.cost = costTab;
+    c.costBase = as_global<uint16_t>(costTab) - maxMvd;
     c.maxMvd = maxMvd;
     c.mvpx = c.mvpy = 0;
     // search bounds that stay inside the extended frame (slicetype.cpp:4417-4420)
@@ -326,10 +373,11 @@ __device__ void search_block(const SearchJob& job, const Geometry& g, int level0
     c.miny = -cuY * 8 - 8;
     c.maxx = (W - cuX - 1) * 8 + 8;
     c.maxy = (H - cuY - 1) * 8 + 8;
-    c.fr = load_row<P>((const P*)job.fencPlane0 + (long long)(c.by + c.r) * stride + c.bx);
+    c.fr = load_row_g<P>(as_global<P>(job.fencPlane0) - padOffset, padOffset + (c.by + c.r) * stride + c.bx);
     unpack_row<P>(c.fr, c.f);
 
     // ---- predictor: lowest-SATD neighbour vector (slicetype.cpp:4438-4476) ----
+    const XG_GLOBAL int32_t* mvs = as_global<int32_t>(job.mvs);
     const bool lastRow = cuY == H - 1;
     const bool v0 = cuX < W - 1, v1 = !lastRow, v2 = !lastRow && cuX > 0, v3 = !lastRow && cuX < W - 1;
     bool v4 = false;
@@ -337,11 +385,11 @@ __device__ void search_block(const SearchJob& job, const Geometry& g, int level0
     if (job.hmeMvs && !level0)
     {
         const int cuXY4 = (cuX / 2) + (cuY / 2) * W / 2;
-        if (job.hmeMvCosts[cuXY4] > 0)
+        if (as_global<int32_t>(job.hmeMvCosts)[cuXY4] > 0)
         {
             v4 = true;
-            hx = job.hmeMvs[2 * cuXY4] * 2;
-            hy = job.hmeMvs[2 * cuXY4 + 1] * 2;
+            hx = as_global<int32_t>(job.hmeMvs)[2 * cuXY4] * 2;
+            hy = as_global<int32_t>(job.hmeMvs)[2 * cuXY4 + 1] * 2;
         }
     }
     int mvpx = 0, mvpy = 0, skipCost = 0x7fffffff;
@@ -352,16 +400,15 @@ __device__ void search_block(const SearchJob& job, const Geometry& g, int level0
         int cx = 0, cy = 0;
         if (mine)
         {
-            cx = job.mvs[2 * (cuXY + off)];
-            cy = job.mvs[2 * (cuXY + off) + 1];
+            cx = mvs[2 * (cuXY + off)];
+            cy = mvs[2 * (cuXY + off) + 1];
         }
         if (c.g == 4)
         {
             cx = hx;
             cy = hy;
         }
-        const bool odd = __any((cx | cy) & 1) != 0;
-        const int cost = cand_satd<P>(c, cx, cy, odd);
+        const int cost = eval<P, EV_SATD>(c, cx, cy, mine || (c.g == 4 && v4), false);
         int mvpcost = COST_MAX;
 #define TAKE(G, VALID)                                                                      \
         if (VALID)                                                                          \
@@ -386,7 +433,7 @@ __device__ void search_block(const SearchJob& job, const Geometry& g, int level0
     }
 
     int mx, my;
-    int fencCost = motion_estimate_lowres<P>(c, mvpx, mvpy, job.method, job.merange, (const P*)job.zeroRef,
+    int fencCost = motion_estimate_lowres<P>(c, mvpx, mvpy, job.method, job.merange, as_global<P>(job.zeroRef),
                                              job.zeroStride, mx, my);
     // bidir skip shortcut (slicetype.cpp:4485-4489)
     if (skipCost < 64 && skipCost < fencCost && job.bBidir)
@@ -408,7 +455,8 @@ __global__ void __launch_bounds__(256) search_diag_kernel(const SearchJob* jobs,
                                                           const uint16_t* costTab, int maxMvd)
 {
     const int W = level0 ? g.W4 : g.W, H = level0 ? g.H4 : g.H;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction
+    const int k = blockIdx.x * 4 + wave;
     const int ylo = max(0, (t - (W - 1) + 1) >> 1), yhi = min(H - 1, t >> 1);
     const int yq = ylo + k;
     if (yq > yhi)

@@ -75,30 +75,56 @@ constexpr int EV_SAD = 0, EV_SATD = 1;
 // group has a candidate in this step (others issue no loads); `priced`: add
 // BitCost::mvcost (source/encoder/bitcost.h:56).  The result is valid in lane
 // 0 of every active group.  All 64 lanes must call this together.
-template <typename P, int KIND>
-__device__ __forceinline__ int eval(const BlockCtx<P>& c, int qx, int qy, bool active, bool priced)
+template <typename P> __device__ __forceinline__ Row<P> zero_row()
 {
-    Row<P> ref;
+    Row<P> z;
 #pragma unroll
     for (int i = 0; i < PixT<P>::NW; i++)
-        ref.w[i] = 0;
-    int t = 0;
+        z.w[i] = 0;
+    return z;
+}
+
+// this lane's row of its group's candidate block (zeros when the group is idle)
+template <typename P> __device__ __forceinline__ Row<P> cand_row(const BlockCtx<P>& c, int qx, int qy, bool active)
+{
+    Row<P> ref = zero_row<P>();
     if (active)
     {
         ref = fetch_plane_row<P>(c, qx, qy);
         if ((qx | qy) & 1)
             ref = avg_row<P>(ref, fetch_plane_row<P>(c, qx + (qx & 1), qy + (qy & 1)));
-        if (priced && c.r < 2)
-        {
-            const int d = (c.r == 0) ? qx - c.mvpx : qy - c.mvpy;
-            t = (int)c.costBase[(unsigned)(clampi(d, -c.maxMvd, c.maxMvd) + c.maxMvd)];
-        }
     }
+    return ref;
+}
+
+// the two MV-cost table reads of (qx,qy): lane 0 of the group takes the x term,
+// lane 1 the y term, every other lane 0.  Summing over the group gives mvcost.
+template <typename P> __device__ __forceinline__ int price_lanes(const BlockCtx<P>& c, int qx, int qy, bool priced)
+{
+    int t = 0;
+    if (priced && c.r < 2)
+    {
+        const int d = (c.r == 0) ? qx - c.mvpx : qy - c.mvpy;
+        t = (int)c.costBase[(unsigned)(clampi(d, -c.maxMvd, c.maxMvd) + c.maxMvd)];
+    }
+    return t;
+}
+
+template <typename P, int KIND> __device__ __forceinline__ int reduce_cost(const BlockCtx<P>& c, const Row<P>& ref, int t)
+{
     if (KIND == EV_SAD)
         return group_sum8(sad_row<P>(c.fr, ref) + t);
     const int s = satd8x8<P>(c.f, ref, c.r);
     t += dpp<DPP_XOR1>(t);
     return s + t;
+}
+
+template <typename P, int KIND>
+__device__ __forceinline__ int eval(const BlockCtx<P>& c, int qx, int qy, bool active, bool priced)
+{
+    const Row<P> ref = cand_row<P>(c, qx, qy, active);
+    const int t = price_lanes<P>(c, qx, qy, active && priced);
+    return reduce_cost<P, KIND>(c, ref, t);
 }
 
 // mvcost of a wave-uniform vector (two scalar-address table reads)
@@ -147,13 +173,25 @@ template <typename P> __device__ __forceinline__ void square_refine(const BlockC
 
 // radius-2 hexagon walk, direction carried in the low 3 bits of the cost:
 // motion.cpp:1041-1118, followed by the square refinement
-template <typename P> __device__ __forceinline__ void hex_search(const BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost)
+// `pre`: costs of the six first points when they were already measured around
+// (bmx,bmy) together with the start candidates, else null
+template <typename P>
+__device__ __forceinline__ void hex_search(const BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost,
+                                           const int* pre)
 {
     int bc;
     {
-        const int cost = fpel_cost<P>(c, bmx + nib(HEX6_X, c.g), bmy + nib(HEX6_Y, c.g), c.g < 6);
-        const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost),
-                  c3 = group_value<3>(cost), c4 = group_value<4>(cost), c5 = group_value<5>(cost);
+        int c0, c1, c2, c3, c4, c5;
+        if (pre)
+        {
+            c0 = pre[0]; c1 = pre[1]; c2 = pre[2]; c3 = pre[3]; c4 = pre[4]; c5 = pre[5];
+        }
+        else
+        {
+            const int cost = fpel_cost<P>(c, bmx + nib(HEX6_X, c.g), bmy + nib(HEX6_Y, c.g), c.g < 6);
+            c0 = group_value<0>(cost); c1 = group_value<1>(cost); c2 = group_value<2>(cost);
+            c3 = group_value<3>(cost); c4 = group_value<4>(cost); c5 = group_value<5>(cost);
+        }
         bc = bcost << 3;
         const bool y0 = y_ok<P>(c, bmy), yp = y_ok<P>(c, bmy + 2), ym = y_ok<P>(c, bmy - 2);
         if (y0) bc = min(bc, (c0 << 3) + 2);
@@ -220,30 +258,47 @@ template <typename P> __device__ __forceinline__ void dia_search(const BlockCtx<
 // MotionEstimate::motionEstimate for a lowres reference (isLowres, no extra
 // candidates, subpelRefine 1).  Returns the cost; the quarter-pel vector comes
 // back in (outx, outy).  Everything returned is wave-uniform.
+//
+// zeroSad / zeroSatd: SAD of the searched full-pel plane and SATD of the
+// closing check's plane at displacement (0,0), measured by the caller together
+// with the predictor candidates so they cost no memory round trip of their own.
 template <typename P>
 __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, int mvpy, int method, int merange,
-                                                      const XG_GLOBAL P* zeroRef, int zeroStride, int& outx, int& outy)
+                                                      int zeroSad, int zeroSatd, int& outx, int& outy)
 {
     c.mvpx = mvpx;
     c.mvpy = mvpy;
     const int qminx = c.minx * 4, qminy = c.miny * 4, qmaxx = c.maxx * 4, qmaxy = c.maxy * 4;
     const int pmvx = clampi(mvpx, qminx, qmaxx), pmvy = clampi(mvpy, qminy, qmaxy);
     int bmx = (pmvx + 2) >> 2, bmy = (pmvy + 2) >> 2;
-    int bcost, bprecost;
+    int bcost, bprecost, mv0cost;
+    int hexc[6];
+    bool hexValid = method != 0;
     {
-        // group 0: clipped quarter-pel predictor (SAD only, no MV cost);
-        // group 1: predictor rounded to full pel; group 2: zero vector
-        const int qx = (c.g == 0) ? pmvx : (c.g == 1) ? bmx * 4 : 0;
-        const int qy = (c.g == 0) ? pmvy : (c.g == 1) ? bmy * 4 : 0;
+        // one pass: group 0 = clipped quarter-pel predictor (SAD only, no MV cost),
+        // group 1 = predictor rounded to full pel (only needed when it has a
+        // sub-pel part), groups 2..7 = the first hexagon around the rounded
+        // predictor, measured speculatively: it is what the hexagon search needs
+        // next unless the zero vector takes over as start point.  Lanes 0/1 of
+        // group 0 carry no price, so they fetch the table entries of mvcost(0,0).
         const bool sub = ((pmvx | pmvy) & 3) != 0, nz = (pmvx | pmvy) != 0;
-        const bool active = c.g == 0 || (c.g == 1 && sub) || (c.g == 2 && nz);
-        const int cost = eval<P, EV_SAD>(c, qx, qy, active, c.g != 0);
-        const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost);
+        const int hi = (c.g >= 2) ? c.g - 2 : 6;      // index 6/7 of the tables is (0,0)
+        const int qx = (c.g == 0) ? pmvx : (bmx + nib(HEX6_X, hi)) * 4;
+        const int qy = (c.g == 0) ? pmvy : (bmy + nib(HEX6_Y, hi)) * 4;
+        const bool active = c.g == 0 || (c.g == 1 && sub) || (c.g >= 2 && hexValid);
+        const Row<P> ref = cand_row<P>(c, qx, qy, active);
+        const int t = price_lanes<P>(c, (c.g == 0) ? 0 : qx, (c.g == 0) ? 0 : qy, active);
+        const int cost = reduce_cost<P, EV_SAD>(c, ref, (c.g == 0) ? 0 : t);
+        mv0cost = group_value<0>(t + dpp<DPP_XOR1>(t));
+        const int c0 = group_value<0>(cost), c1 = group_value<1>(cost);
+        hexc[0] = group_value<2>(cost); hexc[1] = group_value<3>(cost); hexc[2] = group_value<4>(cost);
+        hexc[3] = group_value<5>(cost); hexc[4] = group_value<6>(cost); hexc[5] = group_value<7>(cost);
         bprecost = c0;
         bcost = sub ? c1 : c0;
-        if (nz && c2 < bcost)
+        if (nz && zeroSad + mv0cost < bcost)
         {
-            bcost = c2;
+            bcost = zeroSad + mv0cost;
+            hexValid = hexValid && bmx == 0 && bmy == max(min(0, c.maxy), c.miny);
             bmx = 0;
             bmy = max(min(0, c.maxy), c.miny);
         }
@@ -258,7 +313,7 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     if (method == 0)
         dia_search<P>(c, merange, bmx, bmy, bcost);
     else
-        hex_search<P>(c, merange, bmx, bmy, bcost);
+        hex_search<P>(c, merange, bmx, bmy, bcost, hexValid ? hexc : nullptr);
 
     int bqx, bqy;
     if (bprecost < bcost)
@@ -324,18 +379,8 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     // closing zero-vector check: SATD at (0,0) + mvcost(0,0) <= bcost replaces
     // the vector but not the cost (motion.cpp:1762-1768).  It addresses
     // fpelPlane[0] with the full lumaStride whatever plane set was searched.
-    if (bqx | bqy)
-    {
-        Row<P> z;
-#pragma unroll
-        for (int i = 0; i < PixT<P>::NW; i++)
-            z.w[i] = 0;
-        if (c.g == 0)
-            z = load_row_g<P>(zeroRef, c.by * c.stride + c.bx + c.r * zeroStride);
-        const int cost = group_value<0>(satd8x8<P>(c.f, z, c.r)) + mvcost_u<P>(c, 0, 0);
-        if (cost <= bcost)
-            bqx = bqy = 0;
-    }
+    if ((bqx | bqy) && zeroSatd + mv0cost <= bcost)
+        bqx = bqy = 0;
     outx = bqx;
     outy = bqy;
     return bcost;
@@ -393,8 +438,11 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         }
     }
     int mvpx = 0, mvpy = 0, skipCost = 0x7fffffff;
-    if (v0 || v1 || v4)
+    int zeroSad, zeroSatd;
     {
+        // one pass: groups 0..4 = the predictor candidates (SATD); group 5 = the
+        // block at displacement (0,0) in the plane the closing zero-vector check
+        // reads (SATD); group 6 = (0,0) in the searched full-pel plane (SAD)
         const int off = (c.g == 0) ? 1 : (c.g == 1) ? W : (c.g == 2) ? W - 1 : W + 1;
         const bool mine = (c.g == 0) ? v0 : (c.g == 1) ? v1 : (c.g == 2) ? v2 : (c.g == 3) ? v3 : false;
         int cx = 0, cy = 0;
@@ -408,7 +456,12 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
             cx = hx;
             cy = hy;
         }
-        const int cost = eval<P, EV_SATD>(c, cx, cy, mine || (c.g == 4 && v4), false);
+        Row<P> ref = cand_row<P>(c, cx, cy, mine || (c.g == 4 && v4) || c.g == 6);
+        if (c.g == 5)
+            ref = load_row_g<P>(as_global<P>(job.zeroRef), c.by * stride + c.bx + c.r * job.zeroStride);
+        const int cost = reduce_cost<P, EV_SATD>(c, ref, 0);
+        zeroSatd = group_value<5>(cost);
+        zeroSad = group_value<6>(sad8x8<P>(c.fr, ref));
         int mvpcost = COST_MAX;
 #define TAKE(G, VALID)                                                                      \
         if (VALID)                                                                          \
@@ -433,8 +486,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     }
 
     int mx, my;
-    int fencCost = motion_estimate_lowres<P>(c, mvpx, mvpy, job.method, job.merange, as_global<P>(job.zeroRef),
-                                             job.zeroStride, mx, my);
+    int fencCost = motion_estimate_lowres<P>(c, mvpx, mvpy, job.method, job.merange, zeroSad, zeroSatd, mx, my);
     // bidir skip shortcut (slicetype.cpp:4485-4489)
     if (skipCost < 64 && skipCost < fencCost && job.bBidir)
     {

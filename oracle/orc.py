@@ -194,6 +194,15 @@ class Lowres:
     def mv_costs(self, lst, dist):
         return self._view("lowresMvCosts", lst, dist, self.ncu(), np.int32)
 
+    def ncu4(self):
+        return self.i64("widthInCU4") * self.i64("heightInCU4")
+
+    def lower_mvs(self, lst, dist):
+        return self._view("lowerResMvs", lst, dist, 2 * self.ncu4(), np.int32).reshape(-1, 2)
+
+    def lower_mv_costs(self, lst, dist):
+        return self._view("lowerResMvCosts", lst, dist, self.ncu4(), np.int32)
+
     def lowres_costs(self, d0, d1):
         return self._view("lowresCosts", d0, d1, self.ncu(), np.uint16)
 

@@ -235,6 +235,21 @@ class Context:
         self._chk(self.L.x265gpu_get_mvs(self.h, slot, lst, dist, _ptr(mv), _ptr(cost)))
         return mv, cost
 
+    def hme_block_count(self):
+        """Entries of the quarter-res vector arrays (allocation rule of lowres.cpp:211-213)."""
+        g = self.geom
+        aw, ah = ((g.width // 2) + 7) >> 3, ((g.lines // 2) + 7) >> 3
+        return max(aw, g.widthInCU4) * max(ah, g.heightInCU4)
+
+    def get_hme_mvs(self, slot, lst, dist):
+        """Quarter-res (HME level 0) vectors and costs; the first widthInCU4*heightInCU4 entries are live."""
+        n = self.hme_block_count()
+        mv = np.empty((n, 2), np.int32)
+        cost = np.empty(n, np.int32)
+        self._chk(self.L.x265gpu_get_hme_mvs(self.h, slot, lst, dist, _ptr(mv), _ptr(cost)))
+        live = self.geom.widthInCU4 * self.geom.heightInCU4
+        return mv[:live], cost[:live]
+
     def get_costs(self, slot, d0, d1):
         lc = np.empty(self.geom.cuCount, np.uint16)
         rs = np.empty(self.geom.heightInCU, np.int32)

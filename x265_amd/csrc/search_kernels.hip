@@ -229,6 +229,196 @@ __device__ __forceinline__ void hex_search(const BlockCtx<P>& c, int merange, in
     square_refine<P>(c, bmx, bmy, bcost);
 }
 
+// Up to eight full-pel candidates, one per group, accepted in group order with
+// the reference's strict '<' (COST_MV / COST_MV_X4 semantics, motion.cpp:263-323).
+// `mask` (wave-uniform) says which groups hold a candidate that may be accepted;
+// the others are neither loaded nor compared.
+template <typename P>
+__device__ __forceinline__ void try_points(const BlockCtx<P>& c, int mx, int my, unsigned mask, int& bmx, int& bmy,
+                                           int& bcost)
+{
+    const int cost = fpel_cost<P>(c, mx, my, ((mask >> c.g) & 1u) != 0);
+#define ACCEPT(G)                                                    \
+    if (mask & (1u << G))                                            \
+    {                                                                \
+        const int cg = group_value<G>(cost);                         \
+        if (cg < bcost)                                              \
+        {                                                            \
+            bcost = cg;                                              \
+            bmx = group_value<G>(mx);                                \
+            bmy = group_value<G>(my);                                \
+        }                                                            \
+    }
+    ACCEPT(0) ACCEPT(1) ACCEPT(2) ACCEPT(3) ACCEPT(4) ACCEPT(5) ACCEPT(6) ACCEPT(7)
+#undef ACCEPT
+}
+
+// COST_MV_X4 around (ox,oy) with offsets from nibble tables: all four are
+// accepted subject to their row being in range (motion.cpp:302-323); a second
+// independent x4 (other origin, same offsets) may ride in groups 4..7.
+template <typename P>
+__device__ __forceinline__ unsigned x4_mask(const BlockCtx<P>& c, int oy, uint32_t tabY, int first)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (y_ok<P>(c, oy + nib(tabY, first + k)))
+            m |= 1u << k;
+    return m;
+}
+
+// CROSS(start, x_max, y_max) around (ox,oy): motion.cpp:361-385
+template <typename P>
+__device__ __forceinline__ void umh_cross(const BlockCtx<P>& c, int ox, int oy, int start, int x_max, int y_max,
+                                          int& bmx, int& bmy, int& bcost)
+{
+#pragma unroll
+    for (int dirY = 0; dirY < 2; dirY++)
+    {
+        const int lim = dirY ? y_max : x_max;
+        const int room = dirY ? min(c.maxy - oy, oy - c.miny) : min(c.maxx - ox, ox - c.minx);
+        int i = (short)start;
+        if (lim <= room)
+        {
+            // x4 passes (i, -i, i+2, -i-2); two reference iterations per pass
+            const unsigned rowok = dirY ? 0u : (y_ok<P>(c, oy) ? 0xFu : 0u);
+            while (i < lim - 2)
+            {
+                const bool two = i + 4 < lim - 2;
+                const int ii = i + ((c.g >= 4) ? 4 : 0);
+                const int sel = c.g & 3;
+                const int d = (sel == 0) ? ii : (sel == 1) ? -ii : (sel == 2) ? ii + 2 : -ii - 2;
+                unsigned m;
+                if (dirY)
+                {
+                    m = (y_ok<P>(c, oy + i) ? 1u : 0u) | (y_ok<P>(c, oy - i) ? 2u : 0u) |
+                        (y_ok<P>(c, oy + i + 2) ? 4u : 0u) | (y_ok<P>(c, oy - i - 2) ? 8u : 0u);
+                    if (two)
+                        m |= (y_ok<P>(c, oy + i + 4) ? 16u : 0u) | (y_ok<P>(c, oy - i - 4) ? 32u : 0u) |
+                             (y_ok<P>(c, oy + i + 6) ? 64u : 0u) | (y_ok<P>(c, oy - i - 6) ? 128u : 0u);
+                }
+                else
+                    m = rowok | (two ? rowok << 4 : 0u);
+                try_points<P>(c, dirY ? ox : ox + d, dirY ? oy + d : oy, m, bmx, bmy, bcost);
+                i += two ? 8 : 4;
+            }
+        }
+        // checked single points, (+i, -i) per reference iteration; four iterations per pass
+        while (i < lim)
+        {
+            const int it = c.g >> 1;                 // 0..3
+            const int ii = i + 2 * it;
+            const int d = (c.g & 1) ? -ii : ii;
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const int ik = i + 2 * k;
+                if (ik < lim)
+                {
+                    if (dirY ? (oy + ik <= c.maxy) : (ox + ik <= c.maxx)) m |= 1u << (2 * k);
+                    if (dirY ? (oy - ik >= c.miny) : (ox - ik >= c.minx)) m |= 2u << (2 * k);
+                }
+            }
+            try_points<P>(c, dirY ? ox : ox + d, dirY ? oy + d : oy, m, bmx, bmy, bcost);
+            i += 8;
+        }
+    }
+}
+
+constexpr uint32_t DIA1_X = 0x88889788u;   // (0,-1)(0,1)(-1,0)(1,0) then (0,0) padding
+constexpr uint32_t DIA1_Y = 0x88888897u;
+constexpr uint32_t OCT_X = 0x897A6978u, OCT_Y = 0xA9988776u;   // (0,-2)(-1,-1)(1,-1)(-2,0) | (2,0)(-1,1)(1,1)(0,2)
+constexpr uint32_t RING_X = 0x97A6A697u, RING_Y = 0xAA997766u; // (-1,-2)(1,-2)(-2,-1)(2,-1) | (-2,1)(2,1)(-1,2)(1,2)
+constexpr uint32_t CORN_X = 0x8888AA66u, CORN_Y = 0x8888A6A6u; // (-2,-2)(-2,2)(2,-2)(2,2)
+// hex4[16] (motion.cpp:67-73), eight points per dword:
+// x = {0,0,-2,2,-4,4,-4,4 | -4,4,-4,4,-4,4,-2,2}, y = {-4,4,-3,-3,-2,-2,-1,-1 | 0,0,1,1,2,2,3,3}
+constexpr uint32_t H4X0 = 0xC4C4A688u, H4Y0 = 0x776655C4u, H4X1 = 0xA6C4C4C4u, H4Y1 = 0xBBAA9988u;
+
+// uneven multi-hexagon search, lowres case (no extra candidates): motion.cpp:1142-1326.
+// Returns true when the hexagon walk must follow.
+template <typename P>
+__device__ __forceinline__ bool umh_search(const BlockCtx<P>& c, int pmx, int pmy, int merange, int& bmx, int& bmy,
+                                           int& bcost)
+{
+    const int scale = 4;   // sizeScale[LUMA_8x8] = (8*8) >> 4 (motion.cpp:123-153)
+#define UMH_THRESH(v) (bcost < (((v) >> 4) * scale))
+    const int ucost1 = bcost;
+    int cross_start = 1;
+    const bool pnz = (pmx | pmy) != 0;
+    {
+        // DIA1 around the rounded predictor, and around (0,0) when the predictor is not zero
+        const int sel = c.g & 3;
+        const int ox = (c.g < 4) ? pmx : 0, oy = (c.g < 4) ? pmy : 0;
+        unsigned m = x4_mask<P>(c, pmy, DIA1_Y, 0);
+        if (pnz)
+            m |= x4_mask<P>(c, 0, DIA1_Y, 0) << 4;
+        try_points<P>(c, ox + nib(DIA1_X, sel), oy + nib(DIA1_Y, sel), m, bmx, bmy, bcost);
+    }
+    const int ucost2 = bcost;
+    if ((bmx | bmy) && (bmx != pmx || bmy != pmy))
+    {
+        const int sel = c.g & 3;
+        try_points<P>(c, bmx + nib(DIA1_X, sel), bmy + nib(DIA1_Y, sel), x4_mask<P>(c, bmy, DIA1_Y, 0), bmx, bmy, bcost);
+    }
+    if (bcost == ucost2)
+        cross_start = 3;
+
+    const int ox = bmx, oy = bmy;   // the later cross stays centred here (motion.cpp:1238)
+    if (bcost == ucost2 && UMH_THRESH(2000))
+    {
+        try_points<P>(c, ox + nib(OCT_X, c.g), oy + nib(OCT_Y, c.g),
+                      x4_mask<P>(c, oy, OCT_Y, 0) | (x4_mask<P>(c, oy, OCT_Y, 4) << 4), bmx, bmy, bcost);
+        if (bcost == ucost1 && UMH_THRESH(500))
+            return false;
+        if (bcost == ucost2)
+        {
+            const int range = (short)((merange >> 1) | 1);
+            umh_cross<P>(c, ox, oy, 3, range, range, bmx, bmy, bcost);
+            try_points<P>(c, ox + nib(RING_X, c.g), oy + nib(RING_Y, c.g),
+                          x4_mask<P>(c, oy, RING_Y, 0) | (x4_mask<P>(c, oy, RING_Y, 4) << 4), bmx, bmy, bcost);
+            if (bcost == ucost2)
+                return false;
+            cross_start = range + 2;
+        }
+    }
+
+    umh_cross<P>(c, ox, oy, cross_start, merange, merange >> 1, bmx, bmy, bcost);
+    try_points<P>(c, ox + nib(CORN_X, c.g & 3), oy + nib(CORN_Y, c.g & 3), x4_mask<P>(c, oy, CORN_Y, 0), bmx, bmy, bcost);
+
+    // hexagon grid of growing radius around the best so far
+    const int hx = bmx, hy = bmy;
+    unsigned i = 1;
+    do
+    {
+        const bool near = (int)(4 * i) > min(min(c.maxx - hx, hx - c.minx), min(c.maxy - hy, hy - c.miny));
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+        {
+            const uint32_t tx = half ? H4X1 : H4X0;
+            const uint32_t ty = half ? H4Y1 : H4Y0;
+            const int dx = nib(tx, c.g);
+            const int dy = nib(ty, c.g);
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+            {
+                const int kdx = nib(tx, k);
+                const int kdy = nib(ty, k);
+                // near the border every point is range-checked; otherwise only the row of the
+                // UNSCALED pattern offset is tested (MIN_MV, motion.cpp:1274)
+                const bool ok = near ? in_range<P>(c, hx + kdx * (int)i, hy + kdy * (int)i) : y_ok<P>(c, hy + kdy);
+                if (ok)
+                    m |= 1u << k;
+            }
+            try_points<P>(c, hx + dx * (int)i, hy + dy * (int)i, m, bmx, bmy, bcost);
+        }
+    }
+    while (++i <= (unsigned)(merange >> 2));
+#undef UMH_THRESH
+    return in_range<P>(c, bmx, bmy);
+}
+
 // radius-1 diamond, step packed in the low 4 bits of the cost: motion.cpp:1016-1039
 template <typename P> __device__ __forceinline__ void dia_search(const BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost)
 {
@@ -271,9 +461,10 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     const int qminx = c.minx * 4, qminy = c.miny * 4, qmaxx = c.maxx * 4, qmaxy = c.maxy * 4;
     const int pmvx = clampi(mvpx, qminx, qmaxx), pmvy = clampi(mvpy, qminy, qmaxy);
     int bmx = (pmvx + 2) >> 2, bmy = (pmvy + 2) >> 2;
+    const int pfx = bmx, pfy = bmy;      // predictor rounded to full pel
     int bcost, bprecost, mv0cost;
     int hexc[6];
-    bool hexValid = method != 0;
+    bool hexValid = method == 1;
     {
         // one pass: group 0 = clipped quarter-pel predictor (SAD only, no MV cost),
         // group 1 = predictor rounded to full pel (only needed when it has a
@@ -312,6 +503,11 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
 
     if (method == 0)
         dia_search<P>(c, merange, bmx, bmy, bcost);
+    else if (method == 2)
+    {
+        if (umh_search<P>(c, pfx, pfy, merange, bmx, bmy, bcost))
+            hex_search<P>(c, merange, bmx, bmy, bcost, nullptr);
+    }
     else
         hex_search<P>(c, merange, bmx, bmy, bcost, hexValid ? hexc : nullptr);
 

@@ -265,9 +265,11 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
         (cfg->internalBitDepth != 8 && cfg->internalBitDepth != 10 && cfg->internalBitDepth != 12) ||
         (cfg->maxCUSize != 16 && cfg->maxCUSize != 32 && cfg->maxCUSize != 64))
         return X265GPU_ERR_ARG;
-    if (cfg->searchMethod != X265GPU_HEX_SEARCH && cfg->searchMethod != X265GPU_DIA_SEARCH)
+    auto methodOk = [](int m) { return m == X265GPU_DIA_SEARCH || m == X265GPU_HEX_SEARCH || m == X265GPU_UMH_SEARCH; };
+    if (!methodOk(cfg->searchMethod) || cfg->maxSlices > 1)
         return X265GPU_ERR_UNSUPPORTED;
-    if (cfg->bEnableHME || cfg->maxSlices > 1)
+    if (cfg->bEnableHME && (!methodOk(cfg->hmeSearchMethod[0]) || !methodOk(cfg->hmeSearchMethod[1]) ||
+                            cfg->hmeRange[0] < 4 || cfg->hmeRange[1] < 4))
         return X265GPU_ERR_UNSUPPORTED;
 
     int ndev = 0;
@@ -541,8 +543,10 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
         HIPCHK(hipHostMalloc((void**)&ctx->batchSumsHost, cap * 3 * sizeof(long long), hipHostMallocDefault));
         ctx->batchSumsCap = cap;
     }
-    const int D = ctx->D, nb = g.cuCount;
-    std::vector<SearchJob> sj;
+    const int D = ctx->D, nb = g.cuCount, nb4 = g.cuCount4;
+    const bool hme = ctx->cfg.bEnableHME != 0;
+    std::vector<SearchJob> sj;      // half-res searches
+    std::vector<SearchJob> sj4;     // quarter-res searches (HME level 0), run first
     std::vector<CostJob> cj(n);
     for (int i = 0; i < n; i++)
     {
@@ -557,17 +561,40 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
         Slot& s0 = ctx->slots[r.slotP0];
         Slot& s1 = ctx->slots[r.slotP1];
         const int bBidir = d1 > 0;
-        int32_t* mvs0 = sb.mvs + ((size_t)(0 * D + d0) * nb) * 2;
-        int32_t* mvs1 = sb.mvs + ((size_t)(1 * D + d1) * nb) * 2;
-        int32_t* mc0 = sb.mvCosts + (size_t)(0 * D + d0) * nb;
-        int32_t* mc1 = sb.mvCosts + (size_t)(1 * D + d1) * nb;
-        if (r.doSearch[0])
+        int32_t* mvs[2] = { sb.mvs + ((size_t)(0 * D + d0) * nb) * 2, sb.mvs + ((size_t)(1 * D + d1) * nb) * 2 };
+        int32_t* mc[2] = { sb.mvCosts + (size_t)(0 * D + d0) * nb, sb.mvCosts + (size_t)(1 * D + d1) * nb };
+        for (int l = 0; l < 2; l++)
         {
+            if (!r.doSearch[l])
+                continue;
+            Slot& sr = l ? s1 : s0;
+            const int dist = l ? d1 : d0;
+            int32_t* mvs4 = hme ? sb.mvs4 + ((size_t)(l * D + dist) * nb4) * 2 : nullptr;
+            int32_t* mc4 = hme ? sb.mvCosts4 + (size_t)(l * D + dist) * nb4 : nullptr;
+            if (hme)
+            {
+                // estimateCUCost(..., hme = 1): quarter-res planes, never the weighted reference
+                // (slicetype.cpp:4391); the closing zero check still addresses the half-res plane
+                // with the full stride (motion.cpp:1765, 1777-1778)
+                SearchJob j;
+                memset(&j, 0, sizeof(j));
+                j.fencPlane0 = plane4_origin(ctx, sb.planes4);
+                j.refOrigin = plane4_origin(ctx, sr.planes4);
+                j.zeroRef = plane_origin(ctx, sr.planes);
+                j.zeroStride = g.stride;
+                j.mvs = mvs4;
+                j.mvCosts = mc4;
+                j.bBidir = bBidir;
+                j.level0 = 1;
+                j.method = ctx->cfg.hmeSearchMethod[0];
+                j.merange = ctx->cfg.hmeRange[0];
+                sj4.push_back(j);
+            }
             SearchJob j;
             memset(&j, 0, sizeof(j));
             j.fencPlane0 = plane_origin(ctx, sb.planes);
-            char* ref = s0.planes;
-            if (r.weightedL0)
+            char* ref = sr.planes;
+            if (l == 0 && r.weightedL0)
             {
                 if (!sb.weighted[d0])
                     return fail(ctx, X265GPU_ERR_STATE, "estimate: weighted planes not prepared");
@@ -576,26 +603,15 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
             j.refOrigin = plane_origin(ctx, ref);
             j.zeroRef = j.refOrigin;
             j.zeroStride = g.stride;
-            j.mvs = mvs0;
-            j.mvCosts = mc0;
+            j.mvs = mvs[l];
+            j.mvCosts = mc[l];
+            j.hmeMvs = mvs4;
+            j.hmeMvCosts = mc4;
             j.bBidir = bBidir;
-            j.method = ctx->cfg.searchMethod;
-            j.merange = ctx->cfg.merange;
-            sj.push_back(j);
-        }
-        if (r.doSearch[1])
-        {
-            SearchJob j;
-            memset(&j, 0, sizeof(j));
-            j.fencPlane0 = plane_origin(ctx, sb.planes);
-            j.refOrigin = plane_origin(ctx, s1.planes);
-            j.zeroRef = j.refOrigin;
-            j.zeroStride = g.stride;
-            j.mvs = mvs1;
-            j.mvCosts = mc1;
-            j.bBidir = bBidir;
-            j.method = ctx->cfg.searchMethod;
-            j.merange = ctx->cfg.merange;
+            // with HME the half-res level uses hmeSearchMethod[1] / hmeRange[1] (motion.cpp:1013,
+            // slicetype.cpp:4478); without it x265 hard-wires HEX and s_merange
+            j.method = hme ? ctx->cfg.hmeSearchMethod[1] : ctx->cfg.searchMethod;
+            j.merange = hme ? ctx->cfg.hmeRange[1] : ctx->cfg.merange;
             sj.push_back(j);
         }
         CostJob& c = cj[i];
@@ -604,10 +620,10 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
         c.fencPlane0 = plane_origin(ctx, sb.planes);
         c.ref0Origin = plane_origin(ctx, s0.planes);
         c.ref1Origin = plane_origin(ctx, s1.planes);
-        c.mvs0 = mvs0;
-        c.mvs1 = mvs1;
-        c.mvCosts0 = mc0;
-        c.mvCosts1 = mc1;
+        c.mvs0 = mvs[0];
+        c.mvs1 = mvs[1];
+        c.mvCosts0 = mc[0];
+        c.mvCosts1 = mc[1];
         c.intraCost = sb.intraCost;
         c.invQscale = sb.hasAq ? sb.invQscale : nullptr;
         c.lowresCosts = sb.lowresCosts + q * nb;
@@ -618,18 +634,28 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
         c.bBidir = bBidir;
     }
 
+    const size_t s4Bytes = align256(sizeof(SearchJob) * sj4.size());
     const size_t sBytes = align256(sizeof(SearchJob) * sj.size());
     const size_t cBytes = sizeof(CostJob) * cj.size();
-    int rc = ensure_job_buf(ctx, sBytes + cBytes);
+    int rc = ensure_job_buf(ctx, s4Bytes + sBytes + cBytes);
     if (rc)
         return rc;
-    if (!sj.empty())
+    bool first = true;
+    if (!sj4.empty())
     {
-        rc = upload_jobs(ctx, 0, sj.data(), sizeof(SearchJob) * sj.size(), true);
+        rc = upload_jobs(ctx, 0, sj4.data(), sizeof(SearchJob) * sj4.size(), first);
         if (rc)
             return rc;
+        first = false;
     }
-    rc = upload_jobs(ctx, sBytes, cj.data(), cBytes, sj.empty());
+    if (!sj.empty())
+    {
+        rc = upload_jobs(ctx, s4Bytes, sj.data(), sizeof(SearchJob) * sj.size(), first);
+        if (rc)
+            return rc;
+        first = false;
+    }
+    rc = upload_jobs(ctx, s4Bytes + sBytes, cj.data(), cBytes, first);
     if (rc)
         return rc;
 
@@ -637,13 +663,16 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
     {
         PhaseTimer pt(ctx, X265GPU_PHASE_SEARCH);
         int launches = 0;
-        HIPCHK(launch_search(ctx->stream, g, ctx->bpp, (const SearchJob*)ctx->jobBuf, (int)sj.size(), 0,
+        if (!sj4.empty())
+            HIPCHK(launch_search(ctx->stream, g, ctx->bpp, (const SearchJob*)ctx->jobBuf, (int)sj4.size(), 1,
+                                 ctx->costCentre, ctx->maxMvd, ctx->cfg.maxSlices, &launches));
+        HIPCHK(launch_search(ctx->stream, g, ctx->bpp, (const SearchJob*)(ctx->jobBuf + s4Bytes), (int)sj.size(), 0,
                              ctx->costCentre, ctx->maxMvd, ctx->cfg.maxSlices, &launches));
         pt.stop(launches);
     }
     {
         PhaseTimer pt(ctx, X265GPU_PHASE_COST);
-        HIPCHK(launch_cost(ctx->stream, g, ctx->bpp, (const CostJob*)(ctx->jobBuf + sBytes), n));
+        HIPCHK(launch_cost(ctx->stream, g, ctx->bpp, (const CostJob*)(ctx->jobBuf + s4Bytes + sBytes), n));
         pt.stop(2);
     }
     return X265GPU_OK;

@@ -87,7 +87,7 @@ struct WeightCostJob
 hipError_t launch_lowres_init(hipStream_t s, const Geometry& g, int bpp, const LowresJob* dJobs, int n);
 hipError_t launch_intra(hipStream_t s, const Geometry& g, int bpp, int depth, int lambda, const IntraJob* dJobs,
                         long long* dSums /* [n][2] */, int n);
-hipError_t launch_search(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0,
+hipError_t launch_search(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0, int method,
                          const uint16_t* costTab, int maxMvd, int maxSlices, int* launches);
 hipError_t launch_cost(hipStream_t s, const Geometry& g, int bpp, const CostJob* dJobs, int n);
 hipError_t launch_weight_cost(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJob);

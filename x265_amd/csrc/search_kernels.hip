@@ -37,6 +37,7 @@ constexpr uint32_t HEX6_X = 0x8879A976u;   // first six points: (-2,0)(-1,2)(1,2
 constexpr uint32_t HEX6_Y = 0x88668AA8u;
 constexpr uint32_t SQ1_X = 0x99779788u;    // square1[1..8].x = 0,0,-1,1,-1,-1,1,1      (motion.cpp:66)
 constexpr uint32_t SQ1_Y = 0x97978897u;    // square1[1..8].y = -1,1,0,0,-1,1,-1,1
+constexpr int X265GPU_DIA = 0, X265GPU_HEX = 1, X265GPU_UMH = 2;   // x265gpu_config.searchMethod values
 constexpr uint32_t MOD6M1 = 0x05432105u;   // mod6m1[8] = 5,0,1,2,3,4,5,0 (unbiased)          (motion.cpp:65)
 
 template <typename P>
@@ -173,20 +174,16 @@ template <typename P> __device__ __forceinline__ void square_refine(const BlockC
 
 // radius-2 hexagon walk, direction carried in the low 3 bits of the cost:
 // motion.cpp:1041-1118, followed by the square refinement
-// `pre`: costs of the six first points when they were already measured around
-// (bmx,bmy) together with the start candidates, else null
+// `havePre`: the six first points were already measured around (bmx,bmy)
+// together with the start candidates and their costs are p0..p5
 template <typename P>
 __device__ __forceinline__ void hex_search(const BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost,
-                                           const int* pre)
+                                           bool havePre, int p0, int p1, int p2, int p3, int p4, int p5)
 {
     int bc;
     {
-        int c0, c1, c2, c3, c4, c5;
-        if (pre)
-        {
-            c0 = pre[0]; c1 = pre[1]; c2 = pre[2]; c3 = pre[3]; c4 = pre[4]; c5 = pre[5];
-        }
-        else
+        int c0 = p0, c1 = p1, c2 = p2, c3 = p3, c4 = p4, c5 = p5;
+        if (!havePre)
         {
             const int cost = fpel_cost<P>(c, bmx + nib(HEX6_X, c.g), bmy + nib(HEX6_Y, c.g), c.g < 6);
             c0 = group_value<0>(cost); c1 = group_value<1>(cost); c2 = group_value<2>(cost);
@@ -452,8 +449,8 @@ template <typename P> __device__ __forceinline__ void dia_search(const BlockCtx<
 // zeroSad / zeroSatd: SAD of the searched full-pel plane and SATD of the
 // closing check's plane at displacement (0,0), measured by the caller together
 // with the predictor candidates so they cost no memory round trip of their own.
-template <typename P>
-__device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, int mvpy, int method, int merange,
+template <typename P, int METHOD>
+__device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, int mvpy, int merange,
                                                       int zeroSad, int zeroSatd, int& outx, int& outy)
 {
     c.mvpx = mvpx;
@@ -463,8 +460,8 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     int bmx = (pmvx + 2) >> 2, bmy = (pmvy + 2) >> 2;
     const int pfx = bmx, pfy = bmy;      // predictor rounded to full pel
     int bcost, bprecost, mv0cost;
-    int hexc[6];
-    bool hexValid = method == 1;
+    int h0, h1, h2, h3, h4, h5;
+    bool hexValid = METHOD == X265GPU_HEX;
     {
         // one pass: group 0 = clipped quarter-pel predictor (SAD only, no MV cost),
         // group 1 = predictor rounded to full pel (only needed when it has a
@@ -482,8 +479,8 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
         const int cost = reduce_cost<P, EV_SAD>(c, ref, (c.g == 0) ? 0 : t);
         mv0cost = group_value<0>(t + dpp<DPP_XOR1>(t));
         const int c0 = group_value<0>(cost), c1 = group_value<1>(cost);
-        hexc[0] = group_value<2>(cost); hexc[1] = group_value<3>(cost); hexc[2] = group_value<4>(cost);
-        hexc[3] = group_value<5>(cost); hexc[4] = group_value<6>(cost); hexc[5] = group_value<7>(cost);
+        h0 = group_value<2>(cost); h1 = group_value<3>(cost); h2 = group_value<4>(cost);
+        h3 = group_value<5>(cost); h4 = group_value<6>(cost); h5 = group_value<7>(cost);
         bprecost = c0;
         bcost = sub ? c1 : c0;
         if (nz && zeroSad + mv0cost < bcost)
@@ -501,15 +498,15 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
         return mvcost_u<P>(c, bmx * 4, bmy * 4);
     }
 
-    if (method == 0)
+    if (METHOD == X265GPU_DIA)
         dia_search<P>(c, merange, bmx, bmy, bcost);
-    else if (method == 2)
+    else if (METHOD == X265GPU_UMH)
     {
         if (umh_search<P>(c, pfx, pfy, merange, bmx, bmy, bcost))
-            hex_search<P>(c, merange, bmx, bmy, bcost, nullptr);
+            hex_search<P>(c, merange, bmx, bmy, bcost, false, 0, 0, 0, 0, 0, 0);
     }
     else
-        hex_search<P>(c, merange, bmx, bmy, bcost, hexValid ? hexc : nullptr);
+        hex_search<P>(c, merange, bmx, bmy, bcost, hexValid, h0, h1, h2, h3, h4, h5);
 
     int bqx, bqy;
     if (bprecost < bcost)
@@ -582,7 +579,7 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     return bcost;
 }
 
-template <typename P>
+template <typename P, int METHOD>
 __device__ __forceinline__ void search_block(const SearchJob& job, const Geometry& g, int level0, int cuX, int cuY,
                                              int lane, const uint16_t* costTab, int maxMvd)
 {
@@ -682,7 +679,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     }
 
     int mx, my;
-    int fencCost = motion_estimate_lowres<P>(c, mvpx, mvpy, job.method, job.merange, zeroSad, zeroSatd, mx, my);
+    int fencCost = motion_estimate_lowres<P, METHOD>(c, mvpx, mvpy, job.merange, zeroSad, zeroSatd, mx, my);
     // bidir skip shortcut (slicetype.cpp:4485-4489)
     if (skipCost < 64 && skipCost < fencCost && job.bBidir)
     {
@@ -697,8 +694,10 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     }
 }
 
-// grid: (ceil(blocksOnDiagonal / 4), jobs); 4 waves per workgroup, one block each
-template <typename P>
+// grid: (ceil(blocksOnDiagonal / 4), jobs); 4 waves per workgroup, one block each.
+// The search method is a compile-time parameter: every job of a launch shares it,
+// and the hexagon-only kernel stays free of the multi-hexagon code's registers.
+template <typename P, int METHOD>
 __global__ void __launch_bounds__(256) search_diag_kernel(const SearchJob* jobs, Geometry g, int level0, int t,
                                                           const uint16_t* costTab, int maxMvd)
 {
@@ -711,11 +710,30 @@ __global__ void __launch_bounds__(256) search_diag_kernel(const SearchJob* jobs,
         return;                       // whole wave leaves together
     const int xq = t - 2 * yq;
     const SearchJob job = jobs[blockIdx.y];
-    search_block<P>(job, g, level0, W - 1 - xq, H - 1 - yq, threadIdx.x & 63, costTab, maxMvd);
+    search_block<P, METHOD>(job, g, level0, W - 1 - xq, H - 1 - yq, threadIdx.x & 63, costTab, maxMvd);
+}
+
+template <typename P, int METHOD>
+static void launch_diag(hipStream_t s, dim3 grid, const SearchJob* dJobs, const Geometry& g, int level0, int t,
+                        const uint16_t* costTab, int maxMvd)
+{
+    hipLaunchKernelGGL((search_diag_kernel<P, METHOD>), grid, dim3(256), 0, s, dJobs, g, level0, t, costTab, maxMvd);
+}
+
+template <typename P>
+static void launch_diag_method(int method, hipStream_t s, dim3 grid, const SearchJob* dJobs, const Geometry& g,
+                               int level0, int t, const uint16_t* costTab, int maxMvd)
+{
+    if (method == X265GPU_DIA)
+        launch_diag<P, X265GPU_DIA>(s, grid, dJobs, g, level0, t, costTab, maxMvd);
+    else if (method == X265GPU_UMH)
+        launch_diag<P, X265GPU_UMH>(s, grid, dJobs, g, level0, t, costTab, maxMvd);
+    else
+        launch_diag<P, X265GPU_HEX>(s, grid, dJobs, g, level0, t, costTab, maxMvd);
 }
 
 hipError_t launch_search(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0,
-                         const uint16_t* costTab, int maxMvd, int maxSlices, int* launches)
+                         int method, const uint16_t* costTab, int maxMvd, int maxSlices, int* launches)
 {
     (void)maxSlices;
     if (n <= 0)
@@ -731,9 +749,9 @@ hipError_t launch_search(hipStream_t s, const Geometry& g, int bpp, const Search
             continue;
         dim3 grid((cnt + 3) / 4, n);
         if (bpp == 1)
-            hipLaunchKernelGGL(search_diag_kernel<uint8_t>, grid, dim3(256), 0, s, dJobs, g, level0, t, costTab, maxMvd);
+            launch_diag_method<uint8_t>(method, s, grid, dJobs, g, level0, t, costTab, maxMvd);
         else
-            hipLaunchKernelGGL(search_diag_kernel<uint16_t>, grid, dim3(256), 0, s, dJobs, g, level0, t, costTab, maxMvd);
+            launch_diag_method<uint16_t>(method, s, grid, dJobs, g, level0, t, costTab, maxMvd);
         if (launches)
             (*launches)++;
     }

@@ -665,9 +665,9 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
         int launches = 0;
         if (!sj4.empty())
             HIPCHK(launch_search(ctx->stream, g, ctx->bpp, (const SearchJob*)ctx->jobBuf, (int)sj4.size(), 1,
-                                 ctx->costCentre, ctx->maxMvd, ctx->cfg.maxSlices, &launches));
+                                 sj4[0].method, ctx->costCentre, ctx->maxMvd, ctx->cfg.maxSlices, &launches));
         HIPCHK(launch_search(ctx->stream, g, ctx->bpp, (const SearchJob*)(ctx->jobBuf + s4Bytes), (int)sj.size(), 0,
-                             ctx->costCentre, ctx->maxMvd, ctx->cfg.maxSlices, &launches));
+                             sj[0].method, ctx->costCentre, ctx->maxMvd, ctx->cfg.maxSlices, &launches));
         pt.stop(launches);
     }
     {

@@ -87,8 +87,17 @@ struct WeightCostJob
 hipError_t launch_lowres_init(hipStream_t s, const Geometry& g, int bpp, const LowresJob* dJobs, int n);
 hipError_t launch_intra(hipStream_t s, const Geometry& g, int bpp, int depth, int lambda, const IntraJob* dJobs,
                         long long* dSums /* [n][2] */, int n);
-hipError_t launch_search(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0, int method,
-                         const uint16_t* costTab, int maxMvd, int maxSlices, int* launches);
+// Side streams the search may spread independent jobs over so that the drain of
+// one anti-diagonal launch overlaps the body of another job group's launch.
+struct SearchStreams
+{
+    int count = 0;                 // side streams in use (0: everything on the main stream)
+    hipStream_t side[3] = { nullptr, nullptr, nullptr };
+    hipEvent_t fork = nullptr;     // recorded on the main stream, awaited by the side streams
+    hipEvent_t join[3] = { nullptr, nullptr, nullptr };
+};
+hipError_t launch_search(hipStream_t s, const SearchStreams& aux, const Geometry& g, int bpp, const SearchJob* dJobs, int n,
+                         int level0, int method, const uint16_t* costTab, int maxMvd, int maxSlices, int* launches);
 hipError_t launch_cost(hipStream_t s, const Geometry& g, int bpp, const CostJob* dJobs, int n);
 hipError_t launch_weight_cost(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJob);
 hipError_t launch_weight_planes(hipStream_t s, const Geometry& g, int bpp, int depth, int nPlanes, const void* src,

@@ -20,13 +20,20 @@
 // of one step (sad_x3 / sad_x4 / square refine / four sub-pel points) in
 // parallel, one per 8-lane group.
 //
-// The kernel is bound by vector-L1 accesses (every lane's 8-pixel row is its
-// own cache access), so groups without a candidate issue no loads, the second
-// half-pel plane is only fetched by lanes whose vector has a quarter-pel part,
-// and the two MV-cost table reads of a candidate ride on lanes 0 and 1 of its
-// group and are folded into the row reduction.
+// The kernel is bound by vector-L1 accesses (every lane's 8-pixel row read from
+// global memory is its own cache access), so the wave stages what it is about
+// to re-read in its own slice of LDS with row-coalesced loads: a 32x32 window
+// of the full-pel plane around the search start (re-centred if the walk leaves
+// it), the two MV-cost table windows the walk prices from, and a 10-row window
+// of all four half-pel planes for the sub-pel stage.  Candidate rows then come
+// out of LDS as aligned dwords plus a byte-align (LDS b64/b128 reads off their
+// natural alignment are replayed at 64 cycles).  Groups without a candidate
+// issue no loads, and the two MV-cost reads of a candidate ride on lanes 0 and
+// 1 of its group and are folded into the row reduction.
 #include "device_common.h"
 #include "kernels.h"
+
+#define XG_LDS __attribute__((address_space(3)))
 
 namespace xg {
 
@@ -56,7 +63,94 @@ struct BlockCtx
     int mvpx, mvpy;                // quarter-pel predictor the MV cost is centred on
     const XG_GLOBAL uint16_t* costBase;   // MV-cost table, entry [maxMvd] is MVD 0
     int maxMvd;
+    // this wave's LDS slice and what it currently holds (all wave-uniform)
+    XG_LDS uint32_t* win;          // full-pel window, WIN rows of LdsT<P>::WIN_S dwords
+    XG_LDS uint32_t* sub;          // sub-pel window, 4 planes x SUB_ROWS rows of LdsT<P>::SUB_S dwords
+    XG_LDS uint32_t* tab;          // MV-cost windows, 2 axes x TAB_N entries of 16 bits
+    int winX, winY;                // plane coordinates of the window's first pixel
+    int subX, subY;
+    int tabLoX, tabLoY;            // MVD of entry 0 of each axis' table window
 };
+
+constexpr int WIN = 32;            // full-pel window side, pixels
+constexpr int WIN_PAD = 12;        // pixels between the window's edge and the centre block
+constexpr int SUB_ROWS = 10;       // sub-pel window: 10 rows x 16 pixels per plane
+constexpr int TAB_N = 200;         // MV-cost entries per axis
+constexpr int TAB_HALF = 100;
+constexpr int NOT_STAGED = 1 << 24;
+
+// Row strides in dwords, chosen odd-ish so that the eight rows of a candidate
+// fall into different banks: 12 -> banks 0,12,24,4,16,28,8,20; 20 -> 0,20,8,28,16,4,24,12;
+// 4 -> 0,4,..,28; 9 -> 0,9,..,31.  Every row leaves room for the one dword the
+// byte-align reads past the last pixel.
+template <typename P> struct LdsT;
+template <> struct LdsT<uint8_t>  { static constexpr int WIN_S = 12, SUB_S = 4; };
+template <> struct LdsT<uint16_t> { static constexpr int WIN_S = 20, SUB_S = 9; };
+template <typename P> struct WaveLds
+{
+    static constexpr int WIN_DW = WIN * LdsT<P>::WIN_S + 4;
+    static constexpr int SUB_DW = 4 * SUB_ROWS * LdsT<P>::SUB_S + 4;
+    static constexpr int TAB_DW = TAB_N;            // 2 axes x 200 x 16 bit
+    static constexpr int TOTAL = WIN_DW + SUB_DW + TAB_DW;
+};
+
+// LDS traffic between lanes of one wave needs no hardware wait (the LDS executes
+// a wave's instructions in order); this only stops the compiler from moving
+// accesses across the hand-over.
+__device__ __forceinline__ void lds_handover()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// sixteen pixels in flight between a global load and an LDS store
+template <typename P> struct Px16 { uint32_t w[4 * sizeof(P)]; };
+
+template <typename P> __device__ __forceinline__ Px16<P> load16_g(const XG_GLOBAL P* base, int offsetPixels)
+{
+    Px16<P> s;
+#pragma unroll
+    for (int h = 0; h < (int)sizeof(P); h++)
+    {
+        const u32x4_unaligned v = *(const XG_GLOBAL u32x4_unaligned*)(base + offsetPixels + h * (16 / (int)sizeof(P)));
+        s.w[4 * h] = v.x;
+        s.w[4 * h + 1] = v.y;
+        s.w[4 * h + 2] = v.z;
+        s.w[4 * h + 3] = v.w;
+    }
+    return s;
+}
+
+template <typename P> __device__ __forceinline__ void store16_l(XG_LDS uint32_t* dst, const Px16<P>& s)
+{
+#pragma unroll
+    for (int i = 0; i < 4 * (int)sizeof(P); i++)
+        dst[i] = s.w[i];
+}
+
+// eight pixels starting X pixels into an LDS row: aligned dword reads + byte-align
+template <typename P> __device__ __forceinline__ Row<P> lds_row(const XG_LDS uint32_t* row, int X);
+template <> __device__ __forceinline__ Row<uint8_t> lds_row<uint8_t>(const XG_LDS uint32_t* row, int X)
+{
+    const XG_LDS uint32_t* p = row + (X >> 2);
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    Row<uint8_t> r;
+    r.w[0] = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)X & 3u);
+    r.w[1] = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)X & 3u);
+    return r;
+}
+template <> __device__ __forceinline__ Row<uint16_t> lds_row<uint16_t>(const XG_LDS uint32_t* row, int X)
+{
+    const XG_LDS uint32_t* p = row + (X >> 1);
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
+    const uint32_t sh = ((uint32_t)X & 1u) * 2u;
+    Row<uint16_t> r;
+    r.w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    r.w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    r.w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    r.w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    return r;
+}
 
 // Row r of the block displaced by the quarter-pel vector (qx,qy), from the
 // half-pel plane that vector selects: ReferencePlanes::lowresMC,
@@ -106,7 +200,11 @@ template <typename P> __device__ __forceinline__ int price_lanes(const BlockCtx<
     if (priced && c.r < 2)
     {
         const int d = (c.r == 0) ? qx - c.mvpx : qy - c.mvpy;
-        t = (int)c.costBase[(unsigned)(clampi(d, -c.maxMvd, c.maxMvd) + c.maxMvd)];
+        const int off = d - ((c.r == 0) ? c.tabLoX : c.tabLoY);
+        if ((unsigned)off < (unsigned)TAB_N)
+            t = (int)((const XG_LDS uint16_t*)c.tab)[c.r * TAB_N + off];
+        else
+            t = (int)c.costBase[(unsigned)(clampi(d, -c.maxMvd, c.maxMvd) + c.maxMvd)];
     }
     return t;
 }
@@ -142,15 +240,124 @@ template <typename P> __device__ __forceinline__ bool in_range(const BlockCtx<P>
     return x >= c.minx && x <= c.maxx && y >= c.miny && y <= c.maxy;
 }
 
-// full-pel cost of this lane's group candidate: SAD + mvcost(mv << 2)
-template <typename P> __device__ __forceinline__ int fpel_cost(const BlockCtx<P>& c, int mx, int my, bool active)
+// full-pel cost of this lane's group candidate, SAD + mvcost(mv << 2), read from global memory
+template <typename P> __device__ __forceinline__ int fpel_cost_g(const BlockCtx<P>& c, int mx, int my, bool active)
 {
     return eval<P, EV_SAD>(c, mx * 4, my * 4, active, true);
 }
 
-// 8-point square refinement around (bmx,bmy): motion.cpp:1120-1138
-template <typename P> __device__ __forceinline__ void square_refine(const BlockCtx<P>& c, int& bmx, int& bmy, int& bcost)
+// Stage the full-pel window around the block displaced by (mx,my) and the MV-cost
+// windows around that vector.  One 16-pixel load per lane for the window (two rows
+// of lanes per window row), 25 lanes x 8 entries per table axis.
+template <typename P> __device__ __forceinline__ void stage_search(BlockCtx<P>& c, int mx, int my)
 {
+    const int cx = clampi(c.bx + mx, c.minX, c.maxX), cy = clampi(c.by + my, c.minY, c.maxY);
+    const int wx = clampi(cx - WIN_PAD, c.minX, c.maxX + 8 - WIN);
+    const int wy = clampi(cy - WIN_PAD, c.minY, c.maxY + 8 - WIN);
+    const int lane = c.g * 8 + c.r, row = lane >> 1, half = lane & 1;
+    const Px16<P> px = load16_g<P>(c.base, c.padOffset + (wy + row) * c.stride + wx + 16 * half);
+
+    const int lox = clampi(mx * 4 - c.mvpx - TAB_HALF, -c.maxMvd, c.maxMvd + 1 - TAB_N);
+    const int loy = clampi(my * 4 - c.mvpy - TAB_HALF, -c.maxMvd, c.maxMvd + 1 - TAB_N);
+    const int axis = lane >> 5, k = lane & 31;
+    u32x4_unaligned tv = { 0, 0, 0, 0 };
+    if (k < TAB_N / 8)
+        tv = *(const XG_GLOBAL u32x4_unaligned*)(c.costBase + ((axis ? loy : lox) + c.maxMvd + 8 * k));
+
+    lds_handover();
+    store16_l<P>(c.win + row * LdsT<P>::WIN_S + half * (4 * (int)sizeof(P)), px);
+    if (k < TAB_N / 8)
+    {
+        XG_LDS uint32_t* d = c.tab + axis * (TAB_N / 2) + 4 * k;
+        d[0] = tv.x;
+        d[1] = tv.y;
+        d[2] = tv.z;
+        d[3] = tv.w;
+    }
+    lds_handover();
+    c.winX = wx;
+    c.winY = wy;
+    c.tabLoX = lox;
+    c.tabLoY = loy;
+}
+
+// make sure every block within `ext` pixels of displacement (mx,my) lies in the staged window
+template <typename P> __device__ __forceinline__ void ensure_window(BlockCtx<P>& c, int mx, int my, int ext)
+{
+    const int x0 = clampi(c.bx + mx - ext, c.minX, c.maxX) - c.winX;
+    const int x1 = clampi(c.bx + mx + ext, c.minX, c.maxX) - c.winX;
+    const int y0 = clampi(c.by + my - ext, c.minY, c.maxY) - c.winY;
+    const int y1 = clampi(c.by + my + ext, c.minY, c.maxY) - c.winY;
+    if (x0 < 0 || x1 > WIN - 8 || y0 < 0 || y1 > WIN - 8)
+        stage_search<P>(c, mx, my);
+}
+
+// this lane's row of the block displaced by full-pel (mx,my), out of the staged window
+template <typename P> __device__ __forceinline__ Row<P> win_row(const BlockCtx<P>& c, int mx, int my)
+{
+    const int X = clampi(c.bx + mx, c.minX, c.maxX) - c.winX;
+    const int Y = clampi(c.by + my, c.minY, c.maxY) - c.winY + c.r;
+    return lds_row<P>(c.win + Y * LdsT<P>::WIN_S, X);
+}
+
+// full-pel cost of this lane's group candidate out of the staged window (the
+// caller has run ensure_window for the step's extent)
+template <typename P> __device__ __forceinline__ int fpel_cost(const BlockCtx<P>& c, int mx, int my, bool active)
+{
+    Row<P> ref = zero_row<P>();
+    if (active)
+        ref = win_row<P>(c, mx, my);
+    const int t = price_lanes<P>(c, mx * 4, my * 4, active);
+    return reduce_cost<P, EV_SAD>(c, ref, t);
+}
+
+// Stage rows -1..+8 and columns -1..+14 of all four half-pel planes around the
+// full-pel part of quarter-pel vector (bqx,bqy): everything the half- and
+// quarter-pel steps (up to +-3 quarter pixels from here) can read.
+template <typename P> __device__ __forceinline__ void stage_subpel(BlockCtx<P>& c, int bqx, int bqy)
+{
+    const int sx = clampi(c.bx + (bqx >> 2) - 1, c.minX, c.maxX - 8);
+    const int sy = clampi(c.by + (bqy >> 2) - 1, c.minY, c.maxY - 2);
+    const int lane = c.g * 8 + c.r;
+    const int plane = lane / SUB_ROWS, row = lane - plane * SUB_ROWS;
+    Px16<P> px;
+    if (lane < 4 * SUB_ROWS)
+        px = load16_g<P>(c.base, c.padOffset + plane * c.planeSize + (sy + row) * c.stride + sx);
+    lds_handover();
+    if (lane < 4 * SUB_ROWS)
+        store16_l<P>(c.sub + lane * LdsT<P>::SUB_S, px);
+    lds_handover();
+    c.subX = sx;
+    c.subY = sy;
+}
+
+template <typename P> __device__ __forceinline__ Row<P> sub_row(const BlockCtx<P>& c, int qx, int qy)
+{
+    const int hp = (qy & 2) | ((qx & 2) >> 1);
+    const int X = clampi(c.bx + (qx >> 2), c.minX, c.maxX) - c.subX;
+    const int Y = clampi(c.by + (qy >> 2), c.minY, c.maxY) - c.subY + c.r;
+    return lds_row<P>(c.sub + (hp * SUB_ROWS + Y) * LdsT<P>::SUB_S, X);
+}
+
+// eval() out of the staged sub-pel window
+template <typename P, int KIND>
+__device__ __forceinline__ int eval_sub(const BlockCtx<P>& c, int qx, int qy, bool active)
+{
+    Row<P> ref = zero_row<P>();
+    if (active)
+    {
+        ref = sub_row<P>(c, qx, qy);
+        if ((qx | qy) & 1)
+            ref = avg_row<P>(ref, sub_row<P>(c, qx + (qx & 1), qy + (qy & 1)));
+    }
+    const int t = price_lanes<P>(c, qx, qy, active);
+    return reduce_cost<P, KIND>(c, ref, t);
+}
+
+// 8-point square refinement around (bmx,bmy): motion.cpp:1120-1138
+template <typename P> __device__ __forceinline__ void square_refine(BlockCtx<P>& c, int& bmx, int& bmy, int& bcost)
+{
+    ensure_window<P>(c, bmx, bmy, 1);
     const int cost = fpel_cost<P>(c, bmx + nib(SQ1_X, c.g), bmy + nib(SQ1_Y, c.g), true);
     const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost),
               c3 = group_value<3>(cost), c4 = group_value<4>(cost), c5 = group_value<5>(cost),
@@ -177,7 +384,7 @@ template <typename P> __device__ __forceinline__ void square_refine(const BlockC
 // `havePre`: the six first points were already measured around (bmx,bmy)
 // together with the start candidates and their costs are p0..p5
 template <typename P>
-__device__ __forceinline__ void hex_search(const BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost,
+__device__ __forceinline__ void hex_search(BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost,
                                            bool havePre, int p0, int p1, int p2, int p3, int p4, int p5)
 {
     int bc;
@@ -185,6 +392,7 @@ __device__ __forceinline__ void hex_search(const BlockCtx<P>& c, int merange, in
         int c0 = p0, c1 = p1, c2 = p2, c3 = p3, c4 = p4, c5 = p5;
         if (!havePre)
         {
+            ensure_window<P>(c, bmx, bmy, 2);
             const int cost = fpel_cost<P>(c, bmx + nib(HEX6_X, c.g), bmy + nib(HEX6_Y, c.g), c.g < 6);
             c0 = group_value<0>(cost); c1 = group_value<1>(cost); c2 = group_value<2>(cost);
             c3 = group_value<3>(cost); c4 = group_value<4>(cost); c5 = group_value<5>(cost);
@@ -207,6 +415,7 @@ __device__ __forceinline__ void hex_search(const BlockCtx<P>& c, int merange, in
             for (int i = (merange >> 1) - 1; i > 0 && in_range<P>(c, bmx, bmy); i--)
             {
                 const int idx = dir + (c.g < 3 ? c.g : 0);
+                ensure_window<P>(c, bmx, bmy, 2);
                 const int cost = fpel_cost<P>(c, bmx + nib(HEX2_X, idx), bmy + nib(HEX2_Y, idx), c.g < 3);
                 const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost);
                 bc &= ~7;
@@ -234,7 +443,7 @@ template <typename P>
 __device__ __forceinline__ void try_points(const BlockCtx<P>& c, int mx, int my, unsigned mask, int& bmx, int& bmy,
                                            int& bcost)
 {
-    const int cost = fpel_cost<P>(c, mx, my, ((mask >> c.g) & 1u) != 0);
+    const int cost = fpel_cost_g<P>(c, mx, my, ((mask >> c.g) & 1u) != 0);
 #define ACCEPT(G)                                                    \
     if (mask & (1u << G))                                            \
     {                                                                \
@@ -417,12 +626,13 @@ __device__ __forceinline__ bool umh_search(const BlockCtx<P>& c, int pmx, int pm
 }
 
 // radius-1 diamond, step packed in the low 4 bits of the cost: motion.cpp:1016-1039
-template <typename P> __device__ __forceinline__ void dia_search(const BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost)
+template <typename P> __device__ __forceinline__ void dia_search(BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost)
 {
     int bc = bcost << 4;
     int i = merange;
     do
     {
+        ensure_window<P>(c, bmx, bmy, 1);
         // points (0,-1) (0,1) (-1,0) (1,0) = square1[1..4]
         const int gi = c.g & 3;
         const int cost = fpel_cost<P>(c, bmx + nib(SQ1_X, gi), bmy + nib(SQ1_Y, gi), c.g < 4);
@@ -474,7 +684,12 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
         const int qx = (c.g == 0) ? pmvx : (bmx + nib(HEX6_X, hi)) * 4;
         const int qy = (c.g == 0) ? pmvy : (bmy + nib(HEX6_Y, hi)) * 4;
         const bool active = c.g == 0 || (c.g == 1 && sub) || (c.g >= 2 && hexValid);
-        const Row<P> ref = cand_row<P>(c, qx, qy, active);
+        // the predictor's (possibly interpolated) block comes from global memory, in flight
+        // together with the window loads; the full-pel candidates come out of the window
+        Row<P> ref = cand_row<P>(c, qx, qy, c.g == 0);
+        stage_search<P>(c, bmx, bmy);
+        if (c.g != 0 && active)
+            ref = win_row<P>(c, qx >> 2, qy >> 2);
         const int t = price_lanes<P>(c, (c.g == 0) ? 0 : qx, (c.g == 0) ? 0 : qy, active);
         const int cost = reduce_cost<P, EV_SAD>(c, ref, (c.g == 0) ? 0 : t);
         mv0cost = group_value<0>(t + dpp<DPP_XOR1>(t));
@@ -528,9 +743,10 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
         // workload[1]: four half-pel SADs, SATD at the winner, four quarter-pel
         // SATDs (motion.cpp:48-58, 1667-1699)
         const int gi = c.g & 3;
+        stage_subpel<P>(c, bqx, bqy);
         {
             const int qx = bqx + 2 * nib(SQ1_X, gi), qy = bqy + 2 * nib(SQ1_Y, gi);
-            const int cost = eval<P, EV_SAD>(c, qx, qy, c.g < 4, true);
+            const int cost = eval_sub<P, EV_SAD>(c, qx, qy, c.g < 4);
             const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost),
                       c3 = group_value<3>(cost);
             const bool up = (bqy - 2 >= qminy) && (bqy - 2 <= qmaxy), dn = (bqy + 2 >= qminy) && (bqy + 2 <= qmaxy);
@@ -550,7 +766,7 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
         // whose SATD replaces the running cost before the neighbours are compared
         {
             const int qx = bqx + ((c.g < 4) ? nib(SQ1_X, gi) : 0), qy = bqy + ((c.g < 4) ? nib(SQ1_Y, gi) : 0);
-            const int cost = eval<P, EV_SATD>(c, qx, qy, c.g < 5, true);
+            const int cost = eval_sub<P, EV_SATD>(c, qx, qy, c.g < 5);
             const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost),
                       c3 = group_value<3>(cost);
             bcost = group_value<4>(cost);
@@ -581,7 +797,7 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
 
 template <typename P, int METHOD>
 __device__ __forceinline__ void search_block(const SearchJob& job, const Geometry& g, int level0, int cuX, int cuY,
-                                             int lane, const uint16_t* costTab, int maxMvd)
+                                             int lane, const uint16_t* costTab, int maxMvd, XG_LDS uint32_t* lds)
 {
     const int W = level0 ? g.W4 : g.W, H = level0 ? g.H4 : g.H;
     const int stride = level0 ? g.stride4 : g.stride;
@@ -606,6 +822,11 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     c.costBase = as_global<uint16_t>(costTab) - maxMvd;
     c.maxMvd = maxMvd;
     c.mvpx = c.mvpy = 0;
+    c.win = lds;
+    c.sub = lds + WaveLds<P>::WIN_DW;
+    c.tab = lds + WaveLds<P>::WIN_DW + WaveLds<P>::SUB_DW;
+    c.winX = c.winY = c.subX = c.subY = NOT_STAGED;
+    c.tabLoX = c.tabLoY = NOT_STAGED;
     // search bounds that stay inside the extended frame (slicetype.cpp:4417-4420)
     c.minx = -cuX * 8 - 8;
     c.miny = -cuY * 8 - 8;
@@ -701,6 +922,7 @@ template <typename P, int METHOD>
 __global__ void __launch_bounds__(256) search_diag_kernel(const SearchJob* jobs, Geometry g, int level0, int t,
                                                           const uint16_t* costTab, int maxMvd)
 {
+    __shared__ uint32_t ldsBuf[4 * WaveLds<P>::TOTAL];
     const int W = level0 ? g.W4 : g.W, H = level0 ? g.H4 : g.H;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction
     const int k = blockIdx.x * 4 + wave;
@@ -710,7 +932,8 @@ __global__ void __launch_bounds__(256) search_diag_kernel(const SearchJob* jobs,
         return;                       // whole wave leaves together
     const int xq = t - 2 * yq;
     const SearchJob job = jobs[blockIdx.y];
-    search_block<P, METHOD>(job, g, level0, W - 1 - xq, H - 1 - yq, threadIdx.x & 63, costTab, maxMvd);
+    search_block<P, METHOD>(job, g, level0, W - 1 - xq, H - 1 - yq, threadIdx.x & 63, costTab, maxMvd,
+                            (XG_LDS uint32_t*)ldsBuf + wave * WaveLds<P>::TOTAL);
 }
 
 template <typename P, int METHOD>
@@ -732,12 +955,23 @@ static void launch_diag_method(int method, hipStream_t s, dim3 grid, const Searc
         launch_diag<P, X265GPU_HEX>(s, grid, dJobs, g, level0, t, costTab, maxMvd);
 }
 
-hipError_t launch_search(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0,
-                         int method, const uint16_t* costTab, int maxMvd, int maxSlices, int* launches)
+hipError_t launch_search(hipStream_t s, const SearchStreams& aux, const Geometry& g, int bpp, const SearchJob* dJobs, int n,
+                         int level0, int method, const uint16_t* costTab, int maxMvd, int maxSlices, int* launches)
 {
     (void)maxSlices;
     if (n <= 0)
         return hipSuccess;
+    // job groups: group 0 on the main stream, the others on side streams.  Jobs of one
+    // call never read each other's vectors, so the groups only meet at fork and join.
+    const int groups = (n >= 2 * (aux.count + 1)) ? aux.count + 1 : 1;
+    if (groups > 1)
+    {
+        hipError_t e = hipEventRecord(aux.fork, s);
+        for (int k = 0; k + 1 < groups && e == hipSuccess; k++)
+            e = hipStreamWaitEvent(aux.side[k], aux.fork, 0);
+        if (e != hipSuccess)
+            return e;
+    }
     const int W = level0 ? g.W4 : g.W, H = level0 ? g.H4 : g.H;
     const int tmax = (W - 1) + 2 * (H - 1);
     for (int t = 0; t <= tmax; t++)
@@ -747,15 +981,27 @@ hipError_t launch_search(hipStream_t s, const Geometry& g, int bpp, const Search
         const int cnt = yhi - ylo + 1;
         if (cnt <= 0)
             continue;
-        dim3 grid((cnt + 3) / 4, n);
-        if (bpp == 1)
-            launch_diag_method<uint8_t>(method, s, grid, dJobs, g, level0, t, costTab, maxMvd);
-        else
-            launch_diag_method<uint16_t>(method, s, grid, dJobs, g, level0, t, costTab, maxMvd);
+        for (int k = 0; k < groups; k++)
+        {
+            const int j0 = (int)((long long)n * k / groups), j1 = (int)((long long)n * (k + 1) / groups);
+            hipStream_t st = k ? aux.side[k - 1] : s;
+            dim3 grid((cnt + 3) / 4, j1 - j0);
+            if (bpp == 1)
+                launch_diag_method<uint8_t>(method, st, grid, dJobs + j0, g, level0, t, costTab, maxMvd);
+            else
+                launch_diag_method<uint16_t>(method, st, grid, dJobs + j0, g, level0, t, costTab, maxMvd);
+        }
         if (launches)
-            (*launches)++;
+            (*launches) += groups;
     }
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    for (int k = 0; k + 1 < groups && e == hipSuccess; k++)
+    {
+        e = hipEventRecord(aux.join[k], aux.side[k]);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(s, aux.join[k], 0);
+    }
+    return e;
 }
 
 } // namespace xg

@@ -4,6 +4,7 @@
 #include "kernels.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -65,6 +66,7 @@ struct x265gpu_ctx
     double profMs[X265GPU_PHASE_COUNT] = { 0, 0, 0, 0 };
     int64_t profLaunches[X265GPU_PHASE_COUNT] = { 0, 0, 0, 0 };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    SearchStreams searchAux;
 };
 
 namespace {
@@ -307,6 +309,26 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
             rc = X265GPU_ERR_DEVICE;
             break;
         }
+        {
+            // side streams for the search (X265GPU_SEARCH_STREAMS = total streams, 1..4)
+            const char* e = getenv("X265GPU_SEARCH_STREAMS");
+            int total = e ? atoi(e) : 2;
+            total = total < 1 ? 1 : (total > 4 ? 4 : total);
+            SearchStreams& a = ctx->searchAux;
+            bool ok = hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) == hipSuccess;
+            for (int k = 0; k + 1 < total && ok; k++)
+            {
+                ok = hipStreamCreateWithFlags(&a.side[k], hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&a.join[k], hipEventDisableTiming) == hipSuccess;
+                if (ok)
+                    a.count = k + 1;
+            }
+            if (!ok)
+            {
+                rc = X265GPU_ERR_DEVICE;
+                break;
+            }
+        }
         if (hipMalloc((void**)&ctx->scalar, 256) != hipSuccess)
         {
             rc = X265GPU_ERR_NOMEM;
@@ -354,6 +376,13 @@ void x265gpu_close(x265gpu_ctx* ctx)
     if (ctx->scalar) (void)hipFree(ctx->scalar);
     if (ctx->batchSums) (void)hipFree(ctx->batchSums);
     if (ctx->batchSumsHost) (void)hipHostFree(ctx->batchSumsHost);
+    for (int k = 0; k < 3; k++)
+    {
+        if (ctx->searchAux.side[k]) (void)hipStreamSynchronize(ctx->searchAux.side[k]);
+        if (ctx->searchAux.join[k]) (void)hipEventDestroy(ctx->searchAux.join[k]);
+        if (ctx->searchAux.side[k]) (void)hipStreamDestroy(ctx->searchAux.side[k]);
+    }
+    if (ctx->searchAux.fork) (void)hipEventDestroy(ctx->searchAux.fork);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -664,9 +693,9 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
         PhaseTimer pt(ctx, X265GPU_PHASE_SEARCH);
         int launches = 0;
         if (!sj4.empty())
-            HIPCHK(launch_search(ctx->stream, g, ctx->bpp, (const SearchJob*)ctx->jobBuf, (int)sj4.size(), 1,
+            HIPCHK(launch_search(ctx->stream, ctx->searchAux, g, ctx->bpp, (const SearchJob*)ctx->jobBuf, (int)sj4.size(), 1,
                                  sj4[0].method, ctx->costCentre, ctx->maxMvd, ctx->cfg.maxSlices, &launches));
-        HIPCHK(launch_search(ctx->stream, g, ctx->bpp, (const SearchJob*)(ctx->jobBuf + s4Bytes), (int)sj.size(), 0,
+        HIPCHK(launch_search(ctx->stream, ctx->searchAux, g, ctx->bpp, (const SearchJob*)(ctx->jobBuf + s4Bytes), (int)sj.size(), 0,
                              sj[0].method, ctx->costCentre, ctx->maxMvd, ctx->cfg.maxSlices, &launches));
         pt.stop(launches);
     }

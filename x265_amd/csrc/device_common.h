@@ -164,8 +164,10 @@ template <typename P> __device__ __forceinline__ int sad8x8(const Row<P>& fenc, 
 // blocks) >> 1: source/common/pixel.cpp:239-261, 277-289.  `f` is this lane's
 // unpacked encode row, `r` its lane index inside the group (row number).
 // Horizontal transform in registers, vertical transform across the four lanes
-// of a quad.
-template <typename P> __device__ __forceinline__ int satd8x8(const int f[8], const Row<P>& ref, int r)
+// of a quad.  `extra` (any per-lane values) is added to the result: it enters
+// doubled ahead of the halving, which is exact, so that it rides on the same
+// reduction and every lane of the group ends up with SATD + sum(extra).
+template <typename P> __device__ __forceinline__ int satd8x8(const int f[8], const Row<P>& ref, int r, int extra = 0)
 {
     int d[8];
     unpack_row<P>(ref, d);
@@ -189,7 +191,7 @@ template <typename P> __device__ __forceinline__ int satd8x8(const int f[8], con
 #pragma unroll
     for (int i = 0; i < 8; i++)
         d[i] = ((d[i] ^ m2) - m2) + dpp<DPP_XOR2>(d[i]);
-    int s = 0;
+    int s = 2 * extra;
 #pragma unroll
     for (int i = 0; i < 8; i++)
         s += abs(d[i]);

@@ -60,6 +60,7 @@ struct BlockCtx
     int bx, by;                    // block origin in pixels (wave-uniform)
     int g, r;                      // candidate group and row of this lane
     int minx, miny, maxx, maxy;    // full-pel search bounds mvmin / mvmax (wave-uniform)
+    int xr, yr;                    // maxx - minx, maxy - miny
     int mvpx, mvpy;                // quarter-pel predictor the MV cost is centred on
     const XG_GLOBAL uint16_t* costBase;   // MV-cost table, entry [maxMvd] is MVD 0
     int maxMvd;
@@ -67,9 +68,9 @@ struct BlockCtx
     XG_LDS uint32_t* win;          // full-pel window, WIN rows of LdsT<P>::WIN_S dwords
     XG_LDS uint32_t* sub;          // sub-pel window, 4 planes x SUB_ROWS rows of LdsT<P>::SUB_S dwords
     XG_LDS uint32_t* tab;          // MV-cost windows, 2 axes x TAB_N entries of 16 bits
-    int winX, winY;                // plane coordinates of the window's first pixel
-    int subX, subY;
-    int tabLoX, tabLoY;            // MVD of entry 0 of each axis' table window
+    int relX, relY;                // block origin relative to the window's first pixel
+    int subRelX, subRelY;          // the same for the sub-pel window
+    int tabBiasX, tabBiasY;        // quarter-pel component + bias = index into the 2 x TAB_N table entries
 };
 
 constexpr int WIN = 32;            // full-pel window side, pixels
@@ -166,10 +167,6 @@ template <typename P> __device__ __forceinline__ Row<P> fetch_plane_row(const Bl
 
 constexpr int EV_SAD = 0, EV_SATD = 1;
 
-// Cost of this lane's group candidate at quarter-pel (qx,qy).  `active`: the
-// group has a candidate in this step (others issue no loads); `priced`: add
-// BitCost::mvcost (source/encoder/bitcost.h:56).  The result is valid in lane
-// 0 of every active group.  All 64 lanes must call this together.
 template <typename P> __device__ __forceinline__ Row<P> zero_row()
 {
     Row<P> z;
@@ -179,7 +176,8 @@ template <typename P> __device__ __forceinline__ Row<P> zero_row()
     return z;
 }
 
-// this lane's row of its group's candidate block (zeros when the group is idle)
+// this lane's row of its group's candidate block, read from global memory
+// (zeros when the group is idle)
 template <typename P> __device__ __forceinline__ Row<P> cand_row(const BlockCtx<P>& c, int qx, int qy, bool active)
 {
     Row<P> ref = zero_row<P>();
@@ -192,37 +190,45 @@ template <typename P> __device__ __forceinline__ Row<P> cand_row(const BlockCtx<
     return ref;
 }
 
-// the two MV-cost table reads of (qx,qy): lane 0 of the group takes the x term,
-// lane 1 the y term, every other lane 0.  Summing over the group gives mvcost.
-template <typename P> __device__ __forceinline__ int price_lanes(const BlockCtx<P>& c, int qx, int qy, bool priced)
+// The two MV-cost table reads of (qx,qy), BitCost::mvcost (source/encoder/bitcost.h:56):
+// lane 0 of the group takes the x term, lane 1 the y term, every other lane 0, so that
+// summing over the group adds mvcost.  This form reads the table in global memory.
+template <typename P> __device__ __forceinline__ int price_lanes_g(const BlockCtx<P>& c, int qx, int qy, bool priced)
 {
     int t = 0;
     if (priced && c.r < 2)
     {
         const int d = (c.r == 0) ? qx - c.mvpx : qy - c.mvpy;
-        const int off = d - ((c.r == 0) ? c.tabLoX : c.tabLoY);
-        if ((unsigned)off < (unsigned)TAB_N)
-            t = (int)((const XG_LDS uint16_t*)c.tab)[c.r * TAB_N + off];
-        else
-            t = (int)c.costBase[(unsigned)(clampi(d, -c.maxMvd, c.maxMvd) + c.maxMvd)];
+        t = (int)c.costBase[(unsigned)(clampi(d, -c.maxMvd, c.maxMvd) + c.maxMvd)];
     }
     return t;
+}
+
+// The same out of the staged table windows.  Branch-free: every lane reads (odd
+// rows the y window, even rows the x window) and lanes 2..7 drop the value.  The
+// caller guarantees the vector lies within the staged windows (+-25 pixels of
+// the vector they were staged for).
+template <typename P> __device__ __forceinline__ int price_lanes(const BlockCtx<P>& c, int qx, int qy)
+{
+    const int idx = (c.r & 1) ? qy + c.tabBiasY : qx + c.tabBiasX;
+    const int t = (int)((const XG_LDS uint16_t*)c.tab)[idx];
+    return c.r < 2 ? t : 0;
 }
 
 template <typename P, int KIND> __device__ __forceinline__ int reduce_cost(const BlockCtx<P>& c, const Row<P>& ref, int t)
 {
     if (KIND == EV_SAD)
         return group_sum8(sad_row<P>(c.fr, ref) + t);
-    const int s = satd8x8<P>(c.f, ref, c.r);
-    t += dpp<DPP_XOR1>(t);
-    return s + t;
+    return satd8x8<P>(c.f, ref, c.r, t);
 }
 
+// cost of this lane's group candidate at quarter-pel (qx,qy), read from global
+// memory; valid in every lane of an active group.  All 64 lanes call together.
 template <typename P, int KIND>
 __device__ __forceinline__ int eval(const BlockCtx<P>& c, int qx, int qy, bool active, bool priced)
 {
     const Row<P> ref = cand_row<P>(c, qx, qy, active);
-    const int t = price_lanes<P>(c, qx, qy, active && priced);
+    const int t = price_lanes_g<P>(c, qx, qy, active && priced);
     return reduce_cost<P, KIND>(c, ref, t);
 }
 
@@ -234,10 +240,48 @@ template <typename P> __device__ __forceinline__ int mvcost_u(const BlockCtx<P>&
     return ((int)c.costBase[(unsigned)ix] + (int)c.costBase[(unsigned)iy]) & 0xffff;
 }
 
-template <typename P> __device__ __forceinline__ bool y_ok(const BlockCtx<P>& c, int y) { return y >= c.miny && y <= c.maxy; }
+template <typename P> __device__ __forceinline__ bool y_ok(const BlockCtx<P>& c, int y)
+{
+    return (unsigned)(y - c.miny) <= (unsigned)c.yr;
+}
 template <typename P> __device__ __forceinline__ bool in_range(const BlockCtx<P>& c, int x, int y)
 {
-    return x >= c.minx && x <= c.maxx && y >= c.miny && y <= c.maxy;
+    return (unsigned)(x - c.minx) <= (unsigned)c.xr && (unsigned)(y - c.miny) <= (unsigned)c.yr;
+}
+
+// ---- choosing among the candidates of one step ---------------------------------
+// The reference walks the candidates of a step in a fixed order and keeps one only
+// if it is strictly cheaper than the best so far (COPY2_IF_LT chains, or a packed
+// (cost << k) + direction minimum, motion.cpp:263-353).  Both are the minimum of
+// (cost, position-in-order) pairs with the incumbent in front, so each group
+// forms the key (cost << 7 | order << 3 | group) and one DPP reduction finds the
+// winner; its vector is then read from the winning group's lanes.  This keeps the
+// per-candidate compare/select chains off the scalar unit.
+constexpr int KEY_INVALID = 0x7fffffff;
+__device__ __forceinline__ int make_key(int cost, int order, int g) { return (cost << 7) | (order << 3) | g; }
+
+// minimum over the wave of a value that is uniform within each 8-lane group
+__device__ __forceinline__ int wave_min(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));   // row_ror:8, the row's other group
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Accept the step's winner if it beats the incumbent.  (vx,vy) are the per-lane
+// candidate vectors the keys were formed for.  Returns the winner's order (0: none).
+__device__ __forceinline__ int take_winner(int key, int vx, int vy, int& bx, int& by, int& bcost)
+{
+    if (key < (bcost << 7))
+    {
+        const int lane = (key & 7) << 3;
+        bx = __builtin_amdgcn_readlane(vx, lane);
+        by = __builtin_amdgcn_readlane(vy, lane);
+        bcost = key >> 7;
+        return (key >> 3) & 15;
+    }
+    return 0;
 }
 
 // full-pel cost of this lane's group candidate, SAD + mvcost(mv << 2), read from global memory
@@ -246,9 +290,38 @@ template <typename P> __device__ __forceinline__ int fpel_cost_g(const BlockCtx<
     return eval<P, EV_SAD>(c, mx * 4, my * 4, active, true);
 }
 
+// 25 lanes x 8 entries per axis of the MV-cost table around quarter-pel vector (qx,qy);
+// load and store halves so that callers can put other loads in flight between them
+struct TabStage { u32x4_unaligned v; int lox, loy; };
+template <typename P> __device__ __forceinline__ TabStage tab_load(const BlockCtx<P>& c, int qx, int qy)
+{
+    TabStage t;
+    t.lox = clampi(qx - c.mvpx - TAB_HALF, -c.maxMvd, c.maxMvd + 1 - TAB_N);
+    t.loy = clampi(qy - c.mvpy - TAB_HALF, -c.maxMvd, c.maxMvd + 1 - TAB_N);
+    const int lane = c.g * 8 + c.r, axis = lane >> 5, k = lane & 31;
+    t.v = u32x4_unaligned{ 0, 0, 0, 0 };
+    if (k < TAB_N / 8)
+        t.v = *(const XG_GLOBAL u32x4_unaligned*)(c.costBase + ((axis ? t.loy : t.lox) + c.maxMvd + 8 * k));
+    return t;
+}
+template <typename P> __device__ __forceinline__ void tab_store(BlockCtx<P>& c, const TabStage& t)
+{
+    const int lane = c.g * 8 + c.r, axis = lane >> 5, k = lane & 31;
+    if (k < TAB_N / 8)
+    {
+        XG_LDS uint32_t* d = c.tab + axis * (TAB_N / 2) + 4 * k;
+        d[0] = t.v.x;
+        d[1] = t.v.y;
+        d[2] = t.v.z;
+        d[3] = t.v.w;
+    }
+    c.tabBiasX = -c.mvpx - t.lox;
+    c.tabBiasY = -c.mvpy - t.loy + TAB_N;
+}
+
 // Stage the full-pel window around the block displaced by (mx,my) and the MV-cost
-// windows around that vector.  One 16-pixel load per lane for the window (two rows
-// of lanes per window row), 25 lanes x 8 entries per table axis.
+// windows around that vector.  One 16-pixel load per lane for the window (two
+// lanes per window row).
 template <typename P> __device__ __forceinline__ void stage_search(BlockCtx<P>& c, int mx, int my)
 {
     const int cx = clampi(c.bx + mx, c.minX, c.maxX), cy = clampi(c.by + my, c.minY, c.maxY);
@@ -256,64 +329,46 @@ template <typename P> __device__ __forceinline__ void stage_search(BlockCtx<P>& 
     const int wy = clampi(cy - WIN_PAD, c.minY, c.maxY + 8 - WIN);
     const int lane = c.g * 8 + c.r, row = lane >> 1, half = lane & 1;
     const Px16<P> px = load16_g<P>(c.base, c.padOffset + (wy + row) * c.stride + wx + 16 * half);
-
-    const int lox = clampi(mx * 4 - c.mvpx - TAB_HALF, -c.maxMvd, c.maxMvd + 1 - TAB_N);
-    const int loy = clampi(my * 4 - c.mvpy - TAB_HALF, -c.maxMvd, c.maxMvd + 1 - TAB_N);
-    const int axis = lane >> 5, k = lane & 31;
-    u32x4_unaligned tv = { 0, 0, 0, 0 };
-    if (k < TAB_N / 8)
-        tv = *(const XG_GLOBAL u32x4_unaligned*)(c.costBase + ((axis ? loy : lox) + c.maxMvd + 8 * k));
-
+    const TabStage ts = tab_load<P>(c, mx * 4, my * 4);
     lds_handover();
     store16_l<P>(c.win + row * LdsT<P>::WIN_S + half * (4 * (int)sizeof(P)), px);
-    if (k < TAB_N / 8)
-    {
-        XG_LDS uint32_t* d = c.tab + axis * (TAB_N / 2) + 4 * k;
-        d[0] = tv.x;
-        d[1] = tv.y;
-        d[2] = tv.z;
-        d[3] = tv.w;
-    }
+    tab_store<P>(c, ts);
     lds_handover();
-    c.winX = wx;
-    c.winY = wy;
-    c.tabLoX = lox;
-    c.tabLoY = loy;
+    c.relX = c.bx - wx;
+    c.relY = c.by - wy;
 }
 
 // make sure every block within `ext` pixels of displacement (mx,my) lies in the staged window
 template <typename P> __device__ __forceinline__ void ensure_window(BlockCtx<P>& c, int mx, int my, int ext)
 {
-    const int x0 = clampi(c.bx + mx - ext, c.minX, c.maxX) - c.winX;
-    const int x1 = clampi(c.bx + mx + ext, c.minX, c.maxX) - c.winX;
-    const int y0 = clampi(c.by + my - ext, c.minY, c.maxY) - c.winY;
-    const int y1 = clampi(c.by + my + ext, c.minY, c.maxY) - c.winY;
-    if (x0 < 0 || x1 > WIN - 8 || y0 < 0 || y1 > WIN - 8)
+    const unsigned lim = (unsigned)(WIN - 8 - 2 * ext);
+    if ((unsigned)(c.relX + mx - ext) > lim || (unsigned)(c.relY + my - ext) > lim)
         stage_search<P>(c, mx, my);
 }
 
 // this lane's row of the block displaced by full-pel (mx,my), out of the staged window
 template <typename P> __device__ __forceinline__ Row<P> win_row(const BlockCtx<P>& c, int mx, int my)
 {
-    const int X = clampi(c.bx + mx, c.minX, c.maxX) - c.winX;
-    const int Y = clampi(c.by + my, c.minY, c.maxY) - c.winY + c.r;
-    return lds_row<P>(c.win + Y * LdsT<P>::WIN_S, X);
+    return lds_row<P>(c.win + (c.relY + my + c.r) * LdsT<P>::WIN_S, c.relX + mx);
 }
 
-// full-pel cost of this lane's group candidate out of the staged window (the
-// caller has run ensure_window for the step's extent)
-template <typename P> __device__ __forceinline__ int fpel_cost(const BlockCtx<P>& c, int mx, int my, bool active)
+// Key of this lane's group candidate at full-pel (mx,my) out of the staged window:
+// SAD + mvcost(mv << 2), invalid when the group is idle or the vector's row is
+// outside mvmin.y..mvmax.y.  Idle groups pass any vector inside the window.
+template <typename P>
+__device__ __forceinline__ int fpel_key(const BlockCtx<P>& c, int mx, int my, bool active, int order)
 {
-    Row<P> ref = zero_row<P>();
-    if (active)
-        ref = win_row<P>(c, mx, my);
-    const int t = price_lanes<P>(c, mx * 4, my * 4, active);
-    return reduce_cost<P, EV_SAD>(c, ref, t);
+    const Row<P> ref = win_row<P>(c, mx, my);
+    const int t = price_lanes<P>(c, mx * 4, my * 4);
+    const int cost = reduce_cost<P, EV_SAD>(c, ref, t);
+    const bool ok = active && (unsigned)(my - c.miny) <= (unsigned)c.yr;
+    return wave_min(ok ? make_key(cost, order, c.g) : KEY_INVALID);
 }
 
 // Stage rows -1..+8 and columns -1..+14 of all four half-pel planes around the
-// full-pel part of quarter-pel vector (bqx,bqy): everything the half- and
-// quarter-pel steps (up to +-3 quarter pixels from here) can read.
+// full-pel part of quarter-pel vector (bqx,bqy), which is everything the half-
+// and quarter-pel steps (up to +-3 quarter pixels from here) can read, and the
+// MV-cost windows around that vector.
 template <typename P> __device__ __forceinline__ void stage_subpel(BlockCtx<P>& c, int bqx, int bqy)
 {
     const int sx = clampi(c.bx + (bqx >> 2) - 1, c.minX, c.maxX - 8);
@@ -323,115 +378,71 @@ template <typename P> __device__ __forceinline__ void stage_subpel(BlockCtx<P>& 
     Px16<P> px;
     if (lane < 4 * SUB_ROWS)
         px = load16_g<P>(c.base, c.padOffset + plane * c.planeSize + (sy + row) * c.stride + sx);
+    const TabStage ts = tab_load<P>(c, bqx, bqy);
     lds_handover();
     if (lane < 4 * SUB_ROWS)
         store16_l<P>(c.sub + lane * LdsT<P>::SUB_S, px);
+    tab_store<P>(c, ts);
     lds_handover();
-    c.subX = sx;
-    c.subY = sy;
+    c.subRelX = c.bx - sx;
+    c.subRelY = c.by - sy;
 }
 
 template <typename P> __device__ __forceinline__ Row<P> sub_row(const BlockCtx<P>& c, int qx, int qy)
 {
     const int hp = (qy & 2) | ((qx & 2) >> 1);
-    const int X = clampi(c.bx + (qx >> 2), c.minX, c.maxX) - c.subX;
-    const int Y = clampi(c.by + (qy >> 2), c.minY, c.maxY) - c.subY + c.r;
-    return lds_row<P>(c.sub + (hp * SUB_ROWS + Y) * LdsT<P>::SUB_S, X);
+    return lds_row<P>(c.sub + (hp * SUB_ROWS + c.subRelY + (qy >> 2) + c.r) * LdsT<P>::SUB_S, c.subRelX + (qx >> 2));
 }
 
-// eval() out of the staged sub-pel window
-template <typename P, int KIND>
-__device__ __forceinline__ int eval_sub(const BlockCtx<P>& c, int qx, int qy, bool active)
+// cost at quarter-pel (qx,qy) out of the staged sub-pel window: ReferencePlanes::lowresQPelCost
+// (source/common/lowres.h:95-140) + mvcost.  Branch-free: a vector without a quarter-pel
+// part averages its block with itself.
+template <typename P, int KIND> __device__ __forceinline__ int eval_sub(const BlockCtx<P>& c, int qx, int qy)
 {
-    Row<P> ref = zero_row<P>();
-    if (active)
-    {
-        ref = sub_row<P>(c, qx, qy);
-        if ((qx | qy) & 1)
-            ref = avg_row<P>(ref, sub_row<P>(c, qx + (qx & 1), qy + (qy & 1)));
-    }
-    const int t = price_lanes<P>(c, qx, qy, active);
-    return reduce_cost<P, KIND>(c, ref, t);
+    const Row<P> ref = avg_row<P>(sub_row<P>(c, qx, qy), sub_row<P>(c, qx + (qx & 1), qy + (qy & 1)));
+    return reduce_cost<P, KIND>(c, ref, price_lanes<P>(c, qx, qy));
 }
 
 // 8-point square refinement around (bmx,bmy): motion.cpp:1120-1138
 template <typename P> __device__ __forceinline__ void square_refine(BlockCtx<P>& c, int& bmx, int& bmy, int& bcost)
 {
     ensure_window<P>(c, bmx, bmy, 1);
-    const int cost = fpel_cost<P>(c, bmx + nib(SQ1_X, c.g), bmy + nib(SQ1_Y, c.g), true);
-    const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost),
-              c3 = group_value<3>(cost), c4 = group_value<4>(cost), c5 = group_value<5>(cost),
-              c6 = group_value<6>(cost), c7 = group_value<7>(cost);
-    const bool up = y_ok<P>(c, bmy - 1), dn = y_ok<P>(c, bmy + 1);
-    int dir = 0;
-    if (up && c0 < bcost) { bcost = c0; dir = 1; }
-    if (dn && c1 < bcost) { bcost = c1; dir = 2; }
-    if (c2 < bcost) { bcost = c2; dir = 3; }
-    if (c3 < bcost) { bcost = c3; dir = 4; }
-    if (up && c4 < bcost) { bcost = c4; dir = 5; }
-    if (dn && c5 < bcost) { bcost = c5; dir = 6; }
-    if (up && c6 < bcost) { bcost = c6; dir = 7; }
-    if (dn && c7 < bcost) { bcost = c7; dir = 8; }
-    if (dir)
-    {
-        bmx += nib(SQ1_X, dir - 1);
-        bmy += nib(SQ1_Y, dir - 1);
-    }
+    const int mx = bmx + nib(SQ1_X, c.g), my = bmy + nib(SQ1_Y, c.g);
+    take_winner(fpel_key<P>(c, mx, my, true, c.g + 1), mx, my, bmx, bmy, bcost);
 }
 
-// radius-2 hexagon walk, direction carried in the low 3 bits of the cost:
-// motion.cpp:1041-1118, followed by the square refinement
-// `havePre`: the six first points were already measured around (bmx,bmy)
-// together with the start candidates and their costs are p0..p5
+// radius-2 hexagon walk (motion.cpp:1041-1118) followed by the square refinement.
+// `havePre`: the first hexagon around (bmx,bmy) was already measured together with
+// the start candidates; preKey is its winner key and (preX,preY) the per-lane vectors.
 template <typename P>
 __device__ __forceinline__ void hex_search(BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost,
-                                           bool havePre, int p0, int p1, int p2, int p3, int p4, int p5)
+                                           bool havePre, int preKey, int preX, int preY)
 {
-    int bc;
+    int order;
+    if (havePre)
+        order = take_winner(preKey, preX, preY, bmx, bmy, bcost);
+    else
     {
-        int c0 = p0, c1 = p1, c2 = p2, c3 = p3, c4 = p4, c5 = p5;
-        if (!havePre)
+        ensure_window<P>(c, bmx, bmy, 2);
+        const int hi = c.g < 6 ? c.g : 6;      // index 6 of the tables is (0,0)
+        const int mx = bmx + nib(HEX6_X, hi), my = bmy + nib(HEX6_Y, hi);
+        order = take_winner(fpel_key<P>(c, mx, my, c.g < 6, c.g + 2), mx, my, bmx, bmy, bcost);
+    }
+    if (order)
+    {
+        int dir = order - 2;
+        // half hexagons: three new points per step, one per group 0..2
+        for (int i = (merange >> 1) - 1; i > 0 && in_range<P>(c, bmx, bmy); i--)
         {
             ensure_window<P>(c, bmx, bmy, 2);
-            const int cost = fpel_cost<P>(c, bmx + nib(HEX6_X, c.g), bmy + nib(HEX6_Y, c.g), c.g < 6);
-            c0 = group_value<0>(cost); c1 = group_value<1>(cost); c2 = group_value<2>(cost);
-            c3 = group_value<3>(cost); c4 = group_value<4>(cost); c5 = group_value<5>(cost);
-        }
-        bc = bcost << 3;
-        const bool y0 = y_ok<P>(c, bmy), yp = y_ok<P>(c, bmy + 2), ym = y_ok<P>(c, bmy - 2);
-        if (y0) bc = min(bc, (c0 << 3) + 2);
-        if (yp) { bc = min(bc, (c1 << 3) + 3); bc = min(bc, (c2 << 3) + 4); }
-        if (y0) bc = min(bc, (c3 << 3) + 5);
-        if (ym) { bc = min(bc, (c4 << 3) + 6); bc = min(bc, (c5 << 3) + 7); }
-    }
-    if (bc & 7)
-    {
-        int dir = (bc & 7) - 2;
-        if (y_ok<P>(c, bmy + nib(HEX2_Y, dir + 1)))
-        {
-            bmx += nib(HEX2_X, dir + 1);
-            bmy += nib(HEX2_Y, dir + 1);
-            // half hexagons: three new points per step, one per group 0..2
-            for (int i = (merange >> 1) - 1; i > 0 && in_range<P>(c, bmx, bmy); i--)
-            {
-                const int idx = dir + (c.g < 3 ? c.g : 0);
-                ensure_window<P>(c, bmx, bmy, 2);
-                const int cost = fpel_cost<P>(c, bmx + nib(HEX2_X, idx), bmy + nib(HEX2_Y, idx), c.g < 3);
-                const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost);
-                bc &= ~7;
-                if (y_ok<P>(c, bmy + nib(HEX2_Y, dir + 0))) bc = min(bc, (c0 << 3) + 1);
-                if (y_ok<P>(c, bmy + nib(HEX2_Y, dir + 1))) bc = min(bc, (c1 << 3) + 2);
-                if (y_ok<P>(c, bmy + nib(HEX2_Y, dir + 2))) bc = min(bc, (c2 << 3) + 3);
-                if (!(bc & 7))
-                    break;
-                dir += (bc & 7) - 2;
-                dir = (int)((MOD6M1 >> (4 * (dir + 1))) & 15u);
-                bmx += nib(HEX2_X, dir + 1);
-                bmy += nib(HEX2_Y, dir + 1);
-            }
+            const int idx = dir + (c.g < 3 ? c.g : 0);
+            const int mx = bmx + nib(HEX2_X, idx), my = bmy + nib(HEX2_Y, idx);
+            order = take_winner(fpel_key<P>(c, mx, my, c.g < 3, c.g + 1), mx, my, bmx, bmy, bcost);
+            if (!order)
+                break;
+            dir = (int)((MOD6M1 >> (4 * (dir + order - 1))) & 15u);
         }
     }
-    bcost = bc >> 3;
     square_refine<P>(c, bmx, bmy, bcost);
 }
 
@@ -443,20 +454,9 @@ template <typename P>
 __device__ __forceinline__ void try_points(const BlockCtx<P>& c, int mx, int my, unsigned mask, int& bmx, int& bmy,
                                            int& bcost)
 {
-    const int cost = fpel_cost_g<P>(c, mx, my, ((mask >> c.g) & 1u) != 0);
-#define ACCEPT(G)                                                    \
-    if (mask & (1u << G))                                            \
-    {                                                                \
-        const int cg = group_value<G>(cost);                         \
-        if (cg < bcost)                                              \
-        {                                                            \
-            bcost = cg;                                              \
-            bmx = group_value<G>(mx);                                \
-            bmy = group_value<G>(my);                                \
-        }                                                            \
-    }
-    ACCEPT(0) ACCEPT(1) ACCEPT(2) ACCEPT(3) ACCEPT(4) ACCEPT(5) ACCEPT(6) ACCEPT(7)
-#undef ACCEPT
+    const bool active = ((mask >> c.g) & 1u) != 0;
+    const int cost = fpel_cost_g<P>(c, mx, my, active);
+    take_winner(wave_min(active ? make_key(cost, c.g + 1, c.g) : KEY_INVALID), mx, my, bmx, bmy, bcost);
 }
 
 // COST_MV_X4 around (ox,oy) with offsets from nibble tables: all four are
@@ -625,31 +625,20 @@ __device__ __forceinline__ bool umh_search(const BlockCtx<P>& c, int pmx, int pm
     return in_range<P>(c, bmx, bmy);
 }
 
-// radius-1 diamond, step packed in the low 4 bits of the cost: motion.cpp:1016-1039
+// radius-1 diamond: motion.cpp:1016-1039.  Order values 1, 3, 4, 12 as in the reference's
+// packed direction; the winner's vector is the point itself.
 template <typename P> __device__ __forceinline__ void dia_search(BlockCtx<P>& c, int merange, int& bmx, int& bmy, int& bcost)
 {
-    int bc = bcost << 4;
     int i = merange;
     do
     {
         ensure_window<P>(c, bmx, bmy, 1);
-        // points (0,-1) (0,1) (-1,0) (1,0) = square1[1..4]
-        const int gi = c.g & 3;
-        const int cost = fpel_cost<P>(c, bmx + nib(SQ1_X, gi), bmy + nib(SQ1_Y, gi), c.g < 4);
-        const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost),
-                  c3 = group_value<3>(cost);
-        if (y_ok<P>(c, bmy - 1)) bc = min(bc, (c0 << 4) + 1);
-        if (y_ok<P>(c, bmy + 1)) bc = min(bc, (c1 << 4) + 3);
-        bc = min(bc, (c2 << 4) + 4);
-        bc = min(bc, (c3 << 4) + 12);
-        if (!(bc & 15))
+        const int gi = c.g & 3;      // points (0,-1) (0,1) (-1,0) (1,0) = square1[1..4]
+        const int mx = bmx + nib(SQ1_X, gi), my = bmy + nib(SQ1_Y, gi);
+        if (!take_winner(fpel_key<P>(c, mx, my, c.g < 4, (0xC431 >> (4 * gi)) & 15), mx, my, bmx, bmy, bcost))
             break;
-        bmx -= (int)((uint32_t)bc << 28) >> 30;
-        bmy -= (int)((uint32_t)bc << 30) >> 30;
-        bc &= ~15;
     }
     while (--i && in_range<P>(c, bmx, bmy));
-    bcost = bc >> 4;
 }
 
 // MotionEstimate::motionEstimate for a lowres reference (isLowres, no extra
@@ -670,40 +659,46 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     int bmx = (pmvx + 2) >> 2, bmy = (pmvy + 2) >> 2;
     const int pfx = bmx, pfy = bmy;      // predictor rounded to full pel
     int bcost, bprecost, mv0cost;
-    int h0, h1, h2, h3, h4, h5;
+    int preKey, preX, preY;
     bool hexValid = METHOD == X265GPU_HEX;
     {
-        // one pass: group 0 = clipped quarter-pel predictor (SAD only, no MV cost),
-        // group 1 = predictor rounded to full pel (only needed when it has a
-        // sub-pel part), groups 2..7 = the first hexagon around the rounded
-        // predictor, measured speculatively: it is what the hexagon search needs
-        // next unless the zero vector takes over as start point.  Lanes 0/1 of
-        // group 0 carry no price, so they fetch the table entries of mvcost(0,0).
+        // One pass.  Group 0: the clipped quarter-pel predictor (SAD only, no MV cost), read
+        // from global memory while the window loads are in flight.  Group 1: the predictor
+        // rounded to full pel (used when it has a sub-pel part).  Groups 2..7: the first
+        // hexagon around the rounded predictor, measured speculatively: it is what the
+        // hexagon search needs next unless the zero vector takes over as start point.
         const bool sub = ((pmvx | pmvy) & 3) != 0, nz = (pmvx | pmvy) != 0;
-        const int hi = (c.g >= 2) ? c.g - 2 : 6;      // index 6/7 of the tables is (0,0)
-        const int qx = (c.g == 0) ? pmvx : (bmx + nib(HEX6_X, hi)) * 4;
-        const int qy = (c.g == 0) ? pmvy : (bmy + nib(HEX6_Y, hi)) * 4;
-        const bool active = c.g == 0 || (c.g == 1 && sub) || (c.g >= 2 && hexValid);
-        // the predictor's (possibly interpolated) block comes from global memory, in flight
-        // together with the window loads; the full-pel candidates come out of the window
-        Row<P> ref = cand_row<P>(c, qx, qy, c.g == 0);
+        const Row<P> g0 = cand_row<P>(c, pmvx, pmvy, c.g == 0);
+        const int t0 = price_lanes_g<P>(c, 0, 0, c.g == 0);      // table entries of mvcost(0,0)
         stage_search<P>(c, bmx, bmy);
-        if (c.g != 0 && active)
-            ref = win_row<P>(c, qx >> 2, qy >> 2);
-        const int t = price_lanes<P>(c, (c.g == 0) ? 0 : qx, (c.g == 0) ? 0 : qy, active);
-        const int cost = reduce_cost<P, EV_SAD>(c, ref, (c.g == 0) ? 0 : t);
-        mv0cost = group_value<0>(t + dpp<DPP_XOR1>(t));
+        const int hi = (c.g >= 2) ? c.g - 2 : 6;      // index 6 of the tables is (0,0)
+        preX = bmx + nib(HEX6_X, hi);
+        preY = bmy + nib(HEX6_Y, hi);
+        Row<P> ref = win_row<P>(c, preX, preY);
+        int t = price_lanes<P>(c, preX * 4, preY * 4);
+        if (c.g == 0)
+        {
+            ref = g0;
+            t = 0;
+        }
+        const int cost = reduce_cost<P, EV_SAD>(c, ref, t);
+        mv0cost = group_value<0>(t0 + dpp<DPP_XOR1>(t0));
         const int c0 = group_value<0>(cost), c1 = group_value<1>(cost);
-        h0 = group_value<2>(cost); h1 = group_value<3>(cost); h2 = group_value<4>(cost);
-        h3 = group_value<5>(cost); h4 = group_value<6>(cost); h5 = group_value<7>(cost);
+        preKey = KEY_INVALID;
+        if (METHOD == X265GPU_HEX)
+        {
+            const bool ok = c.g >= 2 && (unsigned)(preY - c.miny) <= (unsigned)c.yr;
+            preKey = wave_min(ok ? make_key(cost, c.g, c.g) : KEY_INVALID);
+        }
         bprecost = c0;
         bcost = sub ? c1 : c0;
         if (nz && zeroSad + mv0cost < bcost)
         {
+            const int zy = max(min(0, c.maxy), c.miny);
             bcost = zeroSad + mv0cost;
-            hexValid = hexValid && bmx == 0 && bmy == max(min(0, c.maxy), c.miny);
+            hexValid = hexValid && bmx == 0 && bmy == zy;
             bmx = 0;
-            bmy = max(min(0, c.maxy), c.miny);
+            bmy = zy;
         }
     }
     if (bcost == 0)
@@ -718,10 +713,10 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     else if (METHOD == X265GPU_UMH)
     {
         if (umh_search<P>(c, pfx, pfy, merange, bmx, bmy, bcost))
-            hex_search<P>(c, merange, bmx, bmy, bcost, false, 0, 0, 0, 0, 0, 0);
+            hex_search<P>(c, merange, bmx, bmy, bcost, false, 0, 0, 0);
     }
     else
-        hex_search<P>(c, merange, bmx, bmy, bcost, hexValid, h0, h1, h2, h3, h4, h5);
+        hex_search<P>(c, merange, bmx, bmy, bcost, hexValid, preKey, preX, preY);
 
     int bqx, bqy;
     if (bprecost < bcost)
@@ -741,47 +736,28 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     else
     {
         // workload[1]: four half-pel SADs, SATD at the winner, four quarter-pel
-        // SATDs (motion.cpp:48-58, 1667-1699)
+        // SATDs (motion.cpp:48-58, 1667-1699).  A candidate counts only if its own
+        // row lies inside mvmin.y..mvmax.y.
         const int gi = c.g & 3;
+        const unsigned qyr = (unsigned)c.yr * 4u;
         stage_subpel<P>(c, bqx, bqy);
         {
             const int qx = bqx + 2 * nib(SQ1_X, gi), qy = bqy + 2 * nib(SQ1_Y, gi);
-            const int cost = eval_sub<P, EV_SAD>(c, qx, qy, c.g < 4);
-            const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost),
-                      c3 = group_value<3>(cost);
-            const bool up = (bqy - 2 >= qminy) && (bqy - 2 <= qmaxy), dn = (bqy + 2 >= qminy) && (bqy + 2 <= qmaxy);
-            const bool mid = (bqy >= qminy) && (bqy <= qmaxy);
-            int bdir = 0;
-            if (up && c0 < bcost) { bcost = c0; bdir = 1; }
-            if (dn && c1 < bcost) { bcost = c1; bdir = 2; }
-            if (mid && c2 < bcost) { bcost = c2; bdir = 3; }
-            if (mid && c3 < bcost) { bcost = c3; bdir = 4; }
-            if (bdir)
-            {
-                bqx += 2 * nib(SQ1_X, bdir - 1);
-                bqy += 2 * nib(SQ1_Y, bdir - 1);
-            }
+            const int cost = eval_sub<P, EV_SAD>(c, qx, qy);
+            const bool ok = c.g < 4 && (unsigned)(qy - qminy) <= qyr;
+            take_winner(wave_min(ok ? make_key(cost, gi + 1, c.g) : KEY_INVALID), qx, qy, bqx, bqy, bcost);
         }
         // groups 0..3: the four quarter-pel neighbours; group 4: the centre itself,
         // whose SATD replaces the running cost before the neighbours are compared
         {
             const int qx = bqx + ((c.g < 4) ? nib(SQ1_X, gi) : 0), qy = bqy + ((c.g < 4) ? nib(SQ1_Y, gi) : 0);
-            const int cost = eval_sub<P, EV_SATD>(c, qx, qy, c.g < 5);
-            const int c0 = group_value<0>(cost), c1 = group_value<1>(cost), c2 = group_value<2>(cost),
-                      c3 = group_value<3>(cost);
-            bcost = group_value<4>(cost);
-            const bool up = (bqy - 1 >= qminy) && (bqy - 1 <= qmaxy), dn = (bqy + 1 >= qminy) && (bqy + 1 <= qmaxy);
-            const bool mid = (bqy >= qminy) && (bqy <= qmaxy);
-            int bdir = 0;
-            if (up && c0 < bcost) { bcost = c0; bdir = 1; }
-            if (dn && c1 < bcost) { bcost = c1; bdir = 2; }
-            if (mid && c2 < bcost) { bcost = c2; bdir = 3; }
-            if (mid && c3 < bcost) { bcost = c3; bdir = 4; }
-            if (bdir)
-            {
-                bqx += nib(SQ1_X, bdir - 1);
-                bqy += nib(SQ1_Y, bdir - 1);
-            }
+            const int cost = eval_sub<P, EV_SATD>(c, qx, qy);
+            const bool ok = c.g == 4 || (c.g < 4 && (unsigned)(qy - qminy) <= qyr);
+            const int key = wave_min(ok ? make_key(cost, c.g < 4 ? gi + 1 : 0, c.g) : KEY_INVALID);
+            const int lane = (key & 7) << 3;
+            bqx = __builtin_amdgcn_readlane(qx, lane);
+            bqy = __builtin_amdgcn_readlane(qy, lane);
+            bcost = key >> 7;
         }
     }
 
@@ -825,13 +801,15 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     c.win = lds;
     c.sub = lds + WaveLds<P>::WIN_DW;
     c.tab = lds + WaveLds<P>::WIN_DW + WaveLds<P>::SUB_DW;
-    c.winX = c.winY = c.subX = c.subY = NOT_STAGED;
-    c.tabLoX = c.tabLoY = NOT_STAGED;
+    c.relX = c.relY = c.subRelX = c.subRelY = NOT_STAGED;
+    c.tabBiasX = c.tabBiasY = 0;
     // search bounds that stay inside the extended frame (slicetype.cpp:4417-4420)
     c.minx = -cuX * 8 - 8;
     c.miny = -cuY * 8 - 8;
     c.maxx = (W - cuX - 1) * 8 + 8;
     c.maxy = (H - cuY - 1) * 8 + 8;
+    c.xr = c.maxx - c.minx;
+    c.yr = c.maxy - c.miny;
     c.fr = load_row_g<P>(as_global<P>(job.fencPlane0) - padOffset, padOffset + (c.by + c.r) * stride + c.bx);
     unpack_row<P>(c.fr, c.f);
 

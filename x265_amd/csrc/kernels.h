@@ -98,6 +98,12 @@ struct SearchStreams
 };
 hipError_t launch_search(hipStream_t s, const SearchStreams& aux, const Geometry& g, int bpp, const SearchJob* dJobs, int n,
                          int level0, int method, const uint16_t* costTab, int maxMvd, int maxSlices, int* launches);
+// single-launch search (row items with in-launch hand-off); dSync holds search_rows_sync_bytes() bytes,
+// word SEARCH_SYNC_ERROR of it is a sticky error flag (a wait ran out) that the caller zeroes once and reads back
+constexpr int SEARCH_SYNC_ERROR = 64;
+size_t search_rows_sync_bytes(const Geometry& g, int n);
+hipError_t launch_search_rows(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0,
+                              int method, const uint16_t* costTab, int maxMvd, int* dSync, int* launches);
 hipError_t launch_cost(hipStream_t s, const Geometry& g, int bpp, const CostJob* dJobs, int n);
 hipError_t launch_weight_cost(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJob);
 hipError_t launch_weight_planes(hipStream_t s, const Geometry& g, int bpp, int depth, int nPlanes, const void* src,

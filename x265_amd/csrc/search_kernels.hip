@@ -70,6 +70,7 @@ struct BlockCtx
     XG_LDS uint32_t* tab;          // MV-cost windows, 2 axes x TAB_N entries of 16 bits
     int relX, relY;                // block origin relative to the window's first pixel
     int subRelX, subRelY;          // the same for the sub-pel window
+    int tabLoX, tabLoY;            // MVD of entry 0 of each axis' staged table window
     int tabBiasX, tabBiasY;        // quarter-pel component + bias = index into the 2 x TAB_N table entries
 };
 
@@ -290,19 +291,25 @@ template <typename P> __device__ __forceinline__ int fpel_cost_g(const BlockCtx<
     return eval<P, EV_SAD>(c, mx * 4, my * 4, active, true);
 }
 
-// 25 lanes x 8 entries per axis of the MV-cost table around quarter-pel vector (qx,qy);
+// 25 lanes x 8 entries per axis of the MV-cost table around the MVD (dcx,dcy);
 // load and store halves so that callers can put other loads in flight between them
 struct TabStage { u32x4_unaligned v; int lox, loy; };
-template <typename P> __device__ __forceinline__ TabStage tab_load(const BlockCtx<P>& c, int qx, int qy)
+template <typename P> __device__ __forceinline__ TabStage tab_load(const BlockCtx<P>& c, int dcx, int dcy)
 {
     TabStage t;
-    t.lox = clampi(qx - c.mvpx - TAB_HALF, -c.maxMvd, c.maxMvd + 1 - TAB_N);
-    t.loy = clampi(qy - c.mvpy - TAB_HALF, -c.maxMvd, c.maxMvd + 1 - TAB_N);
+    t.lox = clampi(dcx - TAB_HALF, -c.maxMvd, c.maxMvd + 1 - TAB_N);
+    t.loy = clampi(dcy - TAB_HALF, -c.maxMvd, c.maxMvd + 1 - TAB_N);
     const int lane = c.g * 8 + c.r, axis = lane >> 5, k = lane & 31;
     t.v = u32x4_unaligned{ 0, 0, 0, 0 };
     if (k < TAB_N / 8)
         t.v = *(const XG_GLOBAL u32x4_unaligned*)(c.costBase + ((axis ? t.loy : t.lox) + c.maxMvd + 8 * k));
     return t;
+}
+// point the table indices at the staged windows for the current predictor
+template <typename P> __device__ __forceinline__ void tab_bias(BlockCtx<P>& c)
+{
+    c.tabBiasX = -c.mvpx - c.tabLoX;
+    c.tabBiasY = -c.mvpy - c.tabLoY + TAB_N;
 }
 template <typename P> __device__ __forceinline__ void tab_store(BlockCtx<P>& c, const TabStage& t)
 {
@@ -315,27 +322,41 @@ template <typename P> __device__ __forceinline__ void tab_store(BlockCtx<P>& c, 
         d[2] = t.v.z;
         d[3] = t.v.w;
     }
-    c.tabBiasX = -c.mvpx - t.lox;
-    c.tabBiasY = -c.mvpy - t.loy + TAB_N;
+    c.tabLoX = t.lox;
+    c.tabLoY = t.loy;
+    tab_bias<P>(c);
 }
 
-// Stage the full-pel window around the block displaced by (mx,my) and the MV-cost
-// windows around that vector.  One 16-pixel load per lane for the window (two
-// lanes per window row).
+// The full-pel window around the block displaced by (mx,my): one 16-pixel load per
+// lane (two lanes per window row), again split into load and store.
+template <typename P> struct WinStage { Px16<P> px; int wx, wy; };
+template <typename P> __device__ __forceinline__ WinStage<P> win_load(const BlockCtx<P>& c, int mx, int my)
+{
+    WinStage<P> w;
+    const int cx = clampi(c.bx + mx, c.minX, c.maxX), cy = clampi(c.by + my, c.minY, c.maxY);
+    w.wx = clampi(cx - WIN_PAD, c.minX, c.maxX + 8 - WIN);
+    w.wy = clampi(cy - WIN_PAD, c.minY, c.maxY + 8 - WIN);
+    const int lane = c.g * 8 + c.r, row = lane >> 1, half = lane & 1;
+    w.px = load16_g<P>(c.base, c.padOffset + (w.wy + row) * c.stride + w.wx + 16 * half);
+    return w;
+}
+template <typename P> __device__ __forceinline__ void win_store(BlockCtx<P>& c, const WinStage<P>& w)
+{
+    const int lane = c.g * 8 + c.r, row = lane >> 1, half = lane & 1;
+    store16_l<P>(c.win + row * LdsT<P>::WIN_S + half * (4 * (int)sizeof(P)), w.px);
+    c.relX = c.bx - w.wx;
+    c.relY = c.by - w.wy;
+}
+
+// Stage the window around displacement (mx,my) and the MV-cost windows around that vector.
 template <typename P> __device__ __forceinline__ void stage_search(BlockCtx<P>& c, int mx, int my)
 {
-    const int cx = clampi(c.bx + mx, c.minX, c.maxX), cy = clampi(c.by + my, c.minY, c.maxY);
-    const int wx = clampi(cx - WIN_PAD, c.minX, c.maxX + 8 - WIN);
-    const int wy = clampi(cy - WIN_PAD, c.minY, c.maxY + 8 - WIN);
-    const int lane = c.g * 8 + c.r, row = lane >> 1, half = lane & 1;
-    const Px16<P> px = load16_g<P>(c.base, c.padOffset + (wy + row) * c.stride + wx + 16 * half);
-    const TabStage ts = tab_load<P>(c, mx * 4, my * 4);
+    const WinStage<P> ws = win_load<P>(c, mx, my);
+    const TabStage ts = tab_load<P>(c, mx * 4 - c.mvpx, my * 4 - c.mvpy);
     lds_handover();
-    store16_l<P>(c.win + row * LdsT<P>::WIN_S + half * (4 * (int)sizeof(P)), px);
+    win_store<P>(c, ws);
     tab_store<P>(c, ts);
     lds_handover();
-    c.relX = c.bx - wx;
-    c.relY = c.by - wy;
 }
 
 // make sure every block within `ext` pixels of displacement (mx,my) lies in the staged window
@@ -378,7 +399,7 @@ template <typename P> __device__ __forceinline__ void stage_subpel(BlockCtx<P>& 
     Px16<P> px;
     if (lane < 4 * SUB_ROWS)
         px = load16_g<P>(c.base, c.padOffset + plane * c.planeSize + (sy + row) * c.stride + sx);
-    const TabStage ts = tab_load<P>(c, bqx, bqy);
+    const TabStage ts = tab_load<P>(c, bqx - c.mvpx, bqy - c.mvpy);
     lds_handover();
     if (lane < 4 * SUB_ROWS)
         store16_l<P>(c.sub + lane * LdsT<P>::SUB_S, px);
@@ -650,7 +671,7 @@ template <typename P> __device__ __forceinline__ void dia_search(BlockCtx<P>& c,
 // with the predictor candidates so they cost no memory round trip of their own.
 template <typename P, int METHOD>
 __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, int mvpy, int merange,
-                                                      int zeroSad, int zeroSatd, int& outx, int& outy)
+                                                      int zeroSad, int zeroSatd, int mvpSad, int mv0cost, int& outx, int& outy)
 {
     c.mvpx = mvpx;
     c.mvpy = mvpy;
@@ -658,40 +679,33 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     const int pmvx = clampi(mvpx, qminx, qmaxx), pmvy = clampi(mvpy, qminy, qmaxy);
     int bmx = (pmvx + 2) >> 2, bmy = (pmvy + 2) >> 2;
     const int pfx = bmx, pfy = bmy;      // predictor rounded to full pel
-    int bcost, bprecost, mv0cost;
+    int bcost, bprecost;
     int preKey, preX, preY;
     bool hexValid = METHOD == X265GPU_HEX;
+    tab_bias<P>(c);
     {
-        // One pass.  Group 0: the clipped quarter-pel predictor (SAD only, no MV cost), read
-        // from global memory while the window loads are in flight.  Group 1: the predictor
-        // rounded to full pel (used when it has a sub-pel part).  Groups 2..7: the first
-        // hexagon around the rounded predictor, measured speculatively: it is what the
-        // hexagon search needs next unless the zero vector takes over as start point.
         const bool sub = ((pmvx | pmvy) & 3) != 0, nz = (pmvx | pmvy) != 0;
-        const Row<P> g0 = cand_row<P>(c, pmvx, pmvy, c.g == 0);
-        const int t0 = price_lanes_g<P>(c, 0, 0, c.g == 0);      // table entries of mvcost(0,0)
-        stage_search<P>(c, bmx, bmy);
+        // the start cost is the SAD (no MV cost) of the block the clipped predictor points at:
+        // the caller measured it unless clipping moved the predictor
+        bprecost = mvpSad;
+        if (pmvx != mvpx || pmvy != mvpy)
+            bprecost = group_value<0>(sad8x8<P>(c.fr, cand_row<P>(c, pmvx, pmvy, c.g == 0)));
+        // One pass out of the window (staged by the caller around a guess; re-staged here if the
+        // guess was off).  Group 1: the predictor rounded to full pel (used when it has a sub-pel
+        // part).  Groups 2..7: the first hexagon around it, measured speculatively: it is what the
+        // hexagon search needs next unless the zero vector takes over as start point.
+        ensure_window<P>(c, bmx, bmy, 2);
         const int hi = (c.g >= 2) ? c.g - 2 : 6;      // index 6 of the tables is (0,0)
         preX = bmx + nib(HEX6_X, hi);
         preY = bmy + nib(HEX6_Y, hi);
-        Row<P> ref = win_row<P>(c, preX, preY);
-        int t = price_lanes<P>(c, preX * 4, preY * 4);
-        if (c.g == 0)
-        {
-            ref = g0;
-            t = 0;
-        }
-        const int cost = reduce_cost<P, EV_SAD>(c, ref, t);
-        mv0cost = group_value<0>(t0 + dpp<DPP_XOR1>(t0));
-        const int c0 = group_value<0>(cost), c1 = group_value<1>(cost);
+        const int cost = reduce_cost<P, EV_SAD>(c, win_row<P>(c, preX, preY), price_lanes<P>(c, preX * 4, preY * 4));
         preKey = KEY_INVALID;
         if (METHOD == X265GPU_HEX)
         {
             const bool ok = c.g >= 2 && (unsigned)(preY - c.miny) <= (unsigned)c.yr;
             preKey = wave_min(ok ? make_key(cost, c.g, c.g) : KEY_INVALID);
         }
-        bprecost = c0;
-        bcost = sub ? c1 : c0;
+        bcost = sub ? group_value<1>(cost) : bprecost;
         if (nz && zeroSad + mv0cost < bcost)
         {
             const int zy = max(min(0, c.maxy), c.miny);
@@ -771,9 +785,15 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     return bcost;
 }
 
-template <typename P, int METHOD>
+// ROWS: the caller walks a block row right to left inside one launch while other
+// waves walk the rows below it.  The right neighbour's vector then comes in
+// (rightX,rightY) from the previous step, the vectors of the row below are read
+// with L1-bypassing (sc1) loads, and this block's vector is stored write-through
+// and handed back in (rightX,rightY).
+template <typename P, int METHOD, bool ROWS>
 __device__ __forceinline__ void search_block(const SearchJob& job, const Geometry& g, int level0, int cuX, int cuY,
-                                             int lane, const uint16_t* costTab, int maxMvd, XG_LDS uint32_t* lds)
+                                             int lane, const uint16_t* costTab, int maxMvd, XG_LDS uint32_t* lds,
+                                             int& rightX, int& rightY, XG_GLOBAL int* rowCount = nullptr, int done = 0)
 {
     const int W = level0 ? g.W4 : g.W, H = level0 ? g.H4 : g.H;
     const int stride = level0 ? g.stride4 : g.stride;
@@ -802,7 +822,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     c.sub = lds + WaveLds<P>::WIN_DW;
     c.tab = lds + WaveLds<P>::WIN_DW + WaveLds<P>::SUB_DW;
     c.relX = c.relY = c.subRelX = c.subRelY = NOT_STAGED;
-    c.tabBiasX = c.tabBiasY = 0;
+    c.tabLoX = c.tabLoY = c.tabBiasX = c.tabBiasY = 0;
     // search bounds that stay inside the extended frame (slicetype.cpp:4417-4420)
     c.minx = -cuX * 8 - 8;
     c.miny = -cuY * 8 - 8;
@@ -830,7 +850,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         }
     }
     int mvpx = 0, mvpy = 0, skipCost = 0x7fffffff;
-    int zeroSad, zeroSatd;
+    int zeroSad, zeroSatd, mvpSad, mv0cost;
     {
         // one pass: groups 0..4 = the predictor candidates (SATD); group 5 = the
         // block at displacement (0,0) in the plane the closing zero-vector check
@@ -838,7 +858,22 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         const int off = (c.g == 0) ? 1 : (c.g == 1) ? W : (c.g == 2) ? W - 1 : W + 1;
         const bool mine = (c.g == 0) ? v0 : (c.g == 1) ? v1 : (c.g == 2) ? v2 : (c.g == 3) ? v3 : false;
         int cx = 0, cy = 0;
-        if (mine)
+        if (ROWS)
+        {
+            if (mine && c.g != 0)
+            {
+                const long long v = __hip_atomic_load((const XG_GLOBAL long long*)(mvs + 2 * (cuXY + off)), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+                cx = (int)v;
+                cy = (int)(v >> 32);
+            }
+            if (c.g == 0)
+            {
+                cx = rightX;     // unused (v0 false) at the first block of a row
+                cy = rightY;
+            }
+        }
+        else if (mine)
         {
             cx = mvs[2 * (cuXY + off)];
             cy = mvs[2 * (cuXY + off) + 1];
@@ -848,13 +883,40 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
             cx = hx;
             cy = hy;
         }
-        Row<P> ref = cand_row<P>(c, cx, cy, mine || (c.g == 4 && v4) || c.g == 6);
+        // A guess at where the search will start, so that its window can be in flight together
+        // with the candidate blocks: the first neighbour vector, treated the way the predictor
+        // will be.  The MV-cost windows are staged around MVD 0, where a search near its
+        // predictor prices from.
+        int sx = 0, sy = 0;
+        if (v0) { sx = group_value<0>(cx); sy = group_value<0>(cy); }
+        else if (v1) { sx = group_value<1>(cx); sy = group_value<1>(cy); }
+        else if (v4) { sx = group_value<4>(cx); sy = group_value<4>(cy); }
+        sx = (clampi(sx, c.minx * 4, c.maxx * 4) + 2) >> 2;
+        sy = (clampi(sy, c.miny * 4, c.maxy * 4) + 2) >> 2;
+
+        const bool cand = mine || (c.g == 4 && v4);
+        Row<P> ref = cand_row<P>(c, cx, cy, cand || c.g == 6);
         if (c.g == 5)
             ref = load_row_g<P>(as_global<P>(job.zeroRef), c.by * stride + c.bx + c.r * job.zeroStride);
+        // table entries of mvcost(0,0) should this group's vector become the predictor
+        // (group 6 stands in for the zero predictor of a block without neighbours)
+        int t0 = 0;
+        if ((cand || c.g == 6) && c.r < 2)
+            t0 = (int)c.costBase[(unsigned)(clampi(c.r == 0 ? -cx : -cy, -maxMvd, maxMvd) + maxMvd)];
+        const WinStage<P> ws = win_load<P>(c, sx, sy);
+        const TabStage ts = tab_load<P>(c, 0, 0);
+        lds_handover();
+        win_store<P>(c, ws);
+        tab_store<P>(c, ts);
+        lds_handover();
+
         const int cost = reduce_cost<P, EV_SATD>(c, ref, 0);
+        const int sad = sad8x8<P>(c.fr, ref);
+        t0 += dpp<DPP_XOR1>(t0);
         zeroSatd = group_value<5>(cost);
-        zeroSad = group_value<6>(sad8x8<P>(c.fr, ref));
+        zeroSad = group_value<6>(sad);
         int mvpcost = COST_MAX;
+        int wg = 6;
 #define TAKE(G, VALID)                                                                      \
         if (VALID)                                                                          \
         {                                                                                   \
@@ -864,6 +926,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
                 mvpcost = cg;                                                               \
                 mvpx = group_value<G>(cx);                                                  \
                 mvpy = group_value<G>(cy);                                                  \
+                wg = G;                                                                     \
             }                                                                               \
             /* tracks the latest candidate while the running best is the zero vector */    \
             if (!(mvpx | mvpy) && job.bBidir)                                               \
@@ -875,22 +938,41 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         TAKE(3, v3)
         TAKE(4, v4)
 #undef TAKE
+        mvpSad = __builtin_amdgcn_readlane(sad, wg * 8);
+        mv0cost = __builtin_amdgcn_readlane(t0, wg * 8);
     }
 
     int mx, my;
-    int fencCost = motion_estimate_lowres<P, METHOD>(c, mvpx, mvpy, job.merange, zeroSad, zeroSatd, mx, my);
+    int fencCost = motion_estimate_lowres<P, METHOD>(c, mvpx, mvpy, job.merange, zeroSad, zeroSatd, mvpSad, mv0cost, mx, my);
     // bidir skip shortcut (slicetype.cpp:4485-4489)
     if (skipCost < 64 && skipCost < fencCost && job.bBidir)
     {
         fencCost = skipCost;
         mx = my = 0;
     }
+    if (ROWS)
+    {
+        // Announce the `done` blocks before this one: the previous block's vector was stored a
+        // whole search ago, and this drain makes sure of it without waiting on anything new.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+            __hip_atomic_store(rowCount, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (lane == 0)
     {
-        job.mvs[2 * cuXY] = mx;
-        job.mvs[2 * cuXY + 1] = my;
+        if (ROWS)
+            __hip_atomic_store((XG_GLOBAL long long*)(as_global<int32_t>(job.mvs) + 2 * cuXY),
+                               (long long)(((unsigned long long)(unsigned)my << 32) | (unsigned)mx), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        else
+        {
+            job.mvs[2 * cuXY] = mx;
+            job.mvs[2 * cuXY + 1] = my;
+        }
         job.mvCosts[cuXY] = fencCost;
     }
+    rightX = mx;
+    rightY = my;
 }
 
 // grid: (ceil(blocksOnDiagonal / 4), jobs); 4 waves per workgroup, one block each.
@@ -910,8 +992,109 @@ __global__ void __launch_bounds__(256) search_diag_kernel(const SearchJob* jobs,
         return;                       // whole wave leaves together
     const int xq = t - 2 * yq;
     const SearchJob job = jobs[blockIdx.y];
-    search_block<P, METHOD>(job, g, level0, W - 1 - xq, H - 1 - yq, threadIdx.x & 63, costTab, maxMvd,
-                            (XG_LDS uint32_t*)ldsBuf + wave * WaveLds<P>::TOTAL);
+    int rx = 0, ry = 0;
+    search_block<P, METHOD, false>(job, g, level0, W - 1 - xq, H - 1 - yq, threadIdx.x & 63, costTab, maxMvd,
+                                   (XG_LDS uint32_t*)ldsBuf + wave * WaveLds<P>::TOTAL, rx, ry);
+}
+
+// ---- one launch for all anti-diagonals ------------------------------------------
+// Work item = one block row of one job; items are handed out in the order (row from
+// the bottom, job), so whoever holds an item only ever waits for an item that was
+// handed out before it, to a wave that is running: no launch-order or residency
+// assumption is needed for progress.  A wave walks its row right to left; before
+// block x' it needs the row below to have finished x' + 2 blocks (below-left is the
+// last of the three vectors it reads there).  Every row publishes its count of
+// finished blocks in sync[SYNC_ROWS + job * H + row]; a block is counted one search
+// later, when its vector's write-through store has certainly drained, so that the
+// publishing wave never sits waiting for that store.
+constexpr int SYNC_HEAD = 0, SYNC_ERROR = 64, SYNC_ROWS = 128;   // each on 256-byte lines of its own
+constexpr int POLL_LIMIT = 1 << 20;
+
+template <typename P, int METHOD>
+__device__ __forceinline__ void search_rows_body(const SearchJob* jobs, int nJobs, const Geometry& g, int level0,
+                                                 const uint16_t* costTab, int maxMvd, int* sync, XG_LDS uint32_t* lds)
+{
+    const int W = level0 ? g.W4 : g.W, H = level0 ? g.H4 : g.H;
+    const int lane = threadIdx.x & 63;
+    XG_GLOBAL int* gsync = (XG_GLOBAL int*)sync;
+    const int nItems = nJobs * H;
+    bool gaveUp = false;
+    for (;;)
+    {
+        int item = 0;
+        if (lane == 0)
+            item = __hip_atomic_fetch_add(gsync + SYNC_HEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= nItems)
+            break;
+        const int yq = item / nJobs, jobIdx = item - yq * nJobs;
+        const SearchJob job = jobs[jobIdx];
+        XG_GLOBAL int* prog = gsync + SYNC_ROWS + jobIdx * H + yq;     // this row's count; the row below is prog[-1]
+        const bool waits = yq > 0;
+        int seen = 0, ahead = 0, rx = 0, ry = 0;
+        for (int xq = 0; xq < W; xq++)
+        {
+            if (waits && !gaveUp)
+            {
+                const int need = min(xq + 2, W);
+                seen = max(seen, __builtin_amdgcn_readfirstlane(ahead));     // the read put in flight one block ago
+                int polls = 0;
+                while (seen < need)
+                {
+                    seen = __hip_atomic_load(prog - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    seen = __builtin_amdgcn_readfirstlane(seen);
+                    if (seen >= need)
+                        break;
+                    // never expected: rather than hang the device, stop waiting (here and, through the
+                    // error word, in every other wave) and report it; the host discards the results
+                    if ((++polls & 1023) == 0)
+                    {
+                        int err = __hip_atomic_load(gsync + SYNC_ERROR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        err = __builtin_amdgcn_readfirstlane(err);
+                        if (err || polls > POLL_LIMIT)
+                        {
+                            if (lane == 0)
+                                __hip_atomic_store(gsync + SYNC_ERROR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            gaveUp = true;
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                asm volatile("" ::: "memory");
+                // look at the row below's count again while this block is searched
+                if (seen < W)
+                    ahead = __hip_atomic_load(prog - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            search_block<P, METHOD, true>(job, g, level0, W - 1 - xq, H - 1 - yq, lane, costTab, maxMvd, lds, rx, ry, prog, xq);
+        }
+        // the last vector's store must have left before the count that announces it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+            __hip_atomic_store(prog, W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// 8 workgroups per compute unit need at most 80 SGPRs and 64 VGPRs
+template <typename P, int METHOD>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8)))
+search_rows_kernel(const SearchJob* jobs, int nJobs, Geometry g, int level0, const uint16_t* costTab, int maxMvd, int* sync)
+{
+    __shared__ uint32_t ldsBuf[4 * WaveLds<P>::TOTAL];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    search_rows_body<P, METHOD>(jobs, nJobs, g, level0, costTab, maxMvd, sync,
+                                (XG_LDS uint32_t*)ldsBuf + wave * WaveLds<P>::TOTAL);
+}
+
+// the multi-hexagon search does not fit that register budget without spilling to scratch
+template <typename P, int METHOD>
+__global__ void __launch_bounds__(256)
+search_rows_kernel_wide(const SearchJob* jobs, int nJobs, Geometry g, int level0, const uint16_t* costTab, int maxMvd, int* sync)
+{
+    __shared__ uint32_t ldsBuf[4 * WaveLds<P>::TOTAL];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    search_rows_body<P, METHOD>(jobs, nJobs, g, level0, costTab, maxMvd, sync,
+                                (XG_LDS uint32_t*)ldsBuf + wave * WaveLds<P>::TOTAL);
 }
 
 template <typename P, int METHOD>
@@ -931,6 +1114,52 @@ static void launch_diag_method(int method, hipStream_t s, dim3 grid, const Searc
         launch_diag<P, X265GPU_UMH>(s, grid, dJobs, g, level0, t, costTab, maxMvd);
     else
         launch_diag<P, X265GPU_HEX>(s, grid, dJobs, g, level0, t, costTab, maxMvd);
+}
+
+template <typename P>
+static void launch_rows_method(int method, hipStream_t s, int blocks, const SearchJob* dJobs, int n, const Geometry& g,
+                               int level0, const uint16_t* costTab, int maxMvd, int* sync)
+{
+    if (method == X265GPU_DIA)
+        hipLaunchKernelGGL((search_rows_kernel<P, X265GPU_DIA>), dim3(blocks), dim3(256), 0, s, dJobs, n, g, level0, costTab,
+                           maxMvd, sync);
+    else if (method == X265GPU_UMH)
+        hipLaunchKernelGGL((search_rows_kernel_wide<P, X265GPU_UMH>), dim3(blocks), dim3(256), 0, s, dJobs, n, g, level0, costTab,
+                           maxMvd, sync);
+    else
+        hipLaunchKernelGGL((search_rows_kernel<P, X265GPU_HEX>), dim3(blocks), dim3(256), 0, s, dJobs, n, g, level0, costTab,
+                           maxMvd, sync);
+}
+
+size_t search_rows_sync_bytes(const Geometry& g, int n)
+{
+    const int H = g.H > g.H4 ? g.H : g.H4;
+    return sizeof(int) * ((size_t)SYNC_ROWS + (size_t)n * H);
+}
+
+hipError_t launch_search_rows(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0,
+                              int method, const uint16_t* costTab, int maxMvd, int* dSync, int* launches)
+{
+    if (n <= 0)
+        return hipSuccess;
+    const int H = level0 ? g.H4 : g.H;
+    // the error word survives from call to call; head and row counts start at zero
+    hipError_t e = hipMemsetAsync(dSync + SYNC_HEAD, 0, sizeof(int) * 64, s);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(dSync + SYNC_ROWS, 0, sizeof(int) * (size_t)n * H, s);
+    if (e != hipSuccess)
+        return e;
+    const int items = n * H;
+    int blocks = (items + 3) / 4;
+    if (blocks > 2048)
+        blocks = 2048;          // 8 workgroups on each of 256 compute units; more would only queue
+    if (bpp == 1)
+        launch_rows_method<uint8_t>(method, s, blocks, dJobs, n, g, level0, costTab, maxMvd, dSync);
+    else
+        launch_rows_method<uint16_t>(method, s, blocks, dJobs, n, g, level0, costTab, maxMvd, dSync);
+    if (launches)
+        (*launches)++;
+    return hipGetLastError();
 }
 
 hipError_t launch_search(hipStream_t s, const SearchStreams& aux, const Geometry& g, int bpp, const SearchJob* dJobs, int n,

@@ -67,6 +67,11 @@ struct x265gpu_ctx
     int64_t profLaunches[X265GPU_PHASE_COUNT] = { 0, 0, 0, 0 };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     SearchStreams searchAux;
+    // single-launch search: row-progress words on the device, and its sticky error word mirrored here
+    bool searchRows = false;
+    int* searchSync = nullptr;
+    size_t searchSyncBytes = 0;
+    int* searchErrHost = nullptr;     // pinned
 };
 
 namespace {
@@ -167,6 +172,39 @@ int alloc_slot(x265gpu_ctx* ctx, Slot& s)
     s.rowPartials = (long long*)(s.base + oRowPartials);
     s.sums = (long long*)(s.base + oSums);
     s.weighted.assign(D, nullptr);
+    return X265GPU_OK;
+}
+
+int ensure_search_sync(x265gpu_ctx* ctx, int n)
+{
+    const size_t bytes = align256(search_rows_sync_bytes(ctx->g, n));
+    if (bytes <= ctx->searchSyncBytes)
+        return X265GPU_OK;
+    if (ctx->searchSync)
+    {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(ctx->searchSync));
+        ctx->searchSync = nullptr;
+        ctx->searchSyncBytes = 0;
+    }
+    HIPCHK(hipMalloc((void**)&ctx->searchSync, bytes));
+    HIPCHK(hipMemsetAsync(ctx->searchSync, 0, bytes, ctx->stream));
+    ctx->searchSyncBytes = bytes;
+    return X265GPU_OK;
+}
+
+// queue a read-back of the search's sticky error word; valid after the next stream synchronise
+int fetch_search_error(x265gpu_ctx* ctx)
+{
+    if (ctx->searchSync)
+        HIPCHK(hipMemcpyAsync(ctx->searchErrHost, ctx->searchSync + SEARCH_SYNC_ERROR, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    return X265GPU_OK;
+}
+
+int check_search_error(x265gpu_ctx* ctx)
+{
+    if (ctx->searchErrHost && ctx->searchErrHost[0])
+        return fail(ctx, X265GPU_ERR_DEVICE, "search: a wait for the row below ran out; results are invalid");
     return X265GPU_OK;
 }
 
@@ -329,6 +367,18 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
                 break;
             }
         }
+        {
+            // "rows": one launch for the whole search with in-launch hand-off between block rows;
+            // default: one launch per anti-diagonal (the faster of the two as measured)
+            const char* e = getenv("X265GPU_SEARCH_MODE");
+            ctx->searchRows = e && !strcmp(e, "rows");
+            if (hipHostMalloc((void**)&ctx->searchErrHost, 64) != hipSuccess)
+            {
+                rc = X265GPU_ERR_NOMEM;
+                break;
+            }
+            ctx->searchErrHost[0] = 0;
+        }
         if (hipMalloc((void**)&ctx->scalar, 256) != hipSuccess)
         {
             rc = X265GPU_ERR_NOMEM;
@@ -383,6 +433,8 @@ void x265gpu_close(x265gpu_ctx* ctx)
         if (ctx->searchAux.side[k]) (void)hipStreamDestroy(ctx->searchAux.side[k]);
     }
     if (ctx->searchAux.fork) (void)hipEventDestroy(ctx->searchAux.fork);
+    if (ctx->searchSync) (void)hipFree(ctx->searchSync);
+    if (ctx->searchErrHost) (void)hipHostFree(ctx->searchErrHost);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -415,8 +467,11 @@ int x265gpu_sync(x265gpu_ctx* ctx)
 {
     if (!ctx)
         return X265GPU_ERR_ARG;
+    int rc = fetch_search_error(ctx);
+    if (rc)
+        return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    return X265GPU_OK;
+    return check_search_error(ctx);
 }
 
 int x265gpu_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd)
@@ -688,7 +743,21 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
     if (rc)
         return rc;
 
-    if (!sj.empty())
+    if (!sj.empty() && ctx->searchRows)
+    {
+        rc = ensure_search_sync(ctx, (int)sj.size());
+        if (rc)
+            return rc;
+        PhaseTimer pt(ctx, X265GPU_PHASE_SEARCH);
+        int launches = 0;
+        if (!sj4.empty())
+            HIPCHK(launch_search_rows(ctx->stream, g, ctx->bpp, (const SearchJob*)ctx->jobBuf, (int)sj4.size(), 1,
+                                      sj4[0].method, ctx->costCentre, ctx->maxMvd, ctx->searchSync, &launches));
+        HIPCHK(launch_search_rows(ctx->stream, g, ctx->bpp, (const SearchJob*)(ctx->jobBuf + s4Bytes), (int)sj.size(), 0,
+                                  sj[0].method, ctx->costCentre, ctx->maxMvd, ctx->searchSync, &launches));
+        pt.stop(launches);
+    }
+    else if (!sj.empty())
     {
         PhaseTimer pt(ctx, X265GPU_PHASE_SEARCH);
         int launches = 0;
@@ -721,7 +790,13 @@ int x265gpu_estimate_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* r
         return rc;
     HIPCHK(hipMemcpyAsync(ctx->batchSumsHost, ctx->batchSums, (size_t)n * 3 * sizeof(long long),
                           hipMemcpyDeviceToHost, ctx->stream));
+    rc = fetch_search_error(ctx);
+    if (rc)
+        return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    rc = check_search_error(ctx);
+    if (rc)
+        return rc;
     for (int i = 0; i < n; i++)
     {
         long long score = ctx->batchSumsHost[3 * i];

@@ -78,7 +78,6 @@ constexpr int WIN = 32;            // full-pel window side, pixels
 constexpr int WIN_PAD = 12;        // pixels between the window's edge and the centre block
 constexpr int SUB_ROWS = 10;       // sub-pel window: 10 rows x 16 pixels per plane
 constexpr int TAB_N = 200;         // MV-cost entries per axis
-constexpr int TAB_HALF = 100;
 constexpr int NOT_STAGED = 1 << 24;
 
 // Row strides in dwords, chosen odd-ish so that the eight rows of a candidate
@@ -293,15 +292,17 @@ template <typename P> __device__ __forceinline__ int fpel_cost_g(const BlockCtx<
 
 // 25 lanes x 8 entries per axis of the MV-cost table around the MVD (dcx,dcy);
 // load and store halves so that callers can put other loads in flight between them
+// CHUNKS lanes x 8 entries per axis, centred: TAB_N / 8 for a search, 1 (+-4 entries) for the sub-pel steps
 struct TabStage { u32x4_unaligned v; int lox, loy; };
-template <typename P> __device__ __forceinline__ TabStage tab_load(const BlockCtx<P>& c, int dcx, int dcy)
+template <typename P, int CHUNKS = TAB_N / 8>
+__device__ __forceinline__ TabStage tab_load(const BlockCtx<P>& c, int dcx, int dcy)
 {
     TabStage t;
-    t.lox = clampi(dcx - TAB_HALF, -c.maxMvd, c.maxMvd + 1 - TAB_N);
-    t.loy = clampi(dcy - TAB_HALF, -c.maxMvd, c.maxMvd + 1 - TAB_N);
+    t.lox = clampi(dcx - 4 * CHUNKS, -c.maxMvd, c.maxMvd + 1 - 8 * CHUNKS);
+    t.loy = clampi(dcy - 4 * CHUNKS, -c.maxMvd, c.maxMvd + 1 - 8 * CHUNKS);
     const int lane = c.g * 8 + c.r, axis = lane >> 5, k = lane & 31;
     t.v = u32x4_unaligned{ 0, 0, 0, 0 };
-    if (k < TAB_N / 8)
+    if (k < CHUNKS)
         t.v = *(const XG_GLOBAL u32x4_unaligned*)(c.costBase + ((axis ? t.loy : t.lox) + c.maxMvd + 8 * k));
     return t;
 }
@@ -311,10 +312,11 @@ template <typename P> __device__ __forceinline__ void tab_bias(BlockCtx<P>& c)
     c.tabBiasX = -c.mvpx - c.tabLoX;
     c.tabBiasY = -c.mvpy - c.tabLoY + TAB_N;
 }
-template <typename P> __device__ __forceinline__ void tab_store(BlockCtx<P>& c, const TabStage& t)
+template <typename P, int CHUNKS = TAB_N / 8>
+__device__ __forceinline__ void tab_store(BlockCtx<P>& c, const TabStage& t)
 {
     const int lane = c.g * 8 + c.r, axis = lane >> 5, k = lane & 31;
-    if (k < TAB_N / 8)
+    if (k < CHUNKS)
     {
         XG_LDS uint32_t* d = c.tab + axis * (TAB_N / 2) + 4 * k;
         d[0] = t.v.x;
@@ -399,11 +401,11 @@ template <typename P> __device__ __forceinline__ void stage_subpel(BlockCtx<P>& 
     Px16<P> px;
     if (lane < 4 * SUB_ROWS)
         px = load16_g<P>(c.base, c.padOffset + plane * c.planeSize + (sy + row) * c.stride + sx);
-    const TabStage ts = tab_load<P>(c, bqx - c.mvpx, bqy - c.mvpy);
+    const TabStage ts = tab_load<P, 1>(c, bqx - c.mvpx, bqy - c.mvpy);
     lds_handover();
     if (lane < 4 * SUB_ROWS)
         store16_l<P>(c.sub + lane * LdsT<P>::SUB_S, px);
-    tab_store<P>(c, ts);
+    tab_store<P, 1>(c, ts);
     lds_handover();
     c.subRelX = c.bx - sx;
     c.subRelY = c.by - sy;
@@ -830,7 +832,12 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     c.maxy = (H - cuY - 1) * 8 + 8;
     c.xr = c.maxx - c.minx;
     c.yr = c.maxy - c.miny;
-    c.fr = load_row_g<P>(as_global<P>(job.fencPlane0) - padOffset, padOffset + (c.by + c.r) * stride + c.bx);
+    // group 0 reads the encode block; the other groups take their row from it across lanes
+    if (c.g == 0)
+        c.fr = load_row_g<P>(as_global<P>(job.fencPlane0) - padOffset, padOffset + (c.by + c.r) * stride + c.bx);
+#pragma unroll
+    for (int i = 0; i < PixT<P>::NW; i++)
+        c.fr.w[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c.r, (int)c.fr.w[i]);
     unpack_row<P>(c.fr, c.f);
 
     // ---- predictor: lowest-SATD neighbour vector (slicetype.cpp:4438-4476) ----
@@ -875,8 +882,9 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         }
         else if (mine)
         {
-            cx = mvs[2 * (cuXY + off)];
-            cy = mvs[2 * (cuXY + off) + 1];
+            const u32x2_unaligned v = *(const XG_GLOBAL u32x2_unaligned*)(mvs + 2 * (cuXY + off));
+            cx = (int)v.x;
+            cy = (int)v.y;
         }
         if (c.g == 4)
         {

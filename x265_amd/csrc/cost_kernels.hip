@@ -56,8 +56,7 @@ __global__ void __launch_bounds__(256) cost_rows_kernel(const CostJob* jobs, Geo
             const int fc1 = job.mvCosts1[cuXY];
             if (fc1 < bcost) { bcost = fc1; listused = 2; }
 
-            int f[8];
-            unpack_row<P>(load_row<P>((const P*)job.fencPlane0 + (long long)(by + r) * g.stride + bx), f);
+            const Cols f = pair_cols<P>(load_row<P>((const P*)job.fencPlane0 + (long long)(by + r) * g.stride + bx));
             const int m0x = job.mvs0[2 * cuXY], m0y = job.mvs0[2 * cuXY + 1];
             const int m1x = job.mvs1[2 * cuXY], m1y = job.mvs1[2 * cuXY + 1];
             const bool odd = __any((m0x | m0y | m1x | m1y) & 1) != 0;
@@ -184,8 +183,7 @@ __global__ void __launch_bounds__(256) weight_cost_kernel(WeightCostJob job, Geo
         const int cuXraw = chunk * 8 + grp;
         const int cuX = min(cuXraw, W - 1);
         const long long off = (long long)(8 * cuY + r) * g.stride + 8 * cuX;
-        int f[8];
-        unpack_row<P>(load_row<P>((const P*)job.fencPlane0 + off), f);
+        const Cols f = pair_cols<P>(load_row<P>((const P*)job.fencPlane0 + off));
         const int satd = satd8x8<P>(f, load_row<P>((const P*)job.refPlane0 + off), r);
         if (cuXraw < W && r == 0)
             acc += (unsigned int)min(satd, job.intraCost[cuX + cuY * W]);

@@ -160,46 +160,91 @@ template <typename P> __device__ __forceinline__ int sad8x8(const Row<P>& fenc, 
     return group_sum8(sad_row<P>(fenc, ref));
 }
 
+// ---- 8x8 SATD on packed 16-bit lanes ---------------------------------------------
 // 8x8 SATD = two 8x4 halves, each (sum of |4x4 Hadamard| over its two 4x4
-// blocks) >> 1: source/common/pixel.cpp:239-261, 277-289.  `f` is this lane's
-// unpacked encode row, `r` its lane index inside the group (row number).
-// Horizontal transform in registers, vertical transform across the four lanes
-// of a quad.  `extra` (any per-lane values) is added to the result: it enters
-// doubled ahead of the halving, which is exact, so that it rides on the same
-// reduction and every lane of the group ends up with SATD + sum(extra).
-template <typename P> __device__ __forceinline__ int satd8x8(const int f[8], const Row<P>& ref, int r, int extra = 0)
+// blocks) >> 1: source/common/pixel.cpp:239-261, 277-289.
+//
+// A lane holds row r of the block as four "column pairs": q[i] = (pixel i,
+// pixel i + 4) in the low and high 16 bits, i.e. the same column of the left and
+// the right 4x4 block, so that every butterfly of the horizontal transform is a
+// packed add/sub between two registers.  The vertical transform runs across the
+// four lanes of a quad (rows r ^ 1, then r ^ 2).  Its last butterfly is never
+// formed: |a + b| + |a - b| = 2 max(|a|, |b|), so both lanes of a pair add
+// max(|a|, |b|).  Values stay within 16 bits for 8-, 10- and 12-bit pixels
+// (8 * 4095 = 32760 ahead of that last step).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+struct Cols { uint32_t q[4]; };
+
+template <typename P> __device__ __forceinline__ Cols pair_cols(const Row<P>& r);
+template <> __device__ __forceinline__ Cols pair_cols<uint8_t>(const Row<uint8_t>& r)
 {
-    int d[8];
-    unpack_row<P>(ref, d);
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        d[i] = f[i] - d[i];
-#pragma unroll
-    for (int h = 0; h < 8; h += 4)
+    Cols c;   // selector bytes: 0-3 = bytes of the second operand, 4-7 = of the first, 0x0c = zero
+    c.q[0] = __builtin_amdgcn_perm(r.w[1], r.w[0], 0x0c040c00u);
+    c.q[1] = __builtin_amdgcn_perm(r.w[1], r.w[0], 0x0c050c01u);
+    c.q[2] = __builtin_amdgcn_perm(r.w[1], r.w[0], 0x0c060c02u);
+    c.q[3] = __builtin_amdgcn_perm(r.w[1], r.w[0], 0x0c070c03u);
+    return c;
+}
+template <> __device__ __forceinline__ Cols pair_cols<uint16_t>(const Row<uint16_t>& r)
+{
+    Cols c;
+    c.q[0] = __builtin_amdgcn_perm(r.w[2], r.w[0], 0x05040100u);
+    c.q[1] = __builtin_amdgcn_perm(r.w[2], r.w[0], 0x07060302u);
+    c.q[2] = __builtin_amdgcn_perm(r.w[3], r.w[1], 0x05040100u);
+    c.q[3] = __builtin_amdgcn_perm(r.w[3], r.w[1], 0x07060302u);
+    return c;
+}
+
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+// SATD core on packed difference columns v[0..3]; `extra` (any per-lane values) is added to
+// the result: it enters doubled ahead of the halving, which is exact, so that it rides on the
+// same reduction.  Every lane of the group ends up with SATD + sum(extra).
+__device__ __forceinline__ int satd8x8_cols(s16x2 v0, s16x2 v1, s16x2 v2, s16x2 v3, int r, int extra)
+{
     {
-        int a0 = d[h] + d[h + 1], a1 = d[h] - d[h + 1];
-        int a2 = d[h + 2] + d[h + 3], a3 = d[h + 2] - d[h + 3];
-        d[h] = a0 + a2;
-        d[h + 1] = a1 + a3;
-        d[h + 2] = a0 - a2;
-        d[h + 3] = a1 - a3;
+        const s16x2 a0 = v0 + v1, a1 = v0 - v1, a2 = v2 + v3, a3 = v2 - v3;
+        v0 = a0 + a2;
+        v1 = a1 + a3;
+        v2 = a0 - a2;
+        v3 = a1 - a3;
     }
-    const int m1 = -(r & 1), m2 = -((r >> 1) & 1);   // 0 or -1: negate own value on odd partner
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        d[i] = ((d[i] ^ m1) - m1) + dpp<DPP_XOR1>(d[i]);
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        d[i] = ((d[i] ^ m2) - m2) + dpp<DPP_XOR2>(d[i]);
-    int s = 2 * extra;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        s += abs(d[i]);
-    s += dpp<DPP_XOR1>(s);
-    s += dpp<DPP_XOR2>(s);
-    s >>= 1;
-    s += dpp<DPP_HALF_MIRROR>(s);
-    return s;
+    // rows r ^ 1: even rows form x + partner, odd rows partner - x
+    const short sgn = (r & 1) ? (short)-1 : (short)1;
+    const s16x2 s1 = { sgn, sgn };
+    v0 = as_s16x2((uint32_t)dpp<DPP_XOR1>((int)as_u32(v0))) + s1 * v0;
+    v1 = as_s16x2((uint32_t)dpp<DPP_XOR1>((int)as_u32(v1))) + s1 * v1;
+    v2 = as_s16x2((uint32_t)dpp<DPP_XOR1>((int)as_u32(v2))) + s1 * v2;
+    v3 = as_s16x2((uint32_t)dpp<DPP_XOR1>((int)as_u32(v3))) + s1 * v3;
+    // rows r ^ 2, folded into the absolute sum
+    uint32_t s = 2u * (uint32_t)extra;
+    const s16x2 zero = { 0, 0 };
+#define XG_SATD_LAST(V)                                                                       \
+    {                                                                                         \
+        const s16x2 ab = __builtin_elementwise_max(V, zero - V);                              \
+        const s16x2 pb = as_s16x2((uint32_t)dpp<DPP_XOR2>((int)as_u32(ab)));                  \
+        s = __builtin_amdgcn_sad_u16(as_u32(__builtin_elementwise_max(ab, pb)), 0u, s);       \
+    }
+    XG_SATD_LAST(v0)
+    XG_SATD_LAST(v1)
+    XG_SATD_LAST(v2)
+    XG_SATD_LAST(v3)
+#undef XG_SATD_LAST
+    int t = (int)s;
+    t += dpp<DPP_XOR1>(t);
+    t += dpp<DPP_XOR2>(t);
+    t >>= 1;
+    t += dpp<DPP_HALF_MIRROR>(t);
+    return t;
+}
+
+// `f` = pair_cols of this lane's encode row, `r` its lane index inside the group (row number)
+template <typename P> __device__ __forceinline__ int satd8x8(const Cols& f, const Row<P>& ref, int r, int extra = 0)
+{
+    const Cols d = pair_cols<P>(ref);
+    return satd8x8_cols(as_s16x2(f.q[0]) - as_s16x2(d.q[0]), as_s16x2(f.q[1]) - as_s16x2(d.q[1]),
+                        as_s16x2(f.q[2]) - as_s16x2(d.q[2]), as_s16x2(f.q[3]) - as_s16x2(d.q[3]), r, extra);
 }
 
 // signed 4-bit table packed in a dword, biased by 8

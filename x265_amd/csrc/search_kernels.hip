@@ -56,7 +56,7 @@ struct BlockCtx
     int stride;
     int minX, maxX, minY, maxY;    // legal block origins (inside the padded buffer)
     Row<P> fr;                     // this lane's encode row, packed
-    int f[8];                      // and unpacked
+    Cols f;                        // and as 16-bit column pairs for the SATD
     int bx, by;                    // block origin in pixels (wave-uniform)
     int g, r;                      // candidate group and row of this lane
     int minx, miny, maxx, maxy;    // full-pel search bounds mvmin / mvmax (wave-uniform)
@@ -838,7 +838,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
 #pragma unroll
     for (int i = 0; i < PixT<P>::NW; i++)
         c.fr.w[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c.r, (int)c.fr.w[i]);
-    unpack_row<P>(c.fr, c.f);
+    c.f = pair_cols<P>(c.fr);
 
     // ---- predictor: lowest-SATD neighbour vector (slicetype.cpp:4438-4476) ----
     const XG_GLOBAL int32_t* mvs = as_global<int32_t>(job.mvs);

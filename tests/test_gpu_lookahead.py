@@ -181,3 +181,57 @@ def test_hme_two_level(depth, methods, ranges):
     finally:
         ctx.close()
         ref.close()
+
+
+def test_weighted_prediction():
+    """weightp: the host guess loop over x265gpu_weight_cost / x265gpu_weight_planes, then searches against
+    the weighted planes (slicetype.cpp:870-971, 4302-4304, 4391).  The clip fades, so weights are found."""
+    W, H, N, depth = 384, 208, 6, 8
+    base = synth.luma_clip(W, H, N, depth, seed=9)[0]
+    rng = np.random.default_rng(3)
+    clip = [np.clip(np.roll(base, i, axis=1).astype(np.int32) * (64 - 6 * i) // 64 + 2 * i + rng.integers(-1, 2, base.shape),
+                    0, 255).astype(np.uint8) for i in range(N)]        # one picture, slow pan, fading
+    param = orc.make_param(W, H, weightp=True)
+    ref = orc.Lookahead(depth, param)
+    ctx = api.Context(W, H, depth=depth, num_slots=N)
+    try:
+        frames = [LowresState(i, i, ctx.D) for i in range(N)]
+        for i, f in enumerate(clip):
+            lr = ref.add_frame(f)
+            v = f.astype(np.int64)
+            ssum = int(v.sum())
+            ssd = int((v * v).sum()) - ssum * ssum // v.size
+            wsum, wssd = lr.wp()
+            wsum[0], wssd[0] = ssum, ssd
+            frames[i].wp_sum, frames[i].wp_ssd = ssum, ssd
+        ctx.set_mvcost(ref.table, ref.centre)
+        PreLookaheadGroup(ctx).process_tasks(frames, clip)
+        est = CostEstimateGroup(ctx, frames, weightp=True)
+        nweighted = 0
+        for (p0, p1, b) in [(0, 1, 1), (0, 2, 2), (0, 2, 1), (1, 3, 3), (1, 3, 2), (0, 5, 5), (2, 5, 3), (3, 4, 4), (2, 4, 4)]:
+            assert est.single_cost(p0, p1, b) == ref.frame_cost(p0, p1, b), (p0, p1, b)
+            _check_request(ref, ctx, frames, p0, p1, b)
+            want = bool(ref.frames[b].i64("isWeighted", b - p0))
+            assert frames[b].weighted.get(b - p0, False) == want, (p0, p1, b)
+            nweighted += want
+        assert nweighted >= 5          # the fade must actually exercise the weighted path
+    finally:
+        ctx.close()
+        ref.close()
+
+
+def test_single_launch_search_mode(monkeypatch):
+    """X265GPU_SEARCH_MODE=rows: the whole search in one launch, rows handing their progress to the row above."""
+    monkeypatch.setenv("X265GPU_SEARCH_MODE", "rows")
+    clip, ref, ctx, frames = _setup(448, 256, 6, 8, seed=21)
+    try:
+        _run_sequence(ref, ctx, frames)
+    finally:
+        ctx.close()
+        ref.close()
+    clip, ref, ctx, frames = _setup(640, 368, 5, 10, seed=22, hme=True)
+    try:
+        _run_sequence(ref, ctx, frames, SEQ[:7])
+    finally:
+        ctx.close()
+        ref.close()

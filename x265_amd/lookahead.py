@@ -7,11 +7,16 @@ the offload boundary, so that parity tests read like calls into the reference:
   CostEstimateGroup.single_cost     <- CostEstimateGroup::singleCost   (slicetype.cpp:4148-4152)
   CostEstimateGroup.add / finish_batch <- ::add / ::finishBatch        (slicetype.cpp:4154-4196)
 
+  LookaheadTLD.weights_analyse      <- LookaheadTLD::weightsAnalyse    (slicetype.cpp:870-971)
+
 The cache check, the bDoSearch decision from the 0x7FFF sentinel, the B-frame
 bias and the intra penalty of estimateFrameCost (slicetype.cpp:4284-4383) are
 host logic and live here; pixels never do.  Each frame of the window owns one
 device slot.
 """
+import numpy as np
+
+_f32 = np.float32
 
 
 class LowresState:
@@ -25,6 +30,68 @@ class LowresState:
         self.cost_est_aq = {}
         self.intra_mbs = [0] * D
         self.pending = set()                                     # (d0, d1) submitted, not fetched
+        # luma sum and sum of squared deviations of the source frame, as calcAdaptiveQuantFrame
+        # leaves them in Lowres::wp_sum[0] / wp_ssd[0] (slicetype.cpp:600-611); host inputs
+        self.wp_sum = 0
+        self.wp_ssd = 0
+        self.weighted = {}                                       # d0 -> weightedRef[d0].isWeighted
+        self.weighted_cost_delta = {}
+
+
+class LookaheadTLD:
+    """weightsAnalyse: the float guess logic stays on the host, in single precision as in the
+    reference; the two pixel passes (weightCostLuma, weight_pp) run on the device."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def weights_analyse(self, fenc, ref):
+        ctx = self.ctx
+        g = ctx.geom
+        delta = fenc.poc - ref.poc
+        fenc.weighted[delta] = False
+        epsilon = _f32(1.0) / _f32(128.0)
+        shift = _f32(1 << (ctx.depth - 8))
+        if fenc.wp_ssd and ref.wp_ssd:
+            guess_scale = np.sqrt(_f32(fenc.wp_ssd) / _f32(ref.wp_ssd))
+        else:
+            guess_scale = _f32(1.0)
+        area = _f32(g.lines * g.width)
+        fenc_mean = _f32(fenc.wp_sum) / area / shift
+        ref_mean = _f32(ref.wp_sum) / area / shift
+        if abs(ref_mean - fenc_mean) < _f32(0.5) and abs(_f32(1.0) - guess_scale) < epsilon:
+            return
+        # WeightParam::setFromWeightAndOffset with normalisation (common/slice.h)
+        w, denom = int(guess_scale * _f32(128) + _f32(0.5)), 7
+        while denom > 0 and w > 127:
+            denom -= 1
+            w >>= 1
+        w = min(w, 127)
+        mindenom, minscale, minoff = denom, w, 0
+        origscore = minscore = ctx.weight_cost(fenc.slot, ref.slot)
+        if not minscore:
+            return
+        cur_scale = minscale
+        cur_offset = int(fenc_mean - ref_mean * _f32(cur_scale) / _f32(1 << mindenom) + _f32(0.5))
+        if cur_offset < -128 or cur_offset > 127:
+            cur_offset = max(-128, min(127, cur_offset))
+            cur_scale = int(_f32(1 << mindenom) * (fenc_mean - _f32(cur_offset)) / ref_mean + _f32(0.5))
+            cur_scale = max(0, min(127, cur_scale))
+        s = ctx.weight_cost(fenc.slot, ref.slot, 1, cur_scale, mindenom, cur_offset)
+        found = False
+        if s < minscore:
+            minscore, minscale, minoff, found = s, cur_scale, cur_offset, True
+        if mindenom > 0 and minscale and not (minscale & 1):
+            idx = (minscale & -minscale).bit_length() - 1
+            sh = min(idx, mindenom)
+            mindenom -= sh
+            minscale >>= sh
+        if not found or (minscale == (1 << mindenom) and minoff == 0) or \
+                _f32(minscore) / _f32(origscore) > _f32(0.998):
+            return
+        fenc.weighted_cost_delta[delta] = minscore // origscore       # integer division, slicetype.cpp:955
+        ctx.weight_planes(fenc.slot, delta, ref.slot, minscale, mindenom, minoff)
+        fenc.weighted[delta] = True
 
 
 class PreLookaheadGroup:
@@ -49,8 +116,9 @@ class PreLookaheadGroup:
 
 
 class CostEstimateGroup:
-    def __init__(self, ctx, frames, ncu_interior=None):
+    def __init__(self, ctx, frames, weightp=False):
         self.ctx = ctx
+        self.tld = LookaheadTLD(ctx) if weightp else None
         self.frames = frames            # list of LowresState indexed like x265's frames[]
         g = ctx.geom
         W, H = g.widthInCU, g.heightInCU
@@ -71,7 +139,13 @@ class CostEstimateGroup:
         if do1:
             fenc.searched[1][d1] = True
         fenc.pending.add((d0, d1))
-        return (self.frames[p0].slot, fenc.slot, self.frames[p1].slot, p0, b, p1, do0, do1, 0)
+        weighted = False
+        if self.tld is not None:               # slicetype.cpp:4300-4304: reset on every request
+            fenc.weighted[d0] = False
+            if do0:
+                self.tld.weights_analyse(fenc, self.frames[p0])
+                weighted = fenc.weighted[d0]
+        return (self.frames[p0].slot, fenc.slot, self.frames[p1].slot, p0, b, p1, do0, do1, int(weighted))
 
     def _collect(self, b, d0, d1, res=None):
         fenc = self.frames[b]

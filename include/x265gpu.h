@@ -42,6 +42,7 @@ extern "C" {
 #define X265GPU_HEX_SEARCH  1
 #define X265GPU_UMH_SEARCH  2
 #define X265GPU_STAR_SEARCH 3
+#define X265GPU_FULL_SEARCH 5
 
 /* where a caller-supplied buffer lives */
 #define X265GPU_MEM_HOST   0
@@ -69,6 +70,8 @@ typedef struct x265gpu_config
     int32_t lookaheadLambda;      /* (int)x265_lambda_tab[X265_LOOKAHEAD_QP]: 1, 16 or 256 */
     int32_t deviceId;
     void*   stream;               /* hipStream_t to run on, or NULL for the library's own */
+    int32_t bKeepFullRes;         /* keep a padded full-resolution luma plane per slot (for x265gpu_pu_motion_estimate) */
+    int32_t reserved;
 } x265gpu_config;
 
 /* Geometry derived exactly as Lowres::create does (source/common/lowres.cpp:84-103). */
@@ -194,6 +197,49 @@ int x265gpu_get_costs(x265gpu_ctx* ctx, int32_t slot, int32_t d0, int32_t d1,
  * context's stream; totals are read back (and optionally reset) here. */
 int x265gpu_profile_enable(x265gpu_ctx* ctx, int32_t on);
 int x265gpu_profile_read(x265gpu_ctx* ctx, int32_t phase, double* ms, int64_t* launches, int32_t reset);
+
+/* ---- full-resolution motion estimation for batches of prediction units ----
+ *
+ * One job = one MotionEstimate::setSourcePU + MotionEstimate::motionEstimate call
+ * on a full-resolution reference (source/encoder/motion.cpp:167-191, 923-1773) as
+ * Search::puMotionEstimation issues them (source/encoder/search.cpp:226-520; with
+ * --threaded-me per CTU-row batch, source/encoder/threadedme.cpp:207-261).  The
+ * caller keeps the AMVP / neighbour logic and Search::setSearchRange
+ * (search.cpp:4969-5022) and passes their results.  Pictures are the slots'
+ * full-resolution planes (config.bKeepFullRes), padded the way PicYuv +
+ * extendPicBorder pad them (margins maxCUSize+32 / maxCUSize+16). */
+typedef struct x265gpu_pu_job
+{
+    int32_t x, y, w, h;                   /* PU rectangle, pixels; w and h multiples of 4, at most 64 */
+    int32_t mvpX, mvpY;                   /* quarter-pel predictor (qmvp) */
+    int32_t mvminX, mvminY, mvmaxX, mvmaxY;   /* full-pel bounds (mvmin / mvmax) */
+    int32_t numCandidates;                /* extra quarter-pel candidates mvc[], at most 12 */
+    int32_t mvc[24];                      /* x, y pairs */
+    int32_t reserved;
+} x265gpu_pu_job;
+
+typedef struct x265gpu_pu_result
+{
+    int32_t mvX, mvY;                     /* outQMv, quarter-pel */
+    int32_t cost;                         /* motionEstimate's return value */
+    int32_t reserved;
+} x265gpu_pu_result;
+
+/* BitCost table for the full-resolution searches (its lambda follows the slice QP,
+ * unlike the lookahead's): same meaning as x265gpu_set_mvcost. */
+int x265gpu_me_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd);
+
+/* searchMethod: X265GPU_DIA_SEARCH, _HEX_, _STAR_ or _FULL_SEARCH (param->searchMethod);
+ * merange: param->searchRange; subpelRefine: param->subpelRefine (0..7, workload table
+ * motion.cpp:48-58).  Results come back in job order; the call returns when they are in `out`. */
+int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t searchMethod,
+                               int32_t merange, int32_t subpelRefine, int32_t n, const x265gpu_pu_job* jobs,
+                               x265gpu_pu_result* out);
+
+/* Copies a slot's padded full-resolution plane to the host (tests): `out` holds
+ * stride * rows pixels, both reported through the pointers. */
+int x265gpu_get_full_plane(x265gpu_ctx* ctx, int32_t slot, void* out, int32_t* stride, int32_t* rows,
+                           int32_t* originX, int32_t* originY);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,8 @@ typedef struct orc_me {
 } orc_me;
 
 void orc_me_init(orc_me* me, const uint16_t* centredCost);
+orc_me* orc_me_create(const uint16_t* centredCost);
+void orc_me_destroy(orc_me* me);
 void orc_me_set_source(orc_me* me, const pixel* fencY, intptr_t stride, intptr_t offset, int w, int h,
                        int method, int searchL0, int searchL1, int refine);
 int  orc_me_buf_satd(orc_me* me, const pixel* ref, intptr_t stride);

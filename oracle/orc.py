@@ -93,6 +93,9 @@ def lib(depth=8):
     L.orc_lowres_i64.argtypes = [vp, C.c_char_p, i, i]
     L.orc_lowres_i64.restype = C.c_int64
     L.orc_me_init.argtypes = [vp, vp]
+    L.orc_me_create.argtypes = [vp]
+    L.orc_me_create.restype = vp
+    L.orc_me_destroy.argtypes = [vp]
     L.orc_me_set_source.argtypes = [vp, vp, ip, ip, i, i, i, i, i, i]
     L.orc_motion_estimate.argtypes = [vp, C.POINTER(RefPlanes), MV, MV, MV, i, vp, i, C.POINTER(MV), C.c_uint32, i]
     L.orc_motion_estimate.restype = i
@@ -244,3 +247,41 @@ class Lookahead:
         if self.tld:
             self.L.orc_tld_destroy(self.tld)
             self.tld = None
+
+
+class FullResME:
+    """MotionEstimate on full-resolution pictures: setSourcePU + motionEstimate per PU (oracle side).
+
+    fenc / ref are padded planes (2-D arrays) with the picture origin at (originY, originX)."""
+
+    def __init__(self, depth, table, centre, fenc, ref, origin_x, origin_y):
+        self.L = lib(depth)
+        self.table = table
+        self.me = self.L.orc_me_create(C.c_void_p(table.ctypes.data + 2 * centre))
+        self.fenc, self.ref = np.ascontiguousarray(fenc), np.ascontiguousarray(ref)
+        assert self.fenc.shape == self.ref.shape and self.fenc.dtype == pixel_dtype(depth)
+        self.stride = self.fenc.shape[1]
+        self.org = origin_y * self.stride + origin_x
+        item = self.fenc.itemsize
+        self.rp = RefPlanes()
+        self.rp.plane[0] = self.ref.ctypes.data + self.org * item
+        self.rp.stride = self.stride
+        self.rp.isLowres = 0
+        self.rp.isHMELowres = 0
+        self.fenc_org = self.fenc.ctypes.data + self.org * item
+
+    def close(self):
+        if self.me:
+            self.L.orc_me_destroy(self.me)
+            self.me = None
+
+    def estimate(self, x, y, w, h, mvp, mvmin, mvmax, method, merange, subpel, mvc=()):
+        """-> ((mvx, mvy), cost)"""
+        L = self.L
+        L.orc_me_set_source(self.me, C.c_void_p(self.fenc_org), self.stride, y * self.stride + x, w, h,
+                            method, method, method, subpel)
+        arr = (MV * max(1, len(mvc)))(*[MV(int(a), int(b)) for a, b in mvc])
+        out = MV()
+        cost = L.orc_motion_estimate(self.me, C.byref(self.rp), MV(*mvmin), MV(*mvmax), MV(*mvp), len(mvc), arr,
+                                     merange, C.byref(out), 1, 0)
+        return (out.x, out.y), cost

@@ -43,6 +43,16 @@ void orc_me_init(orc_me* me, const uint16_t* centredCost)
     me->subpelRefine = 2;
 }
 
+/* heap-allocated instance for callers that cannot size the struct (ctypes) */
+orc_me* orc_me_create(const uint16_t* centredCost)
+{
+    orc_me* me = (orc_me*)malloc(sizeof(orc_me));
+    orc_me_init(me, centredCost);
+    return me;
+}
+
+void orc_me_destroy(orc_me* me) { free(me); }
+
 /* source/encoder/motion.cpp:167-191 */
 void orc_me_set_source(orc_me* me, const pixel* fencY, intptr_t stride, intptr_t offset, int w, int h,
                        int method, int searchL0, int searchL1, int refine)

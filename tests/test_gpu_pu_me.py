@@ -1,0 +1,99 @@
+"""GPU parity of the full-resolution PU motion estimation against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from x265_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+# every luma PU shape of HEVC inter prediction: 2Nx2N, 2NxN, Nx2N and the AMP splits (source/common/common.h:266-279)
+PU_SHAPES = [(8, 8), (8, 4), (4, 8), (16, 16), (16, 8), (8, 16), (16, 4), (16, 12), (4, 16), (12, 16),
+             (32, 32), (32, 16), (16, 32), (32, 8), (32, 24), (8, 32), (24, 32),
+             (64, 64), (64, 32), (32, 64), (64, 16), (64, 48), (16, 64), (48, 64)]
+
+
+def _pictures(W, H, depth, ctu, seed):
+    clip = synth.luma_clip(W, H, 2, depth, seed=seed)
+    mx, my = ctu + 32, ctu + 16
+    fw, fh = -(-W // ctu) * ctu, -(-H // ctu) * ctu
+    pads = [np.pad(f, ((my, my + fh - H), (mx, mx + fw - W)), mode="edge") for f in clip]   # clamp = pad + extend
+    return clip, pads, mx, my, fw, fh
+
+
+def _jobs(rng, fw, fh, mx, my, merange, count):
+    jobs = []
+    while len(jobs) < count:
+        w, h = PU_SHAPES[rng.integers(len(PU_SHAPES))]
+        x = int(rng.integers(0, (fw - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (fh - h) // 4 + 1)) * 4
+        mvp = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+        # Search::setSearchRange: a window of merange around the predictor, kept inside the padded picture
+        lo = (max((mvp[0] >> 2) - merange, -x - mx + 24), max((mvp[1] >> 2) - merange, -y - my + 24))
+        hi = (min((mvp[0] >> 2) + merange, fw - x - w + mx - 24), min((mvp[1] >> 2) + merange, fh - y - h + my - 24))
+        if lo[0] > hi[0] or lo[1] > hi[1]:
+            continue
+        nc = int(rng.integers(0, 4))
+        mvc = [(int(rng.integers(-60, 61)), int(rng.integers(-60, 61))) for _ in range(nc)]
+        jobs.append((x, y, w, h, mvp, lo, hi, mvc))
+    return jobs
+
+
+def _run(depth, method, merange, subpel, count, seed, size=(416, 240), lam=None):
+    W, H = size
+    ctu = 64
+    clip, pads, mx, my, fw, fh = _pictures(W, H, depth, ctu, seed)
+    table, centre = orc.bitcost_table(depth, lam)
+    ref = orc.FullResME(depth, table, centre, pads[1], pads[0], mx, my)
+    ctx = api.Context(W, H, depth=depth, num_slots=2, ctu=ctu, keep_full_res=True)
+    try:
+        ctx.lowres_init(0, clip[0])
+        ctx.lowres_init(1, clip[1])
+        for k in range(2):
+            plane, ox, oy = ctx.get_full_plane(k)
+            assert (ox, oy) == (mx, my)
+            np.testing.assert_array_equal(plane, pads[k], err_msg="padded full-resolution plane %d" % k)
+        ctx.me_set_mvcost(table, centre)
+        jobs = _jobs(np.random.default_rng(seed), fw, fh, mx, my, merange, count)
+        got = ctx.pu_motion_estimate(1, 0, method, merange, subpel, jobs)
+        for j, g in zip(jobs, got):
+            want = ref.estimate(j[0], j[1], j[2], j[3], j[4], j[5], j[6], method, merange, subpel, j[7])
+            assert g == want, (j, g, want)
+    finally:
+        ctx.close()
+        ref.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("method,merange,subpel", [
+    (orc.STAR, 57, 3),        # --me star --merange 57 --subme 3
+    (orc.HEX, 16, 2),
+    (orc.DIA, 16, 1),
+    (orc.STAR, 24, 7),
+    (orc.HEX, 32, 5),
+])
+def test_pu_motion_estimate(depth, method, merange, subpel):
+    _run(depth, method, merange, subpel, 96, seed=100 + depth + merange)
+
+
+def test_pu_exhaustive_search_and_lambda():
+    """--me full on a small range, with a steeper MV cost (higher QP lambda)."""
+    _run(8, orc.FULL, 6, 4, 24, seed=7, lam=9.5)
+
+
+def test_pu_rejects_bad_jobs():
+    ctx = api.Context(416, 240, num_slots=2, keep_full_res=True)
+    try:
+        table, centre = orc.bitcost_table(8)
+        with pytest.raises(api.X265GpuError):                    # no table yet
+            ctx.pu_motion_estimate(0, 1, api.STAR_SEARCH, 57, 3, [(0, 0, 8, 8, (0, 0), (-4, -4), (4, 4), [])])
+        ctx.me_set_mvcost(table, centre)
+        for bad in [(0, 0, 6, 8, (0, 0), (-4, -4), (4, 4), []),              # width not a multiple of 4
+                    (448, 0, 8, 8, (0, 0), (-4, -4), (4, 4), []),            # outside the picture
+                    (0, 0, 8, 8, (0, 0), (-400, -4), (4, 4), [])]:           # vectors leave the padded plane
+            with pytest.raises(api.X265GpuError):
+                ctx.pu_motion_estimate(0, 1, api.STAR_SEARCH, 57, 3, [bad])
+        with pytest.raises(api.X265GpuError):                    # UMH is not offered on this path
+            ctx.pu_motion_estimate(0, 1, api.UMH_SEARCH, 16, 2, [(0, 0, 8, 8, (0, 0), (-4, -4), (4, 4), [])])
+    finally:
+        ctx.close()

@@ -13,14 +13,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libx265gpu.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
-DIA_SEARCH, HEX_SEARCH, UMH_SEARCH, STAR_SEARCH = 0, 1, 2, 3
+DIA_SEARCH, HEX_SEARCH, UMH_SEARCH, STAR_SEARCH, FULL_SEARCH = 0, 1, 2, 3, 5
 PHASES = ("lowres", "intra", "search", "cost")
 
 EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_weight_cost", "x265gpu_weight_planes",
-    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane",
     "x265gpu_profile_enable", "x265gpu_profile_read",
 )
 
@@ -36,7 +36,7 @@ class Config(C.Structure):
         ("searchMethod", C.c_int32), ("merange", C.c_int32), ("bEnableHME", C.c_int32),
         ("hmeSearchMethod", C.c_int32 * 3), ("hmeRange", C.c_int32 * 3), ("bFrameBias", C.c_int32),
         ("maxSlices", C.c_int32), ("lookaheadLambda", C.c_int32), ("deviceId", C.c_int32),
-        ("stream", C.c_void_p),
+        ("stream", C.c_void_p), ("bKeepFullRes", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -54,6 +54,17 @@ class Request(C.Structure):
         ("p0", C.c_int32), ("b", C.c_int32), ("p1", C.c_int32),
         ("doSearch", C.c_int32 * 2), ("weightedL0", C.c_int32),
     ]
+
+
+class PuJob(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32),
+                ("mvpX", C.c_int32), ("mvpY", C.c_int32), ("mvminX", C.c_int32), ("mvminY", C.c_int32),
+                ("mvmaxX", C.c_int32), ("mvmaxY", C.c_int32), ("numCandidates", C.c_int32), ("mvc", C.c_int32 * 24),
+                ("reserved", C.c_int32)]
+
+
+class PuResult(C.Structure):
+    _fields_ = [("mvX", C.c_int32), ("mvY", C.c_int32), ("cost", C.c_int32), ("reserved", C.c_int32)]
 
 
 class FrameCost(C.Structure):
@@ -94,6 +105,9 @@ def load_library():
     L.x265gpu_get_mvs.argtypes = [vp, i32, i32, i32, vp, vp]
     L.x265gpu_get_hme_mvs.argtypes = [vp, i32, i32, i32, vp, vp]
     L.x265gpu_get_costs.argtypes = [vp, i32, i32, i32, vp, vp, C.POINTER(FrameCost)]
+    L.x265gpu_me_set_mvcost.argtypes = [vp, vp, i32]
+    L.x265gpu_pu_motion_estimate.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.x265gpu_get_full_plane.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.x265gpu_profile_enable.argtypes = [vp, i32]
     L.x265gpu_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     _lib = L
@@ -109,7 +123,7 @@ class Context:
 
     def __init__(self, width, height, depth=8, bframes=4, num_slots=8, search=HEX_SEARCH, merange=16,
                  ctu=64, hme=False, hme_methods=(HEX_SEARCH, UMH_SEARCH, UMH_SEARCH), hme_range=(16, 32, 48),
-                 bframe_bias=0, device=0, stream=None):
+                 bframe_bias=0, device=0, stream=None, keep_full_res=False):
         self.L = load_library()
         cfg = Config()
         cfg.sourceWidth, cfg.sourceHeight, cfg.internalBitDepth = width, height, depth
@@ -122,6 +136,7 @@ class Context:
         cfg.lookaheadLambda = {8: 1, 10: 16, 12: 256}[depth]
         cfg.deviceId = device
         cfg.stream = stream
+        cfg.bKeepFullRes = int(keep_full_res)
         self.cfg = cfg
         self.depth = depth
         self.pix = np.uint8 if depth == 8 else np.uint16
@@ -261,6 +276,38 @@ class Context:
         fc = FrameCost()
         self._chk(self.L.x265gpu_get_costs(self.h, slot, d0, d1, None, None, C.byref(fc)))
         return fc.costEst, fc.costEstAq, fc.intraMbs
+
+    # ---- full-resolution PU motion estimation ----
+    def me_set_mvcost(self, table, centre):
+        t = np.ascontiguousarray(table, np.uint16)
+        max_mvd = min(centre, len(t) - 1 - centre)
+        self._chk(self.L.x265gpu_me_set_mvcost(self.h, C.c_void_p(t.ctypes.data + 2 * centre), max_mvd))
+
+    def pu_motion_estimate(self, slot_fenc, slot_ref, method, merange, subpel, jobs):
+        """jobs: iterable of (x, y, w, h, (mvpx, mvpy), (minx, miny), (maxx, maxy), [(cx, cy), ...]);
+        returns [((mvx, mvy), cost), ...] in job order."""
+        jobs = list(jobs)
+        arr = (PuJob * len(jobs))()
+        for k, (x, y, w, h, mvp, mvmin, mvmax, mvc) in enumerate(jobs):
+            j = arr[k]
+            j.x, j.y, j.w, j.h = x, y, w, h
+            j.mvpX, j.mvpY = mvp
+            j.mvminX, j.mvminY = mvmin
+            j.mvmaxX, j.mvmaxY = mvmax
+            j.numCandidates = len(mvc)
+            for i, (cx, cy) in enumerate(mvc):
+                j.mvc[2 * i], j.mvc[2 * i + 1] = int(cx), int(cy)
+        out = (PuResult * len(jobs))()
+        self._chk(self.L.x265gpu_pu_motion_estimate(self.h, slot_fenc, slot_ref, method, merange, subpel, len(jobs), arr, out))
+        return [((o.mvX, o.mvY), o.cost) for o in out]
+
+    def get_full_plane(self, slot):
+        """-> (padded plane as a 2-D array, originX, originY)"""
+        st, rows, ox, oy = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self.L.x265gpu_get_full_plane(self.h, slot, None, C.byref(st), C.byref(rows), C.byref(ox), C.byref(oy)))
+        out = np.empty((rows.value, st.value), self.pix)
+        self._chk(self.L.x265gpu_get_full_plane(self.h, slot, _ptr(out), None, None, None, None))
+        return out, ox.value, oy.value
 
     # ---- instrumentation ----
     def profile_enable(self, on=True):

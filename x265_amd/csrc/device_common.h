@@ -198,10 +198,12 @@ template <> __device__ __forceinline__ Cols pair_cols<uint16_t>(const Row<uint16
 __device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 
-// SATD core on packed difference columns v[0..3]; `extra` (any per-lane values) is added to
-// the result: it enters doubled ahead of the halving, which is exact, so that it rides on the
-// same reduction.  Every lane of the group ends up with SATD + sum(extra).
-__device__ __forceinline__ int satd8x8_cols(s16x2 v0, s16x2 v1, s16x2 v2, s16x2 v3, int r, int extra)
+// SATD of the 8x4 tile held by a quad of lanes, on packed difference columns v0..v3;
+// r = the lane's row inside the tile.  `extra` (any per-lane values) is added to the
+// result: it enters doubled ahead of the halving, which is exact, so that it rides on
+// the same reduction.  Every lane of the quad ends up with satd_8x4 + sum(extra).
+// A tile whose right half carries zero differences yields satd_4x4 of the left half.
+__device__ __forceinline__ int satd8x4_cols(s16x2 v0, s16x2 v1, s16x2 v2, s16x2 v3, int r, int extra = 0)
 {
     {
         const s16x2 a0 = v0 + v1, a1 = v0 - v1, a2 = v2 + v3, a3 = v2 - v3;
@@ -234,7 +236,13 @@ __device__ __forceinline__ int satd8x8_cols(s16x2 v0, s16x2 v1, s16x2 v2, s16x2 
     int t = (int)s;
     t += dpp<DPP_XOR1>(t);
     t += dpp<DPP_XOR2>(t);
-    t >>= 1;
+    return t >> 1;
+}
+
+// 8x8 = the two 8x4 tiles of a group's two quads
+__device__ __forceinline__ int satd8x8_cols(s16x2 v0, s16x2 v1, s16x2 v2, s16x2 v3, int r, int extra)
+{
+    int t = satd8x4_cols(v0, v1, v2, v3, r, extra);
     t += dpp<DPP_HALF_MIRROR>(t);
     return t;
 }

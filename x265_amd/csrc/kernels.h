@@ -104,6 +104,33 @@ constexpr int SEARCH_SYNC_ERROR = 64;
 size_t search_rows_sync_bytes(const Geometry& g, int n);
 hipError_t launch_search_rows(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0,
                               int method, const uint16_t* costTab, int maxMvd, int* dSync, int* launches);
+// ---- full-resolution PU motion estimation ----
+// same layout as x265gpu_pu_job / x265gpu_pu_result
+struct PuJob
+{
+    int x, y, w, h;                    // PU rectangle in the picture, pixels
+    int mvpx, mvpy;                    // quarter-pel predictor
+    int minx, miny, maxx, maxy;        // full-pel search bounds
+    int numCandidates;                 // extra quarter-pel candidates (at most 12)
+    int mvc[24];
+    int reserved;
+};
+struct PuResult { int mvx, mvy, cost, reserved; };
+struct PuFrame
+{
+    const void* fenc;                  // pixel (0,0) of the padded encode picture
+    const void* ref;                   // pixel (0,0) of the padded reference picture
+    int stride;
+    int width, height;                 // interior of the padded pictures (multiples of the CTU size)
+    int marginX, marginY;
+    int depth;
+    int method, merange, subpelRefine;
+    int maxPasses;                     // largest ceil(tiles / 16) over the batch: sizes the LDS per wave
+};
+hipError_t launch_pad_picture(hipStream_t s, int bpp, const void* src, long long srcStride, void* dst, int stride, int rows,
+                              int width, int height, int marginX, int marginY);
+hipError_t launch_pu_search(hipStream_t s, int bpp, const PuFrame& f, const PuJob* dJobs, int n, const uint16_t* costTab,
+                            int maxMvd, PuResult* dOut);
 hipError_t launch_cost(hipStream_t s, const Geometry& g, int bpp, const CostJob* dJobs, int n);
 hipError_t launch_weight_cost(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJob);
 hipError_t launch_weight_planes(hipStream_t s, const Geometry& g, int bpp, int depth, int nPlanes, const void* src,

@@ -1,0 +1,751 @@
+// Full-resolution motion estimation for batches of prediction units.
+//
+// Replaces MotionEstimate::motionEstimate (source/encoder/motion.cpp:923-1773)
+// for a full-resolution reference: integer search (diamond, hexagon, star or
+// exhaustive) on the reconstructed / source luma plane, then sub-pel refinement
+// by true 8-tap interpolation (MotionEstimate::subpelCompare, motion.cpp:1775-1803,
+// filters of source/common/ipfilter.cpp:79-118, 164-203, 362-369) following the
+// subme workload table (motion.cpp:48-58), and the fork's closing zero-vector
+// check (motion.cpp:1762-1768).  Every PU shape whose width and height are
+// multiples of 4 up to 64x64 is handled.
+//
+// One wave per PU.  The PU is cut into tiles of 8x4 pixels (4x4 when the width
+// is not a multiple of 8, which is also how the reference tiles its SATD,
+// source/common/pixel.cpp:1148-1172); a quad of lanes holds the four rows of a
+// tile, sixteen tiles are measured per pass and a 64x64 PU takes eight passes.
+// The encode block sits in LDS in the packed column-pair form the SATD wants,
+// next to each lane's pixel offset and validity mask, so one candidate costs,
+// per pass, one unaligned row load, four byte permutes and four packed SADs.
+// Candidates are visited one after the other in the reference's order with its
+// strict '<' updates on wave-uniform scalars; the parallelism is across the
+// block's pixels and across PUs.
+#include "device_common.h"
+#include "kernels.h"
+
+#define XG_LDS __attribute__((address_space(3)))
+
+namespace xg {
+
+constexpr int PU_DIA = 0, PU_HEX = 1, PU_STAR = 3;   // x265gpu search method values (anything else: exhaustive)
+
+// luma interpolation taps, source/common/constants.cpp:250-256
+__constant__ short k_lumaTaps[4][8] = {
+    { 0, 0, 0, 64, 0, 0, 0, 0 },
+    { -1, 4, -10, 58, 17, -5, 1, 0 },
+    { -1, 4, -11, 40, 40, -11, 4, -1 },
+    { 0, 1, -5, 17, 58, -10, 4, -1 },
+};
+// hex2, mod6m1, square1, offsets for the two-point refinement of the star search (motion.cpp:63-84)
+__constant__ signed char k_hex2[8][2] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };
+__constant__ signed char k_mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+__constant__ signed char k_square1[9][2] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} };
+__constant__ signed char k_twopoint[16][2] = {
+    {-1,0}, {0,-1}, {-1,-1}, {1,-1}, {-1,0}, {1,0}, {-1,1}, {-1,-1},
+    {1,-1}, {1,1}, {-1,0}, {0,1}, {-1,1}, {1,1}, {1,0}, {0,1},
+};
+// the eight points of one star round in the reference's order (motion.cpp:420-470):
+// direction, whether the point sits at half the round's distance, and its point number
+__constant__ signed char k_star8[8][4] = {
+    { 0, -1, 0, 2 }, { -1, -1, 1, 1 }, { 1, -1, 1, 3 }, { -1, 0, 0, 4 },
+    { 1, 0, 0, 5 }, { -1, 1, 1, 6 }, { 1, 1, 1, 8 }, { 0, 1, 0, 7 },
+};
+// subme workload: half-pel iterations, half-pel directions, quarter-pel iterations, quarter-pel directions,
+// SATD at the half-pel stage (motion.cpp:48-58)
+__constant__ signed char k_workload[8][5] = {
+    { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
+    { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 },
+};
+
+constexpr int PU_REC_DW = 8;   // LDS record per lane and pass: 4 dwords encode column pairs, pixel offset, mask, 2 spare
+
+template <typename P>
+struct PuCtx
+{
+    const XG_GLOBAL P* ref;        // reference picture, pixel (0,0)
+    int stride;
+    int x, y, w, h;                // the PU
+    int minX, maxX, minY, maxY;    // legal block origins (inside the padded picture)
+    int passes;
+    int lane;
+    const XG_LDS uint32_t* rec;    // this wave's records, [pass][lane][PU_REC_DW]
+    int minx, miny, maxx, maxy;    // full-pel search bounds
+    const XG_GLOBAL uint16_t* cx;  // MV-cost table shifted by the predictor: cx[q] = cost[q - mvp.x]
+    const XG_GLOBAL uint16_t* cy;
+    int lo, hi;                    // valid index range of cx/cy is [lo - mvp, hi - mvp]; see mvcost()
+    int mvpx, mvpy;
+    int depth;
+    int bmx, bmy, bcost;           // running best of the integer search
+};
+
+// sum over the wave of per-lane values; the total comes back as a wave-uniform scalar
+__device__ __forceinline__ int wave_sum(int v)
+{
+    v += dpp<DPP_XOR1>(v);
+    v += dpp<DPP_XOR2>(v);
+    v += dpp<DPP_HALF_MIRROR>(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);   // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// BitCost::mvcost (source/encoder/bitcost.h:56): uint16 sum of the two table entries
+template <typename P> __device__ __forceinline__ int mvcost(const PuCtx<P>& c, int qx, int qy)
+{
+    const int dx = clampi(qx - c.mvpx, c.lo, c.hi), dy = clampi(qy - c.mvpy, c.lo, c.hi);
+    return ((int)c.cx[dx + c.mvpx] + (int)c.cy[dy + c.mvpy]) & 0xffff;
+}
+
+// origin of the block displaced by full-pel (mx,my), clamped into the padded picture
+// (a no-op for every vector the reference itself can produce)
+template <typename P> __device__ __forceinline__ const XG_GLOBAL P* block_at(const PuCtx<P>& c, int mx, int my)
+{
+    const int X = clampi(c.x + mx, c.minX, c.maxX), Y = clampi(c.y + my, c.minY, c.maxY);
+    return c.ref + ((long long)Y * c.stride + X);
+}
+
+// ---- 8-tap interpolation of this lane's eight pixels --------------------------------
+template <typename P> __device__ __forceinline__ void load16(const XG_GLOBAL P* p, int v[16])
+{
+    Row<P> a = load_row_g<P>(p, 0), b = load_row_g<P>(p, 8);
+    unpack_row<P>(a, v);
+    unpack_row<P>(b, v + 8);
+}
+
+// `p` points at this lane's first pixel at the vector's full-pel part; (xf,yf) its quarter-pel part
+template <typename P>
+__device__ __forceinline__ Row<P> interp_row(const XG_GLOBAL P* p, int stride, int xf, int yf, int depth)
+{
+    const int maxv = (1 << depth) - 1;
+    int out[8];
+    if (!yf)
+    {
+        // interp_horiz_pp_c, ipfilter.cpp:79-118
+        int in[16];
+        load16<P>(p - 3, in);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+        {
+            int s = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                s += in[i + k] * k_lumaTaps[xf][k];
+            out[i] = clampi((s + 32) >> 6, 0, maxv);
+        }
+    }
+    else if (!xf)
+    {
+        // interp_vert_pp_c, ipfilter.cpp:164-203
+        int acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            int in[8];
+            unpack_row<P>(load_row_g<P>(p, (k - 3) * stride), in);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                acc[i] += in[i] * k_lumaTaps[yf][k];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            out[i] = clampi((acc[i] + 32) >> 6, 0, maxv);
+    }
+    else
+    {
+        // interp_hv_pp_c, ipfilter.cpp:362-369: horizontal pass to 14-bit intermediates, vertical pass back
+        const int headRoom = 14 - depth;
+        const int shiftH = 6 - headRoom;
+        const int offH = -(8192 << shiftH);
+        const int shiftV = 6 + headRoom;
+        const int offV = (1 << (shiftV - 1)) + (8192 << 6);
+        int acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll 1
+        for (int k = 0; k < 8; k++)
+        {
+            int in[16];
+            load16<P>(p + (k - 3) * stride - 3, in);
+            const int ty = k_lumaTaps[yf][k];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+                int s = 0;
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                    s += in[i + t] * k_lumaTaps[xf][t];
+                acc[i] += ((s + offH) >> shiftH) * ty;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            out[i] = clampi((acc[i] + offV) >> shiftV, 0, maxv);
+    }
+    return pack_row<P>(out);
+}
+
+// ---- block compares -------------------------------------------------------------------
+
+// SAD or SATD of the block at quarter-pel (qx,qy) (full-pel when both low bits pairs are 0)
+template <typename P, bool SATD> __device__ __forceinline__ int block_cost(const PuCtx<P>& c, int qx, int qy)
+{
+    const XG_GLOBAL P* base = block_at<P>(c, qx >> 2, qy >> 2);
+    const int xf = qx & 3, yf = qy & 3;
+    uint32_t acc = 0;
+#pragma unroll 1
+    for (int k = 0; k < c.passes; k++)
+    {
+        const XG_LDS uint32_t* r = c.rec + (k * 64 + c.lane) * PU_REC_DW;
+        const uint32_t f0 = r[0], f1 = r[1], f2 = r[2], f3 = r[3], mask = r[5];
+        const int off = (int)r[4];
+        Row<P> row;
+        if (xf | yf)
+            row = interp_row<P>(base + off, c.stride, xf, yf, c.depth);
+        else
+            row = load_row_g<P>(base, off);
+        const Cols d = pair_cols<P>(row);
+        if (SATD)
+        {
+            // invalid lanes and masked halves carry zero differences
+            acc += (uint32_t)satd8x4_cols(as_s16x2(f0) - as_s16x2(d.q[0] & mask), as_s16x2(f1) - as_s16x2(d.q[1] & mask),
+                                          as_s16x2(f2) - as_s16x2(d.q[2] & mask), as_s16x2(f3) - as_s16x2(d.q[3] & mask),
+                                          c.lane & 3);
+        }
+        else
+        {
+            acc = __builtin_amdgcn_sad_u16(f0, d.q[0] & mask, acc);
+            acc = __builtin_amdgcn_sad_u16(f1, d.q[1] & mask, acc);
+            acc = __builtin_amdgcn_sad_u16(f2, d.q[2] & mask, acc);
+            acc = __builtin_amdgcn_sad_u16(f3, d.q[3] & mask, acc);
+        }
+    }
+    if (SATD)
+        acc = (c.lane & 3) ? 0u : acc;      // every lane of a quad holds its tile's value: count it once
+    return wave_sum((int)acc);
+}
+
+template <typename P> __device__ __forceinline__ int fpel_cost(const PuCtx<P>& c, int mx, int my)
+{
+    return block_cost<P, false>(c, mx * 4, my * 4) + mvcost<P>(c, mx * 4, my * 4);
+}
+
+template <typename P> __device__ __forceinline__ int subpel_cost(const PuCtx<P>& c, int qx, int qy, bool satd)
+{
+    return (satd ? block_cost<P, true>(c, qx, qy) : block_cost<P, false>(c, qx, qy)) + mvcost<P>(c, qx, qy);
+}
+
+template <typename P> __device__ __forceinline__ bool y_ok(const PuCtx<P>& c, int y) { return y >= c.miny && y <= c.maxy; }
+template <typename P> __device__ __forceinline__ bool in_range(const PuCtx<P>& c, int x, int y)
+{
+    return x >= c.minx && x <= c.maxx && y >= c.miny && y <= c.maxy;
+}
+
+// COST_MV, motion.cpp:263-269
+template <typename P> __device__ __forceinline__ void try_mv(PuCtx<P>& c, int mx, int my)
+{
+    const int cost = fpel_cost<P>(c, mx, my);
+    if (cost < c.bcost)
+    {
+        c.bcost = cost;
+        c.bmx = mx;
+        c.bmy = my;
+    }
+}
+
+// 8-point square refinement, motion.cpp:1120-1138
+template <typename P> __device__ __forceinline__ void square_refine(PuCtx<P>& c)
+{
+    const int ox = c.bmx, oy = c.bmy;
+    int dir = 0;
+#pragma unroll 1
+    for (int k = 1; k <= 8; k++)
+    {
+        const int dx = k_square1[k][0], dy = k_square1[k][1];
+        const int cost = fpel_cost<P>(c, ox + dx, oy + dy);
+        if ((dy == 0 || y_ok<P>(c, oy + dy)) && cost < c.bcost)
+        {
+            c.bcost = cost;
+            dir = k;
+        }
+    }
+    c.bmx = ox + k_square1[dir][0];
+    c.bmy = oy + k_square1[dir][1];
+}
+
+// radius-2 hexagon walk + square refinement, motion.cpp:1041-1140
+template <typename P> __device__ __forceinline__ void hex_search(PuCtx<P>& c, int merange)
+{
+    int bx = c.bmx, by = c.bmy;
+    int bc = c.bcost << 3;
+#pragma unroll 1
+    for (int k = 0; k < 6; k++)
+    {
+        // (-2,0) (-1,2) (1,2) (2,0) (1,-2) (-1,-2) = hex2[1..6], direction values 2..7
+        const int dx = k_hex2[k + 1][0], dy = k_hex2[k + 1][1];
+        const int cost = fpel_cost<P>(c, bx + dx, by + dy);
+        if (y_ok<P>(c, by + dy))
+            bc = min(bc, (cost << 3) + k + 2);
+    }
+    if (bc & 7)
+    {
+        int dir = (bc & 7) - 2;
+        if (y_ok<P>(c, by + k_hex2[dir + 1][1]))
+        {
+            bx += k_hex2[dir + 1][0];
+            by += k_hex2[dir + 1][1];
+#pragma unroll 1
+            for (int i = (merange >> 1) - 1; i > 0 && in_range<P>(c, bx, by); i--)
+            {
+                bc &= ~7;
+#pragma unroll 1
+                for (int k = 0; k < 3; k++)
+                {
+                    const int dx = k_hex2[dir + k][0], dy = k_hex2[dir + k][1];
+                    const int cost = fpel_cost<P>(c, bx + dx, by + dy);
+                    if (y_ok<P>(c, by + dy))
+                        bc = min(bc, (cost << 3) + k + 1);
+                }
+                if (!(bc & 7))
+                    break;
+                dir += (bc & 7) - 2;
+                dir = k_mod6m1[dir + 1];
+                bx += k_hex2[dir + 1][0];
+                by += k_hex2[dir + 1][1];
+            }
+        }
+    }
+    c.bcost = bc >> 3;
+    c.bmx = bx;
+    c.bmy = by;
+    square_refine<P>(c);
+}
+
+// radius-1 diamond, motion.cpp:1016-1039
+template <typename P> __device__ __forceinline__ void dia_search(PuCtx<P>& c, int merange)
+{
+    int bx = c.bmx, by = c.bmy;
+    int bc = c.bcost << 4;
+    int i = merange;
+    do
+    {
+#pragma unroll 1
+        for (int k = 0; k < 4; k++)
+        {
+            const int dx = k_square1[k + 1][0], dy = k_square1[k + 1][1];
+            const int cost = fpel_cost<P>(c, bx + dx, by + dy);
+            const int step = (0xC431 >> (4 * k)) & 15;            // 1, 3, 4, 12
+            if (dy == 0 || y_ok<P>(c, by + dy))
+                bc = min(bc, (cost << 4) + step);
+        }
+        if (!(bc & 15))
+            break;
+        bx -= (int)((uint32_t)bc << 28) >> 30;
+        by -= (int)((uint32_t)bc << 30) >> 30;
+        bc &= ~15;
+    }
+    while (--i && in_range<P>(c, bx, by));
+    c.bcost = bc >> 4;
+    c.bmx = bx;
+    c.bmy = by;
+}
+
+// COST_MV_PT_DIST with the per-point range test of StarPatternSearch's border branch
+// (motion.cpp:249-261, 387-629); inside the frame those tests all hold, so the one
+// form covers both branches of the reference
+template <typename P>
+__device__ __forceinline__ void star_try(PuCtx<P>& c, int mx, int my, int point, int dist, int& bPoint, int& bDist)
+{
+    const int cost = fpel_cost<P>(c, mx, my);
+    if (cost < c.bcost)
+    {
+        c.bcost = cost;
+        c.bmx = mx;
+        c.bmy = my;
+        bPoint = point;
+        bDist = dist;
+    }
+}
+
+template <typename P>
+__device__ __forceinline__ void star_pattern(PuCtx<P>& c, int earlyExitIters, int merange, int& bPoint, int& bDist)
+{
+    const int ox = c.bmx, oy = c.bmy;
+    int rounds = 0;
+    const int last = (int)(short)merange;
+#pragma unroll 1
+    for (int dist = 1; dist < 16 || dist <= last; dist <<= 1)
+    {
+        const int saved = c.bcost;
+        if (dist < 16)
+        {
+            const int h = dist >> 1;
+#pragma unroll 1
+            for (int k = 0; k < 8; k++)
+            {
+                const int sx = k_star8[k][0], sy = k_star8[k][1], half = k_star8[k][2], point = k_star8[k][3];
+                if (half && dist == 1)
+                    continue;                       // the first round has only the four axis points
+                const int d = half ? h : dist;
+                const int mx = ox + sx * d, my = oy + sy * d;
+                // the reference tests only the side a point can leave the range on
+                const bool ok = (sx >= 0 || mx >= c.minx) && (sx <= 0 || mx <= c.maxx) &&
+                                (sy >= 0 || my >= c.miny) && (sy <= 0 || my <= c.maxy);
+                if (ok)
+                    star_try<P>(c, mx, my, point, d, bPoint, bDist);
+            }
+        }
+        else
+        {
+            const int q = dist >> 2;
+#pragma unroll 1
+            for (int k = 0; k < 16; k++)
+            {
+                int sx, sy, mx, my;
+                if (k < 4)
+                {
+                    // top, left, right, bottom
+                    sx = (k == 1) ? -1 : (k == 2) ? 1 : 0;
+                    sy = (k == 0) ? -1 : (k == 3) ? 1 : 0;
+                    mx = ox + sx * dist;
+                    my = oy + sy * dist;
+                }
+                else
+                {
+                    // for idx = 1..3: (xL,yT) (xR,yT) (xL,yB) (xR,yB)
+                    const int idx = ((k - 4) >> 2) + 1, corner = (k - 4) & 3;
+                    sx = (corner & 1) ? 1 : -1;
+                    sy = (corner & 2) ? 1 : -1;
+                    mx = ox + sx * q * idx;
+                    my = oy + sy * (dist - q * idx);
+                }
+                const bool ok = (sx >= 0 || mx >= c.minx) && (sx <= 0 || mx <= c.maxx) &&
+                                (sy >= 0 || my >= c.miny) && (sy <= 0 || my <= c.maxy);
+                if (ok)
+                    star_try<P>(c, mx, my, 0, dist, bPoint, bDist);
+            }
+        }
+        if (c.bcost < saved)
+            rounds = 0;
+        else if (++rounds >= earlyExitIters)
+            return;
+    }
+}
+
+template <typename P>
+__device__ __forceinline__ bool star_two_points(PuCtx<P>& c, int point)
+{
+    const int saved = c.bcost;
+    const int ox = c.bmx, oy = c.bmy;
+#pragma unroll 1
+    for (int k = 0; k < 2; k++)
+    {
+        const int mx = ox + k_twopoint[(point - 1) * 2 + k][0], my = oy + k_twopoint[(point - 1) * 2 + k][1];
+        if (in_range<P>(c, mx, my))
+            try_mv<P>(c, mx, my);
+    }
+    return c.bcost != saved;
+}
+
+// star search driver, motion.cpp:1328-1436
+template <typename P> __device__ __forceinline__ void star_search(PuCtx<P>& c, int merange)
+{
+    int bPoint = 0, bDist = 0;
+    bool first = true;
+#pragma unroll 1
+    for (;;)
+    {
+        if (!first)
+        {
+            bDist = 0;
+            bPoint = 0;
+        }
+        star_pattern<P>(c, first ? 3 : 32, merange, bPoint, bDist);
+        if (bDist == 1)
+        {
+            if (!bPoint)
+                return;
+            const bool moved = star_two_points<P>(c, bPoint);
+            if (!first || !moved)
+                return;
+        }
+        if (first)
+        {
+            first = false;
+            const int raster = 5;
+            if (bDist > raster)
+            {
+#pragma unroll 1
+                for (int ty = c.miny; ty <= c.maxy; ty += raster)
+#pragma unroll 1
+                    for (int tx = c.minx; tx <= c.maxx; tx += raster)
+                    {
+                        if (tx + raster * 3 <= c.maxx)
+                        {
+#pragma unroll 1
+                            for (int k = 0; k < 4; k++)
+                            {
+                                const int mx = tx + raster * k;
+                                // the fourth point is priced with the vector scaled by 8 instead of 4 (motion.cpp:1392)
+                                const int mc = k < 3 ? mvcost<P>(c, mx * 4, ty * 4) : mvcost<P>(c, mx * 8, ty * 8);
+                                const int cost = block_cost<P, false>(c, mx * 4, ty * 4) + mc;
+                                if (cost < c.bcost)
+                                {
+                                    c.bcost = cost;
+                                    c.bmx = mx;
+                                    c.bmy = ty;
+                                }
+                            }
+                            tx += raster * 3;
+                        }
+                        else
+                            try_mv<P>(c, tx, ty);
+                    }
+            }
+        }
+        if (bDist <= 0)
+            return;
+    }
+}
+
+// exhaustive search, motion.cpp:1593-1637
+template <typename P> __device__ __forceinline__ void full_search(PuCtx<P>& c)
+{
+#pragma unroll 1
+    for (int ty = c.miny; ty <= c.maxy; ty++)
+#pragma unroll 1
+        for (int tx = c.minx; tx <= c.maxx; tx++)
+            try_mv<P>(c, tx, ty);
+}
+
+template <typename P>
+__global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, int n, PuFrame f, const uint16_t* costTab,
+                                                        int maxMvd, PuResult* out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t puLds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int pu = blockIdx.x * 4 + wave;
+    if (pu >= n)
+        return;
+    const PuJob& job = jobs[pu];      // read in place: indexing mvc[] of a register copy would go through scratch
+    XG_LDS uint32_t* rec = (XG_LDS uint32_t*)puLds + wave * (f.maxPasses * 64 * PU_REC_DW);
+
+    PuCtx<P> c;
+    c.ref = as_global<P>(f.ref);
+    c.stride = f.stride;
+    c.x = job.x;
+    c.y = job.y;
+    c.w = job.w;
+    c.h = job.h;
+    c.minX = -f.marginX + 4;                       // room for the filter taps and the rows' trailing pixels
+    c.maxX = f.width + f.marginX - job.w - 16;
+    c.minY = -f.marginY + 4;
+    c.maxY = f.height + f.marginY - job.h - 5;
+    c.lane = lane;
+    c.rec = rec;
+    c.minx = job.minx;
+    c.miny = job.miny;
+    c.maxx = job.maxx;
+    c.maxy = job.maxy;
+    c.mvpx = job.mvpx;
+    c.mvpy = job.mvpy;
+    c.cx = as_global<uint16_t>(costTab) - job.mvpx;
+    c.cy = as_global<uint16_t>(costTab) - job.mvpy;
+    c.lo = -maxMvd;
+    c.hi = maxMvd;
+    c.depth = f.depth;
+
+    // ---- the encode block into LDS (MotionEstimate::setSourcePU, motion.cpp:167-191) ----
+    const int segW = (job.w & 7) ? 4 : 8;
+    const int tilesX = job.w / segW, ntiles = tilesX * (job.h >> 2);
+    c.passes = (ntiles + 15) >> 4;
+    const XG_GLOBAL P* fenc = as_global<P>(f.fenc) + ((long long)job.y * f.stride + job.x);
+    for (int k = 0; k < c.passes; k++)
+    {
+        const int t = k * 16 + (lane >> 2);
+        const bool valid = t < ntiles;
+        const int ty = valid ? t / tilesX : 0, tx = valid ? t - ty * tilesX : 0;
+        const int off = (ty * 4 + (lane & 3)) * f.stride + tx * segW;
+        const uint32_t mask = valid ? (segW == 8 ? 0xffffffffu : 0x0000ffffu) : 0u;
+        const Cols fc = pair_cols<P>(load_row_g<P>(fenc, off));
+        XG_LDS uint32_t* r = rec + (k * 64 + lane) * PU_REC_DW;
+        r[0] = fc.q[0] & mask;
+        r[1] = fc.q[1] & mask;
+        r[2] = fc.q[2] & mask;
+        r[3] = fc.q[3] & mask;
+        r[4] = (uint32_t)off;
+        r[5] = mask;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- MotionEstimate::motionEstimate, full-resolution reference ----
+    const int qminx = job.minx * 4, qminy = job.miny * 4, qmaxx = job.maxx * 4, qmaxy = job.maxy * 4;
+    const int pmvx = clampi(job.mvpx, qminx, qmaxx), pmvy = clampi(job.mvpy, qminy, qmaxy);
+    int bestprex = pmvx, bestprey = pmvy;
+    int bprecost = block_cost<P, false>(c, pmvx, pmvy);       // SAD, no MV cost on this term
+    c.bmx = (pmvx + 2) >> 2;
+    c.bmy = (pmvy + 2) >> 2;
+    c.bcost = bprecost;
+    if ((pmvx | pmvy) & 3)
+        c.bcost = fpel_cost<P>(c, c.bmx, c.bmy);
+    if (pmvx | pmvy)
+    {
+        const int cost = block_cost<P, false>(c, 0, 0) + mvcost<P>(c, 0, 0);
+        if (cost < c.bcost)
+        {
+            c.bcost = cost;
+            c.bmx = 0;
+            c.bmy = max(min(0, job.maxy), job.miny);
+        }
+    }
+    // extra quarter-pel candidates, motion.cpp:989-1003
+#pragma unroll 1
+    for (int i = 0; i < job.numCandidates; i++)
+    {
+        const int mx = clampi(job.mvc[2 * i], qminx, qmaxx), my = clampi(job.mvc[2 * i + 1], qminy, qmaxy);
+        if ((mx | my) && (mx != pmvx || my != pmvy) && (mx != bestprex || my != bestprey))
+        {
+            const int cost = subpel_cost<P>(c, mx, my, false);
+            if (cost < bprecost)
+            {
+                bprecost = cost;
+                bestprex = mx;
+                bestprey = my;
+            }
+        }
+    }
+
+    int bqx, bqy, bcost;
+    if (c.bcost == 0)
+    {
+        bqx = c.bmx * 4;
+        bqy = c.bmy * 4;
+        bcost = mvcost<P>(c, bqx, bqy);
+    }
+    else
+    {
+        if (f.method == PU_DIA)
+            dia_search<P>(c, f.merange);
+        else if (f.method == PU_HEX)
+            hex_search<P>(c, f.merange);
+        else if (f.method == PU_STAR)
+            star_search<P>(c, f.merange);
+        else
+            full_search<P>(c);
+
+        bcost = c.bcost;
+        if (bprecost < bcost)
+        {
+            bqx = bestprex;
+            bqy = bestprey;
+            bcost = bprecost;
+        }
+        else
+        {
+            bqx = c.bmx * 4;
+            bqy = c.bmy * 4;
+        }
+
+        if (!bcost)
+            bcost = mvcost<P>(c, bqx, bqy);
+        else
+        {
+            // interpolated sub-pel refinement, motion.cpp:1700-1757
+            const int hpelIters = k_workload[f.subpelRefine][0], hpelDirs = k_workload[f.subpelRefine][1];
+            const int qpelIters = k_workload[f.subpelRefine][2], qpelDirs = k_workload[f.subpelRefine][3];
+            const bool hpelSatd = k_workload[f.subpelRefine][4] != 0;
+            if (hpelSatd)
+                bcost = subpel_cost<P>(c, bqx, bqy, true);
+#pragma unroll 1
+            for (int stage = 0; stage < 2; stage++)
+            {
+                // stage 0: half-pel steps (SAD or SATD); stage 1: quarter-pel steps (SATD)
+                const int iters = stage ? qpelIters : hpelIters, dirs = stage ? qpelDirs : hpelDirs;
+                const int step = stage ? 1 : 2;
+                const bool satd = stage ? true : hpelSatd;
+                if (stage && !hpelSatd)
+                    bcost = subpel_cost<P>(c, bqx, bqy, true);
+#pragma unroll 1
+                for (int iter = 0; iter < iters; iter++)
+                {
+                    int bdir = 0;
+#pragma unroll 1
+                    for (int i = 1; i <= dirs; i++)
+                    {
+                        const int qx = bqx + k_square1[i][0] * step, qy = bqy + k_square1[i][1] * step;
+                        if (qy < qminy || qy > qmaxy)
+                            continue;
+                        const int cost = subpel_cost<P>(c, qx, qy, satd);
+                        if (cost < bcost)
+                        {
+                            bcost = cost;
+                            bdir = i;
+                        }
+                    }
+                    if (!bdir)
+                        break;
+                    bqx += k_square1[bdir][0] * step;
+                    bqy += k_square1[bdir][1] * step;
+                }
+            }
+        }
+    }
+
+    // the fork's closing zero-vector check: the vector is replaced, the cost is not (motion.cpp:1762-1768)
+    if (bqx | bqy)
+    {
+        const int cost = subpel_cost<P>(c, 0, 0, true);
+        if (cost <= bcost)
+            bqx = bqy = 0;
+    }
+    if (lane == 0)
+    {
+        PuResult r;
+        r.mvx = bqx;
+        r.mvy = bqy;
+        r.cost = bcost;
+        r.reserved = 0;
+        out[pu] = r;
+    }
+}
+
+// (src coordinates clamped into the picture) = PicYuv padding + extendPicBorder
+// (source/common/picyuv.cpp:340-400, source/common/pixel.cpp:1044-1058)
+template <typename P>
+__global__ void __launch_bounds__(256) pad_picture_kernel(const P* src, long long srcStride, P* dst, int stride, int rows,
+                                                          int width, int height, int marginX, int marginY)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= stride || y >= rows)
+        return;
+    const int sx = clampi(x - marginX, 0, width - 1), sy = clampi(y - marginY, 0, height - 1);
+    dst[(long long)y * stride + x] = src[(long long)sy * srcStride + sx];
+}
+
+hipError_t launch_pad_picture(hipStream_t s, int bpp, const void* src, long long srcStride, void* dst, int stride, int rows,
+                              int width, int height, int marginX, int marginY)
+{
+    dim3 grid((stride + 255) / 256, rows);
+    if (bpp == 1)
+        hipLaunchKernelGGL(pad_picture_kernel<uint8_t>, grid, dim3(256), 0, s, (const uint8_t*)src, srcStride, (uint8_t*)dst,
+                           stride, rows, width, height, marginX, marginY);
+    else
+        hipLaunchKernelGGL(pad_picture_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)src, srcStride,
+                           (uint16_t*)dst, stride, rows, width, height, marginX, marginY);
+    return hipGetLastError();
+}
+
+hipError_t launch_pu_search(hipStream_t s, int bpp, const PuFrame& f, const PuJob* dJobs, int n, const uint16_t* costTab,
+                            int maxMvd, PuResult* dOut)
+{
+    if (n <= 0)
+        return hipSuccess;
+    const size_t lds = (size_t)4 * f.maxPasses * 64 * PU_REC_DW * sizeof(uint32_t);
+    dim3 grid((n + 3) / 4);
+    if (bpp == 1)
+        hipLaunchKernelGGL(pu_search_kernel<uint8_t>, grid, dim3(256), lds, s, dJobs, n, f, costTab, maxMvd, dOut);
+    else
+        hipLaunchKernelGGL(pu_search_kernel<uint16_t>, grid, dim3(256), lds, s, dJobs, n, f, costTab, maxMvd, dOut);
+    return hipGetLastError();
+}
+
+} // namespace xg

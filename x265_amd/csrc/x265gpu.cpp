@@ -32,6 +32,7 @@ struct Slot
     long long* rowPartials = nullptr;// [D*D][H][3]
     long long* sums = nullptr;       // [D*D][3]   ([0] holds the intra totals in its first two entries)
     std::vector<char*> weighted;     // [D] weighted plane sets, allocated on first use
+    char* full = nullptr;            // padded full-resolution luma (config.bKeepFullRes)
     int poc = 0;
 };
 
@@ -67,6 +68,15 @@ struct x265gpu_ctx
     int64_t profLaunches[X265GPU_PHASE_COUNT] = { 0, 0, 0, 0 };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     SearchStreams searchAux;
+    // full-resolution pictures (config.bKeepFullRes): PicYuv geometry, source/common/picyuv.cpp:75-103
+    int fullW = 0, fullH = 0;         // interior, multiples of the CTU size
+    int fullStride = 0, fullRows = 0;
+    int fullMarginX = 0, fullMarginY = 0;
+    uint16_t* meCostBuf = nullptr;    // BitCost table of the full-resolution searches
+    uint16_t* meCostCentre = nullptr;
+    int meMaxMvd = 0;
+    char* puBuf = nullptr;            // device staging: jobs, then results
+    size_t puBufSize = 0;
     // single-launch search: row-progress words on the device, and its sticky error word mirrored here
     bool searchRows = false;
     int* searchSync = nullptr;
@@ -172,6 +182,8 @@ int alloc_slot(x265gpu_ctx* ctx, Slot& s)
     s.rowPartials = (long long*)(s.base + oRowPartials);
     s.sums = (long long*)(s.base + oSums);
     s.weighted.assign(D, nullptr);
+    if (ctx->fullStride)
+        HIPCHK(hipMalloc((void**)&s.full, (size_t)ctx->fullStride * ctx->fullRows * ctx->bpp));
     return X265GPU_OK;
 }
 
@@ -325,6 +337,16 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
     ctx->bpp = cfg->internalBitDepth > 8 ? 2 : 1;
     ctx->D = cfg->bframes + 2;
     compute_geometry(*cfg, ctx->g);
+    if (cfg->bKeepFullRes)
+    {
+        const int ctu = cfg->maxCUSize;
+        ctx->fullW = (cfg->sourceWidth + ctu - 1) / ctu * ctu;
+        ctx->fullH = (cfg->sourceHeight + ctu - 1) / ctu * ctu;
+        ctx->fullMarginX = ctu + 32;
+        ctx->fullMarginY = ctu + 16;
+        ctx->fullStride = ctx->fullW + 2 * ctx->fullMarginX;
+        ctx->fullRows = ctx->fullH + 2 * ctx->fullMarginY;
+    }
 
     int rc = X265GPU_OK;
     do
@@ -414,6 +436,8 @@ void x265gpu_close(x265gpu_ctx* ctx)
     {
         if (s.base)
             (void)hipFree(s.base);
+        if (s.full)
+            (void)hipFree(s.full);
         for (char* w : s.weighted)
             if (w)
                 (void)hipFree(w);
@@ -433,6 +457,8 @@ void x265gpu_close(x265gpu_ctx* ctx)
         if (ctx->searchAux.side[k]) (void)hipStreamDestroy(ctx->searchAux.side[k]);
     }
     if (ctx->searchAux.fork) (void)hipEventDestroy(ctx->searchAux.fork);
+    if (ctx->meCostBuf) (void)hipFree(ctx->meCostBuf);
+    if (ctx->puBuf) (void)hipFree(ctx->puBuf);
     if (ctx->searchSync) (void)hipFree(ctx->searchSync);
     if (ctx->searchErrHost) (void)hipHostFree(ctx->searchErrHost);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -532,6 +558,9 @@ int x265gpu_lowres_init_batch(x265gpu_ctx* ctx, int32_t n, const int32_t* slots,
         }
         jobs[i].planes = s.planes;
         jobs[i].planes4 = s.planes4;
+        if (s.full)
+            HIPCHK(launch_pad_picture(ctx->stream, ctx->bpp, jobs[i].src, jobs[i].srcStride, s.full, ctx->fullStride,
+                                      ctx->fullRows, g.srcWidth, g.srcHeight, ctx->fullMarginX, ctx->fullMarginY));
     }
     int rc = ensure_job_buf(ctx, sizeof(LowresJob) * n);
     if (rc)
@@ -949,6 +978,116 @@ int x265gpu_get_costs(x265gpu_ctx* ctx, int32_t slot, int32_t d0, int32_t d1, ui
         fc->costEstAq = sums[1];
         fc->intraMbs = (d0 == 0 && d1 == 0) ? 0 : (int32_t)sums[2];
         fc->reserved = 0;
+    }
+    return X265GPU_OK;
+}
+
+int x265gpu_me_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd)
+{
+    if (!ctx || !centre || maxMvd < 1024)
+        return X265GPU_ERR_ARG;
+    if (ctx->meCostBuf)
+    {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(ctx->meCostBuf));
+        ctx->meCostBuf = nullptr;
+    }
+    const size_t count = 2 * (size_t)maxMvd + 1;
+    HIPCHK(hipMalloc((void**)&ctx->meCostBuf, count * sizeof(uint16_t)));
+    HIPCHK(hipMemcpyAsync(ctx->meCostBuf, centre - maxMvd, count * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->meCostCentre = ctx->meCostBuf + maxMvd;
+    ctx->meMaxMvd = maxMvd;
+    return X265GPU_OK;
+}
+
+int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t searchMethod, int32_t merange,
+                               int32_t subpelRefine, int32_t n, const x265gpu_pu_job* jobs, x265gpu_pu_result* out)
+{
+    static_assert(sizeof(x265gpu_pu_job) == sizeof(PuJob) && sizeof(x265gpu_pu_result) == sizeof(PuResult),
+                  "public and device job layouts must match");
+    if (!ctx || n < 0 || (n && (!jobs || !out)))
+        return X265GPU_ERR_ARG;
+    if (!n)
+        return X265GPU_OK;
+    if (!slot_ok(ctx, slotFenc) || !slot_ok(ctx, slotRef))
+        return fail(ctx, X265GPU_ERR_ARG, "pu_motion_estimate: bad slot");
+    if (!ctx->fullStride)
+        return fail(ctx, X265GPU_ERR_STATE, "pu_motion_estimate: context opened without bKeepFullRes");
+    if (!ctx->meCostCentre)
+        return fail(ctx, X265GPU_ERR_STATE, "pu_motion_estimate: MV cost table not set");
+    if (searchMethod != X265GPU_DIA_SEARCH && searchMethod != X265GPU_HEX_SEARCH && searchMethod != X265GPU_STAR_SEARCH &&
+        searchMethod != X265GPU_FULL_SEARCH)
+        return fail(ctx, X265GPU_ERR_UNSUPPORTED, "pu_motion_estimate: search method");
+    if (subpelRefine < 0 || subpelRefine > 7 || merange < 1 || merange > 32767)
+        return fail(ctx, X265GPU_ERR_ARG, "pu_motion_estimate: subpelRefine or merange");
+    int maxPasses = 1;
+    for (int i = 0; i < n; i++)
+    {
+        const x265gpu_pu_job& j = jobs[i];
+        // the PU inside the picture, shapes the tiling handles, vectors that stay inside the padded plane
+        if (j.w < 4 || j.h < 4 || j.w > 64 || j.h > 64 || (j.w & 3) || (j.h & 3) || j.x < 0 || j.y < 0 ||
+            j.x + j.w > ctx->fullW || j.y + j.h > ctx->fullH || j.numCandidates < 0 || j.numCandidates > 12 ||
+            j.mvminX > j.mvmaxX || j.mvminY > j.mvmaxY ||
+            j.x + j.mvminX < -ctx->fullMarginX + 8 || j.x + j.w + j.mvmaxX > ctx->fullW + ctx->fullMarginX - 16 ||
+            j.y + j.mvminY < -ctx->fullMarginY + 8 || j.y + j.h + j.mvmaxY > ctx->fullH + ctx->fullMarginY - 8)
+            return fail(ctx, X265GPU_ERR_ARG, "pu_motion_estimate: bad job");
+        const int segW = (j.w & 7) ? 4 : 8;
+        const int passes = ((j.w / segW) * (j.h / 4) + 15) / 16;
+        maxPasses = passes > maxPasses ? passes : maxPasses;
+    }
+    const size_t jobBytes = align256(sizeof(PuJob) * (size_t)n), outBytes = sizeof(PuResult) * (size_t)n;
+    if (jobBytes + outBytes > ctx->puBufSize)
+    {
+        if (ctx->puBuf)
+        {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipFree(ctx->puBuf));
+            ctx->puBuf = nullptr;
+            ctx->puBufSize = 0;
+        }
+        HIPCHK(hipMalloc((void**)&ctx->puBuf, jobBytes + outBytes));
+        ctx->puBufSize = jobBytes + outBytes;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->puBuf, jobs, sizeof(PuJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    PuFrame f;
+    memset(&f, 0, sizeof(f));
+    const size_t origin = ((size_t)ctx->fullMarginY * ctx->fullStride + ctx->fullMarginX) * ctx->bpp;
+    f.fenc = ctx->slots[slotFenc].full + origin;
+    f.ref = ctx->slots[slotRef].full + origin;
+    f.stride = ctx->fullStride;
+    f.width = ctx->fullW;
+    f.height = ctx->fullH;
+    f.marginX = ctx->fullMarginX;
+    f.marginY = ctx->fullMarginY;
+    f.depth = ctx->cfg.internalBitDepth;
+    f.method = searchMethod;
+    f.merange = merange;
+    f.subpelRefine = subpelRefine;
+    f.maxPasses = maxPasses;
+    HIPCHK(launch_pu_search(ctx->stream, ctx->bpp, f, (const PuJob*)ctx->puBuf, n, ctx->meCostCentre, ctx->meMaxMvd,
+                            (PuResult*)(ctx->puBuf + jobBytes)));
+    HIPCHK(hipMemcpyAsync(out, ctx->puBuf + jobBytes, outBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
+int x265gpu_get_full_plane(x265gpu_ctx* ctx, int32_t slot, void* out, int32_t* stride, int32_t* rows, int32_t* originX,
+                           int32_t* originY)
+{
+    if (!ctx || !slot_ok(ctx, slot))
+        return X265GPU_ERR_ARG;
+    if (!ctx->fullStride)
+        return fail(ctx, X265GPU_ERR_STATE, "get_full_plane: context opened without bKeepFullRes");
+    if (stride) *stride = ctx->fullStride;
+    if (rows) *rows = ctx->fullRows;
+    if (originX) *originX = ctx->fullMarginX;
+    if (originY) *originY = ctx->fullMarginY;
+    if (out)
+    {
+        HIPCHK(hipMemcpyAsync(out, ctx->slots[slot].full, (size_t)ctx->fullStride * ctx->fullRows * ctx->bpp,
+                              hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     return X265GPU_OK;
 }

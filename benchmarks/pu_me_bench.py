@@ -1,0 +1,81 @@
+"""Throughput of the full-resolution PU motion estimation (x265gpu_pu_motion_estimate).
+
+Workload: every square PU (64, 32, 16, 8) of every CTU of one 3840x2160 frame against the previous
+frame, star search, merange 57, subme 3 (BASELINE config 4), zero predictors, search window clipped to
+the padded picture.  Prints one JSON line; `--cpu-pus N` times the CPU oracle on the first N PUs.
+
+    python benchmarks/pu_me_bench.py [--width 3840 --height 2160 --depth 8 --reps 3 --cpu-pus 400]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from x265_amd import api, synth  # noqa: E402
+
+
+def make_jobs(fw, fh, W, H, mx, my, merange, sizes):
+    jobs = []
+    for s in sizes:
+        for y in range(0, H - s + 1, s):
+            for x in range(0, W - s + 1, s):
+                lo = (max(-merange, -x - mx + 24), max(-merange, -y - my + 24))
+                hi = (min(merange, fw - x - s + mx - 24), min(merange, fh - y - s + my - 24))
+                jobs.append((x, y, s, s, (0, 0), lo, hi, []))
+    return jobs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--merange", type=int, default=57)
+    ap.add_argument("--subme", type=int, default=3)
+    ap.add_argument("--cpu-pus", type=int, default=400)
+    a = ap.parse_args()
+    W, H, ctu = a.width, a.height, 64
+    clip = synth.luma_clip(W, H, 2, a.depth, seed=1234)
+    mx, my = ctu + 32, ctu + 16
+    fw, fh = -(-W // ctu) * ctu, -(-H // ctu) * ctu
+    jobs = make_jobs(fw, fh, W, H, mx, my, a.merange, (64, 32, 16, 8))
+
+    from oracle import orc          # the MV cost table is a host input; the oracle builds it like BitCost does
+    table, centre = orc.bitcost_table(a.depth)
+    ctx = api.Context(W, H, depth=a.depth, num_slots=2, ctu=ctu, keep_full_res=True)
+    ctx.lowres_init(0, clip[0])
+    ctx.lowres_init(1, clip[1])
+    ctx.me_set_mvcost(table, centre)
+    ctx.pu_motion_estimate(1, 0, api.STAR_SEARCH, a.merange, a.subme, jobs[:1024])      # warm-up
+    times = []
+    for _ in range(a.reps):
+        t0 = time.perf_counter()
+        res = ctx.pu_motion_estimate(1, 0, api.STAR_SEARCH, a.merange, a.subme, jobs)
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
+    out = {"metric": "full-res PU motion estimations per second (star, merange %d, subme %d)" % (a.merange, a.subme),
+           "value": len(jobs) / dt, "unit": "PU/s", "pus": len(jobs), "seconds": dt,
+           "config": {"workload": "%dx%d %d-bit, square PUs 64/32/16/8 of one frame" % (W, H, a.depth)},
+           "note": "wall time of the call, job upload and result download included"}
+    if a.cpu_pus:
+        pads = [np.pad(f, ((my, my + fh - H), (mx, mx + fw - W)), mode="edge") for f in clip]
+        ref = orc.FullResME(a.depth, table, centre, pads[1], pads[0], mx, my)
+        step = max(1, len(jobs) // a.cpu_pus)
+        sample = jobs[::step]
+        t0 = time.perf_counter()
+        want = [ref.estimate(j[0], j[1], j[2], j[3], j[4], j[5], j[6], orc.STAR, a.merange, a.subme, j[7]) for j in sample]
+        cdt = time.perf_counter() - t0
+        assert want == res[::step], "GPU result differs from the oracle"
+        out["cpu_baseline"] = {"value": len(sample) / cdt, "unit": "PU/s", "cores": 1, "kind": "port",
+                               "sample": "every %dth PU (%d PUs), checked equal to the GPU result" % (step, len(sample))}
+    ctx.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -46,8 +46,6 @@ __global__ void __launch_bounds__(256) cost_rows_kernel(const CostJob* jobs, Geo
         const bool live = cuXraw < W;
         const int cuX = min(cuXraw, W - 1);
         const int cuXY = cuX + cuY * W;
-        const int bx = 8 * cuX;
-
         int bcost = COST_MAX, listused = 0;
         const int fc0 = job.mvCosts0[cuXY];
         if (fc0 < bcost) { bcost = fc0; listused = 1; }
@@ -56,19 +54,36 @@ __global__ void __launch_bounds__(256) cost_rows_kernel(const CostJob* jobs, Geo
             const int fc1 = job.mvCosts1[cuXY];
             if (fc1 < bcost) { bcost = fc1; listused = 2; }
 
-            const Cols f = pair_cols<P>(load_row<P>((const P*)job.fencPlane0 + (long long)(by + r) * g.stride + bx));
-            const int m0x = job.mvs0[2 * cuXY], m0y = job.mvs0[2 * cuXY + 1];
-            const int m1x = job.mvs1[2 * cuXY], m1y = job.mvs1[2 * cuXY + 1];
+            // Pixel rows are fetched in a transposed lane layout, lane = (row, block): the eight
+            // lanes of a row then read neighbouring blocks, which share cache lines whenever
+            // their vectors agree (always for the encode block and the co-located pair), instead
+            // of eight different lines per block.  The averages are formed there, and only the
+            // three rows the SATD needs are brought to the compute layout (block, row).
+            const int lr = grp, lj = r;                       // this lane's row / block while loading
+            const int lcuX = min(chunk * 8 + lj, W - 1);
+            const int lcuXY = lcuX + cuY * W;
+            const int lbx = 8 * lcuX;
+            const int m0x = job.mvs0[2 * lcuXY], m0y = job.mvs0[2 * lcuXY + 1];
+            const int m1x = job.mvs1[2 * lcuXY], m1y = job.mvs1[2 * lcuXY + 1];
             const bool odd = __any((m0x | m0y | m1x | m1y) & 1) != 0;
+            const Row<P> fl = load_row<P>((const P*)job.fencPlane0 + (long long)(by + lr) * g.stride + lbx);
             // average of the two motion-compensated predictions
-            Row<P> a = mc_row<P>(ps0, bx, by, r, m0x, m0y, odd);
-            Row<P> b = mc_row<P>(ps1, bx, by, r, m1x, m1y, odd);
-            int bicost = satd8x8<P>(f, avg_row<P>(a, b), r);
-            if (bicost < bcost) { bcost = bicost; listused = 3; }
+            const Row<P> biMc = avg_row<P>(mc_row<P>(ps0, lbx, by, lr, m0x, m0y, odd), mc_row<P>(ps1, lbx, by, lr, m1x, m1y, odd));
             // average of the co-located blocks
-            a = fetch_row<P>(ps0, bx, by, r, 0, 0);
-            b = fetch_row<P>(ps1, bx, by, r, 0, 0);
-            bicost = satd8x8<P>(f, avg_row<P>(a, b), r);
+            const Row<P> biCo = avg_row<P>(fetch_row<P>(ps0, lbx, by, lr, 0, 0), fetch_row<P>(ps1, lbx, by, lr, 0, 0));
+            const int from = (r * 8 + grp) * 4;               // compute lane (block grp, row r) <- load lane (row r, block grp)
+            Row<P> ft, mt, ct;
+#pragma unroll
+            for (int i = 0; i < PixT<P>::NW; i++)
+            {
+                ft.w[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)fl.w[i]);
+                mt.w[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)biMc.w[i]);
+                ct.w[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)biCo.w[i]);
+            }
+            const Cols f = pair_cols<P>(ft);
+            int bicost = satd8x8<P>(f, mt, r);
+            if (bicost < bcost) { bcost = bicost; listused = 3; }
+            bicost = satd8x8<P>(f, ct, r);
             if (bicost < bcost) { bcost = bicost; listused = 3; }
             bcost += 4;   // lowresPenalty
         }

@@ -137,6 +137,16 @@ template <int G> __device__ __forceinline__ int group_value(int v)
     return __builtin_amdgcn_readlane(v, 8 * G);
 }
 
+// ---- LDS hand-over inside one wave ---------------------------------------------
+// LDS traffic between lanes of one wave needs no hardware wait (the LDS executes
+// a wave's instructions in order); this only stops the compiler from moving
+// accesses across the hand-over.
+__device__ __forceinline__ void lds_handover()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---- block compares -----------------------------------------------------------
 
 // row SAD on packed pixels (v_sad_u8 / v_sad_u16): source/common/pixel.cpp:40-55

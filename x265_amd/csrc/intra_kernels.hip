@@ -4,47 +4,27 @@
 // 706-815) and the primitives it calls for BLOCK_8x8: intra_filter, intra_pred
 // DC / planar / angular (source/common/intrapred.cpp:31-204) and satd 8x8.
 //
-// One wave per 8x8 block.  The 33 neighbour samples and their 1:2:1 smoothed
-// copy sit in LDS; each 8-lane group predicts one mode (lane = row), so the
-// eight first-pass modes (DC, planar, 5,10,..,30) are measured in one pass,
-// then best-2/best+2, then best-1/best+1 -- the reference's order and strict
-// '<' tie-breaks, taken on wave-uniform scalars.  Block rows are independent
-// workgroups; row totals are reduced in LDS, frame totals in a second tiny
-// kernel, so results do not depend on scheduling.
+// One wave per four neighbouring 8x8 blocks.  The 33 neighbour samples of each
+// block and their 1:2:1 smoothed copy sit in LDS; each 8-lane group predicts
+// one mode (lane = row).  The eight first-pass modes (DC, planar, 5,10,..,30)
+// of a block fill one pass, so the four blocks take four; the two refinement
+// passes (best-2/best+2, then best-1/best+1) measure two modes per block and
+// therefore run once for all four blocks, two groups each.  The reference's
+// order and strict '<' tie-breaks are taken on wave-uniform scalars.  Block
+// rows are independent workgroups; row totals are reduced in LDS, frame totals
+// in a second tiny kernel, so results do not depend on scheduling.
 #include "device_common.h"
 #include "kernels.h"
 
 namespace xg {
 
-// SATD core on a ready difference row (see satd8x8 in device_common.h)
-__device__ __forceinline__ int satd8x8_diff(int d[8], int r)
+// SATD of the encode row `f` (column pairs) against the predicted row p[0..7]
+__device__ __forceinline__ int satd_pred(const Cols& f, const int p[8], int r)
 {
-#pragma unroll
-    for (int h = 0; h < 8; h += 4)
-    {
-        int a0 = d[h] + d[h + 1], a1 = d[h] - d[h + 1];
-        int a2 = d[h + 2] + d[h + 3], a3 = d[h + 2] - d[h + 3];
-        d[h] = a0 + a2;
-        d[h + 1] = a1 + a3;
-        d[h + 2] = a0 - a2;
-        d[h + 3] = a1 - a3;
-    }
-    const int m1 = -(r & 1), m2 = -((r >> 1) & 1);
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        d[i] = ((d[i] ^ m1) - m1) + dpp<DPP_XOR1>(d[i]);
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        d[i] = ((d[i] ^ m2) - m2) + dpp<DPP_XOR2>(d[i]);
-    int s = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        s += abs(d[i]);
-    s += dpp<DPP_XOR1>(s);
-    s += dpp<DPP_XOR2>(s);
-    s >>= 1;
-    s += dpp<DPP_HALF_MIRROR>(s);
-    return s;
+    return satd8x8_cols(as_s16x2(f.q[0]) - as_s16x2((uint32_t)p[0] | ((uint32_t)p[4] << 16)),
+                        as_s16x2(f.q[1]) - as_s16x2((uint32_t)p[1] | ((uint32_t)p[5] << 16)),
+                        as_s16x2(f.q[2]) - as_s16x2((uint32_t)p[2] | ((uint32_t)p[6] << 16)),
+                        as_s16x2(f.q[3]) - as_s16x2((uint32_t)p[3] | ((uint32_t)p[7] << 16)), r, 0);
 }
 
 // g_intraFilterFlags[mode] & 8 (source/common/constants.cpp:561-567): for 8x8
@@ -131,7 +111,7 @@ __device__ void predict_row(const int* nb, int mode, int r, int pixelMax, int p[
 template <typename P>
 __global__ void __launch_bounds__(256) intra_kernel(const IntraJob* jobs, Geometry g, int lambda, int pixelMax)
 {
-    __shared__ int nbr[4][80];
+    __shared__ int nbr[4][4][80];          // [wave][block][raw 0..32, smoothed 40..72]
     __shared__ long long red[4][3];
 
     const IntraJob job = jobs[blockIdx.y];
@@ -140,105 +120,124 @@ __global__ void __launch_bounds__(256) intra_kernel(const IntraJob* jobs, Geomet
     const int grp = lane >> 3, r = lane & 7;
     const int W = g.W, H = g.H;
     const P* plane = (const P*)job.plane0;
-    int* nb = nbr[wave];
+    const int by = 8 * cuY;
+    int (*nb)[80] = nbr[wave];
 
     long long accRow = 0, accEst = 0, accAq = 0;
-    const int iters = (W + 3) / 4;
+    const int iters = (W + 15) / 16;
     for (int it = 0; it < iters; it++)
     {
-        const int cuX = it * 4 + wave;
-        const bool live = cuX < W;          // wave-uniform
-        const int bx = 8 * min(cuX, W - 1), by = 8 * cuY;
-        const P* tl = plane + (long long)(by - 1) * g.stride + bx - 1;
-        if (lane < 33)
-            nb[lane] = (lane < 17) ? (int)tl[lane] : (int)tl[(long long)(lane - 16) * g.stride];
-        __syncthreads();
-        if (lane < 33)
+        const int cuX0 = it * 16 + wave * 4;       // this wave's four blocks: cuX0 .. cuX0 + 3 (clamped to the row)
+        // ---- neighbours: 16 lanes per block, lane k takes top sample k+1 and left sample k+1 ----
         {
-            // intraFilter<8>: source/common/intrapred.cpp:31-51
+            const int b = lane >> 4, k = lane & 15;
+            const P* tl = plane + (long long)(by - 1) * g.stride + 8 * min(cuX0 + b, W - 1) - 1;
+            nb[b][1 + k] = (int)tl[1 + k];
+            nb[b][17 + k] = (int)tl[(long long)(1 + k) * g.stride];
+            if (k == 0)
+                nb[b][0] = (int)tl[0];
+        }
+        lds_handover();
+        // intraFilter<8>: source/common/intrapred.cpp:31-51, 33 samples for each of the four blocks
+        for (int i = lane; i < 132; i += 64)
+        {
+            const int b = i / 33, j = i - 33 * b;
+            const int* n = nb[b];
             int f;
-            if (lane == 0)
-                f = (2 * nb[0] + nb[1] + nb[17] + 2) >> 2;
-            else if (lane == 16 || lane == 32)
-                f = nb[lane];
-            else if (lane == 17)
-                f = (2 * nb[17] + nb[0] + nb[18] + 2) >> 2;
+            if (j == 0)
+                f = (2 * n[0] + n[1] + n[17] + 2) >> 2;
+            else if (j == 16 || j == 32)
+                f = n[j];
+            else if (j == 17)
+                f = (2 * n[17] + n[0] + n[18] + 2) >> 2;
             else
-                f = (2 * nb[lane] + nb[lane - 1] + nb[lane + 1] + 2) >> 2;
-            nb[40 + lane] = f;
+                f = (2 * n[j] + n[j - 1] + n[j + 1] + 2) >> 2;
+            nb[b][40 + j] = f;
         }
-        __syncthreads();
+        lds_handover();
 
-        int f[8];
-        unpack_row<P>(load_row<P>(plane + (long long)(by + r) * g.stride + bx), f);
+        int p[8];
+        int icost[4], ilow[4], acost[4], alow[4];
+        // pass 1, once per block: DC, planar, 5, 10, ..., 30
+        const int mode1 = (grp == 0) ? 1 : (grp == 1) ? 0 : 5 * (grp - 1);
+#define XG_INTRA_PASS1(B)                                                                                      \
+        {                                                                                                      \
+            const Cols f = pair_cols<P>(load_row<P>(plane + (long long)(by + r) * g.stride + 8 * min(cuX0 + B, W - 1))); \
+            predict_row(nb[B], mode1, r, pixelMax, p);                                                         \
+            const int c = satd_pred(f, p, r);                                                                  \
+            int ic = COST_MAX, il = 0, ac = COST_MAX, al = 4;                                                  \
+            const int cDC = group_value<0>(c), cPl = group_value<1>(c);                                        \
+            if (cDC < ic) { ic = cDC; il = 1; }                                                                \
+            if (cPl < ic) { ic = cPl; il = 0; }                                                                \
+            const int c5 = group_value<2>(c), c10 = group_value<3>(c), c15 = group_value<4>(c);                \
+            const int c20 = group_value<5>(c), c25 = group_value<6>(c), c30 = group_value<7>(c);               \
+            if (c5 < ac) { ac = c5; al = 5; }                                                                  \
+            if (c10 < ac) { ac = c10; al = 10; }                                                               \
+            if (c15 < ac) { ac = c15; al = 15; }                                                               \
+            if (c20 < ac) { ac = c20; al = 20; }                                                               \
+            if (c25 < ac) { ac = c25; al = 25; }                                                               \
+            if (c30 < ac) { ac = c30; al = 30; }                                                               \
+            icost[B] = ic; ilow[B] = il; acost[B] = ac; alow[B] = al;                                          \
+        }
+        XG_INTRA_PASS1(0)
+        XG_INTRA_PASS1(1)
+        XG_INTRA_PASS1(2)
+        XG_INTRA_PASS1(3)
+#undef XG_INTRA_PASS1
 
-        int p[8], d[8];
-        // pass 1: DC, planar, 5, 10, ..., 30
-        {
-            const int mode = (grp == 0) ? 1 : (grp == 1) ? 0 : 5 * (grp - 1);
-            predict_row(nb, mode, r, pixelMax, p);
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                d[i] = f[i] - p[i];
-        }
-        int c = satd8x8_diff(d, r);
-        int icost = COST_MAX, ilow = 0;
-        {
-            const int cDC = group_value<0>(c), cPl = group_value<1>(c);
-            if (cDC < icost) { icost = cDC; ilow = 1; }
-            if (cPl < icost) { icost = cPl; ilow = 0; }
-        }
-        int acost = COST_MAX, alow = 4;
-        {
-            const int c5 = group_value<2>(c), c10 = group_value<3>(c), c15 = group_value<4>(c);
-            const int c20 = group_value<5>(c), c25 = group_value<6>(c), c30 = group_value<7>(c);
-            if (c5 < acost) { acost = c5; alow = 5; }
-            if (c10 < acost) { acost = c10; alow = 10; }
-            if (c15 < acost) { acost = c15; alow = 15; }
-            if (c20 < acost) { acost = c20; alow = 20; }
-            if (c25 < acost) { acost = c25; alow = 25; }
-            if (c30 < acost) { acost = c30; alow = 30; }
-        }
-        // passes 2 and 3: best-dist, best+dist with the best updated in between
+        // passes 2 and 3 for all four blocks at once: groups 2b and 2b+1 measure best-dist and
+        // best+dist of block b, the best being updated in between as in the reference
+        const int b2 = grp >> 1;
+        const Cols f2 = pair_cols<P>(load_row<P>(plane + (long long)(by + r) * g.stride + 8 * min(cuX0 + b2, W - 1)));
 #pragma unroll
         for (int dist = 2; dist >= 1; dist--)
         {
-            const int minus = alow - dist, plus = alow + dist;
-            const int mode = (grp == 1) ? plus : minus;
-            predict_row(nb, mode, r, pixelMax, p);
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                d[i] = f[i] - p[i];
-            c = satd8x8_diff(d, r);
-            const int cm = group_value<0>(c), cp = group_value<1>(c);
-            if (cm < acost) { acost = cm; alow = minus; }
-            if (cp < acost) { acost = cp; alow = plus; }
+            const int best = (b2 == 0) ? alow[0] : (b2 == 1) ? alow[1] : (b2 == 2) ? alow[2] : alow[3];
+            const int mode = (grp & 1) ? best + dist : best - dist;
+            predict_row(nb[b2], mode, r, pixelMax, p);
+            const int c = satd_pred(f2, p, r);
+#define XG_INTRA_REFINE(B)                                                                 \
+            {                                                                              \
+                const int cm = group_value<2 * B>(c), cp = group_value<2 * B + 1>(c);      \
+                const int minus = alow[B] - dist, plus = alow[B] + dist;                   \
+                if (cm < acost[B]) { acost[B] = cm; alow[B] = minus; }                     \
+                if (cp < acost[B]) { acost[B] = cp; alow[B] = plus; }                      \
+            }
+            XG_INTRA_REFINE(0)
+            XG_INTRA_REFINE(1)
+            XG_INTRA_REFINE(2)
+            XG_INTRA_REFINE(3)
+#undef XG_INTRA_REFINE
         }
-        if (acost < icost) { icost = acost; ilow = alow; }
 
-        icost += 5 * lambda + 4;   // intraPenalty + lowresPenalty
-
-        if (live)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
         {
+            const int cuX = cuX0 + b;
+            if (cuX >= W)          // wave-uniform
+                break;
+            int ic = icost[b], il = ilow[b];
+            if (acost[b] < ic) { ic = acost[b]; il = alow[b]; }
+            ic += 5 * lambda + 4;   // intraPenalty + lowresPenalty
             const int cuXY = cuX + cuY * W;
             const bool scored = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
-            int icostAq = icost;
+            int icAq = ic;
             if (scored && job.invQscale)
-                icostAq = (icost * job.invQscale[cuXY] + 128) >> 8;
+                icAq = (ic * job.invQscale[cuXY] + 128) >> 8;
             if (lane == 0)
             {
-                job.lowresCosts[cuXY] = (uint16_t)min(icost, LOWRES_COST_MASK);
-                job.intraCost[cuXY] = icost;
-                job.intraMode[cuXY] = (uint8_t)ilow;
+                job.lowresCosts[cuXY] = (uint16_t)min(ic, LOWRES_COST_MASK);
+                job.intraCost[cuXY] = ic;
+                job.intraMode[cuXY] = (uint8_t)il;
             }
-            accRow += icostAq;
+            accRow += icAq;
             if (scored)
             {
-                accEst += icost;
-                accAq += icostAq;
+                accEst += ic;
+                accAq += icAq;
             }
         }
-        __syncthreads();   // neighbour buffer is rewritten next iteration
+        lds_handover();   // the neighbour buffer is rewritten next iteration
     }
 
     if (lane == 0)

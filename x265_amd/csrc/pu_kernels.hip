@@ -574,8 +574,7 @@ __global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, int n
         r[4] = (uint32_t)off;
         r[5] = mask;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    lds_handover();
 
     // ---- MotionEstimate::motionEstimate, full-resolution reference ----
     const int qminx = job.minx * 4, qminy = job.miny * 4, qmaxx = job.maxx * 4, qmaxy = job.maxy * 4;

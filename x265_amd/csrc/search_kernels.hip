@@ -95,15 +95,6 @@ template <typename P> struct WaveLds
     static constexpr int TOTAL = WIN_DW + SUB_DW + TAB_DW;
 };
 
-// LDS traffic between lanes of one wave needs no hardware wait (the LDS executes
-// a wave's instructions in order); this only stops the compiler from moving
-// accesses across the hand-over.
-__device__ __forceinline__ void lds_handover()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
 // sixteen pixels in flight between a global load and an LDS store
 template <typename P> struct Px16 { uint32_t w[4 * sizeof(P)]; };
 

@@ -236,6 +236,33 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
                                int32_t merange, int32_t subpelRefine, int32_t n, const x265gpu_pu_job* jobs,
                                x265gpu_pu_result* out);
 
+/* ---- the pixel primitives, one call per batch of blocks ----
+ *
+ * The EncoderPrimitives slots this library's kernels are built from, exposed on the slots'
+ * full-resolution planes so that each can be checked against x265's C primitive:
+ * pu[part].sad / pu[part].satd (pixelcmp_t, source/common/primitives.h:133; all 25 luma
+ * partitions, source/common/pixel.cpp:1088-1172), cu[size].sa8d (pixel.cpp:328-369, 1180-1184),
+ * and pu[part].luma_hpp / luma_vpp / luma_hvpp (filter_pp_t :176, filter_hv_pp_t :181,
+ * source/common/ipfilter.cpp:79-369).  A compare job measures the block at (x,y) of the encode
+ * slot against the reference slot's block displaced by the quarter-pel vector (qmvX,qmvY); with
+ * a fractional vector the reference block is interpolated first, as subpelCompare does
+ * (source/encoder/motion.cpp:1775-1803).  SA8D takes square blocks of 8..64 and full-pel vectors. */
+#define X265GPU_OP_SAD  0
+#define X265GPU_OP_SATD 1
+#define X265GPU_OP_SA8D 2
+typedef struct x265gpu_block_job
+{
+    int32_t x, y, w, h;
+    int32_t qmvX, qmvY;
+    int32_t op;
+    int32_t reserved;
+} x265gpu_block_job;
+int x265gpu_block_compare(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t n, const x265gpu_block_job* jobs,
+                          int32_t* costs);
+/* out receives w*h pixels, rows tight; (xFrac,yFrac) in quarter pixels, 0..3 each */
+int x265gpu_interp_luma(x265gpu_ctx* ctx, int32_t slot, int32_t x, int32_t y, int32_t w, int32_t h, int32_t xFrac,
+                        int32_t yFrac, void* out);
+
 /* Copies a slot's padded full-resolution plane to the host (tests): `out` holds
  * stride * rows pixels, both reported through the pointers. */
 int x265gpu_get_full_plane(x265gpu_ctx* ctx, int32_t slot, void* out, int32_t* stride, int32_t* rows,

@@ -14,13 +14,14 @@ LIB_PATH = os.path.join(_HERE, "libx265gpu.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
 DIA_SEARCH, HEX_SEARCH, UMH_SEARCH, STAR_SEARCH, FULL_SEARCH = 0, 1, 2, 3, 5
+OP_SAD, OP_SATD, OP_SA8D = 0, 1, 2
 PHASES = ("lowres", "intra", "search", "cost")
 
 EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_weight_cost", "x265gpu_weight_planes",
-    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_interp_luma",
     "x265gpu_profile_enable", "x265gpu_profile_read",
 )
 
@@ -67,6 +68,11 @@ class PuResult(C.Structure):
     _fields_ = [("mvX", C.c_int32), ("mvY", C.c_int32), ("cost", C.c_int32), ("reserved", C.c_int32)]
 
 
+class BlockJob(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32),
+                ("qmvX", C.c_int32), ("qmvY", C.c_int32), ("op", C.c_int32), ("reserved", C.c_int32)]
+
+
 class FrameCost(C.Structure):
     _fields_ = [("costEst", C.c_int64), ("costEstAq", C.c_int64), ("intraMbs", C.c_int32), ("reserved", C.c_int32)]
 
@@ -108,6 +114,8 @@ def load_library():
     L.x265gpu_me_set_mvcost.argtypes = [vp, vp, i32]
     L.x265gpu_pu_motion_estimate.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
     L.x265gpu_get_full_plane.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    L.x265gpu_block_compare.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.x265gpu_interp_luma.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.x265gpu_profile_enable.argtypes = [vp, i32]
     L.x265gpu_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     _lib = L
@@ -300,6 +308,21 @@ class Context:
         out = (PuResult * len(jobs))()
         self._chk(self.L.x265gpu_pu_motion_estimate(self.h, slot_fenc, slot_ref, method, merange, subpel, len(jobs), arr, out))
         return [((o.mvX, o.mvY), o.cost) for o in out]
+
+    def block_compare(self, slot_fenc, slot_ref, jobs):
+        """jobs: iterable of (x, y, w, h, qmvx, qmvy, op) with op OP_SAD / OP_SATD / OP_SA8D; returns the costs."""
+        jobs = list(jobs)
+        arr = (BlockJob * len(jobs))()
+        for k, (x, y, w, h, qx, qy, op) in enumerate(jobs):
+            arr[k].x, arr[k].y, arr[k].w, arr[k].h, arr[k].qmvX, arr[k].qmvY, arr[k].op = x, y, w, h, qx, qy, op
+        out = np.empty(len(jobs), np.int32)
+        self._chk(self.L.x265gpu_block_compare(self.h, slot_fenc, slot_ref, len(jobs), arr, _ptr(out)))
+        return out
+
+    def interp_luma(self, slot, x, y, w, h, xfrac, yfrac):
+        out = np.empty((h, w), self.pix)
+        self._chk(self.L.x265gpu_interp_luma(self.h, slot, x, y, w, h, xfrac, yfrac, _ptr(out)))
+        return out
 
     def get_full_plane(self, slot):
         """-> (padded plane as a 2-D array, originX, originY)"""

@@ -127,6 +127,10 @@ struct PuFrame
     int method, merange, subpelRefine;
     int maxPasses;                     // largest ceil(tiles / 16) over the batch: sizes the LDS per wave
 };
+struct BlockJob { int x, y, w, h; int qmvx, qmvy; int op; int reserved; };   // same layout as x265gpu_block_job
+hipError_t launch_block_compare(hipStream_t s, int bpp, const PuFrame& f, const BlockJob* dJobs, int n, int* dOut);
+hipError_t launch_interp_block(hipStream_t s, int bpp, const void* pic, int stride, int x, int y, int w, int h, int xf, int yf,
+                               int depth, void* dOut);
 hipError_t launch_pad_picture(hipStream_t s, int bpp, const void* src, long long srcStride, void* dst, int stride, int rows,
                               int width, int height, int marginX, int marginY);
 hipError_t launch_pu_search(hipStream_t s, int bpp, const PuFrame& f, const PuJob* dJobs, int n, const uint16_t* costTab,

@@ -515,6 +515,34 @@ template <typename P> __device__ __forceinline__ void full_search(PuCtx<P>& c)
             try_mv<P>(c, tx, ty);
 }
 
+// The encode block into LDS (MotionEstimate::setSourcePU, motion.cpp:167-191): per pass and lane the
+// row's column pairs (masked), the row's pixel offset inside the block, and the mask.
+template <typename P>
+__device__ __forceinline__ void stage_encode_block(PuCtx<P>& c, const XG_GLOBAL P* fencPic, int stride, XG_LDS uint32_t* rec)
+{
+    const int segW = (c.w & 7) ? 4 : 8;
+    const int tilesX = c.w / segW, ntiles = tilesX * (c.h >> 2);
+    c.passes = (ntiles + 15) >> 4;
+    const XG_GLOBAL P* fenc = fencPic + ((long long)c.y * stride + c.x);
+    for (int k = 0; k < c.passes; k++)
+    {
+        const int t = k * 16 + (c.lane >> 2);
+        const bool valid = t < ntiles;
+        const int ty = valid ? t / tilesX : 0, tx = valid ? t - ty * tilesX : 0;
+        const int off = (ty * 4 + (c.lane & 3)) * stride + tx * segW;
+        const uint32_t mask = valid ? (segW == 8 ? 0xffffffffu : 0x0000ffffu) : 0u;
+        const Cols fc = pair_cols<P>(load_row_g<P>(fenc, off));
+        XG_LDS uint32_t* r = rec + (k * 64 + c.lane) * PU_REC_DW;
+        r[0] = fc.q[0] & mask;
+        r[1] = fc.q[1] & mask;
+        r[2] = fc.q[2] & mask;
+        r[3] = fc.q[3] & mask;
+        r[4] = (uint32_t)off;
+        r[5] = mask;
+    }
+    lds_handover();
+}
+
 template <typename P>
 __global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, int n, PuFrame f, const uint16_t* costTab,
                                                         int maxMvd, PuResult* out)
@@ -553,28 +581,7 @@ __global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, int n
     c.hi = maxMvd;
     c.depth = f.depth;
 
-    // ---- the encode block into LDS (MotionEstimate::setSourcePU, motion.cpp:167-191) ----
-    const int segW = (job.w & 7) ? 4 : 8;
-    const int tilesX = job.w / segW, ntiles = tilesX * (job.h >> 2);
-    c.passes = (ntiles + 15) >> 4;
-    const XG_GLOBAL P* fenc = as_global<P>(f.fenc) + ((long long)job.y * f.stride + job.x);
-    for (int k = 0; k < c.passes; k++)
-    {
-        const int t = k * 16 + (lane >> 2);
-        const bool valid = t < ntiles;
-        const int ty = valid ? t / tilesX : 0, tx = valid ? t - ty * tilesX : 0;
-        const int off = (ty * 4 + (lane & 3)) * f.stride + tx * segW;
-        const uint32_t mask = valid ? (segW == 8 ? 0xffffffffu : 0x0000ffffu) : 0u;
-        const Cols fc = pair_cols<P>(load_row_g<P>(fenc, off));
-        XG_LDS uint32_t* r = rec + (k * 64 + lane) * PU_REC_DW;
-        r[0] = fc.q[0] & mask;
-        r[1] = fc.q[1] & mask;
-        r[2] = fc.q[2] & mask;
-        r[3] = fc.q[3] & mask;
-        r[4] = (uint32_t)off;
-        r[5] = mask;
-    }
-    lds_handover();
+    stage_encode_block<P>(c, as_global<P>(f.fenc), f.stride, rec);
 
     // ---- MotionEstimate::motionEstimate, full-resolution reference ----
     const int qminx = job.minx * 4, qminy = job.miny * 4, qmaxx = job.maxx * 4, qmaxy = job.maxy * 4;
@@ -707,6 +714,138 @@ __global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, int n
     }
 }
 
+// ---- primitive-level entry points ----------------------------------------------------
+
+// sum of |H8 D H8| over the 8x8 block held by an 8-lane group (lane = row): sa8d_8x8 before
+// its rounding, source/common/pixel.cpp:291-326.  Every lane of the group gets the total.
+template <typename P> __device__ __forceinline__ int had8x8_abs(const Row<P>& fenc, const Row<P>& ref, int r)
+{
+    int a[8], b[8], d[8];
+    unpack_row<P>(fenc, a);
+    unpack_row<P>(ref, b);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        d[i] = a[i] - b[i];
+    // horizontal 8-point transform (any butterfly order: only magnitudes are summed)
+#pragma unroll
+    for (int span = 1; span < 8; span <<= 1)
+    {
+        int t[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            t[i] = (i & span) ? d[i ^ span] - d[i] : d[i] + d[i ^ span];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            d[i] = t[i];
+    }
+    // vertical 8-point transform across the group's lanes: r ^ 1, r ^ 2, r ^ 4
+    const int m1 = -(r & 1), m2 = -((r >> 1) & 1), m4 = -((r >> 2) & 1);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        d[i] = ((d[i] ^ m1) - m1) + dpp<DPP_XOR1>(d[i]);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        d[i] = ((d[i] ^ m2) - m2) + dpp<DPP_XOR2>(d[i]);
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+    {
+        // lane r ^ 4 = the half-row mirror (r -> 7 - r) followed by the quad reversal (q -> 3 - q)
+        const int partner = dpp<0x1B>(dpp<DPP_HALF_MIRROR>(d[i]));
+        s += abs(((d[i] ^ m4) - m4) + partner);
+    }
+    return group_sum8(s);
+}
+
+// One wave per job: SAD / SATD of a w x h block against the reference block displaced by a
+// quarter-pel vector (pixelcmp_t slots pu[].sad / pu[].satd behind MotionEstimate::subpelCompare),
+// or SA8D of a square block (cu[].sa8d, source/common/pixel.cpp:328-369).
+template <typename P>
+__global__ void __launch_bounds__(256) block_compare_kernel(const BlockJob* jobs, int n, PuFrame f, int* out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t puLds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + wave;
+    if (idx >= n)
+        return;
+    const BlockJob& job = jobs[idx];
+    XG_LDS uint32_t* rec = (XG_LDS uint32_t*)puLds + wave * (f.maxPasses * 64 * PU_REC_DW);
+    PuCtx<P> c;
+    c.ref = as_global<P>(f.ref);
+    c.stride = f.stride;
+    c.x = job.x;
+    c.y = job.y;
+    c.w = job.w;
+    c.h = job.h;
+    c.minX = -f.marginX + 4;
+    c.maxX = f.width + f.marginX - job.w - 16;
+    c.minY = -f.marginY + 4;
+    c.maxY = f.height + f.marginY - job.h - 5;
+    c.lane = lane;
+    c.rec = rec;
+    c.depth = f.depth;
+    int cost;
+    if (job.op == 2)
+    {
+        const int size = job.w, grp = lane >> 3, r = lane & 7;
+        const XG_GLOBAL P* fenc = as_global<P>(f.fenc) + ((long long)job.y * f.stride + job.x);
+        const XG_GLOBAL P* ref = block_at<P>(c, job.qmvx >> 2, job.qmvy >> 2);
+        if (size == 8)
+        {
+            const int s = had8x8_abs<P>(load_row_g<P>(fenc, r * f.stride), load_row_g<P>(ref, r * f.stride), r);
+            cost = (group_value<0>(s) + 2) >> 2;
+        }
+        else
+        {
+            // two 16x16 tiles per pass: groups 0..3 and 4..7 hold a tile's four 8x8 blocks
+            const int tiles = (size >> 4) * (size >> 4);
+            cost = 0;
+#pragma unroll 1
+            for (int t0 = 0; t0 < tiles; t0 += 2)
+            {
+                const int t = min(t0 + (grp >> 2), tiles - 1);
+                const int tx = t % (size >> 4), ty = t / (size >> 4);
+                const int off = (16 * ty + 8 * ((grp >> 1) & 1) + r) * f.stride + 16 * tx + 8 * (grp & 1);
+                const int s = had8x8_abs<P>(load_row_g<P>(fenc, off), load_row_g<P>(ref, off), r);
+                cost += (group_value<0>(s) + group_value<1>(s) + group_value<2>(s) + group_value<3>(s) + 2) >> 2;
+                if (t0 + 1 < tiles)
+                    cost += (group_value<4>(s) + group_value<5>(s) + group_value<6>(s) + group_value<7>(s) + 2) >> 2;
+            }
+        }
+    }
+    else
+    {
+        stage_encode_block<P>(c, as_global<P>(f.fenc), f.stride, rec);
+        cost = job.op == 1 ? block_cost<P, true>(c, job.qmvx, job.qmvy) : block_cost<P, false>(c, job.qmvx, job.qmvy);
+    }
+    if (lane == 0)
+        out[idx] = cost;
+}
+
+// luma_hpp / luma_vpp / luma_hvpp of one block (filter_pp_t, filter_hv_pp_t): one thread per
+// 8-pixel row segment, output tight (stride = w)
+template <typename P>
+__global__ void __launch_bounds__(256) interp_block_kernel(const P* pic, int stride, int x, int y, int w, int h, int xf,
+                                                           int yf, int depth, P* out)
+{
+    const int segs = (w + 7) >> 3;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= segs * h)
+        return;
+    const int row = i / segs, seg = i - row * segs;
+    const XG_GLOBAL P* p = (const XG_GLOBAL P*)pic + ((long long)(y + row) * stride + x + 8 * seg);
+    Row<P> r;
+    if (xf | yf)
+        r = interp_row<P>(p, stride, xf, yf, depth);
+    else
+        r = load_row_g<P>(p, 0);
+    int v[8];
+    unpack_row<P>(r, v);
+    for (int k = 0; k < 8 && 8 * seg + k < w; k++)
+        out[(long long)row * w + 8 * seg + k] = (P)v[k];
+}
+
 // (src coordinates clamped into the picture) = PicYuv padding + extendPicBorder
 // (source/common/picyuv.cpp:340-400, source/common/pixel.cpp:1044-1058)
 template <typename P>
@@ -744,6 +883,33 @@ hipError_t launch_pu_search(hipStream_t s, int bpp, const PuFrame& f, const PuJo
         hipLaunchKernelGGL(pu_search_kernel<uint8_t>, grid, dim3(256), lds, s, dJobs, n, f, costTab, maxMvd, dOut);
     else
         hipLaunchKernelGGL(pu_search_kernel<uint16_t>, grid, dim3(256), lds, s, dJobs, n, f, costTab, maxMvd, dOut);
+    return hipGetLastError();
+}
+
+hipError_t launch_block_compare(hipStream_t s, int bpp, const PuFrame& f, const BlockJob* dJobs, int n, int* dOut)
+{
+    if (n <= 0)
+        return hipSuccess;
+    const size_t lds = (size_t)4 * f.maxPasses * 64 * PU_REC_DW * sizeof(uint32_t);
+    dim3 grid((n + 3) / 4);
+    if (bpp == 1)
+        hipLaunchKernelGGL(block_compare_kernel<uint8_t>, grid, dim3(256), lds, s, dJobs, n, f, dOut);
+    else
+        hipLaunchKernelGGL(block_compare_kernel<uint16_t>, grid, dim3(256), lds, s, dJobs, n, f, dOut);
+    return hipGetLastError();
+}
+
+hipError_t launch_interp_block(hipStream_t s, int bpp, const void* pic, int stride, int x, int y, int w, int h, int xf, int yf,
+                               int depth, void* dOut)
+{
+    const int threads = ((w + 7) >> 3) * h;
+    dim3 grid((threads + 255) / 256);
+    if (bpp == 1)
+        hipLaunchKernelGGL(interp_block_kernel<uint8_t>, grid, dim3(256), 0, s, (const uint8_t*)pic, stride, x, y, w, h, xf,
+                           yf, depth, (uint8_t*)dOut);
+    else
+        hipLaunchKernelGGL(interp_block_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)pic, stride, x, y, w, h,
+                           xf, yf, depth, (uint16_t*)dOut);
     return hipGetLastError();
 }
 

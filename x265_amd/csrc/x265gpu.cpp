@@ -982,6 +982,41 @@ int x265gpu_get_costs(x265gpu_ctx* ctx, int32_t slot, int32_t d0, int32_t d1, ui
     return X265GPU_OK;
 }
 
+namespace {
+PuFrame pu_frame(const x265gpu_ctx* ctx, int slotFenc, int slotRef)
+{
+    PuFrame f;
+    memset(&f, 0, sizeof(f));
+    const size_t origin = ((size_t)ctx->fullMarginY * ctx->fullStride + ctx->fullMarginX) * ctx->bpp;
+    f.fenc = ctx->slots[slotFenc].full + origin;
+    f.ref = ctx->slots[slotRef].full + origin;
+    f.stride = ctx->fullStride;
+    f.width = ctx->fullW;
+    f.height = ctx->fullH;
+    f.marginX = ctx->fullMarginX;
+    f.marginY = ctx->fullMarginY;
+    f.depth = ctx->cfg.internalBitDepth;
+    f.maxPasses = 1;
+    return f;
+}
+
+int ensure_pu_buf(x265gpu_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->puBufSize)
+        return X265GPU_OK;
+    if (ctx->puBuf)
+    {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(ctx->puBuf));
+        ctx->puBuf = nullptr;
+        ctx->puBufSize = 0;
+    }
+    HIPCHK(hipMalloc((void**)&ctx->puBuf, bytes));
+    ctx->puBufSize = bytes;
+    return X265GPU_OK;
+}
+} // namespace
+
 int x265gpu_me_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd)
 {
     if (!ctx || !centre || maxMvd < 1024)
@@ -1037,30 +1072,11 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
         maxPasses = passes > maxPasses ? passes : maxPasses;
     }
     const size_t jobBytes = align256(sizeof(PuJob) * (size_t)n), outBytes = sizeof(PuResult) * (size_t)n;
-    if (jobBytes + outBytes > ctx->puBufSize)
-    {
-        if (ctx->puBuf)
-        {
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            HIPCHK(hipFree(ctx->puBuf));
-            ctx->puBuf = nullptr;
-            ctx->puBufSize = 0;
-        }
-        HIPCHK(hipMalloc((void**)&ctx->puBuf, jobBytes + outBytes));
-        ctx->puBufSize = jobBytes + outBytes;
-    }
+    int rc = ensure_pu_buf(ctx, jobBytes + outBytes);
+    if (rc)
+        return rc;
     HIPCHK(hipMemcpyAsync(ctx->puBuf, jobs, sizeof(PuJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    PuFrame f;
-    memset(&f, 0, sizeof(f));
-    const size_t origin = ((size_t)ctx->fullMarginY * ctx->fullStride + ctx->fullMarginX) * ctx->bpp;
-    f.fenc = ctx->slots[slotFenc].full + origin;
-    f.ref = ctx->slots[slotRef].full + origin;
-    f.stride = ctx->fullStride;
-    f.width = ctx->fullW;
-    f.height = ctx->fullH;
-    f.marginX = ctx->fullMarginX;
-    f.marginY = ctx->fullMarginY;
-    f.depth = ctx->cfg.internalBitDepth;
+    PuFrame f = pu_frame(ctx, slotFenc, slotRef);
     f.method = searchMethod;
     f.merange = merange;
     f.subpelRefine = subpelRefine;
@@ -1068,6 +1084,68 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
     HIPCHK(launch_pu_search(ctx->stream, ctx->bpp, f, (const PuJob*)ctx->puBuf, n, ctx->meCostCentre, ctx->meMaxMvd,
                             (PuResult*)(ctx->puBuf + jobBytes)));
     HIPCHK(hipMemcpyAsync(out, ctx->puBuf + jobBytes, outBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
+int x265gpu_block_compare(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t n, const x265gpu_block_job* jobs,
+                          int32_t* costs)
+{
+    static_assert(sizeof(x265gpu_block_job) == sizeof(BlockJob), "public and device job layouts must match");
+    if (!ctx || n < 0 || (n && (!jobs || !costs)))
+        return X265GPU_ERR_ARG;
+    if (!n)
+        return X265GPU_OK;
+    if (!slot_ok(ctx, slotFenc) || !slot_ok(ctx, slotRef))
+        return fail(ctx, X265GPU_ERR_ARG, "block_compare: bad slot");
+    if (!ctx->fullStride)
+        return fail(ctx, X265GPU_ERR_STATE, "block_compare: context opened without bKeepFullRes");
+    PuFrame f = pu_frame(ctx, slotFenc, slotRef);
+    for (int i = 0; i < n; i++)
+    {
+        const x265gpu_block_job& j = jobs[i];
+        const int fx = j.x + (j.qmvX >> 2), fy = j.y + (j.qmvY >> 2);
+        bool ok = j.w >= 4 && j.h >= 4 && j.w <= 64 && j.h <= 64 && !(j.w & 3) && !(j.h & 3) && j.x >= 0 && j.y >= 0 &&
+                  j.x + j.w <= ctx->fullW && j.y + j.h <= ctx->fullH && j.op >= X265GPU_OP_SAD && j.op <= X265GPU_OP_SA8D &&
+                  fx >= -ctx->fullMarginX + 8 && fx + j.w <= ctx->fullW + ctx->fullMarginX - 16 &&
+                  fy >= -ctx->fullMarginY + 8 && fy + j.h <= ctx->fullH + ctx->fullMarginY - 8;
+        if (ok && j.op == X265GPU_OP_SA8D)
+            ok = j.w == j.h && (j.w == 8 || j.w == 16 || j.w == 32 || j.w == 64) && !((j.qmvX | j.qmvY) & 3);
+        if (!ok)
+            return fail(ctx, X265GPU_ERR_ARG, "block_compare: bad job");
+        const int segW = (j.w & 7) ? 4 : 8;
+        const int passes = ((j.w / segW) * (j.h / 4) + 15) / 16;
+        f.maxPasses = passes > f.maxPasses ? passes : f.maxPasses;
+    }
+    const size_t jobBytes = align256(sizeof(BlockJob) * (size_t)n), outBytes = sizeof(int32_t) * (size_t)n;
+    int rc = ensure_pu_buf(ctx, jobBytes + outBytes);
+    if (rc)
+        return rc;
+    HIPCHK(hipMemcpyAsync(ctx->puBuf, jobs, sizeof(BlockJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(launch_block_compare(ctx->stream, ctx->bpp, f, (const BlockJob*)ctx->puBuf, n, (int*)(ctx->puBuf + jobBytes)));
+    HIPCHK(hipMemcpyAsync(costs, ctx->puBuf + jobBytes, outBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
+int x265gpu_interp_luma(x265gpu_ctx* ctx, int32_t slot, int32_t x, int32_t y, int32_t w, int32_t h, int32_t xFrac,
+                        int32_t yFrac, void* out)
+{
+    if (!ctx || !out || !slot_ok(ctx, slot))
+        return X265GPU_ERR_ARG;
+    if (!ctx->fullStride)
+        return fail(ctx, X265GPU_ERR_STATE, "interp_luma: context opened without bKeepFullRes");
+    if (w < 1 || h < 1 || w > 64 || h > 64 || xFrac < 0 || xFrac > 3 || yFrac < 0 || yFrac > 3 ||
+        x < -ctx->fullMarginX + 8 || x + w > ctx->fullW + ctx->fullMarginX - 16 ||
+        y < -ctx->fullMarginY + 8 || y + h > ctx->fullH + ctx->fullMarginY - 8)
+        return fail(ctx, X265GPU_ERR_ARG, "interp_luma: bad block");
+    const size_t bytes = (size_t)w * h * ctx->bpp;
+    int rc = ensure_pu_buf(ctx, bytes);
+    if (rc)
+        return rc;
+    const PuFrame f = pu_frame(ctx, slot, slot);
+    HIPCHK(launch_interp_block(ctx->stream, ctx->bpp, f.ref, f.stride, x, y, w, h, xFrac, yFrac, f.depth, ctx->puBuf));
+    HIPCHK(hipMemcpyAsync(out, ctx->puBuf, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return X265GPU_OK;
 }

@@ -1,6 +1,7 @@
 """GPU: the HIP path against the committed golden vectors (tests/golden/*.npz), and
 size-independent properties at the benchmark's full frame size."""
 import importlib.util
+import json
 import os
 import zlib
 
@@ -26,13 +27,14 @@ def _table(depth):
     return orc.bitcost_table(depth)
 
 
-@pytest.mark.parametrize("name", ["lookahead_8bit", "lookahead_10bit"])
+@pytest.mark.parametrize("name", ["lookahead_8bit", "lookahead_10bit", "lookahead_umh_8bit", "lookahead_hme_10bit"])
 def test_against_golden(name):
     mg = _mg()
     want = np.load(os.path.join(HERE, "golden", name + ".npz"))
     W, H, N, depth, bframes, seed, with_aq = [int(v) for v in want["meta"]]
+    search = json.loads(str(want["search"]))
     clip = synth.luma_clip(W, H, N, depth, seed=seed)
-    with api.Context(W, H, depth=depth, bframes=bframes, num_slots=N) as ctx:
+    with api.Context(W, H, depth=depth, bframes=bframes, num_slots=N, **search) as ctx:
         ctx.set_mvcost(*_table(depth))
         frames = [LowresState(i, i, ctx.D) for i in range(N)]
         aq = [mg.aq_factors(ctx.geom.cuCount, seed + i) for i in range(N)] if with_aq else None
@@ -61,9 +63,28 @@ def test_against_golden(name):
                 mv, c = ctx.get_mvs(b, 1, d1)
                 np.testing.assert_array_equal(mv, want["mv1_%d" % k])
                 np.testing.assert_array_equal(c, want["mvcost1_%d" % k])
+            if search.get("hme"):
+                mv, c = ctx.get_hme_mvs(b, 0, d0)
+                np.testing.assert_array_equal(mv, want["hme_mv0_%d" % k])
+                np.testing.assert_array_equal(c, want["hme_mvcost0_%d" % k])
             lc, rs, _ = ctx.get_costs(b, d0, d1)
             np.testing.assert_array_equal(lc, want["lowres_costs_%d" % k])
             np.testing.assert_array_equal(rs, want["row_satds_%d" % k])
+
+
+@pytest.mark.parametrize("name", ["pu_me_star_8bit", "pu_me_hex_10bit"])
+def test_pu_me_against_golden(name):
+    mg = _mg()
+    want = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    W, H, depth, seed, method, merange, subme, count = [int(v) for v in want["meta"]]
+    clip, pads, mx, my, fw, fh = mg.pu_pictures(W, H, depth, seed)
+    jobs = mg.pu_jobs(np.random.default_rng(seed), fw, fh, mx, my, merange, count)
+    with api.Context(W, H, depth=depth, num_slots=2, keep_full_res=True) as ctx:
+        ctx.lowres_init(0, clip[0])
+        ctx.lowres_init(1, clip[1])
+        ctx.me_set_mvcost(*_table(depth))
+        got = ctx.pu_motion_estimate(1, 0, method, merange, subme, jobs)
+    np.testing.assert_array_equal(np.array([[mv[0], mv[1], c] for mv, c in got], np.int32), want["results"])
 
 
 @pytest.mark.parametrize("depth", [8, 10])

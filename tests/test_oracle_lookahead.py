@@ -22,11 +22,12 @@ def _golden_module():
     return m
 
 
-@pytest.mark.parametrize("name", ["lookahead_8bit", "lookahead_10bit"])
+@pytest.mark.parametrize("name", ["lookahead_8bit", "lookahead_10bit", "lookahead_umh_8bit", "lookahead_hme_10bit",
+                                  "pu_me_star_8bit", "pu_me_hex_10bit"])
 def test_oracle_matches_golden(oracle_built, name):
     mg = _golden_module()
     want = np.load(os.path.join(HERE, "golden", name + ".npz"))
-    got = mg.generate(name)
+    got = mg.generate_pu(name) if name.startswith("pu_me") else mg.generate(name)
     assert sorted(got.keys()) == sorted(want.files)
     for k in want.files:
         np.testing.assert_array_equal(got[k], want[k], err_msg=k)

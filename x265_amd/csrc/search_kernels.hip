@@ -352,11 +352,16 @@ template <typename P> __device__ __forceinline__ void stage_search(BlockCtx<P>& 
     lds_handover();
 }
 
-// make sure every block within `ext` pixels of displacement (mx,my) lies in the staged window
+// Make sure every block within `ext` pixels of displacement (mx,my) lies in the staged window
+// and every such vector's MVD lies in the staged MV-cost windows.  The two are separate
+// conditions: the MV cost is relative to the unclipped predictor, so a window that still holds
+// the blocks says nothing about the table when the predictor was clipped or guessed.
 template <typename P> __device__ __forceinline__ void ensure_window(BlockCtx<P>& c, int mx, int my, int ext)
 {
     const unsigned lim = (unsigned)(WIN - 8 - 2 * ext);
-    if ((unsigned)(c.relX + mx - ext) > lim || (unsigned)(c.relY + my - ext) > lim)
+    const unsigned tlim = (unsigned)(TAB_N - 1 - 8 * ext);
+    if ((unsigned)(c.relX + mx - ext) > lim || (unsigned)(c.relY + my - ext) > lim ||
+        (unsigned)(4 * (mx - ext) + c.tabBiasX) > tlim || (unsigned)(4 * (my - ext) + c.tabBiasY - TAB_N) > tlim)
         stage_search<P>(c, mx, my);
 }
 

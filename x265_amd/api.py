@@ -77,18 +77,19 @@ class FrameCost(C.Structure):
     _fields_ = [("costEst", C.c_int64), ("costEstAq", C.c_int64), ("intraMbs", C.c_int32), ("reserved", C.c_int32)]
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """Loads libx265gpu.so; raises if it has not been built (see __graft_entry__.build)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load_library(path=None):
+    """Loads libx265gpu.so (or a test build of it at `path`); raises if it has not been built
+    (see __graft_entry__.build)."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise X265GpuError("%s not found: build the HIP library first (python -c 'import __graft_entry__ as g; "
-                           "g.build()')" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+                           "g.build()')" % path)
+    L = C.CDLL(path)
     vp, i32, ip = C.c_void_p, C.c_int32, C.c_ssize_t
     L.x265gpu_open.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.x265gpu_close.argtypes = [vp]
@@ -118,7 +119,7 @@ def load_library():
     L.x265gpu_interp_luma.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.x265gpu_profile_enable.argtypes = [vp, i32]
     L.x265gpu_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
-    _lib = L
+    _libs[path] = L
     return L
 
 
@@ -131,8 +132,8 @@ class Context:
 
     def __init__(self, width, height, depth=8, bframes=4, num_slots=8, search=HEX_SEARCH, merange=16,
                  ctu=64, hme=False, hme_methods=(HEX_SEARCH, UMH_SEARCH, UMH_SEARCH), hme_range=(16, 32, 48),
-                 bframe_bias=0, device=0, stream=None, keep_full_res=False):
-        self.L = load_library()
+                 bframe_bias=0, device=0, stream=None, keep_full_res=False, lib_path=None):
+        self.L = load_library(lib_path)
         cfg = Config()
         cfg.sourceWidth, cfg.sourceHeight, cfg.internalBitDepth = width, height, depth
         cfg.maxCUSize, cfg.bframes, cfg.numSlots = ctu, bframes, num_slots

@@ -819,6 +819,13 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     c.win = lds;
     c.sub = lds + WaveLds<P>::WIN_DW;
     c.tab = lds + WaveLds<P>::WIN_DW + WaveLds<P>::SUB_DW;
+#ifdef XG_POISON_LDS
+    // test build: whatever the wave reads from LDS without having staged it first shows up
+    // as a result that changes with this constant
+    for (int i = lane; i < WaveLds<P>::TOTAL; i += 64)
+        lds[i] = XG_POISON_LDS;
+    lds_handover();
+#endif
     c.relX = c.relY = c.subRelX = c.subRelY = NOT_STAGED;
     c.tabLoX = c.tabLoY = c.tabBiasX = c.tabBiasY = 0;
     // search bounds that stay inside the extended frame (slicetype.cpp:4417-4420)

@@ -78,12 +78,12 @@ def plan_step(ctx, nframes, bframes):
     return r1, r2
 
 
-def cpu_baseline(width, height, depth, bframes, sample_frames, seed):
+def cpu_baseline(width, height, depth, bframes, sample_frames, seed, hme=False):
     """The oracle (a scalar C port of the reference path) on one host core, same request pattern."""
     from oracle import orc
     from x265_amd import synth
     clip = synth.luma_clip(width, height, sample_frames, depth, seed=seed)
-    param = orc.make_param(width, height, bframes=bframes)
+    param = orc.make_param(width, height, bframes=bframes, hme=hme)
     t0 = time.perf_counter()
     ref = orc.Lookahead(depth, param)
     for f in clip:
@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--frames", type=int, default=60, help="frames per step (one device batch)")
     ap.add_argument("--bframes", type=int, default=4)
     ap.add_argument("--cpu-frames", type=int, default=60, help="frames in the bounded CPU baseline sample (0 = skip)")
+    ap.add_argument("--hme", action="store_true", help="--hme: quarter-res hex then half-res umh (x265's defaults, ranges 16 / 32)")
     args = ap.parse_args()
 
     import torch
@@ -139,7 +140,7 @@ def main():
     slots = list(range(F))
 
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = api.Context(W, H, depth=D, bframes=args.bframes, num_slots=F, device=local_rank, stream=stream)
+    ctx = api.Context(W, H, depth=D, bframes=args.bframes, num_slots=F, device=local_rank, stream=stream, hme=args.hme)
     table, centre = orc.bitcost_table(D)          # host-built input table (float math stays on the host)
     ctx.set_mvcost(table, centre)
     r1, r2 = plan_step(ctx, F, args.bframes)
@@ -223,15 +224,15 @@ def main():
         "metric": "lookahead frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8" if D == 8 else "u16", "data": "synthetic",
-        "config": {"workload": "%dx%d %d-bit lookahead, bframes %d, b-adapt 2 batch order, %d-frame segment per step"
-                               % (W, H, D, args.bframes, F),
+        "config": {"workload": "%dx%d %d-bit lookahead%s, bframes %d, b-adapt 2 batch order, %d-frame segment per step"
+                               % (W, H, D, " with --hme (hex / umh)" if args.hme else "", args.bframes, F),
                    "frames_per_step": F, "search_requests_per_step": n_search, "cost_requests_per_step": n_cost,
                    "blocks_per_frame": n, "sharding": "frame segments per rank, RCCL all_gather of cost scalars"
                    if distributed else "single GPU"},
         "roofline": roofline, "kernels": kernels,
     }
     if rank == 0 and args.cpu_frames > 0:
-        out["cpu_baseline"] = cpu_baseline(W, H, D, args.bframes, args.cpu_frames, 1234)
+        out["cpu_baseline"] = cpu_baseline(W, H, D, args.bframes, args.cpu_frames, 1234, args.hme)
     ctx.close()
     if distributed:
         dist.barrier()

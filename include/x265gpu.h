@@ -236,6 +236,16 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
                                int32_t merange, int32_t subpelRefine, int32_t n, const x265gpu_pu_job* jobs,
                                x265gpu_pu_result* out);
 
+/* ---- adaptive-quantisation block energies and weighted-prediction frame sums ----
+ *
+ * The pixel passes of LookaheadTLD::calcAdaptiveQuantFrame (source/encoder/slicetype.cpp:454-704) for a
+ * 4:2:0 picture and qgSize >= 16: energy[by * ceil(w/16) + bx] = acEnergyCu(blockX, blockY) (:266-285), and
+ * the raw per-plane accumulators Lowres::wp_sum[] / wp_ssd[] as acEnergyVar leaves them (:51-59), before the
+ * mean is removed at :678-685.  The caller keeps the float mapping from energy to QP offsets.  Planes are the
+ * unpadded source planes (luma sourceWidth x sourceHeight, chroma half of each); strides in pixels. */
+int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const void* u, const void* v, intptr_t strideC,
+                      int32_t memKind, uint32_t* energy, uint64_t wpSum[3], uint64_t wpSsd[3]);
+
 /* ---- the pixel primitives, one call per batch of blocks ----
  *
  * The EncoderPrimitives slots this library's kernels are built from, exposed on the slots'

@@ -66,6 +66,8 @@ void orc_extend_pic_border(pixel* pic, intptr_t stride, int width, int height, i
 void orc_weight_pp(const pixel* src, pixel* dst, intptr_t stride, int width, int height,
                    int w0, int round, int shift, int offset);
 uint64_t orc_pixel_var(int size, const pixel* pix, intptr_t stride);
+void orc_aq_energy(const pixel* y, intptr_t sy, const pixel* u, const pixel* v, intptr_t sc, int w, int h,
+                   uint32_t* energy, uint64_t* wp);
 
 void orc_intra_filter(int tuSize, const pixel* samples, pixel* filtered);
 void orc_intra_pred(int size, int mode, pixel* dst, intptr_t dstStride, const pixel* srcPix, int bFilter);

@@ -92,6 +92,7 @@ def lib(depth=8):
     L.orc_lowres_ptr.restype = vp
     L.orc_lowres_i64.argtypes = [vp, C.c_char_p, i, i]
     L.orc_lowres_i64.restype = C.c_int64
+    L.orc_aq_energy.argtypes = [vp, ip, vp, vp, ip, i, i, vp, vp]
     L.orc_me_init.argtypes = [vp, vp]
     L.orc_me_create.argtypes = [vp]
     L.orc_me_create.restype = vp

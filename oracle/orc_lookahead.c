@@ -279,6 +279,42 @@ void orc_intra_estimate(orc_tld* t, orc_lowres* fenc, const orc_param* p)
     fenc->costEstAq[0][0] = costEstAq;
 }
 
+/* ---------------------------------------------------------------- AQ block energies */
+
+/* One plane's share of acEnergyCu: pixel_var of a size x size block whose samples beyond the
+ * picture are the replicated edge (PicYuv::copyFromPicture pads the source that way,
+ * source/common/picyuv.cpp:340-400), then acEnergyVar (source/encoder/slicetype.cpp:51-59). */
+static uint32_t ac_energy_plane(const pixel* plane, intptr_t stride, int w, int h, int x0, int y0, int size, int shift,
+                                uint64_t* wpSum, uint64_t* wpSsd)
+{
+    pixel blk[16 * 16];
+    for (int y = 0; y < size; y++)
+        for (int x = 0; x < size; x++)
+            blk[y * size + x] = plane[(intptr_t)imin(y0 + y, h - 1) * stride + imin(x0 + x, w - 1)];
+    uint64_t sum_ssd = orc_pixel_var(size, blk, size);
+    uint32_t sum = (uint32_t)sum_ssd, ssd = (uint32_t)(sum_ssd >> 32);
+    *wpSum += sum;
+    *wpSsd += ssd;
+    return ssd - (uint32_t)(((uint64_t)sum * sum) >> shift);
+}
+
+/* acEnergyCu over the frame, 4:2:0, 16x16 blocks: source/encoder/slicetype.cpp:266-285 and the
+ * block loop of calcAdaptiveQuantFrame (:520-527, :560-566).  wp[0..2] = wp_sum, wp[3..5] = wp_ssd. */
+void orc_aq_energy(const pixel* y, intptr_t sy, const pixel* u, const pixel* v, intptr_t sc, int w, int h,
+                   uint32_t* energy, uint64_t* wp)
+{
+    memset(wp, 0, 6 * sizeof(uint64_t));
+    int k = 0;
+    for (int by = 0; by < h; by += 16)
+        for (int bx = 0; bx < w; bx += 16, k++)
+        {
+            uint32_t e = ac_energy_plane(y, sy, w, h, bx, by, 16, 8, &wp[0], &wp[3]);
+            e += ac_energy_plane(u, sc, w >> 1, h >> 1, bx >> 1, by >> 1, 8, 6, &wp[1], &wp[4]);
+            e += ac_energy_plane(v, sc, w >> 1, h >> 1, bx >> 1, by >> 1, 8, 6, &wp[2], &wp[5]);
+            energy[k] = e;
+        }
+}
+
 /* ---------------------------------------------------------------- weighted prediction */
 
 /* source/encoder/slicetype.cpp:817-850 */

@@ -205,3 +205,33 @@ def test_bitcost_table(oracle_built):
         np.testing.assert_array_equal(t[c + 1:], t[:c][::-1])   # symmetric in the sign of the MVD
     t8, c8 = orc.bitcost_table(8)
     assert 2 * int(t8[c8]) == 2                           # mvcost(0,0) at the 8-bit lookahead lambda
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_aq_energy_against_numpy(oracle_built, depth):
+    """acEnergyCu per 16x16 block and the wp accumulators, against a direct numpy formulation:
+    energy = sum over Y (16x16), U, V (8x8) of ssd - (sum^2 >> log2(pixels)), all in uint32 arithmetic."""
+    W, H = 90, 52
+    rng = np.random.default_rng(depth)
+    dt = np.uint8 if depth == 8 else np.uint16
+    top = (1 << depth) - 1
+    planes = [rng.integers(0, top + 1, s).astype(dt) for s in ((H, W), (H // 2, W // 2), (H // 2, W // 2))]
+    bw, bh = (W + 15) // 16, (H + 15) // 16
+    got_e = np.zeros(bw * bh, np.uint32)
+    got_wp = np.zeros(6, np.uint64)
+    L = orc.lib(depth)
+    L.orc_aq_energy(orc.ptr(planes[0]), W, orc.ptr(planes[1]), orc.ptr(planes[2]), W // 2, W, H,
+                    orc.ptr(got_e), orc.ptr(got_wp))
+    want_e = np.zeros(bw * bh, np.uint64)
+    want_wp = np.zeros(6, np.uint64)
+    for i, (p, size, shift) in enumerate(zip(planes, (16, 8, 8), (8, 6, 6))):
+        pad = np.pad(p.astype(np.uint64), ((0, bh * size - p.shape[0]), (0, bw * size - p.shape[1])), mode="edge")
+        for by in range(bh):
+            for bx in range(bw):
+                blk = pad[by * size:(by + 1) * size, bx * size:(bx + 1) * size]
+                s, q = int(blk.sum()), int((blk * blk).sum()) & 0xffffffff
+                want_wp[i] += s
+                want_wp[3 + i] += q
+                want_e[by * bw + bx] += (q - ((s * s) >> shift)) & 0xffffffff
+    np.testing.assert_array_equal(got_e, (want_e & 0xffffffff).astype(np.uint32))
+    np.testing.assert_array_equal(got_wp, want_wp)

@@ -21,7 +21,7 @@ EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_weight_cost", "x265gpu_weight_planes",
-    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_interp_luma",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_interp_luma",
     "x265gpu_profile_enable", "x265gpu_profile_read",
 )
 
@@ -116,6 +116,7 @@ def load_library(path=None):
     L.x265gpu_pu_motion_estimate.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
     L.x265gpu_get_full_plane.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.x265gpu_block_compare.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.x265gpu_aq_energy.argtypes = [vp, vp, ip, vp, vp, ip, i32, vp, vp, vp]
     L.x265gpu_interp_luma.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.x265gpu_profile_enable.argtypes = [vp, i32]
     L.x265gpu_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
@@ -324,6 +325,17 @@ class Context:
         out = np.empty((h, w), self.pix)
         self._chk(self.L.x265gpu_interp_luma(self.h, slot, x, y, w, h, xfrac, yfrac, _ptr(out)))
         return out
+
+    def aq_energy(self, y, u, v):
+        """acEnergyCu of every 16x16 block plus the raw wp_sum / wp_ssd accumulators of a 4:2:0 picture (host planes)."""
+        y, u, v = (np.ascontiguousarray(p, self.pix) for p in (y, u, v))
+        g = self.cfg
+        blocks = ((g.sourceWidth + 15) >> 4) * ((g.sourceHeight + 15) >> 4)
+        energy = np.empty(blocks, np.uint32)
+        wsum, wssd = np.zeros(3, np.uint64), np.zeros(3, np.uint64)
+        self._chk(self.L.x265gpu_aq_energy(self.h, _ptr(y), y.shape[1], _ptr(u), _ptr(v), u.shape[1], MEM_HOST,
+                                           _ptr(energy), _ptr(wsum), _ptr(wssd)))
+        return energy, wsum, wssd
 
     def get_full_plane(self, slot):
         """-> (padded plane as a 2-D array, originX, originY)"""

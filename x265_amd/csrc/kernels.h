@@ -135,6 +135,16 @@ hipError_t launch_pad_picture(hipStream_t s, int bpp, const void* src, long long
                               int width, int height, int marginX, int marginY);
 hipError_t launch_pu_search(hipStream_t s, int bpp, const PuFrame& f, const PuJob* dJobs, int n, const uint16_t* costTab,
                             int maxMvd, PuResult* dOut);
+// AQ block energies: tight (unpadded) planes on the device, 4:2:0
+struct AqJob
+{
+    const void* luma; const void* u; const void* v;
+    long long lumaStride, chromaStride;      // pixels
+    int width, height;                       // luma size
+    uint32_t* energy;                        // [ceil(h/16)][ceil(w/16)]
+    unsigned long long* wp;                  // [0..2] wp_sum Y,U,V; [3..5] wp_ssd Y,U,V (zeroed by the caller)
+};
+hipError_t launch_aq_energy(hipStream_t s, int bpp, const AqJob& job);
 hipError_t launch_cost(hipStream_t s, const Geometry& g, int bpp, const CostJob* dJobs, int n);
 hipError_t launch_weight_cost(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJob);
 hipError_t launch_weight_planes(hipStream_t s, const Geometry& g, int bpp, int depth, int nPlanes, const void* src,

@@ -1088,6 +1088,68 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
     return X265GPU_OK;
 }
 
+int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const void* u, const void* v, intptr_t strideC,
+                      int32_t memKind, uint32_t* energy, uint64_t wpSum[3], uint64_t wpSsd[3])
+{
+    if (!ctx || !y || !u || !v || !energy || !wpSum || !wpSsd)
+        return X265GPU_ERR_ARG;
+    const int w = ctx->cfg.sourceWidth, h = ctx->cfg.sourceHeight, cw = w >> 1, ch = h >> 1;
+    if (strideY < w || strideC < cw || cw < 1 || ch < 1)
+        return fail(ctx, X265GPU_ERR_ARG, "aq_energy: bad stride or picture size");
+    const int blocks = ((w + 15) >> 4) * ((h + 15) >> 4);
+    const size_t lumaBytes = (size_t)w * h * ctx->bpp, chromaBytes = (size_t)cw * ch * ctx->bpp;
+    const size_t outBytes = align256(sizeof(uint32_t) * (size_t)blocks) + 256;
+    AqJob job;
+    memset(&job, 0, sizeof(job));
+    job.width = w;
+    job.height = h;
+    int rc = ensure_pu_buf(ctx, outBytes);
+    if (rc)
+        return rc;
+    if (memKind == X265GPU_MEM_HOST)
+    {
+        rc = ensure_src_stage(ctx, align256(lumaBytes) + 2 * align256(chromaBytes));
+        if (rc)
+            return rc;
+        char* dy = ctx->srcStage;
+        char* du = dy + align256(lumaBytes);
+        char* dv = du + align256(chromaBytes);
+        HIPCHK(hipMemcpy2DAsync(dy, (size_t)w * ctx->bpp, y, (size_t)strideY * ctx->bpp, (size_t)w * ctx->bpp, h,
+                                hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpy2DAsync(du, (size_t)cw * ctx->bpp, u, (size_t)strideC * ctx->bpp, (size_t)cw * ctx->bpp, ch,
+                                hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpy2DAsync(dv, (size_t)cw * ctx->bpp, v, (size_t)strideC * ctx->bpp, (size_t)cw * ctx->bpp, ch,
+                                hipMemcpyHostToDevice, ctx->stream));
+        job.luma = dy;
+        job.u = du;
+        job.v = dv;
+        job.lumaStride = w;
+        job.chromaStride = cw;
+    }
+    else
+    {
+        job.luma = y;
+        job.u = u;
+        job.v = v;
+        job.lumaStride = strideY;
+        job.chromaStride = strideC;
+    }
+    job.energy = (uint32_t*)ctx->puBuf;
+    job.wp = (unsigned long long*)(ctx->puBuf + align256(sizeof(uint32_t) * (size_t)blocks));
+    HIPCHK(hipMemsetAsync(job.wp, 0, 256, ctx->stream));
+    HIPCHK(launch_aq_energy(ctx->stream, ctx->bpp, job));
+    unsigned long long wp[6];
+    HIPCHK(hipMemcpyAsync(energy, job.energy, sizeof(uint32_t) * (size_t)blocks, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(wp, job.wp, sizeof(wp), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 3; i++)
+    {
+        wpSum[i] = wp[i];
+        wpSsd[i] = wp[3 + i];
+    }
+    return X265GPU_OK;
+}
+
 int x265gpu_block_compare(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t n, const x265gpu_block_job* jobs,
                           int32_t* costs)
 {

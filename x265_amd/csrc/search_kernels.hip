@@ -254,9 +254,11 @@ __device__ __forceinline__ int make_key(int cost, int order, int g) { return (co
 // minimum over the wave of a value that is uniform within each 8-lane group
 __device__ __forceinline__ int wave_min(int v)
 {
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));   // row_ror:8, the row's other group
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3
+    // lanes a step does not write keep KEY_INVALID, the identity of min, which lets the compiler
+    // fold each move into the v_min itself
+    v = min(v, __builtin_amdgcn_update_dpp(KEY_INVALID, v, 0x128, 0xf, 0xf, false));   // row_ror:8, the row's other group
+    v = min(v, __builtin_amdgcn_update_dpp(KEY_INVALID, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+    v = min(v, __builtin_amdgcn_update_dpp(KEY_INVALID, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3
     return __builtin_amdgcn_readlane(v, 63);
 }
 
@@ -416,9 +418,12 @@ template <typename P> __device__ __forceinline__ Row<P> sub_row(const BlockCtx<P
 // cost at quarter-pel (qx,qy) out of the staged sub-pel window: ReferencePlanes::lowresQPelCost
 // (source/common/lowres.h:95-140) + mvcost.  Branch-free: a vector without a quarter-pel
 // part averages its block with itself.
-template <typename P, int KIND> __device__ __forceinline__ int eval_sub(const BlockCtx<P>& c, int qx, int qy)
+// `anyOdd` (wave-uniform): some lane's vector has a quarter-pel part; without one the second fetch is skipped.
+template <typename P, int KIND> __device__ __forceinline__ int eval_sub(const BlockCtx<P>& c, int qx, int qy, bool anyOdd)
 {
-    const Row<P> ref = avg_row<P>(sub_row<P>(c, qx, qy), sub_row<P>(c, qx + (qx & 1), qy + (qy & 1)));
+    Row<P> ref = sub_row<P>(c, qx, qy);
+    if (anyOdd)
+        ref = avg_row<P>(ref, sub_row<P>(c, qx + (qx & 1), qy + (qy & 1)));
     return reduce_cost<P, KIND>(c, ref, price_lanes<P>(c, qx, qy));
 }
 
@@ -755,7 +760,7 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
         stage_subpel<P>(c, bqx, bqy);
         {
             const int qx = bqx + 2 * nib(SQ1_X, gi), qy = bqy + 2 * nib(SQ1_Y, gi);
-            const int cost = eval_sub<P, EV_SAD>(c, qx, qy);
+            const int cost = eval_sub<P, EV_SAD>(c, qx, qy, ((bqx | bqy) & 1) != 0);     // half-pel steps keep the parity
             const bool ok = c.g < 4 && (unsigned)(qy - qminy) <= qyr;
             take_winner(wave_min(ok ? make_key(cost, gi + 1, c.g) : KEY_INVALID), qx, qy, bqx, bqy, bcost);
         }
@@ -763,7 +768,7 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
         // whose SATD replaces the running cost before the neighbours are compared
         {
             const int qx = bqx + ((c.g < 4) ? nib(SQ1_X, gi) : 0), qy = bqy + ((c.g < 4) ? nib(SQ1_Y, gi) : 0);
-            const int cost = eval_sub<P, EV_SATD>(c, qx, qy);
+            const int cost = eval_sub<P, EV_SATD>(c, qx, qy, true);
             const bool ok = c.g == 4 || (c.g < 4 && (unsigned)(qy - qminy) <= qyr);
             const int key = wave_min(ok ? make_key(cost, c.g < 4 ? gi + 1 : 0, c.g) : KEY_INVALID);
             const int lane = (key & 7) << 3;

@@ -34,12 +34,82 @@ __device__ __forceinline__ bool uses_filtered(int mode) { return mode == 0 || mo
 // Row r of the 8x8 prediction for `mode` (0 planar, 1 DC, 2..34 angular).
 // nb[0..32] raw neighbours, nb[40..72] smoothed; layout [0] corner,
 // [1..16] top + top-right, [17..32] left + bottom-left.
-__device__ void predict_row(const int* nb, int mode, int r, int pixelMax, int p[8])
+//
+// Angular modes (intra_pred_ang_c, source/common/intrapred.cpp:123-204): the eight lanes of
+// the group first lay the mode's reference array ref[-8..16] out in `ext` (ext[j] = ref[j - 8]):
+// the main side (top for vertical modes, left for horizontal ones), the corner at ref[-1], and
+// for negative angles the other side projected through the inverse angle.  Every predicted
+// sample is then the 1/32-pel interpolation of two neighbouring entries.  Horizontal modes are
+// the vertical formula on swapped sides, transposed: lane r is column r there, so the entry
+// offset changes per sample instead of per lane; one loop serves both.  `ext` is this group's
+// own 32 ints of LDS.  DC / planar (WITH_FLAT) only occur in the first pass.
+template <bool WITH_FLAT>
+__device__ __forceinline__ void predict_row(const int* nb, int* ext, int mode, int r, int pixelMax, int p[8])
 {
-    const int* raw = nb;
-    if (mode == 1)
+    const bool hor = mode < 18;
+    const int angOff = hor ? 10 - mode : mode - 26;
+    const int aabs = angOff < 0 ? -angOff : angOff;
+    // |angle| for offsets 0..8: 0,2,5,9,13,17,21,26,32 (angleTable, intrapred.cpp:136)
+    const int angMag = (int)((0x201A15110D090502ull >> (8 * ((aabs - 1) & 7))) & 0xff) & -(int)(aabs != 0);
+    const int angle = angOff < 0 ? -angMag : angMag;
+    // inverse angles for offsets -1..-8: 4096,1638,910,630,482,390,315,256 (invAngleTable, :137)
+    const int inv = (aabs <= 4) ? ((aabs <= 2) ? (aabs <= 1 ? 4096 : 1638) : (aabs == 3 ? 910 : 630))
+                                : ((aabs <= 6) ? (aabs == 5 ? 482 : 390) : (aabs == 7 ? 315 : 256));
+    const bool ang = !WITH_FLAT || mode >= 2;
+    const int* s = (mode == 0 || mode == 2 || mode == 18 || mode == 34) ? nb + 40 : nb;
+    // main side first sample index in `s`, side first sample index
+    const int mainBase = hor ? 17 : 1, sideBase = hor ? 1 : 17;
+    // ---- reference array: 25 entries, lane r writes entries r, r + 8, r + 16 (and 24 by lane 0) ----
+#pragma unroll
+    for (int j0 = 0; j0 < 32; j0 += 8)
+    {
+        const int j = j0 + r, i = j - 8;                  // ref index
+        if (j <= 24)
+        {
+            int v;
+            if (i >= 0)
+                v = s[mainBase + i];
+            else if (i == -1)
+                v = s[0];
+            else
+                v = s[sideBase - 1 + ((128 + (-1 - i) * inv) >> 8)];     // ref[i] = side[(i * invAngle + 128) >> 8] mirrored
+            ext[j] = v;
+        }
+    }
+    lds_handover();
+    if (ang)
+    {
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+        {
+            // (yy, xx): position in the un-transposed prediction
+            const int yy = hor ? x : r, xx = hor ? r : x;
+            const int angSum = (yy + 1) * angle;
+            const int idx = (angSum >> 5) + xx + 8, frac = angSum & 31;
+            const int a = ext[idx], b = ext[idx + 1];
+            p[x] = ((32 - frac) * a + frac * b + 16) >> 5;
+        }
+        if (angle == 0)
+        {
+            // pure vertical / horizontal with the edge filter (bFilter, size <= 16): :170-180
+            // un-transposed column 0 = corner-relative gradient along the side
+            if (hor)
+            {
+                if (r == 0)
+                {
+#pragma unroll
+                    for (int x = 0; x < 8; x++)
+                        p[x] = clampi((int)(short)(ext[8] + ((s[sideBase + x] - s[0]) >> 1)), 0, pixelMax);
+                }
+            }
+            else
+                p[0] = clampi((int)(short)(ext[8] + ((s[sideBase + r] - s[0]) >> 1)), 0, pixelMax);
+        }
+    }
+    if (WITH_FLAT && mode == 1)
     {
         // intra_pred_dc_c with the edge filter on (bFilter = size <= 16)
+        const int* raw = nb;
         int dc = 8;
 #pragma unroll
         for (int i = 0; i < 8; i++)
@@ -49,69 +119,22 @@ __device__ void predict_row(const int* nb, int mode, int r, int pixelMax, int p[
         for (int x = 0; x < 8; x++)
             p[x] = (r == 0) ? ((raw[1 + x] + 3 * dc + 2) >> 2) : dc;
         p[0] = (r == 0) ? ((raw[1] + raw[17] + 2 * dc + 2) >> 2) : ((raw[17 + r] + 3 * dc + 2) >> 2);
-        return;
     }
-    const int* s = uses_filtered(mode) ? nb + 40 : nb;
-    if (mode == 0)
+    if (WITH_FLAT && mode == 0)
     {
         const int tr = s[9], bl = s[25], lf = s[17 + r];
 #pragma unroll
         for (int x = 0; x < 8; x++)
             p[x] = ((7 - x) * lf + (7 - r) * s[1 + x] + (x + 1) * tr + (r + 1) * bl + 8) >> 4;
-        return;
     }
-
-    // angular: horizontal modes are the vertical formula on swapped neighbours,
-    // transposed; sw(k) maps an index of the swapped array back to `s`
-    const bool hor = mode < 18;
-    const int angOff = hor ? 10 - mode : mode - 26;
-    // angleTable[8 + angOff], invAngleTable[-angOff - 1]
-    const int aabs = angOff < 0 ? -angOff : angOff;
-    // |angle| for offsets 0..8: 0,2,5,9,13,17,21,26,32
-    const int angMag = (aabs == 0) ? 0 : (aabs == 1) ? 2 : (aabs == 2) ? 5 : (aabs == 3) ? 9 : (aabs == 4) ? 13
-                     : (aabs == 5) ? 17 : (aabs == 6) ? 21 : (aabs == 7) ? 26 : 32;
-    const int angle = angOff < 0 ? -angMag : angMag;
-    // inverse angles for offsets -1..-8: 4096,1638,910,630,482,390,315,256
-    const int inv = (aabs == 1) ? 4096 : (aabs == 2) ? 1638 : (aabs == 3) ? 910 : (aabs == 4) ? 630
-                  : (aabs == 5) ? 482 : (aabs == 6) ? 390 : (aabs == 7) ? 315 : 256;
-
-#define SW(k) (hor ? (((k) == 0) ? 0 : (((k) <= 16) ? (k) + 16 : (k) - 16)) : (k))
-#pragma unroll
-    for (int x = 0; x < 8; x++)
-    {
-        // (yy, xx): position in the un-transposed prediction
-        const int yy = hor ? x : r;
-        const int xx = hor ? r : x;
-        int v;
-        if (angle == 0)
-        {
-            v = s[SW(1 + xx)];
-            if (xx == 0)
-            {
-                int t = s[SW(1)] + ((s[SW(17 + yy)] - s[SW(0)]) >> 1);
-                v = clampi((int)(short)t, 0, pixelMax);
-            }
-        }
-        else
-        {
-            const int angSum = (yy + 1) * angle;
-            const int off = angSum >> 5, frac = angSum & 31;
-            // ref[i]: i >= -1 -> swapped[i + 1]; i < -1 -> projected side sample
-            int i0 = off + xx, i1 = i0 + 1;
-            int k0 = (i0 >= -1) ? i0 + 1 : 16 + ((128 + (-1 - i0) * inv) >> 8);
-            int k1 = (i1 >= -1) ? i1 + 1 : 16 + ((128 + (-1 - i1) * inv) >> 8);
-            const int a = s[SW(k0)], b = s[SW(k1)];
-            v = frac ? (((32 - frac) * a + frac * b + 16) >> 5) : a;
-        }
-        p[x] = v;
-    }
-#undef SW
+    lds_handover();     // `ext` is rewritten by the next call
 }
 
 template <typename P>
 __global__ void __launch_bounds__(256) intra_kernel(const IntraJob* jobs, Geometry g, int lambda, int pixelMax)
 {
     __shared__ int nbr[4][4][80];          // [wave][block][raw 0..32, smoothed 40..72]
+    __shared__ int extRef[4][8][32];       // [wave][group]: the angular reference array being used
     __shared__ long long red[4][3];
 
     const IntraJob job = jobs[blockIdx.y];
@@ -122,6 +145,7 @@ __global__ void __launch_bounds__(256) intra_kernel(const IntraJob* jobs, Geomet
     const P* plane = (const P*)job.plane0;
     const int by = 8 * cuY;
     int (*nb)[80] = nbr[wave];
+    int* ext = extRef[wave][grp];
 
     long long accRow = 0, accEst = 0, accAq = 0;
     const int iters = (W + 15) / 16;
@@ -163,7 +187,7 @@ __global__ void __launch_bounds__(256) intra_kernel(const IntraJob* jobs, Geomet
 #define XG_INTRA_PASS1(B)                                                                                      \
         {                                                                                                      \
             const Cols f = pair_cols<P>(load_row<P>(plane + (long long)(by + r) * g.stride + 8 * min(cuX0 + B, W - 1))); \
-            predict_row(nb[B], mode1, r, pixelMax, p);                                                         \
+            predict_row<true>(nb[B], ext, mode1, r, pixelMax, p);                                                         \
             const int c = satd_pred(f, p, r);                                                                  \
             int ic = COST_MAX, il = 0, ac = COST_MAX, al = 4;                                                  \
             const int cDC = group_value<0>(c), cPl = group_value<1>(c);                                        \
@@ -194,7 +218,7 @@ __global__ void __launch_bounds__(256) intra_kernel(const IntraJob* jobs, Geomet
         {
             const int best = (b2 == 0) ? alow[0] : (b2 == 1) ? alow[1] : (b2 == 2) ? alow[2] : alow[3];
             const int mode = (grp & 1) ? best + dist : best - dist;
-            predict_row(nb[b2], mode, r, pixelMax, p);
+            predict_row<false>(nb[b2], ext, mode, r, pixelMax, p);
             const int c = satd_pred(f2, p, r);
 #define XG_INTRA_REFINE(B)                                                                 \
             {                                                                              \

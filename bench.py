@@ -98,6 +98,46 @@ def cpu_baseline(width, height, depth, bframes, sample_frames, seed, hme=False):
                       % (sample_frames, width, height, depth, dt)}
 
 
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "latest_pmc_summary.json")
+
+
+def _pmc_kernel(kernel_name):
+    """Counters of one kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/run_pmc.sh + summarize_pmc.py), or None."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            summary = json.load(f)
+    except (OSError, ValueError):
+        return None
+    for name, counters in summary.items():
+        if kernel_name in name:
+            return counters
+    return None
+
+
+def pmc_traffic_per_launch(kernel_name):
+    """Bytes per launch between L2 and memory: (2 x FETCH_SIZE + WRITE_SIZE) KiB per dispatch.  FETCH_SIZE counts
+    128-byte requests as 64 bytes on gfx950, hence the factor 2 on the read side."""
+    c = _pmc_kernel(kernel_name)
+    if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or not c.get("dispatches"):
+        return None
+    return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / c["dispatches"]
+
+
+def valu_utilisation(kernel_name, units, ms_per_step):
+    """Share of the chip's VALU issue slots the dominant kernel fills: wave-level VALU instructions per step
+    (counter pass: SQ_INSTS_VALU per wave x waves) x 4 cycles each / (1024 SIMDs x clock x time)."""
+    c = _pmc_kernel(kernel_name)
+    if not c or not units or not c.get("SQ_WAVES") or "SQ_INSTS_VALU" not in c:
+        return None
+    per_wave = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+    clock_hz = 2.4e9
+    cycles = per_wave * units * 4.0 / 1024.0
+    return {"valu_insts_per_block_search": per_wave, "salu_insts_per_block_search": c.get("SQ_INSTS_SALU", 0) / c["SQ_WAVES"],
+            "frac_of_valu_issue_at_2.4GHz": cycles / (clock_hz * ms_per_step * 1e-3),
+            "note": "one wave = one 8x8 block search; instruction counts from profiles/latest_pmc_summary.json"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,13 +252,24 @@ def main():
                       "avg_launch_us": 1000.0 * ms_step / max(1.0, l_step),
                       "achieved_GBs": alg[k] / (ms_step * 1e-3) / 1e9}
     dom = kernels[dominant]
-    roofline = {"bound": "hbm", "kernel": {"lowres": "lowres_init_kernel", "intra": "intra_kernel",
-                                           "search": "search_diag_kernel", "cost": "cost_rows_kernel"}[dominant],
-                "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
-                "avg_launch_us": dom["avg_launch_us"], "launches_per_step": dom["launches_per_step"],
-                "algorithmic_bytes_per_launch": alg[dominant] / max(1.0, dom["launches_per_step"]),
-                "note": "integer SAD/SATD search is dependency/VALU bound, not HBM bound; per-kernel figures in 'kernels'"}
+    kernel_name = {"lowres": "lowres_init_kernel", "intra": "intra_kernel", "search": "search_diag_kernel",
+                   "cost": "cost_rows_kernel"}[dominant]
+    # The search spreads its job groups over concurrent streams (X265GPU_SEARCH_STREAMS, default 2): that many
+    # launches are in flight at a time, so one launch lasts (streams x phase time / launches) while the phase's
+    # aggregate rate is bytes / phase time.  rocprofv3's per-kernel average duration is the former.
+    streams = 1
+    if dominant == "search" and os.environ.get("X265GPU_SEARCH_MODE", "diag") != "rows":
+        streams = max(1, min(4, int(os.environ.get("X265GPU_SEARCH_STREAMS", "2"))))
+    bytes_per_launch = alg[dominant] / max(1.0, dom["launches_per_step"])
+    avg_launch_us = streams * dom["avg_launch_us"]
+    roofline = {"bound": "hbm", "kernel": kernel_name,
+                "achieved": streams * bytes_per_launch / (avg_launch_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(kernel_name),
+                "avg_launch_us": avg_launch_us, "concurrent_launches": streams,
+                "launches_per_step": dom["launches_per_step"], "algorithmic_bytes_per_launch": bytes_per_launch,
+                "note": "the integer SAD/SATD search is VALU-issue bound, not HBM bound (see 'valu'); "
+                        "per-phase figures in 'kernels'"}
+    valu = valu_utilisation(kernel_name, n_search * n if dominant == "search" else None, dom["ms_per_step"])
 
     out = {
         "metric": "lookahead frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
@@ -229,7 +280,7 @@ def main():
                    "frames_per_step": F, "search_requests_per_step": n_search, "cost_requests_per_step": n_cost,
                    "blocks_per_frame": n, "sharding": "frame segments per rank, RCCL all_gather of cost scalars"
                    if distributed else "single GPU"},
-        "roofline": roofline, "kernels": kernels,
+        "roofline": roofline, "valu": valu, "kernels": kernels,
     }
     if rank == 0 and args.cpu_frames > 0:
         out["cpu_baseline"] = cpu_baseline(W, H, D, args.bframes, args.cpu_frames, 1234, args.hme)

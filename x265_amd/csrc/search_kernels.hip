@@ -278,9 +278,16 @@ __device__ __forceinline__ int take_winner(int key, int vx, int vy, int& bx, int
 }
 
 // full-pel cost of this lane's group candidate, SAD + mvcost(mv << 2), read from global memory
+// (plane 0 only, one fetch: the long-range steps of the multi-hexagon search, which no window covers)
 template <typename P> __device__ __forceinline__ int fpel_cost_g(const BlockCtx<P>& c, int mx, int my, bool active)
 {
-    return eval<P, EV_SAD>(c, mx * 4, my * 4, active, true);
+    Row<P> ref = zero_row<P>();
+    if (active)
+    {
+        const int X = clampi(c.bx + mx, c.minX, c.maxX), Y = clampi(c.by + my, c.minY, c.maxY) + c.r;
+        ref = load_row_g<P>(c.base, c.padOffset + Y * c.stride + X);
+    }
+    return reduce_cost<P, EV_SAD>(c, ref, price_lanes_g<P>(c, mx * 4, my * 4, active));
 }
 
 // 25 lanes x 8 entries per axis of the MV-cost table around the MVD (dcx,dcy);

@@ -110,6 +110,19 @@ int fail(x265gpu_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// Makes the context's device current for the duration of an entry point and puts the caller's
+// device back afterwards: a process may drive several contexts (one per GPU) from one thread.
+struct DeviceScope
+{
+    int prev = -1;
+    explicit DeviceScope(const x265gpu_ctx* ctx);
+    ~DeviceScope()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
 // Lowres::create, source/common/lowres.cpp:84-103 and :171-177, :211-213
 void compute_geometry(const x265gpu_config& cfg, Geometry& g)
 {
@@ -145,6 +158,13 @@ void compute_geometry(const x265gpu_config& cfg, Geometry& g)
         int aw = ((g.width / 2) + 7) >> 3, ah = ((g.lines / 2) + 7) >> 3;
         g.cuCount4 = (aw > g.W4 ? aw : g.W4) * (ah > g.H4 ? ah : g.H4);
     }
+}
+
+DeviceScope::DeviceScope(const x265gpu_ctx* ctx)
+{
+    int cur = -1;
+    if (ctx && hipGetDevice(&cur) == hipSuccess && cur != ctx->cfg.deviceId && hipSetDevice(ctx->cfg.deviceId) == hipSuccess)
+        prev = cur;
 }
 
 int alloc_slot(x265gpu_ctx* ctx, Slot& s)
@@ -327,6 +347,18 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->deviceId < 0 || cfg->deviceId >= ndev)
         return X265GPU_ERR_DEVICE;
+    // the caller's current device is put back when this function returns
+    struct Restore
+    {
+        int dev = -1;
+        ~Restore()
+        {
+            if (dev >= 0)
+                (void)hipSetDevice(dev);
+        }
+    } restore;
+    if (hipGetDevice(&restore.dev) != hipSuccess)
+        restore.dev = -1;
     if (hipSetDevice(cfg->deviceId) != hipSuccess)
         return X265GPU_ERR_DEVICE;
 
@@ -428,6 +460,7 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
 
 void x265gpu_close(x265gpu_ctx* ctx)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx)
         return;
     if (ctx->stream)
@@ -491,6 +524,7 @@ const char* x265gpu_last_error(const x265gpu_ctx* ctx) { return ctx ? ctx->err.c
 
 int x265gpu_sync(x265gpu_ctx* ctx)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx)
         return X265GPU_ERR_ARG;
     int rc = fetch_search_error(ctx);
@@ -502,6 +536,7 @@ int x265gpu_sync(x265gpu_ctx* ctx)
 
 int x265gpu_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || !centre || maxMvd < 1024)
         return X265GPU_ERR_ARG;
     if (ctx->costBuf)
@@ -522,6 +557,7 @@ int x265gpu_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd)
 int x265gpu_lowres_init_batch(x265gpu_ctx* ctx, int32_t n, const int32_t* slots, const void* const* lumas,
                               const intptr_t* strides, int32_t memKind, const int32_t* pocs)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || n < 0 || (n && (!slots || !lumas || !strides)))
         return X265GPU_ERR_ARG;
     if (!n)
@@ -577,11 +613,13 @@ int x265gpu_lowres_init_batch(x265gpu_ctx* ctx, int32_t n, const int32_t* slots,
 int x265gpu_lowres_init(x265gpu_ctx* ctx, int32_t slot, const void* luma, intptr_t stride, int32_t memKind,
                         int32_t poc)
 {
+    DeviceScope deviceScope(ctx);
     return x265gpu_lowres_init_batch(ctx, 1, &slot, &luma, &stride, memKind, &poc);
 }
 
 int x265gpu_lowres_set_aq(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQscaleFactor)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || !slot_ok(ctx, slot))
         return X265GPU_ERR_ARG;
     Slot& s = ctx->slots[slot];
@@ -598,6 +636,7 @@ int x265gpu_lowres_set_aq(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQsca
 
 int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || n < 0 || (n && !slots))
         return X265GPU_ERR_ARG;
     if (!n)
@@ -807,11 +846,13 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
 
 int x265gpu_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs)
 {
+    DeviceScope deviceScope(ctx);
     return run_estimate(ctx, n, reqs, false);
 }
 
 int x265gpu_estimate_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, x265gpu_frame_cost* out)
 {
+    DeviceScope deviceScope(ctx);
     if (!out && n)
         return X265GPU_ERR_ARG;
     int rc = run_estimate(ctx, n, reqs, true);
@@ -842,6 +883,7 @@ int x265gpu_estimate_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* r
 int x265gpu_weight_cost(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t wtPresent, int32_t scale,
                         int32_t log2Denom, int32_t offset, uint32_t* cost)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || !slot_ok(ctx, slotFenc) || !slot_ok(ctx, slotRef) || !cost)
         return X265GPU_ERR_ARG;
     const Geometry& g = ctx->g;
@@ -875,6 +917,7 @@ int x265gpu_weight_cost(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int
 int x265gpu_weight_planes(x265gpu_ctx* ctx, int32_t slotFenc, int32_t dist, int32_t slotRef, int32_t scale,
                           int32_t log2Denom, int32_t offset)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || !slot_ok(ctx, slotFenc) || !slot_ok(ctx, slotRef) || dist < 1 || dist >= ctx->D)
         return X265GPU_ERR_ARG;
     const Geometry& g = ctx->g;
@@ -892,6 +935,7 @@ int x265gpu_weight_planes(x265gpu_ctx* ctx, int32_t slotFenc, int32_t dist, int3
 
 int x265gpu_get_plane(x265gpu_ctx* ctx, int32_t slot, int32_t planeIdx, void* paddedBuffer)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || !slot_ok(ctx, slot) || planeIdx < 0 || planeIdx > 7 || !paddedBuffer)
         return X265GPU_ERR_ARG;
     const Geometry& g = ctx->g;
@@ -912,6 +956,7 @@ int x265gpu_get_plane(x265gpu_ctx* ctx, int32_t slot, int32_t planeIdx, void* pa
 
 int x265gpu_get_intra(x265gpu_ctx* ctx, int32_t slot, int32_t* intraCost, uint8_t* intraMode)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || !slot_ok(ctx, slot))
         return X265GPU_ERR_ARG;
     Slot& s = ctx->slots[slot];
@@ -925,6 +970,7 @@ int x265gpu_get_intra(x265gpu_ctx* ctx, int32_t slot, int32_t* intraCost, uint8_
 
 int x265gpu_get_mvs(x265gpu_ctx* ctx, int32_t slot, int32_t list, int32_t dist, int32_t* mvsXY, int32_t* mvCosts)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || !slot_ok(ctx, slot) || list < 0 || list > 1 || dist < 0 || dist >= ctx->D)
         return X265GPU_ERR_ARG;
     Slot& s = ctx->slots[slot];
@@ -939,6 +985,7 @@ int x265gpu_get_mvs(x265gpu_ctx* ctx, int32_t slot, int32_t list, int32_t dist, 
 
 int x265gpu_get_hme_mvs(x265gpu_ctx* ctx, int32_t slot, int32_t list, int32_t dist, int32_t* mvsXY, int32_t* mvCosts)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || !slot_ok(ctx, slot) || list < 0 || list > 1 || dist < 0 || dist >= ctx->D || !ctx->g.cuCount4)
         return X265GPU_ERR_ARG;
     Slot& s = ctx->slots[slot];
@@ -954,6 +1001,7 @@ int x265gpu_get_hme_mvs(x265gpu_ctx* ctx, int32_t slot, int32_t list, int32_t di
 int x265gpu_get_costs(x265gpu_ctx* ctx, int32_t slot, int32_t d0, int32_t d1, uint16_t* lowresCosts,
                       int32_t* rowSatds, x265gpu_frame_cost* fc)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || !slot_ok(ctx, slot) || d0 < 0 || d0 >= ctx->D || d1 < 0 || d1 >= ctx->D)
         return X265GPU_ERR_ARG;
     Slot& s = ctx->slots[slot];
@@ -1019,6 +1067,7 @@ int ensure_pu_buf(x265gpu_ctx* ctx, size_t bytes)
 
 int x265gpu_me_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || !centre || maxMvd < 1024)
         return X265GPU_ERR_ARG;
     if (ctx->meCostBuf)
@@ -1039,6 +1088,7 @@ int x265gpu_me_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxM
 int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t searchMethod, int32_t merange,
                                int32_t subpelRefine, int32_t n, const x265gpu_pu_job* jobs, x265gpu_pu_result* out)
 {
+    DeviceScope deviceScope(ctx);
     static_assert(sizeof(x265gpu_pu_job) == sizeof(PuJob) && sizeof(x265gpu_pu_result) == sizeof(PuResult),
                   "public and device job layouts must match");
     if (!ctx || n < 0 || (n && (!jobs || !out)))
@@ -1091,6 +1141,7 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
 int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const void* u, const void* v, intptr_t strideC,
                       int32_t memKind, uint32_t* energy, uint64_t wpSum[3], uint64_t wpSsd[3])
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || !y || !u || !v || !energy || !wpSum || !wpSsd)
         return X265GPU_ERR_ARG;
     const int w = ctx->cfg.sourceWidth, h = ctx->cfg.sourceHeight, cw = w >> 1, ch = h >> 1;
@@ -1153,6 +1204,7 @@ int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const v
 int x265gpu_block_compare(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t n, const x265gpu_block_job* jobs,
                           int32_t* costs)
 {
+    DeviceScope deviceScope(ctx);
     static_assert(sizeof(x265gpu_block_job) == sizeof(BlockJob), "public and device job layouts must match");
     if (!ctx || n < 0 || (n && (!jobs || !costs)))
         return X265GPU_ERR_ARG;
@@ -1193,6 +1245,7 @@ int x265gpu_block_compare(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, i
 int x265gpu_interp_luma(x265gpu_ctx* ctx, int32_t slot, int32_t x, int32_t y, int32_t w, int32_t h, int32_t xFrac,
                         int32_t yFrac, void* out)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || !out || !slot_ok(ctx, slot))
         return X265GPU_ERR_ARG;
     if (!ctx->fullStride)
@@ -1215,6 +1268,7 @@ int x265gpu_interp_luma(x265gpu_ctx* ctx, int32_t slot, int32_t x, int32_t y, in
 int x265gpu_get_full_plane(x265gpu_ctx* ctx, int32_t slot, void* out, int32_t* stride, int32_t* rows, int32_t* originX,
                            int32_t* originY)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || !slot_ok(ctx, slot))
         return X265GPU_ERR_ARG;
     if (!ctx->fullStride)
@@ -1234,6 +1288,7 @@ int x265gpu_get_full_plane(x265gpu_ctx* ctx, int32_t slot, void* out, int32_t* s
 
 int x265gpu_profile_enable(x265gpu_ctx* ctx, int32_t on)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx)
         return X265GPU_ERR_ARG;
     ctx->prof = on != 0;
@@ -1242,6 +1297,7 @@ int x265gpu_profile_enable(x265gpu_ctx* ctx, int32_t on)
 
 int x265gpu_profile_read(x265gpu_ctx* ctx, int32_t phase, double* ms, int64_t* launches, int32_t reset)
 {
+    DeviceScope deviceScope(ctx);
     if (!ctx || phase < 0 || phase >= X265GPU_PHASE_COUNT)
         return X265GPU_ERR_ARG;
     if (ms)

@@ -149,20 +149,27 @@ def main():
     ap.add_argument("--frames", type=int, default=60, help="frames per step (one device batch)")
     ap.add_argument("--bframes", type=int, default=4)
     ap.add_argument("--cpu-frames", type=int, default=60, help="frames in the bounded CPU baseline sample (0 = skip)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the gather even at world size 1 (rehearsal of the N>1 path)")
     ap.add_argument("--hme", action="store_true", help="--hme: quarter-res hex then half-res umh (x265's defaults, ranges 16 / 32)")
     args = ap.parse_args()
+
+    # Libraries under the process group print banners on stdout; keep fd 1 for the one JSON line.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the lookahead path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from oracle import orc
     from x265_amd import api, synth
@@ -288,8 +295,11 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    os.close(json_fd)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -71,7 +71,8 @@ typedef struct x265gpu_config
     int32_t deviceId;
     void*   stream;               /* hipStream_t to run on, or NULL for the library's own */
     int32_t bKeepFullRes;         /* keep a padded full-resolution luma plane per slot (for x265gpu_pu_motion_estimate) */
-    int32_t reserved;
+    int32_t bMcstfFilter;         /* param->bEnableTemporalFilter: Lowres::init downscales with the (a+b+c+d+2)>>2 filter
+                                     and also makes the quarter-res planes (source/common/lowres.cpp:377-378, :388-398) */
 } x265gpu_config;
 
 /* Geometry derived exactly as Lowres::create does (source/common/lowres.cpp:84-103). */
@@ -245,6 +246,29 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
  * unpadded source planes (luma sourceWidth x sourceHeight, chroma half of each); strides in pixels. */
 int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const void* u, const void* v, intptr_t strideC,
                       int32_t memKind, uint32_t* energy, uint64_t wpSum[3], uint64_t wpSsd[3]);
+
+/* The whole of LookaheadTLD::calcAdaptiveQuantFrame (source/encoder/slicetype.cpp:454-686) for a 4:2:0
+ * picture with qgSize >= 16 and rc.aqMode NONE / VARIANCE / AUTO_VARIANCE / AUTO_VARIANCE_BIASED: the block
+ * energies come from the device pass above, the double-precision mapping to QP offsets (:486-505, :539-643)
+ * and x265_exp2fix8 (source/common/common.cpp:96-103) run on the host in this call, in the reference's order
+ * of operations.  Arrays hold one entry per 16x16 block, ceil(w/16) per row; they are left untouched when
+ * aqMode is NONE (x265 does not allocate them then) or when bSkipOffsets is set (the rc.bStatRead && cuTree
+ * && referenced-frame case, :483).  wpSum / wpSsd receive Lowres::wp_sum / wp_ssd as the function leaves
+ * them: with bWeightedPred the mean is removed from wp_ssd (:663-686); without it and without AQ no energy
+ * pass runs and both are zero.  With slot >= 0 the resulting invQscaleFactor is also installed for that slot
+ * (as x265gpu_lowres_set_aq does).  rc.hevcAq and X265_AQ_EDGE are not covered: X265GPU_ERR_UNSUPPORTED. */
+typedef struct x265gpu_aq_params
+{
+    int32_t aqMode;               /* param->rc.aqMode, 0..3 */
+    int32_t bWeightedPred;        /* param->bEnableWeightedPred || param->bEnableWeightedBiPred */
+    int32_t bHDR10Opt;            /* param->bHDR10Opt: luma-average dependent offset (:613-635) */
+    int32_t bSkipOffsets;
+    double  aqStrength;           /* param->rc.aqStrength */
+} x265gpu_aq_params;
+int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t strideY, const void* u, const void* v,
+                     intptr_t strideC, int32_t memKind, const x265gpu_aq_params* params,
+                     const float* quantOffsets /* Frame::m_quantOffsets or NULL */, double* qpAqOffset,
+                     double* qpCuTreeOffset, int32_t* invQscaleFactor, uint64_t wpSum[3], uint64_t wpSsd[3]);
 
 /* ---- the pixel primitives, one call per batch of blocks ----
  *

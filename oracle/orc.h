@@ -60,6 +60,8 @@ int  orc_satd(int w, int h, const pixel* a, intptr_t sa, const pixel* b, intptr_
 int  orc_sa8d(int size, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
 void orc_pixelavg_pp(int w, int h, pixel* dst, intptr_t ds, const pixel* s0, intptr_t ss0,
                      const pixel* s1, intptr_t ss1);
+void orc_frame_init_lowres_core_mcstf(const pixel* src0, pixel* dst0, pixel* dsth, pixel* dstv, pixel* dstc,
+                                      intptr_t src_stride, intptr_t dst_stride, int width, int height);
 void orc_frame_init_lowres_core(const pixel* src0, pixel* dst0, pixel* dsth, pixel* dstv, pixel* dstc,
                                 intptr_t src_stride, intptr_t dst_stride, int width, int height);
 void orc_extend_pic_border(pixel* pic, intptr_t stride, int width, int height, int marginX, int marginY);
@@ -68,6 +70,11 @@ void orc_weight_pp(const pixel* src, pixel* dst, intptr_t stride, int width, int
 uint64_t orc_pixel_var(int size, const pixel* pix, intptr_t stride);
 void orc_aq_energy(const pixel* y, intptr_t sy, const pixel* u, const pixel* v, intptr_t sc, int w, int h,
                    uint32_t* energy, uint64_t* wp);
+int  orc_exp2fix8(double x);
+void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, const pixel* v, intptr_t sc,
+                                   int w, int h, int aqMode, double aqStrength, int weightedPred, int hdr10,
+                                   int skipOffsets, const float* quantOffsets, double* qpAqOffset,
+                                   double* qpCuTreeOffset, int* invQscaleFactor, uint64_t* wp);
 
 void orc_intra_filter(int tuSize, const pixel* samples, pixel* filtered);
 void orc_intra_pred(int size, int mode, pixel* dst, intptr_t dstStride, const pixel* srcPix, int bFilter);
@@ -130,6 +137,7 @@ typedef struct orc_param {
     int bEnableWeightedPred;
     int maxSlices;
     int lookaheadSearchMethod;/* x265 hard-wires ORC_HEX (source/encoder/slicetype.cpp:4402-4404) */
+    int bEnableTemporalFilter;/* --mcstf: mean downscale filter + quarter-res planes (source/common/lowres.cpp:377-400) */
 } orc_param;
 
 typedef struct orc_lowres {

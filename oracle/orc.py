@@ -27,7 +27,7 @@ class Param(C.Structure):
         ("sourceWidth", C.c_int), ("sourceHeight", C.c_int), ("maxCUSize", C.c_int), ("bframes", C.c_int),
         ("bEnableHME", C.c_int), ("hmeSearchMethod", C.c_int * 3), ("hmeRange", C.c_int * 3),
         ("qgSize", C.c_int), ("bFrameBias", C.c_int), ("bEnableWeightedPred", C.c_int), ("maxSlices", C.c_int),
-        ("lookaheadSearchMethod", C.c_int),
+        ("lookaheadSearchMethod", C.c_int), ("bEnableTemporalFilter", C.c_int),
     ]
 
 
@@ -61,6 +61,7 @@ def lib(depth=8):
     L.orc_sa8d.argtypes = [i, vp, ip, vp, ip]
     L.orc_pixelavg_pp.argtypes = [i, i, vp, ip, vp, ip, vp, ip]
     L.orc_frame_init_lowres_core.argtypes = [vp, vp, vp, vp, vp, ip, ip, i, i]
+    L.orc_frame_init_lowres_core_mcstf.argtypes = [vp, vp, vp, vp, vp, ip, ip, i, i]
     L.orc_extend_pic_border.argtypes = [vp, ip, i, i, i, i]
     L.orc_weight_pp.argtypes = [vp, vp, ip, i, i, i, i, i, i]
     L.orc_pixel_var.argtypes = [i, vp, ip]
@@ -93,6 +94,8 @@ def lib(depth=8):
     L.orc_lowres_i64.argtypes = [vp, C.c_char_p, i, i]
     L.orc_lowres_i64.restype = C.c_int64
     L.orc_aq_energy.argtypes = [vp, ip, vp, vp, ip, i, i, vp, vp]
+    L.orc_exp2fix8.argtypes = [C.c_double]
+    L.orc_calc_adaptive_quant_frame.argtypes = [vp, ip, vp, vp, ip, i, i, i, C.c_double, i, i, i, vp, vp, vp, vp, vp]
     L.orc_me_init.argtypes = [vp, vp]
     L.orc_me_create.argtypes = [vp]
     L.orc_me_create.restype = vp
@@ -115,7 +118,7 @@ def ptr(a):
 
 
 def make_param(width, height, bframes=4, hme=False, weightp=False, ctu=64, search=HEX,
-               hme_methods=(HEX, UMH, UMH), hme_range=(16, 32, 48), bframe_bias=0):
+               hme_methods=(HEX, UMH, UMH), hme_range=(16, 32, 48), bframe_bias=0, mcstf=False):
     p = Param()
     p.sourceWidth, p.sourceHeight, p.maxCUSize, p.bframes = width, height, ctu, bframes
     p.bEnableHME = int(hme)
@@ -127,6 +130,7 @@ def make_param(width, height, bframes=4, hme=False, weightp=False, ctu=64, searc
     p.bEnableWeightedPred = int(weightp)
     p.maxSlices = 1
     p.lookaheadSearchMethod = search
+    p.bEnableTemporalFilter = int(mcstf)
     return p
 
 
@@ -286,3 +290,20 @@ class FullResME:
         cost = L.orc_motion_estimate(self.me, C.byref(self.rp), MV(*mvmin), MV(*mvmax), MV(*mvp), len(mvc), arr,
                                      merange, C.byref(out), 1, 0)
         return (out.x, out.y), cost
+
+
+def calc_adaptive_quant_frame(depth, y, u, v, aq_mode, strength, weightp=False, hdr10=False, skip_offsets=False,
+                              quant_offsets=None):
+    """calcAdaptiveQuantFrame on tight 4:2:0 planes -> (qpAqOffset, qpCuTreeOffset, invQscaleFactor, wp_sum, wp_ssd)."""
+    L = lib(depth)
+    h, w = y.shape
+    n = ((w + 15) // 16) * ((h + 15) // 16)
+    qa = np.full(n, np.nan)
+    qc = np.full(n, np.nan)
+    inv = np.full(n, -1, np.int32)
+    wp = np.zeros(6, np.uint64)
+    qo = None if quant_offsets is None else np.ascontiguousarray(quant_offsets, np.float32)
+    L.orc_calc_adaptive_quant_frame(ptr(y), y.strides[0] // y.itemsize, ptr(u), ptr(v), u.strides[0] // u.itemsize,
+                                    w, h, aq_mode, float(strength), int(weightp), int(hdr10), int(skip_offsets),
+                                    None if qo is None else ptr(qo), ptr(qa), ptr(qc), ptr(inv), ptr(wp))
+    return qa, qc, inv, wp[:3].copy(), wp[3:].copy()

@@ -42,7 +42,7 @@ orc_lowres* orc_lowres_create(const orc_param* p, int withAq)
         lr->buffer[i] = lr->buffer[0] + i * lr->planesize;
         lr->rp.plane[i] = lr->buffer[i] + lr->padoffset;
     }
-    if (p->bEnableHME)
+    if (p->bEnableHME || p->bEnableTemporalFilter)
     {
         size_t half = lr->planesize / 2, padHalf = lr->padoffset / 2;
         lr->lowerResBuffer[0] = (pixel*)calloc(4 * half, sizeof(pixel));
@@ -159,16 +159,16 @@ void orc_lowres_init(orc_lowres* lr, const orc_param* p, const pixel* luma, intp
     }
 
     intptr_t ls = lr->rp.stride;
-    orc_frame_init_lowres_core(luma, lr->rp.plane[0], lr->rp.plane[1], lr->rp.plane[2], lr->rp.plane[3],
-                               stride, ls, lr->width, lr->lines);
+    void (*core)(const pixel*, pixel*, pixel*, pixel*, pixel*, intptr_t, intptr_t, int, int) =
+        p->bEnableTemporalFilter ? orc_frame_init_lowres_core_mcstf : orc_frame_init_lowres_core;
+    core(luma, lr->rp.plane[0], lr->rp.plane[1], lr->rp.plane[2], lr->rp.plane[3], stride, ls, lr->width, lr->lines);
     for (int i = 0; i < 4; i++)
         orc_extend_pic_border(lr->rp.plane[i], ls, lr->width, lr->lines, lr->marginX, lr->marginY);
 
-    if (p->bEnableHME)
+    if (p->bEnableHME || p->bEnableTemporalFilter)
     {
-        orc_frame_init_lowres_core(lr->rp.plane[0], lr->rp.lowerPlane[0], lr->rp.lowerPlane[1],
-                                   lr->rp.lowerPlane[2], lr->rp.lowerPlane[3], ls, ls / 2,
-                                   lr->width / 2, lr->lines / 2);
+        core(lr->rp.plane[0], lr->rp.lowerPlane[0], lr->rp.lowerPlane[1], lr->rp.lowerPlane[2], lr->rp.lowerPlane[3],
+             ls, ls / 2, lr->width / 2, lr->lines / 2);
         for (int i = 0; i < 4; i++)
             orc_extend_pic_border(lr->rp.lowerPlane[i], ls / 2, lr->width / 2, lr->lines / 2,
                                   lr->marginX / 2, lr->marginY / 2);
@@ -313,6 +313,154 @@ void orc_aq_energy(const pixel* y, intptr_t sy, const pixel* u, const pixel* v, 
             e += ac_energy_plane(v, sc, w >> 1, h >> 1, bx >> 1, by >> 1, 8, 6, &wp[2], &wp[5]);
             energy[k] = e;
         }
+}
+
+/* x265_exp2fix8, source/common/common.cpp:96-103; the fraction table is
+ * x265_exp2_lut (source/common/constants.cpp:552-558) = round(256 * (2^(i/64) - 1)) */
+int orc_exp2fix8(double x)
+{
+    static int lut[64], ready;
+    if (!ready)
+    {
+        for (int i = 0; i < 64; i++)
+            lut[i] = (int)lround(256.0 * (pow(2.0, i / 64.0) - 1.0));
+        ready = 1;
+    }
+    int i = (int)(x * (-64.f / 6.f) + 512.5f);
+    if (i < 0)
+        return 0;
+    if (i > 1023)
+        return 0xffff;
+    return (lut[i & 63] + 256) << (i >> 6) >> 8;
+}
+
+/* LookaheadTLD::calcAdaptiveQuantFrame, source/encoder/slicetype.cpp:454-686, for 4:2:0,
+ * qgSize >= 16 (16x16 blocks, modeOneConst 14.427f, modeTwoConst 11.f), without hevcAq and
+ * the edge mode.  Block by block in the reference's order: acEnergyCu is called from the
+ * same places, so wp_sum / wp_ssd accumulate exactly as they do there.  wp[0..2] = wp_sum,
+ * wp[3..5] = wp_ssd.  Arrays may be null when the mode does not write them. */
+void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, const pixel* v, intptr_t sc,
+                                   int w, int h, int aqMode, double aqStrength, int weightedPred, int hdr10,
+                                   int skipOffsets, const float* quantOffsets, double* qpAqOffset,
+                                   double* qpCuTreeOffset, int* invQscaleFactor, uint64_t* wp)
+{
+    const float modeOneConst = 14.427f, modeTwoConst = 11.f;
+    const int bw = (w + 15) >> 4, bh = (h + 15) >> 4, blockCount = bw * bh;
+    memset(wp, 0, 6 * sizeof(uint64_t));
+#define ORC_ENERGY(bx, by) \
+    (ac_energy_plane(y, sy, w, h, bx, by, 16, 8, &wp[0], &wp[3]) + \
+     ac_energy_plane(u, sc, w >> 1, h >> 1, (bx) >> 1, (by) >> 1, 8, 6, &wp[1], &wp[4]) + \
+     ac_energy_plane(v, sc, w >> 1, h >> 1, (bx) >> 1, (by) >> 1, 8, 6, &wp[2], &wp[5]))
+
+    if (!skipOffsets)
+    {
+        if (aqMode == 0 || aqStrength == 0)
+        {
+            if (aqMode && aqStrength == 0)
+            {
+                for (int i = 0; i < blockCount; i++)
+                {
+                    if (quantOffsets)
+                    {
+                        qpCuTreeOffset[i] = qpAqOffset[i] = quantOffsets[i];
+                        invQscaleFactor[i] = orc_exp2fix8(qpCuTreeOffset[i]);
+                    }
+                    else
+                    {
+                        qpCuTreeOffset[i] = qpAqOffset[i] = 0;
+                        invQscaleFactor[i] = 256;
+                    }
+                }
+            }
+            if (weightedPred)
+                for (int by = 0; by < h; by += 16)
+                    for (int bx = 0; bx < w; bx += 16)
+                        (void)ORC_ENERGY(bx, by);
+        }
+        else
+        {
+            int k = 0;
+            double avg_adj_pow2 = 0, avg_adj = 0, qp_adj = 0, bias_strength = 0, strength = 0;
+            if (aqMode == 2 || aqMode == 3)
+            {
+                double bit_depth_correction = 1.f / (1 << (2 * (ORC_DEPTH - 8)));
+                for (int by = 0; by < h; by += 16)
+                    for (int bx = 0; bx < w; bx += 16)
+                    {
+                        uint32_t energy = ORC_ENERGY(bx, by);
+                        qp_adj = pow(energy * bit_depth_correction + 1, 0.1);
+                        qpCuTreeOffset[k++] = qp_adj;
+                        avg_adj += qp_adj;
+                        avg_adj_pow2 += qp_adj * qp_adj;
+                    }
+                avg_adj /= blockCount;
+                avg_adj_pow2 /= blockCount;
+                strength = aqStrength * avg_adj;
+                avg_adj = avg_adj - 0.5f * (avg_adj_pow2 - modeTwoConst) / avg_adj;
+                bias_strength = aqStrength;
+            }
+            else
+                strength = aqStrength * 1.0397f;
+
+            k = 0;
+            for (int by = 0; by < h; by += 16)
+                for (int bx = 0; bx < w; bx += 16, k++)
+                {
+                    if (aqMode == 3)
+                    {
+                        qp_adj = qpCuTreeOffset[k];
+                        qp_adj = strength * (qp_adj - avg_adj) + bias_strength * (1.f - modeTwoConst / (qp_adj * qp_adj));
+                    }
+                    else if (aqMode == 2)
+                    {
+                        qp_adj = qpCuTreeOffset[k];
+                        qp_adj = strength * (qp_adj - avg_adj);
+                    }
+                    else
+                    {
+                        uint32_t energy = ORC_ENERGY(bx, by);
+                        qp_adj = strength * (log2((double)(energy > 1 ? energy : 1)) - (modeOneConst + 2 * (ORC_DEPTH - 8)));
+                    }
+                    if (hdr10)
+                    {
+                        /* lumaSumCu (:288-301): the low word of pixel_var over the same padded block */
+                        uint64_t s0 = 0, s1 = 0;
+                        (void)ac_energy_plane(y, sy, w, h, bx, by, 16, 8, &s0, &s1);
+                        uint32_t lumaAvg = (uint32_t)s0 / 256;
+                        if (lumaAvg < 301) qp_adj += 3;
+                        else if (lumaAvg < 367) qp_adj += 2;
+                        else if (lumaAvg < 434) qp_adj += 1;
+                        else if (lumaAvg >= 501 && lumaAvg < 567) qp_adj -= 1;
+                        else if (lumaAvg >= 567 && lumaAvg < 634) qp_adj -= 2;
+                        else if (lumaAvg >= 634 && lumaAvg < 701) qp_adj -= 3;
+                        else if (lumaAvg >= 701 && lumaAvg < 767) qp_adj -= 4;
+                        else if (lumaAvg >= 767 && lumaAvg < 834) qp_adj -= 5;
+                        else if (lumaAvg >= 834) qp_adj -= 6;
+                    }
+                    if (quantOffsets)
+                        qp_adj += quantOffsets[k];
+                    qpAqOffset[k] = qp_adj;
+                    qpCuTreeOffset[k] = qp_adj;
+                    invQscaleFactor[k] = orc_exp2fix8(qp_adj);
+                }
+        }
+    }
+    if (weightedPred)
+    {
+        if (skipOffsets)
+            for (int by = 0; by < h; by += 16)
+                for (int bx = 0; bx < w; bx += 16)
+                    (void)ORC_ENERGY(bx, by);
+        int maxCol = ((w + 8) >> 4) << 4, maxRow = ((h + 8) >> 4) << 4;
+        int width[3] = { maxCol, maxCol >> 1, maxCol >> 1 };
+        int height[3] = { maxRow, maxRow >> 1, maxRow >> 1 };
+        for (int i = 0; i < 3; i++)
+        {
+            uint64_t sum = wp[i], ssd = wp[3 + i];
+            wp[3 + i] = ssd - (sum * sum + (width[i] * height[i]) / 2) / (width[i] * height[i]);
+        }
+    }
+#undef ORC_ENERGY
 }
 
 /* ---------------------------------------------------------------- weighted prediction */

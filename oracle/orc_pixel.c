@@ -173,6 +173,27 @@ void orc_frame_init_lowres_core(const pixel* src0, pixel* dst0, pixel* dsth, pix
     }
 }
 
+/* the same four planes with the plain rounded 2x2 mean, used when the
+ * temporal filter is on: source/common/pixel.cpp:1017-1039 */
+void orc_frame_init_lowres_core_mcstf(const pixel* src0, pixel* dst0, pixel* dsth, pixel* dstv, pixel* dstc,
+                                      intptr_t src_stride, intptr_t dst_stride, int width, int height)
+{
+    for (int y = 0; y < height; y++)
+    {
+        const pixel* r0 = src0 + (intptr_t)2 * y * src_stride;
+        const pixel* r1 = r0 + src_stride;
+        const pixel* r2 = r1 + src_stride;
+        for (int x = 0; x < width; x++)
+        {
+            int c0 = 2 * x, c1 = c0 + 1, c2 = c0 + 2;
+            dst0[y * dst_stride + x] = (pixel)((r0[c0] + r1[c0] + r0[c1] + r1[c1] + 2) >> 2);
+            dsth[y * dst_stride + x] = (pixel)((r0[c1] + r1[c1] + r0[c2] + r1[c2] + 2) >> 2);
+            dstv[y * dst_stride + x] = (pixel)((r1[c0] + r2[c0] + r1[c1] + r2[c1] + 2) >> 2);
+            dstc[y * dst_stride + x] = (pixel)((r1[c1] + r2[c1] + r1[c2] + r2[c2] + 2) >> 2);
+        }
+    }
+}
+
 /* replicate edges into the margins: left/right per row
  * (source/common/ipfilter.cpp:59-77), then whole padded top and bottom rows,
  * `stride` pixels starting marginX left of the picture

@@ -79,6 +79,27 @@ def test_lowres_planes_and_intra(depth, size):
         ref.close()
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+def test_mcstf_downscale_filter(depth):
+    """--mcstf: rounded 2x2 mean instead of cascaded averages, and quarter-res planes without HME."""
+    W, H = 424, 242
+    clip, ref, ctx, frames = _setup(W, H, 2, depth, mcstf=True)
+    try:
+        for i in range(2):
+            for p in range(4):
+                np.testing.assert_array_equal(ctx.get_plane(i, p), ref.frames[i].buffer(p), err_msg="plane %d" % p)
+                np.testing.assert_array_equal(ctx.get_plane(i, 4 + p), ref.frames[i].lower_buffer(p),
+                                              err_msg="quarter-res plane %d" % p)
+            cost, mode = ctx.get_intra(i)
+            np.testing.assert_array_equal(cost, ref.frames[i].intra_cost())
+        est = CostEstimateGroup(ctx, frames)
+        assert est.single_cost(0, 1, 1) == ref.frame_cost(0, 1, 1, False)
+        _check_request(ref, ctx, frames, 0, 1, 1)
+    finally:
+        ctx.close()
+        ref.close()
+
+
 @pytest.mark.parametrize("depth,with_aq", [(8, False), (8, True), (10, True)])
 def test_single_cost_sequence(depth, with_aq):
     """Lazy request order (no pool): every singleCost is its own batch."""

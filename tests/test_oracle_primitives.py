@@ -109,6 +109,12 @@ def test_downscale_and_border(oracle_built, depth):
         want = spec.lowres_planes(src, w, h)
         for o, wnt in zip(outs, want):
             np.testing.assert_array_equal(o[:, :w], wnt)
+        # the temporal-filter variant: rounded mean of the same 2x2 neighbourhoods (pixel.cpp:1017-1039)
+        L.orc_frame_init_lowres_core_mcstf(_p(src), *[_p(o) for o in outs], ss, ds, w, h)
+        s32 = src.astype(np.int64)
+        for o, (dy, dx) in zip(outs, ((0, 0), (0, 1), (1, 0), (1, 1))):
+            q = sum(s32[dy + a:dy + a + 2 * h:2, dx + b:dx + b + 2 * w:2] for a in (0, 1) for b in (0, 1))
+            np.testing.assert_array_equal(o[:, :w], (q + 2) >> 2)
     mx, my = 5, 3
     pic = rng.integers(0, 1 << depth, size=(h + 2 * my, w + 2 * mx)).astype(dt)
     inner = pic[my:my + h, mx:mx + w].copy()
@@ -235,3 +241,30 @@ def test_aq_energy_against_numpy(oracle_built, depth):
                 want_e[by * bw + bx] += (q - ((s * s) >> shift)) & 0xffffffff
     np.testing.assert_array_equal(got_e, (want_e & 0xffffffff).astype(np.uint32))
     np.testing.assert_array_equal(got_wp, want_wp)
+
+
+def test_adaptive_quant_frame_oracle_pins(oracle_built):
+    """x265_exp2fix8 known values and calcAdaptiveQuantFrame's variance mode against a numpy statement of it."""
+    L = orc.lib(8)
+    assert [L.orc_exp2fix8(x) for x in (0.0, 6.0, -6.0, 12.0, 60.0, -100.0)] == [256, 128, 512, 64, 0, 0xffff]
+    rng = np.random.default_rng(77)
+    W, H = 96, 64
+    y = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    y[:32] = 90
+    u = rng.integers(100, 140, (H // 2, W // 2)).astype(np.uint8)
+    v = rng.integers(0, 256, (H // 2, W // 2)).astype(np.uint8)
+    energy = np.zeros(24, np.uint32)
+    wp = np.zeros(6, np.uint64)
+    L.orc_aq_energy(_p(y), W, _p(u), _p(v), W // 2, W, H, _p(energy), _p(wp))
+    qa, qc, inv, wsum, wssd = orc.calc_adaptive_quant_frame(8, y, u, v, 1, 1.0, weightp=True)
+    want = 1.0 * float(np.float32(1.0397)) * (np.log2(np.maximum(energy, 1).astype(np.float64)) - float(np.float32(14.427)))
+    np.testing.assert_allclose(qa, want, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(qa, qc)
+    assert np.all(np.abs(inv - 256 * 2.0 ** (-qa / 6)) <= 3.0)
+    np.testing.assert_array_equal(wsum, wp[:3])
+    for i, area in enumerate((W * H, W * H // 4, W * H // 4)):
+        s_, q_ = int(wp[i]), int(wp[3 + i])
+        assert int(wssd[i]) == q_ - (s_ * s_ + area // 2) // area
+    # without weighted prediction and with AQ off nothing is measured
+    _, _, inv0, wsum0, _ = orc.calc_adaptive_quant_frame(8, y, u, v, 0, 1.0)
+    assert np.all(inv0 == -1) and not wsum0.any()

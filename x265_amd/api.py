@@ -21,7 +21,7 @@ EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_weight_cost", "x265gpu_weight_planes",
-    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_interp_luma",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_interp_luma",
     "x265gpu_profile_enable", "x265gpu_profile_read",
 )
 
@@ -37,7 +37,7 @@ class Config(C.Structure):
         ("searchMethod", C.c_int32), ("merange", C.c_int32), ("bEnableHME", C.c_int32),
         ("hmeSearchMethod", C.c_int32 * 3), ("hmeRange", C.c_int32 * 3), ("bFrameBias", C.c_int32),
         ("maxSlices", C.c_int32), ("lookaheadLambda", C.c_int32), ("deviceId", C.c_int32),
-        ("stream", C.c_void_p), ("bKeepFullRes", C.c_int32), ("reserved", C.c_int32),
+        ("stream", C.c_void_p), ("bKeepFullRes", C.c_int32), ("bMcstfFilter", C.c_int32),
     ]
 
 
@@ -66,6 +66,11 @@ class PuJob(C.Structure):
 
 class PuResult(C.Structure):
     _fields_ = [("mvX", C.c_int32), ("mvY", C.c_int32), ("cost", C.c_int32), ("reserved", C.c_int32)]
+
+
+class AqParams(C.Structure):
+    _fields_ = [("aqMode", C.c_int32), ("bWeightedPred", C.c_int32), ("bHDR10Opt", C.c_int32),
+                ("bSkipOffsets", C.c_int32), ("aqStrength", C.c_double)]
 
 
 class BlockJob(C.Structure):
@@ -117,6 +122,7 @@ def load_library(path=None):
     L.x265gpu_get_full_plane.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.x265gpu_block_compare.argtypes = [vp, i32, i32, i32, vp, vp]
     L.x265gpu_aq_energy.argtypes = [vp, vp, ip, vp, vp, ip, i32, vp, vp, vp]
+    L.x265gpu_aq_frame.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp, vp, vp, vp, vp, vp, vp]
     L.x265gpu_interp_luma.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.x265gpu_profile_enable.argtypes = [vp, i32]
     L.x265gpu_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
@@ -133,7 +139,7 @@ class Context:
 
     def __init__(self, width, height, depth=8, bframes=4, num_slots=8, search=HEX_SEARCH, merange=16,
                  ctu=64, hme=False, hme_methods=(HEX_SEARCH, UMH_SEARCH, UMH_SEARCH), hme_range=(16, 32, 48),
-                 bframe_bias=0, device=0, stream=None, keep_full_res=False, lib_path=None):
+                 bframe_bias=0, device=0, stream=None, keep_full_res=False, mcstf=False, lib_path=None):
         self.L = load_library(lib_path)
         cfg = Config()
         cfg.sourceWidth, cfg.sourceHeight, cfg.internalBitDepth = width, height, depth
@@ -147,6 +153,7 @@ class Context:
         cfg.deviceId = device
         cfg.stream = stream
         cfg.bKeepFullRes = int(keep_full_res)
+        cfg.bMcstfFilter = int(mcstf)
         self.cfg = cfg
         self.depth = depth
         self.pix = np.uint8 if depth == 8 else np.uint16
@@ -336,6 +343,23 @@ class Context:
         self._chk(self.L.x265gpu_aq_energy(self.h, _ptr(y), y.shape[1], _ptr(u), _ptr(v), u.shape[1], MEM_HOST,
                                            _ptr(energy), _ptr(wsum), _ptr(wssd)))
         return energy, wsum, wssd
+
+    def aq_frame(self, y, u, v, aq_mode, strength, weightp=False, hdr10=False, skip_offsets=False,
+                 quant_offsets=None, slot=-1):
+        """calcAdaptiveQuantFrame of a 4:2:0 picture (host planes) ->
+        (qpAqOffset, qpCuTreeOffset, invQscaleFactor, wp_sum, wp_ssd); arrays the mode leaves unwritten keep NaN / -1."""
+        y, u, v = (np.ascontiguousarray(p, self.pix) for p in (y, u, v))
+        g = self.cfg
+        blocks = ((g.sourceWidth + 15) >> 4) * ((g.sourceHeight + 15) >> 4)
+        qa, qc = np.full(blocks, np.nan), np.full(blocks, np.nan)
+        inv = np.full(blocks, -1, np.int32)
+        wsum, wssd = np.zeros(3, np.uint64), np.zeros(3, np.uint64)
+        prm = AqParams(int(aq_mode), int(weightp), int(hdr10), int(skip_offsets), float(strength))
+        qo = None if quant_offsets is None else np.ascontiguousarray(quant_offsets, np.float32)
+        self._chk(self.L.x265gpu_aq_frame(self.h, slot, _ptr(y), y.shape[1], _ptr(u), _ptr(v), u.shape[1], MEM_HOST,
+                                          C.byref(prm), None if qo is None else _ptr(qo), _ptr(qa), _ptr(qc), _ptr(inv),
+                                          _ptr(wsum), _ptr(wssd)))
+        return qa, qc, inv, wsum, wssd
 
     def get_full_plane(self, slot):
         """-> (padded plane as a 2-D array, originX, originY)"""

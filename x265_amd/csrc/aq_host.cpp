@@ -1,0 +1,125 @@
+// Host half of adaptive quantisation: the double-precision mapping from block
+// energies to QP offsets and quantiser scale factors.
+//
+// Follows LookaheadTLD::calcAdaptiveQuantFrame for qgSize >= 16
+// (source/encoder/slicetype.cpp:539-643) operation by operation, including where
+// the reference mixes float constants into double expressions, because
+// x265_exp2fix8 truncates and a last-bit difference can move a scale factor.
+// The pixel work (block energies, luma sums, frame sums) is done on the device
+// before this runs.
+#include "kernels.h"
+
+#include <math.h>
+
+// every product and sum below rounds on its own, as the reference's scalar build does
+#pragma STDC FP_CONTRACT OFF
+
+namespace xg {
+
+namespace {
+
+// 256 * (2^(i/64) - 1) rounded: the 64-entry fraction table behind x265_exp2fix8
+// (x265_exp2_lut, source/common/constants.cpp:552-558)
+struct Exp2Table
+{
+    int v[64];
+    Exp2Table()
+    {
+        for (int i = 0; i < 64; i++)
+            v[i] = (int)lround(256.0 * (exp2(i / 64.0) - 1.0));
+    }
+};
+const Exp2Table exp2Table;
+
+// the luma-average steps of the HDR10 option (slicetype.cpp:613-635); block sums are of 16x16 samples
+double hdr10_shift(uint32_t lumaSum)
+{
+    const uint32_t avg = lumaSum / 256;
+    static const struct { uint32_t below; int add; } steps[] = {
+        { 301, 3 }, { 367, 2 }, { 434, 1 }, { 501, 0 }, { 567, -1 }, { 634, -2 }, { 701, -3 }, { 767, -4 }, { 834, -5 } };
+    for (const auto& s : steps)
+        if (avg < s.below)
+            return s.add;
+    return -6;
+}
+
+} // namespace
+
+// x265_exp2fix8 (source/common/common.cpp:96-103): 2^(-x/6) in 8.8 fixed point
+int aq_exp2fix8(double x)
+{
+    const int i = (int)(x * (-64.f / 6.f) + 512.5f);
+    if (i < 0)
+        return 0;
+    if (i > 1023)
+        return 0xffff;
+    return (exp2Table.v[i & 63] + 256) << (i >> 6) >> 8;
+}
+
+void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy, const uint32_t* lumaSum,
+                      const float* quantOffsets, double* qpAqOffset, double* qpCuTreeOffset, int32_t* invQscale)
+{
+    const float modeOneConst = 14.427f, modeTwoConst = 11.f;   // the qgSize > 8 constants (slicetype.cpp:470-473)
+    double strength, avg = 0, bias = 0;
+    const bool autoVariance = p.aqMode == 2 || p.aqMode == 3;
+    if (autoVariance)
+    {
+        // first pass (:541-578): activity = (energy + 1)^0.1, kept in qpCuTreeOffset, and its first two moments
+        const double depthScale = 1.f / (1 << (2 * (p.depth - 8)));
+        double sum = 0, sumSq = 0;
+        for (int i = 0; i < blocks; i++)
+        {
+            const double a = pow(energy[i] * depthScale + 1, 0.1);
+            qpCuTreeOffset[i] = a;
+            sum += a;
+            sumSq += a * a;
+        }
+        sum /= blocks;
+        sumSq /= blocks;
+        strength = p.strength * sum;
+        avg = sum - 0.5f * (sumSq - modeTwoConst) / sum;
+        bias = p.strength;
+    }
+    else
+        strength = p.strength * 1.0397f;
+
+    const float modeOneOffset = modeOneConst + 2 * (p.depth - 8);
+    for (int i = 0; i < blocks; i++)
+    {
+        double q;
+        if (p.aqMode == 3)
+        {
+            const double a = qpCuTreeOffset[i];
+            q = strength * (a - avg) + bias * (1.f - modeTwoConst / (a * a));
+        }
+        else if (p.aqMode == 2)
+            q = strength * (qpCuTreeOffset[i] - avg);
+        else
+        {
+            const uint32_t e = energy[i] > 1 ? energy[i] : 1;
+            q = strength * (log2((double)e) - modeOneOffset);
+        }
+        if (p.hdr10)
+            q += hdr10_shift(lumaSum[i]);
+        if (quantOffsets)
+            q += quantOffsets[i];
+        qpAqOffset[i] = q;
+        qpCuTreeOffset[i] = q;
+        invQscale[i] = aq_exp2fix8(q);
+    }
+}
+
+// wp_ssd with the mean removed over the picture rounded to the nearest multiple
+// of 16 each way, 4:2:0 (slicetype.cpp:672-685)
+void aq_finish_wp(int width, int height, unsigned long long sum[3], unsigned long long ssd[3])
+{
+    const int w = ((width + 8) >> 4) << 4, h = ((height + 8) >> 4) << 4;
+    for (int i = 0; i < 3; i++)
+    {
+        const int pw = i ? w >> 1 : w, ph = i ? h >> 1 : h;
+        const unsigned long long area = (unsigned long long)(pw * ph);
+        ssd[i] = ssd[i] - (sum[i] * sum[i] + (unsigned long long)((pw * ph) / 2)) / area;
+    }
+}
+
+} // namespace xg

@@ -82,7 +82,11 @@ __global__ void __launch_bounds__(256) aq_energy_kernel(AqJob job)
     // the V energy sits in lanes 8..15: bring it to lane 0's side with the row mirror (lane i <-> 15 - i)
     const uint32_t eV = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)eC, 0x140, 0xf, 0xf, true);
     if (live && k == 0)
+    {
         job.energy[(long long)by * blocksX + bx] = eY + eC + eV;
+        if (job.lumaSum)
+            job.lumaSum[(long long)by * blocksX + bx] = sumY;
+    }
     // frame sums: lane 0 of a block carries Y and U, lane 8 carries V
     if (live && (k == 0 || k == 8))
     {

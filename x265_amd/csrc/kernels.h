@@ -19,6 +19,7 @@ struct Geometry
     long long planeSize, padOffset; // pixels
     long long planeSize4, padOffset4;
     int stride4, width4, lines4, marginX4, marginY4;
+    int mcstfFilter;                // 1: (a+b+c+d+2)>>2 downscale (frameInitLowresCoreMCSTF, source/common/pixel.cpp:1017-1039)
 };
 
 struct LowresJob
@@ -142,9 +143,23 @@ struct AqJob
     long long lumaStride, chromaStride;      // pixels
     int width, height;                       // luma size
     uint32_t* energy;                        // [ceil(h/16)][ceil(w/16)]
+    uint32_t* lumaSum;                       // same shape: sum of the block's 256 luma samples (lumaSumCu), or null
     unsigned long long* wp;                  // [0..2] wp_sum Y,U,V; [3..5] wp_ssd Y,U,V (zeroed by the caller)
 };
 hipError_t launch_aq_energy(hipStream_t s, int bpp, const AqJob& job);
+
+// Host half of calcAdaptiveQuantFrame: block energies -> QP offsets (aq_host.cpp).
+struct AqFrameParams
+{
+    int aqMode;          // 1 variance, 2 auto-variance, 3 auto-variance biased
+    int depth;
+    int hdr10;
+    double strength;     // rc.aqStrength
+};
+int aq_exp2fix8(double x);
+void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy, const uint32_t* lumaSum,
+                      const float* quantOffsets, double* qpAqOffset, double* qpCuTreeOffset, int32_t* invQscale);
+void aq_finish_wp(int width, int height, unsigned long long sum[3], unsigned long long ssd[3]);
 hipError_t launch_cost(hipStream_t s, const Geometry& g, int bpp, const CostJob* dJobs, int n);
 hipError_t launch_weight_cost(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJob);
 hipError_t launch_weight_planes(hipStream_t s, const Geometry& g, int bpp, int depth, int nPlanes, const void* src,

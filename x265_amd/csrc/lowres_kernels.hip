@@ -29,8 +29,15 @@ struct DownscaleArgs
     int marginX, marginY;
 };
 
+// The two 2x2 filters: the lookahead's cascaded rounding averages
+// (source/common/pixel.cpp:607) and the plain rounded mean the temporal-filter
+// path uses instead (source/common/pixel.cpp:1026).  `v` is the vertical
+// partial of a column (rounded average, or plain sum for the mean).
+template <bool MEAN> __device__ __forceinline__ int vpart(int a, int b) { return MEAN ? a + b : ravg(a, b); }
+template <bool MEAN> __device__ __forceinline__ int hpart(int a, int b) { return MEAN ? (a + b + 2) >> 2 : ravg(a, b); }
+
 // One thread: 8 consecutive output positions of one padded row, all 4 planes.
-template <typename P>
+template <typename P, bool MEAN>
 __device__ void downscale_span(const DownscaleArgs<P>& a, int span, int prow)
 {
     const int px0 = span * 8 - a.marginX;      // first output x of the span (may be negative)
@@ -59,16 +66,16 @@ __device__ void downscale_span(const DownscaleArgs<P>& a, int span, int prow)
 #pragma unroll
         for (int k = 0; k < 18; k++)
         {
-            v01[k] = ravg(t0[k], t1[k]);
-            v12[k] = ravg(t1[k], t2[k]);
+            v01[k] = vpart<MEAN>(t0[k], t1[k]);
+            v12[k] = vpart<MEAN>(t1[k], t2[k]);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++)
         {
-            o0[i] = ravg(v01[2 * i], v01[2 * i + 1]);
-            oh[i] = ravg(v01[2 * i + 1], v01[2 * i + 2]);
-            ov[i] = ravg(v12[2 * i], v12[2 * i + 1]);
-            oc[i] = ravg(v12[2 * i + 1], v12[2 * i + 2]);
+            o0[i] = hpart<MEAN>(v01[2 * i], v01[2 * i + 1]);
+            oh[i] = hpart<MEAN>(v01[2 * i + 1], v01[2 * i + 2]);
+            ov[i] = hpart<MEAN>(v12[2 * i], v12[2 * i + 1]);
+            oc[i] = hpart<MEAN>(v12[2 * i + 1], v12[2 * i + 2]);
         }
     }
     else
@@ -85,12 +92,12 @@ __device__ void downscale_span(const DownscaleArgs<P>& a, int span, int prow)
             {
                 const int c0 = min(2 * x, a.srcWidth - 1), c1 = min(2 * x + 1, a.srcWidth - 1),
                           c2 = min(2 * x + 2, a.srcWidth - 1);
-                const int a0 = ravg(s0[c0], s1[c0]), a1 = ravg(s0[c1], s1[c1]), a2 = ravg(s0[c2], s1[c2]);
-                const int b0 = ravg(s1[c0], s2[c0]), b1 = ravg(s1[c1], s2[c1]), b2 = ravg(s1[c2], s2[c2]);
-                l0 = ravg(a0, a1);
-                lh = ravg(a1, a2);
-                lv = ravg(b0, b1);
-                lc = ravg(b1, b2);
+                const int a0 = vpart<MEAN>(s0[c0], s1[c0]), a1 = vpart<MEAN>(s0[c1], s1[c1]), a2 = vpart<MEAN>(s0[c2], s1[c2]);
+                const int b0 = vpart<MEAN>(s1[c0], s2[c0]), b1 = vpart<MEAN>(s1[c1], s2[c1]), b2 = vpart<MEAN>(s1[c2], s2[c2]);
+                l0 = hpart<MEAN>(a0, a1);
+                lh = hpart<MEAN>(a1, a2);
+                lv = hpart<MEAN>(b0, b1);
+                lc = hpart<MEAN>(b1, b2);
                 prevx = x;
             }
             // stride-rounding slack right of the margin stays zero, as calloc leaves it
@@ -151,7 +158,10 @@ __global__ void __launch_bounds__(256) lowres_init_kernel(const LowresJob* jobs,
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= spans * rows)
         return;
-    downscale_span<P>(a, idx % spans, idx / spans);
+    if (g.mcstfFilter)
+        downscale_span<P, true>(a, idx % spans, idx / spans);
+    else
+        downscale_span<P, false>(a, idx % spans, idx / spans);
 }
 
 hipError_t launch_lowres_init(hipStream_t s, const Geometry& g, int bpp, const LowresJob* dJobs, int n)
@@ -166,7 +176,7 @@ hipError_t launch_lowres_init(hipStream_t s, const Geometry& g, int bpp, const L
         else
             hipLaunchKernelGGL(lowres_init_kernel<uint16_t>, grid, dim3(256), 0, s, dJobs, g, 0);
     }
-    if (g.W4 > 0)
+    if (g.stride4 > 0)
     {
         const int work = (g.stride4 / 8) * (g.lines4 + 2 * g.marginY4);
         dim3 grid((work + 255) / 256, n);

@@ -143,7 +143,9 @@ void compute_geometry(const x265gpu_config& cfg, Geometry& g)
     g.lines = g.H * 8;
     g.planeSize = (long long)stride * (g.lines + 2 * g.marginY);
     g.padOffset = (long long)stride * g.marginY + g.marginX;
-    if (cfg.bEnableHME)
+    g.mcstfFilter = cfg.bMcstfFilter ? 1 : 0;
+    // quarter-res planes exist with --hme or --mcstf (source/common/lowres.cpp:171, :388)
+    if (cfg.bEnableHME || cfg.bMcstfFilter)
     {
         g.stride4 = stride / 2;
         g.width4 = g.width / 2;
@@ -606,7 +608,7 @@ int x265gpu_lowres_init_batch(x265gpu_ctx* ctx, int32_t n, const int32_t* slots,
         return rc;
     PhaseTimer pt(ctx, X265GPU_PHASE_LOWRES);
     HIPCHK(launch_lowres_init(ctx->stream, g, ctx->bpp, (const LowresJob*)ctx->jobBuf, n));
-    pt.stop(g.W4 > 0 ? 2 : 1);
+    pt.stop(g.stride4 > 0 ? 2 : 1);
     return X265GPU_OK;
 }
 
@@ -1138,23 +1140,24 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
     return X265GPU_OK;
 }
 
-int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const void* u, const void* v, intptr_t strideC,
-                      int32_t memKind, uint32_t* energy, uint64_t wpSum[3], uint64_t wpSsd[3])
+namespace {
+
+// One device pass over a 4:2:0 picture: block energies, optional block luma sums
+// and the six frame accumulators, copied to the host.
+int run_aq_energy(x265gpu_ctx* ctx, const char* who, const void* y, intptr_t strideY, const void* u, const void* v,
+                  intptr_t strideC, int32_t memKind, uint32_t* energy, uint32_t* lumaSum, unsigned long long wp[6])
 {
-    DeviceScope deviceScope(ctx);
-    if (!ctx || !y || !u || !v || !energy || !wpSum || !wpSsd)
-        return X265GPU_ERR_ARG;
     const int w = ctx->cfg.sourceWidth, h = ctx->cfg.sourceHeight, cw = w >> 1, ch = h >> 1;
     if (strideY < w || strideC < cw || cw < 1 || ch < 1)
-        return fail(ctx, X265GPU_ERR_ARG, "aq_energy: bad stride or picture size");
+        return fail(ctx, X265GPU_ERR_ARG, (std::string(who) + ": bad stride or picture size").c_str());
     const int blocks = ((w + 15) >> 4) * ((h + 15) >> 4);
     const size_t lumaBytes = (size_t)w * h * ctx->bpp, chromaBytes = (size_t)cw * ch * ctx->bpp;
-    const size_t outBytes = align256(sizeof(uint32_t) * (size_t)blocks) + 256;
+    const size_t arrayBytes = align256(sizeof(uint32_t) * (size_t)blocks);
     AqJob job;
     memset(&job, 0, sizeof(job));
     job.width = w;
     job.height = h;
-    int rc = ensure_pu_buf(ctx, outBytes);
+    int rc = ensure_pu_buf(ctx, 2 * arrayBytes + 256);
     if (rc)
         return rc;
     if (memKind == X265GPU_MEM_HOST)
@@ -1186,18 +1189,99 @@ int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const v
         job.chromaStride = strideC;
     }
     job.energy = (uint32_t*)ctx->puBuf;
-    job.wp = (unsigned long long*)(ctx->puBuf + align256(sizeof(uint32_t) * (size_t)blocks));
+    job.lumaSum = lumaSum ? (uint32_t*)(ctx->puBuf + arrayBytes) : nullptr;
+    job.wp = (unsigned long long*)(ctx->puBuf + 2 * arrayBytes);
     HIPCHK(hipMemsetAsync(job.wp, 0, 256, ctx->stream));
     HIPCHK(launch_aq_energy(ctx->stream, ctx->bpp, job));
-    unsigned long long wp[6];
     HIPCHK(hipMemcpyAsync(energy, job.energy, sizeof(uint32_t) * (size_t)blocks, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(wp, job.wp, sizeof(wp), hipMemcpyDeviceToHost, ctx->stream));
+    if (lumaSum)
+        HIPCHK(hipMemcpyAsync(lumaSum, job.lumaSum, sizeof(uint32_t) * (size_t)blocks, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(wp, job.wp, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
+} // namespace
+
+int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const void* u, const void* v, intptr_t strideC,
+                      int32_t memKind, uint32_t* energy, uint64_t wpSum[3], uint64_t wpSsd[3])
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || !y || !u || !v || !energy || !wpSum || !wpSsd)
+        return X265GPU_ERR_ARG;
+    unsigned long long wp[6];
+    int rc = run_aq_energy(ctx, "aq_energy", y, strideY, u, v, strideC, memKind, energy, nullptr, wp);
+    if (rc)
+        return rc;
     for (int i = 0; i < 3; i++)
     {
         wpSum[i] = wp[i];
         wpSsd[i] = wp[3 + i];
     }
+    return X265GPU_OK;
+}
+
+int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t strideY, const void* u, const void* v,
+                     intptr_t strideC, int32_t memKind, const x265gpu_aq_params* params, const float* quantOffsets,
+                     double* qpAqOffset, double* qpCuTreeOffset, int32_t* invQscaleFactor, uint64_t wpSum[3],
+                     uint64_t wpSsd[3])
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || !params || !y || !u || !v || !wpSum || !wpSsd)
+        return X265GPU_ERR_ARG;
+    if (params->aqMode < 0 || params->aqMode > 3)
+        return fail(ctx, X265GPU_ERR_UNSUPPORTED, "aq_frame: aqMode must be 0..3 (edge-based and HEVC AQ are not covered)");
+    if (slot >= 0 && !slot_ok(ctx, slot))
+        return fail(ctx, X265GPU_ERR_ARG, "aq_frame: bad slot");
+    const int w = ctx->cfg.sourceWidth, h = ctx->cfg.sourceHeight;
+    const int blocks = ((w + 15) >> 4) * ((h + 15) >> 4);
+    const bool offsets = !params->bSkipOffsets && params->aqMode != 0;
+    const bool mapped = offsets && params->aqStrength != 0;     // slicetype.cpp:486: the energy-driven modes
+    if (offsets && (!qpAqOffset || !qpCuTreeOffset || !invQscaleFactor))
+        return X265GPU_ERR_ARG;
+    if (slot >= 0 && blocks != ctx->g.cuCount)
+        return fail(ctx, X265GPU_ERR_ARG, "aq_frame: 16x16 block grid differs from the slot's 8x8 lowres grid");
+
+    unsigned long long wp[6] = { 0, 0, 0, 0, 0, 0 };
+    // acEnergyCu runs once per block when a mode maps energies (:547, :609) or weighted prediction wants the
+    // frame sums (:508-513, :665-670); otherwise not at all
+    if (mapped || params->bWeightedPred)
+    {
+        std::vector<uint32_t> energy((size_t)blocks), lumaSum(params->bHDR10Opt && mapped ? (size_t)blocks : 0);
+        int rc = run_aq_energy(ctx, "aq_frame", y, strideY, u, v, strideC, memKind, energy.data(),
+                               lumaSum.empty() ? nullptr : lumaSum.data(), wp);
+        if (rc)
+            return rc;
+        if (mapped)
+        {
+            AqFrameParams p;
+            p.aqMode = params->aqMode;
+            p.depth = ctx->cfg.internalBitDepth;
+            p.hdr10 = params->bHDR10Opt != 0;
+            p.strength = params->aqStrength;
+            aq_frame_offsets(p, blocks, energy.data(), lumaSum.empty() ? nullptr : lumaSum.data(), quantOffsets,
+                             qpAqOffset, qpCuTreeOffset, invQscaleFactor);
+        }
+    }
+    if (offsets && !mapped)
+    {
+        // aqMode on with zero strength (:488-505): the caller's offsets alone, or none
+        for (int i = 0; i < blocks; i++)
+        {
+            const double q = quantOffsets ? quantOffsets[i] : 0.0;
+            qpAqOffset[i] = qpCuTreeOffset[i] = q;
+            invQscaleFactor[i] = quantOffsets ? aq_exp2fix8(q) : 256;
+        }
+    }
+    if (params->bWeightedPred)
+        aq_finish_wp(w, h, wp, wp + 3);
+    for (int i = 0; i < 3; i++)
+    {
+        wpSum[i] = wp[i];
+        wpSsd[i] = wp[3 + i];
+    }
+    if (slot >= 0 && offsets)
+        return x265gpu_lowres_set_aq(ctx, slot, invQscaleFactor);
     return X265GPU_OK;
 }
 

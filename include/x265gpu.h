@@ -270,6 +270,34 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
                      const float* quantOffsets /* Frame::m_quantOffsets or NULL */, double* qpAqOffset,
                      double* qpCuTreeOffset, int32_t* invQscaleFactor, uint64_t wpSum[3], uint64_t wpSsd[3]);
 
+/* ---- cuTree: propagation of block costs along the lookahead's motion vectors ----
+ *
+ * The data passes of Lookahead::cuTree (source/encoder/slicetype.cpp:3665-3766) on the arrays the
+ * estimate calls left on the device (intraCost, invQscaleFactor, lowresCosts, lowresMvs); the walk over
+ * the mini-GOPs stays in the caller.  Each slot carries a propagateCost array (Lowres::propagateCost).
+ *   x265gpu_cutree_clear      memset(frames[i]->propagateCost, 0, ...)                       (:3692-3728)
+ *   x265gpu_cutree_swap       std::swap of two frames' propagateCost (lookaheadDepth 0)      (:3699, :3760)
+ *   x265gpu_cutree_propagate  estimateCUPropagate(p0, p1, b, referenced) without its closing
+ *                             cuTreeFinish: primitives.propagateCost (source/common/pixel.cpp:906-932)
+ *                             per block row, then the scatter into frames p0 / p1        (:3768-3870)
+ *                             d0 = b - p0, d1 = p1 - b; fpsFactor = CLIP_DURATION(frame) /
+ *                             CLIP_DURATION(average) (:3781); bipredWeight as at :3772.  The request
+ *                             (d0, d1) of slotB must have been estimated before.
+ *   x265gpu_cutree_finish     cuTreeFinish for qgSize > 8 without hevcAq (:4024-4061): fpsFactor is the
+ *                             integer of :4024, weightDelta that of :4025-4028, cuTreeStrength
+ *                             Lookahead::m_cuTreeStrength (:1075).  log2 runs on the host (libm).
+ *                             qpCuTreeOffset is read-modify-write: blocks with a zero scaled intra
+ *                             cost keep their value.
+ * The uint16 saturation of the reference's CLIP_ADD is order independent (all addends >= 0), so the
+ * device adds with atomics into wide cells and clamps on read; results are bit-exact. */
+int x265gpu_cutree_clear(x265gpu_ctx* ctx, int32_t slot);
+int x265gpu_cutree_swap(x265gpu_ctx* ctx, int32_t slotA, int32_t slotB);
+int x265gpu_cutree_propagate(x265gpu_ctx* ctx, int32_t slotP0, int32_t slotP1, int32_t slotB, int32_t d0, int32_t d1,
+                             int32_t referenced, double fpsFactor, int32_t bipredWeight);
+int x265gpu_cutree_get_propagate_cost(x265gpu_ctx* ctx, int32_t slot, uint16_t* propagateCost);
+int x265gpu_cutree_finish(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, double weightDelta, double cuTreeStrength,
+                          const double* qpAqOffset, double* qpCuTreeOffset);
+
 /* ---- the pixel primitives, one call per batch of blocks ----
  *
  * The EncoderPrimitives slots this library's kernels are built from, exposed on the slots'

@@ -167,6 +167,11 @@ typedef struct orc_lowres {
     orc_refplanes weightedRef[ORC_BFRAME_MAX + 2];
     int      weightedRefIsWeighted[ORC_BFRAME_MAX + 2];
     double   weightedCostDelta[ORC_BFRAME_MAX + 2];
+    /* cuTree state (allocated with AQ): source/common/lowres.cpp:121-140 */
+    uint16_t* propagateCost;
+    double*  qpAqOffset;
+    double*  qpCuTreeOffset;
+    int      sliceType;       /* X265_TYPE_* (source/x265.h): only B (5) is told apart by cuTree */
 } orc_lowres;
 
 typedef struct orc_tld {
@@ -192,6 +197,24 @@ int64_t orc_estimate_frame_cost(orc_tld* t, const orc_param* p, orc_lowres** fra
 uint32_t orc_weight_cost_luma(orc_tld* t, orc_lowres* fenc, orc_lowres* ref,
                               int wtPresent, int scale, int denom, int offset);
 void orc_weights_analyse(orc_tld* t, orc_lowres* fenc, orc_lowres* ref);
+
+/* ---- cuTree (orc_cutree.c) ---- */
+#define ORC_TYPE_B 5
+typedef struct orc_cutree_param {
+    int fpsNum, fpsDenom;
+    int bBPyramid;
+    int bEnableWeightedBiPred;
+    int lookaheadDepth;
+    int vbvBufferSize;
+    double qCompress;
+} orc_cutree_param;
+void orc_propagate_cost(int* dst, const uint16_t* propagateIn, const int32_t* intraCosts, const uint16_t* interCosts,
+                        const int32_t* invQscales, const double* fpsFactor, int len);
+void orc_estimate_cu_propagate(const orc_cutree_param* cp, orc_lowres** frames, int* scratch, double averageDuration,
+                               int p0, int p1, int b, int referenced);
+void orc_cutree_finish(const orc_cutree_param* cp, orc_lowres* frame, double averageDuration, int ref0Distance);
+void orc_cutree(orc_tld* t, const orc_param* p, const orc_cutree_param* cp, orc_lowres** frames, int numframes, int bIntra);
+void orc_lowres_set_slice_type(orc_lowres* lr, int sliceType);
 
 /* field accessors for ctypes */
 void* orc_lowres_ptr(orc_lowres* lr, const char* field, int i, int j);

@@ -31,6 +31,11 @@ class Param(C.Structure):
     ]
 
 
+class CuTreeParam(C.Structure):
+    _fields_ = [("fpsNum", C.c_int), ("fpsDenom", C.c_int), ("bBPyramid", C.c_int), ("bEnableWeightedBiPred", C.c_int),
+                ("lookaheadDepth", C.c_int), ("vbvBufferSize", C.c_int), ("qCompress", C.c_double)]
+
+
 class RefPlanes(C.Structure):
     _fields_ = [("plane", C.c_void_p * 4), ("lowerPlane", C.c_void_p * 4), ("stride", C.c_ssize_t),
                 ("isLowres", C.c_int), ("isHMELowres", C.c_int)]
@@ -96,6 +101,9 @@ def lib(depth=8):
     L.orc_aq_energy.argtypes = [vp, ip, vp, vp, ip, i, i, vp, vp]
     L.orc_exp2fix8.argtypes = [C.c_double]
     L.orc_calc_adaptive_quant_frame.argtypes = [vp, ip, vp, vp, ip, i, i, i, C.c_double, i, i, i, vp, vp, vp, vp, vp]
+    L.orc_cutree.argtypes = [vp, C.POINTER(Param), C.POINTER(CuTreeParam), C.POINTER(vp), i, i]
+    L.orc_lowres_set_slice_type.argtypes = [vp, i]
+    L.orc_propagate_cost.argtypes = [vp, vp, vp, vp, vp, vp, i]
     L.orc_me_init.argtypes = [vp, vp]
     L.orc_me_create.argtypes = [vp]
     L.orc_me_create.restype = vp
@@ -220,6 +228,18 @@ class Lowres:
     def wp(self):
         return self._view("wp_sum", 0, 0, 3, np.uint64), self._view("wp_ssd", 0, 0, 3, np.uint64)
 
+    def propagate_cost(self):
+        return self._view("propagateCost", 0, 0, self.ncu(), np.uint16)
+
+    def qp_aq_offset(self):
+        return self._view("qpAqOffset", 0, 0, self.ncu(), np.float64)
+
+    def qp_cutree_offset(self):
+        return self._view("qpCuTreeOffset", 0, 0, self.ncu(), np.float64)
+
+    def set_slice_type(self, t):
+        self.L.orc_lowres_set_slice_type(self.h, int(t))
+
 
 class Lookahead:
     """Drives the oracle's estimateFrameCost over a list of frames."""
@@ -244,6 +264,12 @@ class Lookahead:
     def frame_cost(self, p0, p1, b, intra_penalty=False):
         arr = (C.c_void_p * len(self.frames))(*[f.h for f in self.frames])
         return self.L.orc_estimate_frame_cost(self.tld, C.byref(self.param), arr, p0, p1, b, int(intra_penalty))
+
+    def cu_tree(self, cp, numframes, b_intra, first=0):
+        """Lookahead::cuTree over frames[first .. first + numframes]."""
+        sub = self.frames[first:first + numframes + 1]
+        arr = (C.c_void_p * len(sub))(*[f.h for f in sub])
+        self.L.orc_cutree(self.tld, C.byref(self.param), C.byref(cp), arr, numframes, int(b_intra))
 
     def close(self):
         for f in self.frames:

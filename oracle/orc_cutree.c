@@ -1,0 +1,229 @@
+/* TEST ORACLE - not part of the product.  CPU restatement of x265's cuTree
+ * propagation, used only by tests to check the HIP path.
+ *
+ * Follows Lookahead::cuTree, estimateCUPropagate and cuTreeFinish
+ * (source/encoder/slicetype.cpp:3665-3874, 4016-4064) and the C primitive
+ * estimateCUPropagateCost (source/common/pixel.cpp:906-932), for qgSize >= 16
+ * without hevcAq. */
+#include "orc.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+static double clip_duration(double f) /* CLIP_DURATION, source/encoder/ratecontrol.h:44-49 */
+{
+    return f < 0.01 ? 0.01 : (f > 1.00 ? 1.00 : f);
+}
+
+/* source/common/pixel.cpp:906-932 */
+void orc_propagate_cost(int* dst, const uint16_t* propagateIn, const int32_t* intraCosts, const uint16_t* interCosts,
+                        const int32_t* invQscales, const double* fpsFactor, int len)
+{
+    double fps = *fpsFactor / 256;
+    for (int i = 0; i < len; i++)
+    {
+        int intraCost = intraCosts[i];
+        int interCost = imin(intraCosts[i], interCosts[i] & ORC_LOWRES_COST_MASK);
+        double propagateIntra = intraCost * invQscales[i];
+        double propagateAmount = (double)propagateIn[i] + propagateIntra * fps;
+        double propagateNum = (double)(intraCost - interCost);
+        double propagateDenom = (double)intraCost;
+        dst[i] = (int)(propagateAmount * propagateNum / propagateDenom + 0.5);
+    }
+}
+
+static void clip_add(uint16_t* s, int x)
+{
+    int v = *s + x;
+    *s = (uint16_t)(v < 65535 ? v : 65535);
+}
+
+/* source/encoder/slicetype.cpp:4016-4064 (the qgSize > 8, non-hevcAq branch) */
+void orc_cutree_finish(const orc_cutree_param* cp, orc_lowres* frame, double averageDuration, int ref0Distance)
+{
+    int fpsFactor = (int)(clip_duration(averageDuration) / clip_duration((double)cp->fpsDenom / cp->fpsNum) * 256);
+    double strength = 5.0 * (1.0 - cp->qCompress);      /* m_cuTreeStrength, :1075 */
+    double weightdelta = 0.0;
+    if (ref0Distance && frame->weightedCostDelta[ref0Distance - 1] > 0)
+        weightdelta = 1.0 - frame->weightedCostDelta[ref0Distance - 1];
+    for (int i = 0; i < frame->cuCount; i++)
+    {
+        int intracost = (frame->intraCost[i] * frame->invQscaleFactor[i] + 128) >> 8;
+        if (intracost)
+        {
+            int propagateCost = (frame->propagateCost[i] * fpsFactor + 128) >> 8;
+            double log2_ratio = log2(intracost + propagateCost) - log2(intracost) + weightdelta;
+            frame->qpCuTreeOffset[i] = frame->qpAqOffset[i] - strength * log2_ratio;
+        }
+    }
+}
+
+/* source/encoder/slicetype.cpp:3768-3874 */
+void orc_estimate_cu_propagate(const orc_cutree_param* cp, orc_lowres** frames, int* scratch, double averageDuration,
+                               int p0, int p1, int b, int referenced)
+{
+    orc_lowres* fb = frames[b];
+    const int W = fb->widthInCU, H = fb->heightInCU;
+    uint16_t* refCosts[2] = { frames[p0]->propagateCost, frames[p1]->propagateCost };
+    int32_t distScaleFactor = (((b - p0) << 8) + ((p1 - p0) >> 1)) / (p1 - p0);
+    int32_t bipredWeight = cp->bEnableWeightedBiPred ? 64 - (distScaleFactor >> 2) : 32;
+    int32_t bipredWeights[2] = { bipredWeight, 64 - bipredWeight };
+    int listDist[2] = { b - p0, p1 - b };
+    const uint16_t* lowresCosts = fb->lowresCosts[b - p0][p1 - b];
+
+    memset(scratch, 0, W * sizeof(int));
+    uint16_t* propagateCost = fb->propagateCost;
+    double fpsFactor = clip_duration((double)cp->fpsDenom / cp->fpsNum) / clip_duration(averageDuration);
+    if (!referenced)
+        memset(fb->propagateCost, 0, W * sizeof(uint16_t));
+
+    for (int blocky = 0; blocky < H; blocky++)
+    {
+        int cuIndex = blocky * W;
+        orc_propagate_cost(scratch, propagateCost, fb->intraCost + cuIndex, lowresCosts + cuIndex,
+                           fb->invQscaleFactor + cuIndex, &fpsFactor, W);
+        if (referenced)
+            propagateCost += W;
+        for (int blockx = 0; blockx < W; blockx++, cuIndex++)
+        {
+            int32_t amount = scratch[blockx];
+            if (amount <= 0)
+                continue;
+            int32_t lists_used = lowresCosts[cuIndex] >> ORC_LOWRES_COST_SHIFT;
+            for (int list = 0; list < 2; list++)
+            {
+                if (!((lists_used >> list) & 1))
+                    continue;
+                int32_t listamount = amount;
+                if (lists_used == 3)
+                    listamount = (listamount * bipredWeights[list] + 32) >> 6;
+                const orc_mv* mvs = fb->lowresMvs[list][listDist[list]];
+                if (!mvs[cuIndex].x && !mvs[cuIndex].y)
+                {
+                    clip_add(&refCosts[list][cuIndex], listamount);
+                    continue;
+                }
+                int32_t x = mvs[cuIndex].x, y = mvs[cuIndex].y;
+                int32_t cux = (x >> 5) + blockx, cuy = (y >> 5) + blocky;
+                int32_t idx0 = cux + cuy * W;
+                x &= 31;
+                y &= 31;
+                const int32_t weight[4] = { (32 - y) * (32 - x), (32 - y) * x, y * (32 - x), y * x };
+                for (int k = 0; k < 4; k++)
+                {
+                    int tx = cux + (k & 1), ty = cuy + (k >> 1);
+                    if (tx >= 0 && tx < W && ty >= 0 && ty < H)
+                        clip_add(&refCosts[list][idx0 + (k & 1) + (k >> 1) * W], (listamount * weight[k] + 512) >> 10);
+                }
+            }
+        }
+    }
+    if (cp->vbvBufferSize && cp->lookaheadDepth && referenced)
+        orc_cutree_finish(cp, fb, averageDuration, b == p1 ? b - p0 : 0);
+}
+
+static void swap_propagate(orc_lowres* a, orc_lowres* b)
+{
+    uint16_t* t = a->propagateCost;
+    a->propagateCost = b->propagateCost;
+    b->propagateCost = t;
+}
+
+/* source/encoder/slicetype.cpp:3665-3766 */
+void orc_cutree(orc_tld* t, const orc_param* p, const orc_cutree_param* cp, orc_lowres** frames, int numframes, int bIntra)
+{
+    int idx = !bIntra;
+    int lastnonb, curnonb = 1;
+    int bframes = 0;
+    const int cuCount = frames[0]->cuCount;
+    int* scratch = (int*)malloc(sizeof(int) * frames[0]->widthInCU);
+
+    double totalDuration = 0.0;
+    for (int j = 0; j <= numframes; j++)
+        totalDuration += (double)cp->fpsDenom / cp->fpsNum;
+    double averageDuration = totalDuration / (numframes + 1);
+
+    int i = numframes;
+    while (i > 0 && frames[i]->sliceType == ORC_TYPE_B)
+        i--;
+    lastnonb = i;
+
+    if (!cp->lookaheadDepth)
+    {
+        if (bIntra)
+        {
+            memset(frames[0]->propagateCost, 0, cuCount * sizeof(uint16_t));
+            memcpy(frames[0]->qpCuTreeOffset, frames[0]->qpAqOffset, cuCount * sizeof(double));
+            free(scratch);
+            return;
+        }
+        swap_propagate(frames[lastnonb], frames[0]);
+        memset(frames[0]->propagateCost, 0, cuCount * sizeof(uint16_t));
+    }
+    else
+    {
+        if (lastnonb < idx)
+        {
+            free(scratch);
+            return;
+        }
+        memset(frames[lastnonb]->propagateCost, 0, cuCount * sizeof(uint16_t));
+    }
+
+    while (i-- > idx)
+    {
+        curnonb = i;
+        while (frames[curnonb]->sliceType == ORC_TYPE_B && curnonb > 0)
+            curnonb--;
+        if (curnonb < idx)
+            break;
+
+        orc_estimate_frame_cost(t, p, frames, curnonb, lastnonb, lastnonb, 0);
+        memset(frames[curnonb]->propagateCost, 0, cuCount * sizeof(uint16_t));
+        bframes = lastnonb - curnonb - 1;
+        if (cp->bBPyramid && bframes > 1)
+        {
+            int middle = (bframes + 1) / 2 + curnonb;
+            orc_estimate_frame_cost(t, p, frames, curnonb, lastnonb, middle, 0);
+            memset(frames[middle]->propagateCost, 0, cuCount * sizeof(uint16_t));
+            while (i > curnonb)
+            {
+                int p0 = i > middle ? middle : curnonb;
+                int p1 = i < middle ? middle : lastnonb;
+                if (i != middle)
+                {
+                    orc_estimate_frame_cost(t, p, frames, p0, p1, i, 0);
+                    orc_estimate_cu_propagate(cp, frames, scratch, averageDuration, p0, p1, i, 0);
+                }
+                i--;
+            }
+            orc_estimate_cu_propagate(cp, frames, scratch, averageDuration, curnonb, lastnonb, middle, 1);
+        }
+        else
+        {
+            while (i > curnonb)
+            {
+                orc_estimate_frame_cost(t, p, frames, curnonb, lastnonb, i, 0);
+                orc_estimate_cu_propagate(cp, frames, scratch, averageDuration, curnonb, lastnonb, i, 0);
+                i--;
+            }
+        }
+        orc_estimate_cu_propagate(cp, frames, scratch, averageDuration, curnonb, lastnonb, lastnonb, 1);
+        lastnonb = curnonb;
+    }
+
+    if (!cp->lookaheadDepth)
+    {
+        orc_estimate_frame_cost(t, p, frames, 0, lastnonb, lastnonb, 0);
+        orc_estimate_cu_propagate(cp, frames, scratch, averageDuration, 0, lastnonb, lastnonb, 1);
+        swap_propagate(frames[lastnonb], frames[0]);
+    }
+
+    orc_cutree_finish(cp, frames[lastnonb], averageDuration, lastnonb);
+    if (cp->bBPyramid && bframes > 1 && !cp->vbvBufferSize)
+        orc_cutree_finish(cp, frames[lastnonb + (bframes + 1) / 2], averageDuration, 0);
+    free(scratch);
+}

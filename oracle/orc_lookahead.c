@@ -59,7 +59,12 @@ orc_lowres* orc_lowres_create(const orc_param* p, int withAq)
         lr->heightInCU4 = ((p->sourceHeight / 4) + ORC_CU - 1) >> 3;
     }
     if (withAq)
+    {
         lr->invQscaleFactor = (int*)calloc(lr->cuCount, sizeof(int));
+        lr->propagateCost = (uint16_t*)calloc(lr->cuCount, sizeof(uint16_t));
+        lr->qpAqOffset = (double*)calloc(lr->cuCount, sizeof(double));
+        lr->qpCuTreeOffset = (double*)calloc(lr->cuCount, sizeof(double));
+    }
     lr->intraCost = (int32_t*)malloc(sizeof(int32_t) * lr->cuCount);
     lr->intraMode = (uint8_t*)malloc(lr->cuCount);
     for (int i = 0; i < p->bframes + 2; i++)
@@ -92,6 +97,9 @@ void orc_lowres_destroy(orc_lowres* lr)
     free(lr->buffer[0]);
     free(lr->lowerResBuffer[0]);
     free(lr->invQscaleFactor);
+    free(lr->propagateCost);
+    free(lr->qpAqOffset);
+    free(lr->qpCuTreeOffset);
     free(lr->intraCost);
     free(lr->intraMode);
     for (int i = 0; i < ORC_BFRAME_MAX + 2; i++)
@@ -782,6 +790,8 @@ int64_t orc_estimate_frame_cost(orc_tld* t, const orc_param* p, orc_lowres** fra
 
 /* ---------------------------------------------------------------- ctypes accessors */
 
+void orc_lowres_set_slice_type(orc_lowres* lr, int sliceType) { lr->sliceType = sliceType; }
+
 void* orc_lowres_ptr(orc_lowres* lr, const char* f, int i, int j)
 {
     if (!strcmp(f, "plane")) return lr->rp.plane[i];
@@ -791,6 +801,9 @@ void* orc_lowres_ptr(orc_lowres* lr, const char* f, int i, int j)
     if (!strcmp(f, "intraCost")) return lr->intraCost;
     if (!strcmp(f, "intraMode")) return lr->intraMode;
     if (!strcmp(f, "invQscaleFactor")) return lr->invQscaleFactor;
+    if (!strcmp(f, "propagateCost")) return lr->propagateCost;
+    if (!strcmp(f, "qpAqOffset")) return lr->qpAqOffset;
+    if (!strcmp(f, "qpCuTreeOffset")) return lr->qpCuTreeOffset;
     if (!strcmp(f, "rowSatds")) return lr->rowSatds[i][j];
     if (!strcmp(f, "lowresCosts")) return lr->lowresCosts[i][j];
     if (!strcmp(f, "lowresMvs")) return lr->lowresMvs[i][j];

@@ -268,3 +268,21 @@ def test_adaptive_quant_frame_oracle_pins(oracle_built):
     # without weighted prediction and with AQ off nothing is measured
     _, _, inv0, wsum0, _ = orc.calc_adaptive_quant_frame(8, y, u, v, 0, 1.0)
     assert np.all(inv0 == -1) and not wsum0.any()
+
+
+def test_propagate_cost_oracle_pin(oracle_built):
+    """estimateCUPropagateCost (pixel.cpp:906-932) against the same arithmetic in numpy float64."""
+    L = orc.lib(8)
+    rng = np.random.default_rng(5)
+    n = 333
+    intra = rng.integers(1, 20000, n).astype(np.int32)
+    inter = (rng.integers(0, 1 << 14, n) | (rng.integers(0, 4, n) << 14)).astype(np.uint16)
+    prop = rng.integers(0, 65536, n).astype(np.uint16)
+    invq = rng.integers(1, 2000, n).astype(np.int32)
+    fps = np.array([0.04 / 0.0417], np.float64)
+    dst = np.zeros(n, np.int32)
+    L.orc_propagate_cost(_p(dst), _p(prop), _p(intra), _p(inter), _p(invq), _p(fps), n)
+    ic = intra.astype(np.float64)
+    amount = prop.astype(np.float64) + (intra * invq).astype(np.float64) * (fps[0] / 256)
+    num = (intra - np.minimum(intra, inter & 0x3FFF)).astype(np.float64)
+    np.testing.assert_array_equal(dst, (amount * num / ic + 0.5).astype(np.int32))

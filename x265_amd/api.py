@@ -22,6 +22,8 @@ EXPORTS = (
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_weight_cost", "x265gpu_weight_planes",
     "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_interp_luma",
+    "x265gpu_cutree_clear", "x265gpu_cutree_swap", "x265gpu_cutree_propagate", "x265gpu_cutree_get_propagate_cost",
+    "x265gpu_cutree_finish",
     "x265gpu_profile_enable", "x265gpu_profile_read",
 )
 
@@ -122,6 +124,11 @@ def load_library(path=None):
     L.x265gpu_get_full_plane.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.x265gpu_block_compare.argtypes = [vp, i32, i32, i32, vp, vp]
     L.x265gpu_aq_energy.argtypes = [vp, vp, ip, vp, vp, ip, i32, vp, vp, vp]
+    L.x265gpu_cutree_clear.argtypes = [vp, i32]
+    L.x265gpu_cutree_swap.argtypes = [vp, i32, i32]
+    L.x265gpu_cutree_propagate.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.c_double, i32]
+    L.x265gpu_cutree_get_propagate_cost.argtypes = [vp, i32, vp]
+    L.x265gpu_cutree_finish.argtypes = [vp, i32, i32, C.c_double, C.c_double, vp, vp]
     L.x265gpu_aq_frame.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp, vp, vp, vp, vp, vp, vp]
     L.x265gpu_interp_luma.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.x265gpu_profile_enable.argtypes = [vp, i32]
@@ -360,6 +367,29 @@ class Context:
                                           C.byref(prm), None if qo is None else _ptr(qo), _ptr(qa), _ptr(qc), _ptr(inv),
                                           _ptr(wsum), _ptr(wssd)))
         return qa, qc, inv, wsum, wssd
+
+    # ---- cuTree ----
+    def cutree_clear(self, slot):
+        self._chk(self.L.x265gpu_cutree_clear(self.h, slot))
+
+    def cutree_swap(self, slot_a, slot_b):
+        self._chk(self.L.x265gpu_cutree_swap(self.h, slot_a, slot_b))
+
+    def cutree_propagate(self, slot_p0, slot_p1, slot_b, d0, d1, referenced, fps_factor, bipred_weight):
+        self._chk(self.L.x265gpu_cutree_propagate(self.h, slot_p0, slot_p1, slot_b, d0, d1, int(referenced),
+                                                  float(fps_factor), int(bipred_weight)))
+
+    def cutree_get_propagate_cost(self, slot):
+        out = np.empty(self.geom.widthInCU * self.geom.heightInCU, np.uint16)
+        self._chk(self.L.x265gpu_cutree_get_propagate_cost(self.h, slot, _ptr(out)))
+        return out
+
+    def cutree_finish(self, slot, fps_factor, weight_delta, strength, qp_aq_offset, qp_cutree_offset):
+        """qp_cutree_offset (float64, contiguous) is updated in place."""
+        assert qp_aq_offset.dtype == np.float64 and qp_cutree_offset.dtype == np.float64
+        assert qp_aq_offset.flags.c_contiguous and qp_cutree_offset.flags.c_contiguous
+        self._chk(self.L.x265gpu_cutree_finish(self.h, slot, int(fps_factor), float(weight_delta), float(strength),
+                                               _ptr(qp_aq_offset), _ptr(qp_cutree_offset)))
 
     def get_full_plane(self, slot):
         """-> (padded plane as a 2-D array, originX, originY)"""

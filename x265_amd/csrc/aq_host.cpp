@@ -122,4 +122,22 @@ void aq_finish_wp(int width, int height, unsigned long long sum[3], unsigned lon
     }
 }
 
+// Lookahead::cuTreeFinish, the qgSize > 8 loop (source/encoder/slicetype.cpp:4052-4061): blocks
+// whose scaled intra cost is zero keep their previous offset.
+void cutree_finish_offsets(int blocks, const int32_t* intraCost, const int32_t* invQscale, const unsigned long long* totals,
+                           int fpsFactor, double weightDelta, double strength, const double* qpAqOffset,
+                           double* qpCuTreeOffset)
+{
+    for (int i = 0; i < blocks; i++)
+    {
+        const int intra = (intraCost[i] * invQscale[i] + 128) >> 8;
+        if (!intra)
+            continue;
+        const int inherited = (int)(totals[i] < 65535 ? totals[i] : 65535);
+        const int propagated = (inherited * fpsFactor + 128) >> 8;
+        const double ratio = log2((double)(intra + propagated)) - log2((double)intra) + weightDelta;
+        qpCuTreeOffset[i] = qpAqOffset[i] - strength * ratio;
+    }
+}
+
 } // namespace xg

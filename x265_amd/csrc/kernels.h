@@ -160,6 +160,25 @@ int aq_exp2fix8(double x);
 void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy, const uint32_t* lumaSum,
                       const float* quantOffsets, double* qpAqOffset, double* qpCuTreeOffset, int32_t* invQscale);
 void aq_finish_wp(int width, int height, unsigned long long sum[3], unsigned long long ssd[3]);
+// cuTreeFinish for qgSize > 8 (aq_host.cpp): propagate totals -> qpCuTreeOffset
+void cutree_finish_offsets(int blocks, const int32_t* intraCost, const int32_t* invQscale, const unsigned long long* totals,
+                           int fpsFactor, double weightDelta, double strength, const double* qpAqOffset,
+                           double* qpCuTreeOffset);
+
+// One estimateCUPropagate(p0, p1, b): frame b's blocks hand their amounts to frames p0 / p1.
+struct PropagateJob
+{
+    const int32_t* intraCost;
+    const uint16_t* lowresCosts;             // lowresCosts[b - p0][p1 - b]
+    const int32_t* invQscale;
+    const unsigned long long* propagateIn;   // frame b's own totals, or null for an unreferenced frame
+    const int32_t* mvs[2];                   // lowresMvs[0][b - p0], lowresMvs[1][p1 - b]
+    unsigned long long* refCosts[2];         // totals of frames p0 and p1
+    int W, H;
+    int bipredWeight;                        // list 0's share of 64
+    double fps;                              // fpsFactor / 256
+};
+hipError_t launch_cutree_propagate(hipStream_t s, const PropagateJob& job);
 hipError_t launch_cost(hipStream_t s, const Geometry& g, int bpp, const CostJob* dJobs, int n);
 hipError_t launch_weight_cost(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJob);
 hipError_t launch_weight_planes(hipStream_t s, const Geometry& g, int bpp, int depth, int nPlanes, const void* src,

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace xg;
@@ -23,6 +24,7 @@ struct Slot
     uint8_t* intraMode = nullptr;
     int32_t* invQscale = nullptr;
     bool hasAq = false;
+    unsigned long long* propagate = nullptr; // cuTree: unsaturated propagateCost totals, [n]
     int32_t* mvs = nullptr;        // [2][D][n][2]
     int32_t* mvCosts = nullptr;    // [2][D][n]
     int32_t* mvs4 = nullptr;       // [2][D][n4][2]
@@ -180,6 +182,7 @@ int alloc_slot(x265gpu_ctx* ctx, Slot& s)
     const size_t oIntraCost = take(sizeof(int32_t) * n);
     const size_t oIntraMode = take(n);
     const size_t oInvQ = take(sizeof(int32_t) * n);
+    const size_t oPropagate = take(sizeof(unsigned long long) * n);
     const size_t oMvs = take(sizeof(int32_t) * 2 * (size_t)2 * D * n);
     const size_t oMvCosts = take(sizeof(int32_t) * (size_t)2 * D * n);
     const size_t oMvs4 = take(sizeof(int32_t) * 2 * (size_t)2 * D * n4);
@@ -195,6 +198,7 @@ int alloc_slot(x265gpu_ctx* ctx, Slot& s)
     s.intraCost = (int32_t*)(s.base + oIntraCost);
     s.intraMode = (uint8_t*)(s.base + oIntraMode);
     s.invQscale = (int32_t*)(s.base + oInvQ);
+    s.propagate = (unsigned long long*)(s.base + oPropagate);
     s.mvs = (int32_t*)(s.base + oMvs);
     s.mvCosts = (int32_t*)(s.base + oMvCosts);
     s.mvs4 = (int32_t*)(s.base + oMvs4);
@@ -1137,6 +1141,106 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
                             (PuResult*)(ctx->puBuf + jobBytes)));
     HIPCHK(hipMemcpyAsync(out, ctx->puBuf + jobBytes, outBytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
+/* ---- cuTree ---- */
+
+int x265gpu_cutree_clear(x265gpu_ctx* ctx, int32_t slot)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || !slot_ok(ctx, slot))
+        return X265GPU_ERR_ARG;
+    HIPCHK(hipMemsetAsync(ctx->slots[slot].propagate, 0, sizeof(unsigned long long) * ctx->g.cuCount, ctx->stream));
+    return X265GPU_OK;
+}
+
+int x265gpu_cutree_swap(x265gpu_ctx* ctx, int32_t slotA, int32_t slotB)
+{
+    if (!ctx || !slot_ok(ctx, slotA) || !slot_ok(ctx, slotB))
+        return X265GPU_ERR_ARG;
+    std::swap(ctx->slots[slotA].propagate, ctx->slots[slotB].propagate);
+    return X265GPU_OK;
+}
+
+int x265gpu_cutree_propagate(x265gpu_ctx* ctx, int32_t slotP0, int32_t slotP1, int32_t slotB, int32_t d0, int32_t d1,
+                             int32_t referenced, double fpsFactor, int32_t bipredWeight)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || !slot_ok(ctx, slotP0) || !slot_ok(ctx, slotP1) || !slot_ok(ctx, slotB) || d0 < 1 || d0 >= ctx->D ||
+        d1 < 0 || d1 >= ctx->D || bipredWeight < 0 || bipredWeight > 64)
+        return X265GPU_ERR_ARG;
+    Slot& sb = ctx->slots[slotB];
+    if (!sb.hasAq)
+        return fail(ctx, X265GPU_ERR_STATE, "cutree_propagate: the frame has no invQscaleFactor (x265gpu_lowres_set_aq)");
+    const size_t nb = ctx->g.cuCount;
+    PropagateJob job;
+    memset(&job, 0, sizeof(job));
+    job.intraCost = sb.intraCost;
+    job.lowresCosts = sb.lowresCosts + ((size_t)d0 * ctx->D + d1) * nb;
+    job.invQscale = sb.invQscale;
+    job.propagateIn = referenced ? sb.propagate : nullptr;
+    job.mvs[0] = sb.mvs + ((size_t)0 * ctx->D + d0) * nb * 2;
+    job.mvs[1] = sb.mvs + ((size_t)1 * ctx->D + d1) * nb * 2;
+    job.refCosts[0] = ctx->slots[slotP0].propagate;
+    job.refCosts[1] = ctx->slots[slotP1].propagate;
+    job.W = ctx->g.W;
+    job.H = ctx->g.H;
+    job.bipredWeight = bipredWeight;
+    job.fps = fpsFactor / 256;
+    // an unreferenced frame's own cells are a zeroed row in the reference (slicetype.cpp:3784-3785):
+    // nothing reads them again before the next clear, but keep the visible state the same
+    if (!referenced)
+        HIPCHK(hipMemsetAsync(sb.propagate, 0, sizeof(unsigned long long) * ctx->g.W, ctx->stream));
+    HIPCHK(launch_cutree_propagate(ctx->stream, job));
+    return X265GPU_OK;
+}
+
+namespace {
+int fetch_propagate(x265gpu_ctx* ctx, int slot, std::vector<unsigned long long>& acc)
+{
+    acc.resize(ctx->g.cuCount);
+    HIPCHK(hipMemcpyAsync(acc.data(), ctx->slots[slot].propagate, sizeof(unsigned long long) * acc.size(),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    return X265GPU_OK;
+}
+} // namespace
+
+int x265gpu_cutree_get_propagate_cost(x265gpu_ctx* ctx, int32_t slot, uint16_t* propagateCost)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || !slot_ok(ctx, slot) || !propagateCost)
+        return X265GPU_ERR_ARG;
+    std::vector<unsigned long long> acc;
+    int rc = fetch_propagate(ctx, slot, acc);
+    if (rc)
+        return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < acc.size(); i++)
+        propagateCost[i] = (uint16_t)(acc[i] < 65535 ? acc[i] : 65535);
+    return X265GPU_OK;
+}
+
+int x265gpu_cutree_finish(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, double weightDelta, double cuTreeStrength,
+                          const double* qpAqOffset, double* qpCuTreeOffset)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || !slot_ok(ctx, slot) || !qpAqOffset || !qpCuTreeOffset)
+        return X265GPU_ERR_ARG;
+    Slot& s = ctx->slots[slot];
+    if (!s.hasAq)
+        return fail(ctx, X265GPU_ERR_STATE, "cutree_finish: the frame has no invQscaleFactor (x265gpu_lowres_set_aq)");
+    const size_t nb = ctx->g.cuCount;
+    std::vector<unsigned long long> acc;
+    std::vector<int32_t> intra(nb), invQ(nb);
+    int rc = fetch_propagate(ctx, slot, acc);
+    if (rc)
+        return rc;
+    HIPCHK(hipMemcpyAsync(intra.data(), s.intraCost, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(invQ.data(), s.invQscale, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    cutree_finish_offsets((int)nb, intra.data(), invQ.data(), acc.data(), fpsFactor, weightDelta, cuTreeStrength,
+                          qpAqOffset, qpCuTreeOffset);
     return X265GPU_OK;
 }
 

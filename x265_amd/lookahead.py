@@ -8,6 +8,9 @@ the offload boundary, so that parity tests read like calls into the reference:
   CostEstimateGroup.add / finish_batch <- ::add / ::finishBatch        (slicetype.cpp:4154-4196)
 
   LookaheadTLD.weights_analyse      <- LookaheadTLD::weightsAnalyse    (slicetype.cpp:870-971)
+  CuTree.cu_tree / estimate_cu_propagate / cu_tree_finish
+                                    <- Lookahead::cuTree, ::estimateCUPropagate, ::cuTreeFinish
+                                       (slicetype.cpp:3665-3874, 4016-4064)
 
 The cache check, the bDoSearch decision from the 0x7FFF sentinel, the B-frame
 bias and the intra penalty of estimateFrameCost (slicetype.cpp:4284-4383) are
@@ -17,6 +20,9 @@ device slot.
 import numpy as np
 
 _f32 = np.float32
+
+# X265_TYPE_* (source/x265.h)
+TYPE_AUTO, TYPE_IDR, TYPE_I, TYPE_P, TYPE_BREF, TYPE_B = range(6)
 
 
 class LowresState:
@@ -36,6 +42,9 @@ class LowresState:
         self.wp_ssd = 0
         self.weighted = {}                                       # d0 -> weightedRef[d0].isWeighted
         self.weighted_cost_delta = {}
+        self.slice_type = TYPE_AUTO                              # Lowres::sliceType
+        self.qp_aq_offset = None                                 # float64[n], from calcAdaptiveQuantFrame
+        self.qp_cutree_offset = None
 
 
 class LookaheadTLD:
@@ -180,3 +189,107 @@ class CostEstimateGroup:
         for (_, b, d0, d1), rc in zip(self.batch, res):
             self._collect(b, d0, d1, rc)
         self.batch = []
+
+
+def _clip_duration(f):
+    """CLIP_DURATION (source/encoder/ratecontrol.h:44-49)"""
+    return min(max(f, 0.01), 1.00)
+
+
+class CuTree:
+    """Lookahead::cuTree: the walk over the mini-GOPs is host logic; the per-block passes run on the device.
+
+    Parameters follow x265_param: fps_num / fps_denom, b_pyramid (bBPyramid), weighted_bipred
+    (bEnableWeightedBiPred), lookahead_depth, vbv_buffer_size (rc.vbvBufferSize), q_compress (rc.qCompress)."""
+
+    def __init__(self, ctx, fps_num=30, fps_denom=1, b_pyramid=False, weighted_bipred=False, lookahead_depth=20,
+                 vbv_buffer_size=0, q_compress=0.6):
+        self.ctx = ctx
+        self.frame_duration = float(fps_denom) / fps_num
+        self.b_pyramid = b_pyramid
+        self.weighted_bipred = weighted_bipred
+        self.lookahead_depth = lookahead_depth
+        self.vbv = vbv_buffer_size
+        self.strength = 5.0 * (1.0 - q_compress)                 # m_cuTreeStrength, slicetype.cpp:1075
+
+    def cu_tree_finish(self, frame, average_duration, ref0_distance):
+        fps_factor = int(_clip_duration(average_duration) / _clip_duration(self.frame_duration) * 256)
+        delta = 0.0
+        if ref0_distance and frame.weighted_cost_delta.get(ref0_distance - 1, 0) > 0:
+            delta = 1.0 - frame.weighted_cost_delta[ref0_distance - 1]
+        self.ctx.cutree_finish(frame.slot, fps_factor, delta, self.strength, frame.qp_aq_offset, frame.qp_cutree_offset)
+
+    def estimate_cu_propagate(self, frames, average_duration, p0, p1, b, referenced):
+        dist_scale = (((b - p0) << 8) + ((p1 - p0) >> 1)) // (p1 - p0)
+        bipred_weight = 64 - (dist_scale >> 2) if self.weighted_bipred else 32
+        fps_factor = _clip_duration(self.frame_duration) / _clip_duration(average_duration)
+        self.ctx.cutree_propagate(frames[p0].slot, frames[p1].slot, frames[b].slot, b - p0, p1 - b, referenced,
+                                  fps_factor, bipred_weight)
+        if self.vbv and self.lookahead_depth and referenced:
+            self.cu_tree_finish(frames[b], average_duration, b - p0 if b == p1 else 0)
+
+    def cu_tree(self, frames, numframes, b_intra):
+        ctx = self.ctx
+        idx = 0 if b_intra else 1
+        bframes = 0
+        total = 0.0
+        for _ in range(numframes + 1):
+            total += self.frame_duration
+        average_duration = total / (numframes + 1)
+
+        i = numframes
+        while i > 0 and frames[i].slice_type == TYPE_B:
+            i -= 1
+        lastnonb = i
+
+        if not self.lookahead_depth:
+            if b_intra:
+                ctx.cutree_clear(frames[0].slot)
+                frames[0].qp_cutree_offset[:] = frames[0].qp_aq_offset
+                return
+            ctx.cutree_swap(frames[lastnonb].slot, frames[0].slot)
+            ctx.cutree_clear(frames[0].slot)
+        else:
+            if lastnonb < idx:
+                return
+            ctx.cutree_clear(frames[lastnonb].slot)
+
+        est = CostEstimateGroup(ctx, frames)
+        while i > idx:
+            i -= 1
+            curnonb = i
+            while frames[curnonb].slice_type == TYPE_B and curnonb > 0:
+                curnonb -= 1
+            if curnonb < idx:
+                break
+            est.single_cost(curnonb, lastnonb, lastnonb)
+            ctx.cutree_clear(frames[curnonb].slot)
+            bframes = lastnonb - curnonb - 1
+            if self.b_pyramid and bframes > 1:
+                middle = (bframes + 1) // 2 + curnonb
+                est.single_cost(curnonb, lastnonb, middle)
+                ctx.cutree_clear(frames[middle].slot)
+                while i > curnonb:
+                    p0 = middle if i > middle else curnonb
+                    p1 = middle if i < middle else lastnonb
+                    if i != middle:
+                        est.single_cost(p0, p1, i)
+                        self.estimate_cu_propagate(frames, average_duration, p0, p1, i, 0)
+                    i -= 1
+                self.estimate_cu_propagate(frames, average_duration, curnonb, lastnonb, middle, 1)
+            else:
+                while i > curnonb:
+                    est.single_cost(curnonb, lastnonb, i)
+                    self.estimate_cu_propagate(frames, average_duration, curnonb, lastnonb, i, 0)
+                    i -= 1
+            self.estimate_cu_propagate(frames, average_duration, curnonb, lastnonb, lastnonb, 1)
+            lastnonb = curnonb
+
+        if not self.lookahead_depth:
+            est.single_cost(0, lastnonb, lastnonb)
+            self.estimate_cu_propagate(frames, average_duration, 0, lastnonb, lastnonb, 1)
+            ctx.cutree_swap(frames[lastnonb].slot, frames[0].slot)
+
+        self.cu_tree_finish(frames[lastnonb], average_duration, lastnonb)
+        if self.b_pyramid and bframes > 1 and not self.vbv:
+            self.cu_tree_finish(frames[lastnonb + (bframes + 1) // 2], average_duration, 0)

@@ -43,6 +43,10 @@ extern "C" {
 #define X265GPU_UMH_SEARCH  2
 #define X265GPU_STAR_SEARCH 3
 #define X265GPU_FULL_SEARCH 5
+/* not an x265 method value: MotionEstimate::diamondSearch (source/encoder/motion.cpp:631-788), the coarse
+ * search behind an area's starting vector (Search::puMotionEstimation with isMVP, source/encoder/search.cpp:360-364).
+ * merange, subpelRefine and the candidate list are ignored; the result vector is in FULL pixels, as there. */
+#define X265GPU_AREA_DIAMOND_SEARCH 16
 
 /* where a caller-supplied buffer lives */
 #define X265GPU_MEM_HOST   0

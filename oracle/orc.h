@@ -119,6 +119,8 @@ int  orc_me_buf_satd(orc_me* me, const pixel* ref, intptr_t stride);
 int  orc_motion_estimate(orc_me* me, const orc_refplanes* ref, orc_mv mvmin, orc_mv mvmax, orc_mv qmvp,
                          int numCandidates, const orc_mv* mvc, int merange, orc_mv* outQMv,
                          uint32_t maxSlices, int hmePlane);
+/* MotionEstimate::diamondSearch: full-pel vector out, returns its SAD + MV cost */
+int  orc_diamond_search(orc_me* me, const orc_refplanes* ref, orc_mv mvmin, orc_mv mvmax, orc_mv qmvp, orc_mv* outMV);
 const pixel* orc_lowres_mc(const orc_refplanes* ref, intptr_t blockOffset, orc_mv qmv, pixel* buf,
                            intptr_t* outstride, int hme);
 int  orc_lowres_qpel_cost(orc_me* me, const orc_refplanes* ref, intptr_t blockOffset, orc_mv qmv,

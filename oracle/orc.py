@@ -111,6 +111,8 @@ def lib(depth=8):
     L.orc_me_set_source.argtypes = [vp, vp, ip, ip, i, i, i, i, i, i]
     L.orc_motion_estimate.argtypes = [vp, C.POINTER(RefPlanes), MV, MV, MV, i, vp, i, C.POINTER(MV), C.c_uint32, i]
     L.orc_motion_estimate.restype = i
+    L.orc_diamond_search.argtypes = [vp, C.POINTER(RefPlanes), MV, MV, MV, C.POINTER(MV)]
+    L.orc_diamond_search.restype = i
     L.libc_free = C.CDLL(None).free
     L.libc_free.argtypes = [vp]
     _libs[depth] = L
@@ -316,6 +318,18 @@ class FullResME:
         cost = L.orc_motion_estimate(self.me, C.byref(self.rp), MV(*mvmin), MV(*mvmax), MV(*mvp), len(mvc), arr,
                                      merange, C.byref(out), 1, 0)
         return (out.x, out.y), cost
+
+
+def _frme_diamond(self, x, y, w, h, mvp, mvmin, mvmax):
+    """MotionEstimate::diamondSearch -> ((full-pel mvx, mvy), cost)"""
+    L = self.L
+    L.orc_me_set_source(self.me, C.c_void_p(self.fenc_org), self.stride, y * self.stride + x, w, h, 3, 3, 3, 3)
+    out = MV()
+    cost = L.orc_diamond_search(self.me, C.byref(self.rp), MV(*mvmin), MV(*mvmax), MV(*mvp), C.byref(out))
+    return (out.x, out.y), cost
+
+
+FullResME.diamond_search = _frme_diamond
 
 
 def calc_adaptive_quant_frame(depth, y, u, v, aq_mode, strength, weightp=False, hdr10=False, skip_offsets=False,

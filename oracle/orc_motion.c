@@ -5,6 +5,8 @@
  * source/common/lowres.h:72-117.  The visiting order of candidates and every
  * strict '<' tie-break follow the reference; its quirks are kept and marked. */
 #include "orc.h"
+
+#include <limits.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -676,6 +678,130 @@ static int subpel_compare(srch* s, orc_mv qmv, int useSatd)
     else
         orc_luma_hvpp(me->bw, me->bh, fref, rs, buf, me->bw, xf, yf);
     return useSatd ? cmp_satd(me, buf, me->bw) : cmp_sad(me, buf, me->bw);
+}
+
+/* MotionEstimate::diamondSearch, source/encoder/motion.cpp:631-788: the coarse
+ * search Search::puMotionEstimation runs for an area's starting vector
+ * (isMVP, source/encoder/search.cpp:360-364).  Full-pel in, full-pel out.
+ *
+ * COST_MV_X4 in this fork adds its offsets to omv (motion.cpp:302-323), while
+ * diamondSearch hands it absolute coordinates: inside the range the measured
+ * position is therefore omv + (the coordinate written at the call site), and
+ * that sum is also what bmv receives.  try_x4() has the macro's semantics, so
+ * the call sites below pass the same arguments as the reference's. */
+int orc_diamond_search(orc_me* me, const orc_refplanes* ref, orc_mv mvmin, orc_mv mvmax, orc_mv qmvp, orc_mv* outMV)
+{
+    srch S;
+    srch* s = &S;
+    s->me = me;
+    s->ref = ref;
+    s->hme = 0;
+    s->stride = ref->stride;
+    s->fref = ref->plane[0] + me->blockOffset;
+    s->mvmin = mvmin;
+    s->mvmax = mvmax;
+    me->mvp = qmvp;
+    s->cx = me->cost - qmvp.x;
+    s->cy = me->cost - qmvp.y;
+    s->bcost = INT_MAX;
+    s->bmv.x = s->bmv.y = 0;
+    orc_mv omv = s->bmv;
+
+    for (int dist = 1; dist <= 4; dist <<= 1)
+    {
+        const orc_mv bmv0 = s->bmv;
+        const int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        const int top2 = omv.y - (dist >> 1), bottom2 = omv.y + (dist >> 1);
+        const int left2 = omv.x - (dist >> 1), right2 = omv.x + (dist >> 1);
+        if (top >= mvmin.y && left >= mvmin.x && right <= mvmax.x && bottom <= mvmax.y)
+        {
+            const int a[8] = { omv.x, top, omv.x, bottom, left, omv.y, right, omv.y };
+            const int b[8] = { left2, top2, right2, top2, left2, bottom2, right2, bottom2 };
+            try_x4(s, omv, a);
+            try_x4(s, omv, b);
+        }
+        else
+        {
+            if (top >= mvmin.y)
+                try_mv(s, omv.x, top);
+            if (top2 >= mvmin.y)
+            {
+                if (left2 >= mvmin.x)
+                    try_mv(s, left2, top2);
+                if (right2 <= mvmax.x)
+                    try_mv(s, right2, top2);
+            }
+            if (left >= mvmin.x)
+                try_mv(s, left, omv.y);
+            if (right <= mvmax.x)
+                try_mv(s, right, omv.y);
+            if (bottom2 <= mvmax.y)
+            {
+                if (left2 >= mvmin.x)
+                    try_mv(s, left2, bottom2);
+                if (right2 <= mvmax.x)
+                    try_mv(s, right2, bottom2);
+            }
+            if (bottom <= mvmax.y)
+                try_mv(s, omv.x, bottom);
+        }
+        if (s->bmv.x == bmv0.x && s->bmv.y == bmv0.y)
+            break;
+    }
+
+    omv = s->bmv;
+    for (int dist = 8; dist <= 64; dist += 8)
+    {
+        const orc_mv bmv0 = s->bmv;
+        const int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        const int inside = top >= mvmin.y && left >= mvmin.x && right <= mvmax.x && bottom <= mvmax.y;
+        if (inside)
+        {
+            const int a[8] = { omv.x, top, left, omv.y, right, omv.y, omv.x, bottom };
+            try_x4(s, omv, a);
+        }
+        else
+        {
+            if (top >= mvmin.y)
+                try_mv(s, omv.x, top);
+            if (left >= mvmin.x)
+                try_mv(s, left, omv.y);
+            if (right <= mvmax.x)
+                try_mv(s, right, omv.y);
+            if (bottom <= mvmax.y)
+                try_mv(s, omv.x, bottom);
+        }
+        for (int index = 1; index < 4; index++)
+        {
+            const int posYT = top + (dist >> 2) * index, posYB = bottom - (dist >> 2) * index;
+            const int posXL = omv.x - (dist >> 2) * index, posXR = omv.x + (dist >> 2) * index;
+            if (inside)
+            {
+                const int a[8] = { posXL, posYT, posXR, posYT, posXL, posYB, posXR, posYB };
+                try_x4(s, omv, a);
+                continue;
+            }
+            if (posYT >= mvmin.y)
+            {
+                if (posXL >= mvmin.x)
+                    try_mv(s, posXL, posYT);
+                if (posXR <= mvmax.x)
+                    try_mv(s, posXR, posYT);
+            }
+            if (posYB <= mvmax.y)
+            {
+                if (posXL >= mvmin.x)
+                    try_mv(s, posXL, posYB);
+                if (posXR <= mvmax.x)
+                    try_mv(s, posXR, posYB);
+            }
+        }
+        if (s->bmv.x == bmv0.x && s->bmv.y == bmv0.y)
+            break;
+        omv = s->bmv;
+    }
+    *outMV = s->bmv;
+    return s->bcost;
 }
 
 int orc_motion_estimate(orc_me* me, const orc_refplanes* ref, orc_mv mvmin, orc_mv mvmax, orc_mv qmvp,

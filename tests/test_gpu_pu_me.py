@@ -97,3 +97,37 @@ def test_pu_rejects_bad_jobs():
             ctx.pu_motion_estimate(0, 1, api.UMH_SEARCH, 16, 2, [(0, 0, 8, 8, (0, 0), (-4, -4), (4, 4), [])])
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_area_diamond_search(depth):
+    """MotionEstimate::diamondSearch (the isMVP search of puMotionEstimation): zero predictor, range 32,
+    full-pel result.  The reference's relative COST_MV_X4 doubles the origin inside the range; the
+    vectors below move, so that branch is exercised with a non-zero origin."""
+    W, H, ctu = 416, 240, 64
+    clip, pads, mx, my, fw, fh = _pictures(W, H, depth, ctu, seed=9)
+    table, centre = orc.bitcost_table(depth)
+    ref = orc.FullResME(depth, table, centre, pads[1], pads[0], mx, my)
+    with api.Context(W, H, depth=depth, num_slots=2, ctu=ctu, keep_full_res=True) as ctx:
+        ctx.lowres_init(0, clip[0])
+        ctx.lowres_init(1, clip[1])
+        ctx.me_set_mvcost(table, centre)
+        rng = np.random.default_rng(31)
+        jobs = []
+        for _ in range(128):
+            w, h = PU_SHAPES[rng.integers(len(PU_SHAPES))]
+            x = int(rng.integers(0, (fw - w) // 4 + 1)) * 4
+            y = int(rng.integers(0, (fh - h) // 4 + 1)) * 4
+            mvp = (0, 0) if rng.integers(3) else (int(rng.integers(-12, 13)), int(rng.integers(-12, 13)))
+            r = 32
+            lo = (max(-r, -x - 8), max(-r, -y - 8))                     # setSearchRange also clips near the picture edge
+            hi = (min(r, fw - x - w + 8), min(r, fh - y - h + 8))
+            jobs.append((x, y, w, h, mvp, lo, hi, []))
+        got = ctx.pu_motion_estimate(1, 0, api.AREA_DIAMOND_SEARCH, 32, 0, jobs)
+        moved = 0
+        for j, g in zip(jobs, got):
+            want = ref.diamond_search(j[0], j[1], j[2], j[3], j[4], j[5], j[6])
+            assert g == want, (j, g, want)
+            moved += int(max(abs(g[0][0]), abs(g[0][1])) >= 8)
+        assert moved > 0
+    ref.close()

@@ -27,6 +27,7 @@
 namespace xg {
 
 constexpr int PU_DIA = 0, PU_HEX = 1, PU_STAR = 3;   // x265gpu search method values (anything else: exhaustive)
+constexpr int PU_AREA_DIAMOND = 16;                  // MotionEstimate::diamondSearch instead of motionEstimate
 
 // luma interpolation taps, source/common/constants.cpp:250-256
 __constant__ short k_lumaTaps[4][8] = {
@@ -515,6 +516,135 @@ template <typename P> __device__ __forceinline__ void full_search(PuCtx<P>& c)
             try_mv<P>(c, tx, ty);
 }
 
+// COST_MV_X4 as this fork defines it (motion.cpp:302-323): the offset is added to `o`, the
+// candidate is measured whatever its row, and accepted only when the row is in range.
+template <typename P> __device__ __forceinline__ void try_rel(PuCtx<P>& c, int ox, int oy, int dx, int dy)
+{
+    const int x = ox + dx, y = oy + dy;
+    const int cost = fpel_cost<P>(c, x, y);
+    if (y_ok<P>(c, y) && cost < c.bcost)
+    {
+        c.bcost = cost;
+        c.bmx = x;
+        c.bmy = y;
+    }
+}
+
+// MotionEstimate::diamondSearch (motion.cpp:631-788), the coarse search behind an area's
+// starting vector.  Inside the range the reference hands absolute coordinates to the relative
+// COST_MV_X4, so the position measured (and stored) is o + coordinate; try_rel keeps that.
+template <typename P> __device__ __forceinline__ void area_diamond_search(PuCtx<P>& c)
+{
+    c.bcost = 0x7fffffff;
+    c.bmx = c.bmy = 0;
+    int ox = 0, oy = 0;
+#pragma unroll 1
+    for (int dist = 1; dist <= 4; dist <<= 1)
+    {
+        const int sx = c.bmx, sy = c.bmy;
+        const int h = dist >> 1;
+        const int top = oy - dist, bottom = oy + dist, left = ox - dist, right = ox + dist;
+        const int top2 = oy - h, bottom2 = oy + h, left2 = ox - h, right2 = ox + h;
+        if (top >= c.miny && left >= c.minx && right <= c.maxx && bottom <= c.maxy)
+        {
+            try_rel<P>(c, ox, oy, ox, top);
+            try_rel<P>(c, ox, oy, ox, bottom);
+            try_rel<P>(c, ox, oy, left, oy);
+            try_rel<P>(c, ox, oy, right, oy);
+            try_rel<P>(c, ox, oy, left2, top2);
+            try_rel<P>(c, ox, oy, right2, top2);
+            try_rel<P>(c, ox, oy, left2, bottom2);
+            try_rel<P>(c, ox, oy, right2, bottom2);
+        }
+        else
+        {
+            if (top >= c.miny)
+                try_mv<P>(c, ox, top);
+            if (top2 >= c.miny)
+            {
+                if (left2 >= c.minx)
+                    try_mv<P>(c, left2, top2);
+                if (right2 <= c.maxx)
+                    try_mv<P>(c, right2, top2);
+            }
+            if (left >= c.minx)
+                try_mv<P>(c, left, oy);
+            if (right <= c.maxx)
+                try_mv<P>(c, right, oy);
+            if (bottom2 <= c.maxy)
+            {
+                if (left2 >= c.minx)
+                    try_mv<P>(c, left2, bottom2);
+                if (right2 <= c.maxx)
+                    try_mv<P>(c, right2, bottom2);
+            }
+            if (bottom <= c.maxy)
+                try_mv<P>(c, ox, bottom);
+        }
+        if (c.bmx == sx && c.bmy == sy)
+            break;
+    }
+    ox = c.bmx;
+    oy = c.bmy;
+#pragma unroll 1
+    for (int dist = 8; dist <= 64; dist += 8)
+    {
+        const int sx = c.bmx, sy = c.bmy;
+        const int top = oy - dist, bottom = oy + dist, left = ox - dist, right = ox + dist;
+        const bool inside = top >= c.miny && left >= c.minx && right <= c.maxx && bottom <= c.maxy;
+        if (inside)
+        {
+            try_rel<P>(c, ox, oy, ox, top);
+            try_rel<P>(c, ox, oy, left, oy);
+            try_rel<P>(c, ox, oy, right, oy);
+            try_rel<P>(c, ox, oy, ox, bottom);
+        }
+        else
+        {
+            if (top >= c.miny)
+                try_mv<P>(c, ox, top);
+            if (left >= c.minx)
+                try_mv<P>(c, left, oy);
+            if (right <= c.maxx)
+                try_mv<P>(c, right, oy);
+            if (bottom <= c.maxy)
+                try_mv<P>(c, ox, bottom);
+        }
+#pragma unroll 1
+        for (int index = 1; index < 4; index++)
+        {
+            const int q = (dist >> 2) * index;
+            const int yt = top + q, yb = bottom - q, xl = ox - q, xr = ox + q;
+            if (inside)
+            {
+                try_rel<P>(c, ox, oy, xl, yt);
+                try_rel<P>(c, ox, oy, xr, yt);
+                try_rel<P>(c, ox, oy, xl, yb);
+                try_rel<P>(c, ox, oy, xr, yb);
+                continue;
+            }
+            if (yt >= c.miny)
+            {
+                if (xl >= c.minx)
+                    try_mv<P>(c, xl, yt);
+                if (xr <= c.maxx)
+                    try_mv<P>(c, xr, yt);
+            }
+            if (yb <= c.maxy)
+            {
+                if (xl >= c.minx)
+                    try_mv<P>(c, xl, yb);
+                if (xr <= c.maxx)
+                    try_mv<P>(c, xr, yb);
+            }
+        }
+        if (c.bmx == sx && c.bmy == sy)
+            break;
+        ox = c.bmx;
+        oy = c.bmy;
+    }
+}
+
 // The encode block into LDS (MotionEstimate::setSourcePU, motion.cpp:167-191): per pass and lane the
 // row's column pairs (masked), the row's pixel offset inside the block, and the mask.
 template <typename P>
@@ -582,6 +712,21 @@ __global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, int n
     c.depth = f.depth;
 
     stage_encode_block<P>(c, as_global<P>(f.fenc), f.stride, rec);
+
+    if (f.method == PU_AREA_DIAMOND)
+    {
+        area_diamond_search<P>(c);
+        if (lane == 0)
+        {
+            PuResult r;
+            r.mvx = c.bmx;                 // full-pel, as diamondSearch returns it
+            r.mvy = c.bmy;
+            r.cost = c.bcost;
+            r.reserved = 0;
+            out[pu] = r;
+        }
+        return;
+    }
 
     // ---- MotionEstimate::motionEstimate, full-resolution reference ----
     const int qminx = job.minx * 4, qminy = job.miny * 4, qmaxx = job.maxx * 4, qmaxy = job.maxy * 4;

@@ -302,6 +302,26 @@ int x265gpu_cutree_get_propagate_cost(x265gpu_ctx* ctx, int32_t slot, uint16_t* 
 int x265gpu_cutree_finish(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, double weightDelta, double cuTreeStrength,
                           const double* qpAqOffset, double* qpCuTreeOffset);
 
+/* ---- picture statistics for histogram-based scene-cut detection (--hist-scenecut) ----
+ *
+ * LookaheadTLD::collectPictureStatistics (source/encoder/slicetype.cpp:1809-1834) for a 4:2:0 picture: the
+ * luma histogram and means of the 4x4 segments of the quarter-sample picture that Lowres::init derives from
+ * lowresPlane[0] (source/common/lowres.cpp:404-414; the slot must have been through x265gpu_lowres_init with
+ * this picture's luma), the subsampled chroma histograms and means (:1688-1759), the frame means (:1827-1829)
+ * and the three picture variances (:1567-1650).  Fields and index order are Lowres's own
+ * (source/common/lowres.h:245-253).  The scene-cut decision that compares these between frames
+ * (:3323-3482) stays in the caller. */
+typedef struct x265gpu_hist_stats_t
+{
+    uint32_t picHistogram[4][4][3][256];              /* [segment in width][segment in height][plane][bin] */
+    uint64_t averageIntensityPerSegment[4][4][3];
+    uint8_t  averageIntensity[3];
+    uint8_t  pad[5];
+    uint16_t picAvgVariance, picAvgVarianceCb, picAvgVarianceCr, pad2;
+} x265gpu_hist_stats_t;
+int x265gpu_hist_stats(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t strideY, const void* u, const void* v,
+                       intptr_t strideC, int32_t memKind, x265gpu_hist_stats_t* out);
+
 /* ---- the pixel primitives, one call per batch of blocks ----
  *
  * The EncoderPrimitives slots this library's kernels are built from, exposed on the slots'

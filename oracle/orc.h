@@ -218,6 +218,17 @@ void orc_cutree_finish(const orc_cutree_param* cp, orc_lowres* frame, double ave
 void orc_cutree(orc_tld* t, const orc_param* p, const orc_cutree_param* cp, orc_lowres** frames, int numframes, int bIntra);
 void orc_lowres_set_slice_type(orc_lowres* lr, int sliceType);
 
+/* ---- histogram scene-cut statistics (orc_scenecut.c) ---- */
+typedef struct orc_hist_stats {
+    uint32_t picHistogram[4][4][3][256];              /* [segment x][segment y][plane][bin] */
+    uint64_t averageIntensityPerSegment[4][4][3];
+    uint8_t  averageIntensity[3];
+    uint8_t  pad[5];
+    uint16_t picAvgVariance, picAvgVarianceCb, picAvgVarianceCr, pad2;
+} orc_hist_stats;
+void orc_collect_picture_statistics(const pixel* lowresPlane0, intptr_t lowresStride, const pixel* y, intptr_t sy,
+                                    const pixel* u, const pixel* v, intptr_t sc, int w, int h, orc_hist_stats* out);
+
 /* field accessors for ctypes */
 void* orc_lowres_ptr(orc_lowres* lr, const char* field, int i, int j);
 int64_t orc_lowres_i64(orc_lowres* lr, const char* field, int i, int j);

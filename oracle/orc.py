@@ -36,6 +36,12 @@ class CuTreeParam(C.Structure):
                 ("lookaheadDepth", C.c_int), ("vbvBufferSize", C.c_int), ("qCompress", C.c_double)]
 
 
+class HistStats(C.Structure):
+    _fields_ = [("picHistogram", C.c_uint32 * 256 * 3 * 4 * 4), ("averageIntensityPerSegment", C.c_uint64 * 3 * 4 * 4),
+                ("averageIntensity", C.c_uint8 * 3), ("pad", C.c_uint8 * 5), ("picAvgVariance", C.c_uint16),
+                ("picAvgVarianceCb", C.c_uint16), ("picAvgVarianceCr", C.c_uint16), ("pad2", C.c_uint16)]
+
+
 class RefPlanes(C.Structure):
     _fields_ = [("plane", C.c_void_p * 4), ("lowerPlane", C.c_void_p * 4), ("stride", C.c_ssize_t),
                 ("isLowres", C.c_int), ("isHMELowres", C.c_int)]
@@ -104,6 +110,7 @@ def lib(depth=8):
     L.orc_cutree.argtypes = [vp, C.POINTER(Param), C.POINTER(CuTreeParam), C.POINTER(vp), i, i]
     L.orc_lowres_set_slice_type.argtypes = [vp, i]
     L.orc_propagate_cost.argtypes = [vp, vp, vp, vp, vp, vp, i]
+    L.orc_collect_picture_statistics.argtypes = [vp, ip, vp, ip, vp, vp, ip, i, i, C.POINTER(HistStats)]
     L.orc_me_init.argtypes = [vp, vp]
     L.orc_me_create.argtypes = [vp]
     L.orc_me_create.restype = vp
@@ -347,3 +354,15 @@ def calc_adaptive_quant_frame(depth, y, u, v, aq_mode, strength, weightp=False, 
                                     w, h, aq_mode, float(strength), int(weightp), int(hdr10), int(skip_offsets),
                                     None if qo is None else ptr(qo), ptr(qa), ptr(qc), ptr(inv), ptr(wp))
     return qa, qc, inv, wp[:3].copy(), wp[3:].copy()
+
+
+def collect_picture_statistics(lowres, y, u, v):
+    """collectPictureStatistics for the frame behind `lowres` (an initialised Lowres) -> HistStats."""
+    L = lowres.L
+    h, w = y.shape
+    item = y.itemsize
+    plane0 = lowres.L.orc_lowres_ptr(lowres.h, b"buffer", 0, 0) + lowres.i64("padoffset") * item
+    st = HistStats()
+    L.orc_collect_picture_statistics(C.c_void_p(plane0), lowres.i64("stride"), ptr(y), y.strides[0] // item, ptr(u), ptr(v),
+                                     u.strides[0] // item, w, h, C.byref(st))
+    return st

@@ -286,3 +286,37 @@ def test_propagate_cost_oracle_pin(oracle_built):
     amount = prop.astype(np.float64) + (intra * invq).astype(np.float64) * (fps[0] / 256)
     num = (intra - np.minimum(intra, inter & 0x3FFF)).astype(np.float64)
     np.testing.assert_array_equal(dst, (amount * num / ic + 0.5).astype(np.int32))
+
+
+def test_picture_statistics_oracle_pin(oracle_built):
+    """collectPictureStatistics against numpy: quarter-sample luma histogram, subsampled chroma histogram, variances."""
+    depth, W, H = 8, 200, 136
+    rng = np.random.default_rng(12)
+    y = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    u = rng.integers(0, 256, (H // 2, W // 2)).astype(np.uint8)
+    v = rng.integers(0, 256, (H // 2, W // 2)).astype(np.uint8)
+    param = orc.make_param(W, H)
+    lr = orc.Lowres(orc.lib(depth), depth, param)
+    lr.init(y, 0)
+    st = orc.collect_picture_statistics(lr, y, u, v)
+    hist = np.ctypeslib.as_array(st.picHistogram)
+    g = lr.geometry
+    plane0 = lr.buffer(0).reshape(-1, g["stride"])[g["marginY"]:, g["marginX"]:].astype(np.int64)
+    lr_pic = plane0[:2 * (H // 4), :2 * (W // 4)]
+    a, b = (lr_pic[0::2, 0::2] + lr_pic[1::2, 0::2] + 1) >> 1, (lr_pic[0::2, 1::2] + lr_pic[1::2, 1::2] + 1) >> 1
+    quarter = (a + b + 1) >> 1
+    qw, qh = W // 4, H // 4
+    sw, sh = qw // 4, qh // 4
+    for sx, sy in ((0, 0), (3, 3), (1, 3)):
+        x1 = qw if sx == 3 else (sx + 1) * sw
+        y1 = qh if sy == 3 else (sy + 1) * sh
+        seg = quarter[sy * sh:y1, sx * sw:x1]
+        np.testing.assert_array_equal(hist[sx, sy, 0], (np.bincount(seg.ravel(), minlength=256) + 1) << 4)
+    cw, chh = W // 4, H // 4
+    segu = u[: chh >> 1, : cw >> 1][0::4, 0::4]
+    np.testing.assert_array_equal(hist[0, 0, 1], (np.bincount(segu.ravel(), minlength=256) + 1) << 4)
+    blocks = y.astype(np.int64).reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(H // 8, W // 8, 64)
+    var = (blocks ** 2).sum(-1) - ((blocks.sum(-1) ** 2) >> 6)
+    rows = (var.sum(1) // W) & 0xFFFF
+    assert st.picAvgVariance == (int(rows.sum()) // H) & 0xFFFF
+    lr.close()

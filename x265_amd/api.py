@@ -24,9 +24,19 @@ EXPORTS = (
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_weight_cost", "x265gpu_weight_planes",
     "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_interp_luma",
     "x265gpu_cutree_clear", "x265gpu_cutree_swap", "x265gpu_cutree_propagate", "x265gpu_cutree_get_propagate_cost",
-    "x265gpu_cutree_finish",
+    "x265gpu_cutree_finish", "x265gpu_hist_stats",
     "x265gpu_profile_enable", "x265gpu_profile_read",
 )
+
+
+def hist_stats_dict(st):
+    """Any ctypes struct with x265gpu_hist_stats_t's layout -> plain numpy / int values."""
+    return {
+        "picHistogram": np.ctypeslib.as_array(st.picHistogram).copy(),
+        "averageIntensityPerSegment": np.ctypeslib.as_array(st.averageIntensityPerSegment).copy(),
+        "averageIntensity": np.ctypeslib.as_array(st.averageIntensity).copy(),
+        "picAvgVariance": (st.picAvgVariance, st.picAvgVarianceCb, st.picAvgVarianceCr),
+    }
 
 
 class X265GpuError(RuntimeError):
@@ -74,6 +84,12 @@ class PuResult(C.Structure):
 class AqParams(C.Structure):
     _fields_ = [("aqMode", C.c_int32), ("bWeightedPred", C.c_int32), ("bHDR10Opt", C.c_int32),
                 ("bSkipOffsets", C.c_int32), ("aqStrength", C.c_double)]
+
+
+class HistStats(C.Structure):
+    _fields_ = [("picHistogram", C.c_uint32 * 256 * 3 * 4 * 4), ("averageIntensityPerSegment", C.c_uint64 * 3 * 4 * 4),
+                ("averageIntensity", C.c_uint8 * 3), ("pad", C.c_uint8 * 5), ("picAvgVariance", C.c_uint16),
+                ("picAvgVarianceCb", C.c_uint16), ("picAvgVarianceCr", C.c_uint16), ("pad2", C.c_uint16)]
 
 
 class BlockJob(C.Structure):
@@ -130,6 +146,7 @@ def load_library(path=None):
     L.x265gpu_cutree_propagate.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.c_double, i32]
     L.x265gpu_cutree_get_propagate_cost.argtypes = [vp, i32, vp]
     L.x265gpu_cutree_finish.argtypes = [vp, i32, i32, C.c_double, C.c_double, vp, vp]
+    L.x265gpu_hist_stats.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp]
     L.x265gpu_aq_frame.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp, vp, vp, vp, vp, vp, vp]
     L.x265gpu_interp_luma.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.x265gpu_profile_enable.argtypes = [vp, i32]
@@ -368,6 +385,15 @@ class Context:
                                           C.byref(prm), None if qo is None else _ptr(qo), _ptr(qa), _ptr(qc), _ptr(inv),
                                           _ptr(wsum), _ptr(wssd)))
         return qa, qc, inv, wsum, wssd
+
+    def hist_stats(self, slot, y, u, v):
+        """collectPictureStatistics of a 4:2:0 picture whose luma was given to lowres_init(slot, ...) ->
+        dict of numpy arrays / ints named after Lowres's fields."""
+        y, u, v = (np.ascontiguousarray(p, self.pix) for p in (y, u, v))
+        st = HistStats()
+        self._chk(self.L.x265gpu_hist_stats(self.h, slot, _ptr(y), y.shape[1], _ptr(u), _ptr(v), u.shape[1], MEM_HOST,
+                                            C.byref(st)))
+        return hist_stats_dict(st)
 
     # ---- cuTree ----
     def cutree_clear(self, slot):

@@ -8,8 +8,10 @@
 // The pixel work (block energies, luma sums, frame sums) is done on the device
 // before this runs.
 #include "kernels.h"
+#include "../../include/x265gpu.h"
 
 #include <math.h>
+#include <string.h>
 
 // every product and sum below rounds on its own, as the reference's scalar build does
 #pragma STDC FP_CONTRACT OFF
@@ -137,6 +139,62 @@ void cutree_finish_offsets(int blocks, const int32_t* intraCost, const int32_t* 
         const int propagated = (inherited * fpsFactor + 128) >> 8;
         const double ratio = log2((double)(intra + propagated)) - log2((double)intra) + weightDelta;
         qpCuTreeOffset[i] = qpAqOffset[i] - strength * ratio;
+    }
+}
+
+// The arithmetic collectPictureStatistics applies to the raw counts
+// (source/encoder/slicetype.cpp:1688-1831): every bin starts at 1 and is scaled by 16 afterwards, chroma
+// sums are scaled by 16 for the 4x4 subsampling, and the per-segment means are rounded divisions whose
+// operands are taken exactly as the reference writes them - including the terms where it puts a segment's
+// height remainder next to its width.
+void hist_finish(int width, int height, const uint32_t* hist, const unsigned long long* sums,
+                 const unsigned long long* rowVar, int maxRows, x265gpu_hist_stats_t* out)
+{
+    memset(out, 0, sizeof(*out));
+    unsigned long long frameSum[3] = { 0, 0, 0 };
+    const uint32_t qw = (uint32_t)width / 4, qh = (uint32_t)height / 4;
+    for (uint32_t sx = 0; sx < 4; sx++)
+        for (uint32_t sy = 0; sy < 4; sy++)
+            for (int plane = 0; plane < 3; plane++)
+            {
+                const int cell = (int)(sx * 4 + sy) * 3 + plane;
+                for (int b = 0; b < 256; b++)
+                    out->picHistogram[sx][sy][plane][b] = (hist[cell * 256 + b] + 1) << 4;
+                // luma segments tile the quarter-sample picture, chroma segments the full-size one
+                const uint32_t pw = plane ? (uint32_t)width : qw, ph = plane ? (uint32_t)height : qh;
+                const uint32_t segW = pw / 4, segH = ph / 4;
+                const uint32_t wo = sx == 3 ? pw - 4 * segW : 0, ho = sy == 3 ? ph - 4 * segH : 0;
+                unsigned long long sum = sums[cell];
+                uint8_t mean;
+                if (plane == 0)
+                {
+                    mean = (uint8_t)((sum + (((segW + wo) * (segW + ho)) >> 1)) / ((segW + wo) * (segH + ho)));
+                    frameSum[0] += sum << 4;
+                }
+                else
+                {
+                    sum <<= 4;
+                    frameSum[plane] += sum;
+                    const uint32_t area = (segW + wo) * (segH + ho);
+                    const uint32_t div = plane == 1 ? area >> 2 : ((segW + ho) * (segH + ho)) >> 2;
+                    mean = (uint8_t)((sum + (area >> 3)) / div);
+                }
+                out->averageIntensityPerSegment[sx][sy][plane] = mean;
+            }
+    const uint32_t area = (uint32_t)width * (uint32_t)height;
+    out->averageIntensity[0] = (uint8_t)((frameSum[0] + (area >> 1)) / area);
+    out->averageIntensity[1] = (uint8_t)((frameSum[1] + (area >> 3)) / (area >> 2));
+    out->averageIntensity[2] = (uint8_t)((frameSum[2] + (area >> 3)) / (area >> 2));
+
+    // computePictureStatistics (:1567-1650): row means truncated to 16 bits, then the mean of those
+    uint16_t* dst[3] = { &out->picAvgVariance, &out->picAvgVarianceCb, &out->picAvgVarianceCr };
+    for (int plane = 0; plane < 3; plane++)
+    {
+        const int w = plane ? width >> 1 : width, h = plane ? height >> 1 : height, size = plane ? 4 : 8;
+        unsigned long long tot = 0;
+        for (int by = 0; by * size < h; by++)
+            tot += (uint16_t)(rowVar[(size_t)plane * maxRows + by] / (unsigned long long)w);
+        *dst[plane] = (uint16_t)(tot / (unsigned long long)h);
     }
 }
 

@@ -179,6 +179,27 @@ struct PropagateJob
     double fps;                              // fpsFactor / 256
 };
 hipError_t launch_cutree_propagate(hipStream_t s, const PropagateJob& job);
+
+// Histogram scene-cut statistics of one 4:2:0 picture.
+struct HistJob
+{
+    const void* lowres0;      // origin of the slot's half-res plane 0
+    int lowresStride;
+    const void* y; const void* u; const void* v;
+    long long strideY, strideC;              // pixels
+    int width, height, depth;
+    uint32_t* hist;                          // [16 segments][3 planes][256] raw sample counts (zeroed)
+    unsigned long long* sums;                // [16][3] raw sample sums (zeroed)
+    unsigned long long* rowVar;              // [3][maxRows] block-variance sums per block row (zeroed)
+    int maxRows;
+};
+hipError_t launch_hist_stats(hipStream_t s, int bpp, const HistJob& job);
+} // namespace xg
+struct x265gpu_hist_stats_t;
+namespace xg {
+// raw counts -> Lowres::picHistogram / averageIntensity* / picAvgVariance* (aq_host.cpp)
+void hist_finish(int width, int height, const uint32_t* hist, const unsigned long long* sums,
+                 const unsigned long long* rowVar, int maxRows, x265gpu_hist_stats_t* out);
 hipError_t launch_cost(hipStream_t s, const Geometry& g, int bpp, const CostJob* dJobs, int n);
 hipError_t launch_weight_cost(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJob);
 hipError_t launch_weight_planes(hipStream_t s, const Geometry& g, int bpp, int depth, int nPlanes, const void* src,

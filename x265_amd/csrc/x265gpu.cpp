@@ -1246,6 +1246,40 @@ int x265gpu_cutree_finish(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, dou
 
 namespace {
 
+// A caller's 4:2:0 source picture as the kernels read it: device planes are used in place,
+// host planes are copied tight into the context's staging buffer first.
+struct YuvOnDevice
+{
+    const void* y; const void* u; const void* v;
+    long long strideY, strideC;
+};
+
+int stage_yuv(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const void* u, const void* v, intptr_t strideC,
+              int32_t memKind, YuvOnDevice& out)
+{
+    const int w = ctx->cfg.sourceWidth, h = ctx->cfg.sourceHeight, cw = w >> 1, ch = h >> 1;
+    if (memKind != X265GPU_MEM_HOST)
+    {
+        out = { y, u, v, (long long)strideY, (long long)strideC };
+        return X265GPU_OK;
+    }
+    const size_t lumaBytes = (size_t)w * h * ctx->bpp, chromaBytes = (size_t)cw * ch * ctx->bpp;
+    int rc = ensure_src_stage(ctx, align256(lumaBytes) + 2 * align256(chromaBytes));
+    if (rc)
+        return rc;
+    char* dy = ctx->srcStage;
+    char* du = dy + align256(lumaBytes);
+    char* dv = du + align256(chromaBytes);
+    HIPCHK(hipMemcpy2DAsync(dy, (size_t)w * ctx->bpp, y, (size_t)strideY * ctx->bpp, (size_t)w * ctx->bpp, h,
+                            hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpy2DAsync(du, (size_t)cw * ctx->bpp, u, (size_t)strideC * ctx->bpp, (size_t)cw * ctx->bpp, ch,
+                            hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpy2DAsync(dv, (size_t)cw * ctx->bpp, v, (size_t)strideC * ctx->bpp, (size_t)cw * ctx->bpp, ch,
+                            hipMemcpyHostToDevice, ctx->stream));
+    out = { dy, du, dv, (long long)w, (long long)cw };
+    return X265GPU_OK;
+}
+
 // One device pass over a 4:2:0 picture: block energies, optional block luma sums
 // and the six frame accumulators, copied to the host.
 int run_aq_energy(x265gpu_ctx* ctx, const char* who, const void* y, intptr_t strideY, const void* u, const void* v,
@@ -1255,7 +1289,6 @@ int run_aq_energy(x265gpu_ctx* ctx, const char* who, const void* y, intptr_t str
     if (strideY < w || strideC < cw || cw < 1 || ch < 1)
         return fail(ctx, X265GPU_ERR_ARG, (std::string(who) + ": bad stride or picture size").c_str());
     const int blocks = ((w + 15) >> 4) * ((h + 15) >> 4);
-    const size_t lumaBytes = (size_t)w * h * ctx->bpp, chromaBytes = (size_t)cw * ch * ctx->bpp;
     const size_t arrayBytes = align256(sizeof(uint32_t) * (size_t)blocks);
     AqJob job;
     memset(&job, 0, sizeof(job));
@@ -1264,34 +1297,15 @@ int run_aq_energy(x265gpu_ctx* ctx, const char* who, const void* y, intptr_t str
     int rc = ensure_pu_buf(ctx, 2 * arrayBytes + 256);
     if (rc)
         return rc;
-    if (memKind == X265GPU_MEM_HOST)
-    {
-        rc = ensure_src_stage(ctx, align256(lumaBytes) + 2 * align256(chromaBytes));
-        if (rc)
-            return rc;
-        char* dy = ctx->srcStage;
-        char* du = dy + align256(lumaBytes);
-        char* dv = du + align256(chromaBytes);
-        HIPCHK(hipMemcpy2DAsync(dy, (size_t)w * ctx->bpp, y, (size_t)strideY * ctx->bpp, (size_t)w * ctx->bpp, h,
-                                hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpy2DAsync(du, (size_t)cw * ctx->bpp, u, (size_t)strideC * ctx->bpp, (size_t)cw * ctx->bpp, ch,
-                                hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpy2DAsync(dv, (size_t)cw * ctx->bpp, v, (size_t)strideC * ctx->bpp, (size_t)cw * ctx->bpp, ch,
-                                hipMemcpyHostToDevice, ctx->stream));
-        job.luma = dy;
-        job.u = du;
-        job.v = dv;
-        job.lumaStride = w;
-        job.chromaStride = cw;
-    }
-    else
-    {
-        job.luma = y;
-        job.u = u;
-        job.v = v;
-        job.lumaStride = strideY;
-        job.chromaStride = strideC;
-    }
+    YuvOnDevice pic;
+    rc = stage_yuv(ctx, y, strideY, u, v, strideC, memKind, pic);
+    if (rc)
+        return rc;
+    job.luma = pic.y;
+    job.u = pic.u;
+    job.v = pic.v;
+    job.lumaStride = pic.strideY;
+    job.chromaStride = pic.strideC;
     job.energy = (uint32_t*)ctx->puBuf;
     job.lumaSum = lumaSum ? (uint32_t*)(ctx->puBuf + arrayBytes) : nullptr;
     job.wp = (unsigned long long*)(ctx->puBuf + 2 * arrayBytes);
@@ -1386,6 +1400,54 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
     }
     if (slot >= 0 && offsets)
         return x265gpu_lowres_set_aq(ctx, slot, invQscaleFactor);
+    return X265GPU_OK;
+}
+
+int x265gpu_hist_stats(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t strideY, const void* u, const void* v,
+                       intptr_t strideC, int32_t memKind, x265gpu_hist_stats_t* out)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || !slot_ok(ctx, slot) || !y || !u || !v || !out)
+        return X265GPU_ERR_ARG;
+    const int w = ctx->cfg.sourceWidth, h = ctx->cfg.sourceHeight;
+    if (w < 64 || h < 64 || strideY < w || strideC < (w >> 1))
+        return fail(ctx, X265GPU_ERR_ARG, "hist_stats: picture smaller than 64x64 or bad stride");
+    const int maxRows = (h + 7) / 8;
+    const size_t histBytes = sizeof(uint32_t) * 16 * 3 * 256, sumBytes = sizeof(unsigned long long) * 16 * 3;
+    const size_t rowBytes = sizeof(unsigned long long) * 3 * (size_t)maxRows;
+    const size_t total = align256(histBytes) + align256(sumBytes) + align256(rowBytes);
+    int rc = ensure_pu_buf(ctx, total);
+    if (rc)
+        return rc;
+    YuvOnDevice pic;
+    rc = stage_yuv(ctx, y, strideY, u, v, strideC, memKind, pic);
+    if (rc)
+        return rc;
+    HistJob job;
+    memset(&job, 0, sizeof(job));
+    job.lowres0 = ctx->slots[slot].planes + (size_t)ctx->g.padOffset * ctx->bpp;
+    job.lowresStride = ctx->g.stride;
+    job.y = pic.y;
+    job.u = pic.u;
+    job.v = pic.v;
+    job.strideY = pic.strideY;
+    job.strideC = pic.strideC;
+    job.width = w;
+    job.height = h;
+    job.depth = ctx->cfg.internalBitDepth;
+    job.hist = (uint32_t*)ctx->puBuf;
+    job.sums = (unsigned long long*)(ctx->puBuf + align256(histBytes));
+    job.rowVar = (unsigned long long*)(ctx->puBuf + align256(histBytes) + align256(sumBytes));
+    job.maxRows = maxRows;
+    HIPCHK(hipMemsetAsync(ctx->puBuf, 0, total, ctx->stream));
+    HIPCHK(launch_hist_stats(ctx->stream, ctx->bpp, job));
+    std::vector<uint32_t> hist(16 * 3 * 256);
+    std::vector<unsigned long long> sums(16 * 3), rowVar(3 * (size_t)maxRows);
+    HIPCHK(hipMemcpyAsync(hist.data(), job.hist, histBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(sums.data(), job.sums, sumBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(rowVar.data(), job.rowVar, rowBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hist_finish(w, h, hist.data(), sums.data(), rowVar.data(), maxRows, out);
     return X265GPU_OK;
 }
 

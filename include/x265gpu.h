@@ -70,13 +70,19 @@ typedef struct x265gpu_config
     int32_t hmeSearchMethod[3];
     int32_t hmeRange[3];
     int32_t bFrameBias;
-    int32_t maxSlices;
+    int32_t maxSlices;            /* param->maxSlices (encoder slices).  Accepted and without effect on the lowres path:
+                                     above 1 motionEstimate clamps a full-pel result whose row left mvmin.y..mvmax.y
+                                     (motion.cpp:1654-1659), and without extra candidates every search method already
+                                     tests each candidate's row against that range */
     int32_t lookaheadLambda;      /* (int)x265_lambda_tab[X265_LOOKAHEAD_QP]: 1, 16 or 256 */
     int32_t deviceId;
     void*   stream;               /* hipStream_t to run on, or NULL for the library's own */
     int32_t bKeepFullRes;         /* keep a padded full-resolution luma plane per slot (for x265gpu_pu_motion_estimate) */
     int32_t bMcstfFilter;         /* param->bEnableTemporalFilter: Lowres::init downscales with the (a+b+c+d+2)>>2 filter
                                      and also makes the quarter-res planes (source/common/lowres.cpp:377-378, :388-398) */
+    int32_t lookaheadSlices;      /* param->lookaheadSlices as Lookahead::Lookahead sees it (after the "no pool" and
+                                     "height < 720" resets, source/encoder/slicetype.cpp:1110-1120); 0 or 1: whole frames.
+                                     The slice layout follows :1122-1133 and is reported by x265gpu_get_geometry. */
 } x265gpu_config;
 
 /* Geometry derived exactly as Lowres::create does (source/common/lowres.cpp:84-103). */
@@ -89,6 +95,8 @@ typedef struct x265gpu_geometry
     int32_t widthInCU4, heightInCU4;   /* quarter-res (HME level 0) block grid, 0 if HME is off */
     int64_t planeSize;            /* pixels per padded plane */
     int64_t padOffset;            /* pixels from buffer start to pixel (0,0) */
+    int32_t numCoopSlices;        /* Lookahead::m_numCoopSlices (1: whole frames) */
+    int32_t numRowsPerSlice;      /* Lookahead::m_numRowsPerSlice; the last slice also takes the remainder rows */
 } x265gpu_geometry;
 
 /* One cost-estimation request = one CostEstimateGroup::estimateFrameCost body
@@ -100,6 +108,11 @@ typedef struct x265gpu_request
     int32_t p0, b, p1;                /* frame indices: distances are b-p0 and p1-b */
     int32_t doSearch[2];              /* run the L0 / L1 motion search for this request */
     int32_t weightedL0;               /* L0 search reads the weighted planes set with x265gpu_weight_planes */
+    int32_t bCoopSlices;              /* the request is a CostEstimateGroup::singleCost outside batch mode on a lookahead
+                                         with cooperative slices (slicetype.cpp:4312-4343): every slice's bottom block row
+                                         starts without the predictors of the row below it (:4248-4276).  Ignored when
+                                         the context has one slice.  Only the searches differ; sums and per-block costs
+                                         are the totals over all slices, as x265 adds them up (:4336-4342). */
 } x265gpu_request;
 
 /* per-request scalars, as stored by x265 in Lowres::costEst/costEstAq/intraMbs */

@@ -140,6 +140,7 @@ typedef struct orc_param {
     int maxSlices;
     int lookaheadSearchMethod;/* x265 hard-wires ORC_HEX (source/encoder/slicetype.cpp:4402-4404) */
     int bEnableTemporalFilter;/* --mcstf: mean downscale filter + quarter-res planes (source/common/lowres.cpp:377-400) */
+    int lookaheadSlices;      /* as Lookahead::Lookahead reads it (source/encoder/slicetype.cpp:1122); 0/1: whole frames */
 } orc_param;
 
 typedef struct orc_lowres {
@@ -196,6 +197,9 @@ void orc_tld_destroy(orc_tld* t);
 void orc_intra_estimate(orc_tld* t, orc_lowres* fenc, const orc_param* p);
 int64_t orc_estimate_frame_cost(orc_tld* t, const orc_param* p, orc_lowres** frames,
                                 int p0, int p1, int b, int bIntraPenalty);
+int64_t orc_estimate_frame_cost_single(orc_tld* t, const orc_param* p, orc_lowres** frames,
+                                       int p0, int p1, int b, int bIntraPenalty);
+int orc_coop_slices(const orc_param* p, int heightInCU, int* numRowsPerSlice);
 uint32_t orc_weight_cost_luma(orc_tld* t, orc_lowres* fenc, orc_lowres* ref,
                               int wtPresent, int scale, int denom, int offset);
 void orc_weights_analyse(orc_tld* t, orc_lowres* fenc, orc_lowres* ref);

@@ -28,6 +28,7 @@ class Param(C.Structure):
         ("bEnableHME", C.c_int), ("hmeSearchMethod", C.c_int * 3), ("hmeRange", C.c_int * 3),
         ("qgSize", C.c_int), ("bFrameBias", C.c_int), ("bEnableWeightedPred", C.c_int), ("maxSlices", C.c_int),
         ("lookaheadSearchMethod", C.c_int), ("bEnableTemporalFilter", C.c_int),
+        ("lookaheadSlices", C.c_int),
     ]
 
 
@@ -97,6 +98,9 @@ def lib(depth=8):
     L.orc_intra_estimate.argtypes = [vp, vp, C.POINTER(Param)]
     L.orc_estimate_frame_cost.argtypes = [vp, C.POINTER(Param), C.POINTER(vp), i, i, i, i]
     L.orc_estimate_frame_cost.restype = C.c_int64
+    L.orc_estimate_frame_cost_single.argtypes = [vp, C.POINTER(Param), C.POINTER(vp), i, i, i, i]
+    L.orc_estimate_frame_cost_single.restype = C.c_int64
+    L.orc_coop_slices.argtypes = [C.POINTER(Param), i, C.POINTER(i)]
     L.orc_weight_cost_luma.argtypes = [vp, vp, vp, i, i, i, i]
     L.orc_weight_cost_luma.restype = C.c_uint32
     L.orc_weights_analyse.argtypes = [vp, vp, vp]
@@ -135,7 +139,8 @@ def ptr(a):
 
 
 def make_param(width, height, bframes=4, hme=False, weightp=False, ctu=64, search=HEX,
-               hme_methods=(HEX, UMH, UMH), hme_range=(16, 32, 48), bframe_bias=0, mcstf=False):
+               hme_methods=(HEX, UMH, UMH), hme_range=(16, 32, 48), bframe_bias=0, mcstf=False,
+               lookahead_slices=0, max_slices=1):
     p = Param()
     p.sourceWidth, p.sourceHeight, p.maxCUSize, p.bframes = width, height, ctu, bframes
     p.bEnableHME = int(hme)
@@ -145,7 +150,8 @@ def make_param(width, height, bframes=4, hme=False, weightp=False, ctu=64, searc
     p.qgSize = 32
     p.bFrameBias = bframe_bias
     p.bEnableWeightedPred = int(weightp)
-    p.maxSlices = 1
+    p.maxSlices = max_slices
+    p.lookaheadSlices = lookahead_slices
     p.lookaheadSearchMethod = search
     p.bEnableTemporalFilter = int(mcstf)
     return p
@@ -270,9 +276,11 @@ class Lookahead:
         self.frames.append(lr)
         return lr
 
-    def frame_cost(self, p0, p1, b, intra_penalty=False):
+    def frame_cost(self, p0, p1, b, intra_penalty=False, single=False):
+        """estimateFrameCost; single: outside batch mode (cooperative slices apply)."""
         arr = (C.c_void_p * len(self.frames))(*[f.h for f in self.frames])
-        return self.L.orc_estimate_frame_cost(self.tld, C.byref(self.param), arr, p0, p1, b, int(intra_penalty))
+        fn = self.L.orc_estimate_frame_cost_single if single else self.L.orc_estimate_frame_cost
+        return fn(self.tld, C.byref(self.param), arr, p0, p1, b, int(intra_penalty))
 
     def cu_tree(self, cp, numframes, b_intra, first=0):
         """Lookahead::cuTree over frames[first .. first + numframes]."""

@@ -736,9 +736,27 @@ static void estimate_cu(orc_tld* t, const orc_param* p, orc_lowres** frames, int
         (uint16_t)(imin(bcost, ORC_LOWRES_COST_MASK) | (listused << ORC_LOWRES_COST_SHIFT));
 }
 
-/* source/encoder/slicetype.cpp:4284-4383, whole-frame branch */
-int64_t orc_estimate_frame_cost(orc_tld* t, const orc_param* p, orc_lowres** frames,
-                                int p0, int p1, int b, int bIntraPenalty)
+/* Lookahead::Lookahead, source/encoder/slicetype.cpp:1122-1133 */
+int orc_coop_slices(const orc_param* p, int heightInCU, int* numRowsPerSlice)
+{
+    int rows = heightInCU, slices = 1;
+    if (p->lookaheadSlices > 1)
+    {
+        rows = heightInCU / p->lookaheadSlices;
+        rows = imax(rows, 10);
+        rows = imin(rows, heightInCU);
+        slices = heightInCU / rows;
+    }
+    if (numRowsPerSlice)
+        *numRowsPerSlice = rows;
+    return slices;
+}
+
+/* source/encoder/slicetype.cpp:4284-4383.  batchMode: CostEstimateGroup::m_batchMode; outside it a
+ * lookahead with cooperative slices splits the block loop (:4312-4343, the slice tasks of
+ * processTasks :4248-4276 run here one after the other; their sums are order independent). */
+static int64_t estimate_frame_cost(orc_tld* t, const orc_param* p, orc_lowres** frames,
+                                   int p0, int p1, int b, int bIntraPenalty, int batchMode)
 {
     orc_lowres* fenc = frames[b];
     int64_t score;
@@ -758,23 +776,48 @@ int64_t orc_estimate_frame_cost(orc_tld* t, const orc_param* p, orc_lowres** fra
         fenc->costEst[b - p0][p1 - b] = 0;
         fenc->costEstAq[b - p0][p1 - b] = 0;
 
-        if (p->bEnableHME)
+        int rowsPerSlice;
+        const int numCoopSlices = orc_coop_slices(p, fenc->heightInCU, &rowsPerSlice);
+        if (!batchMode && numCoopSlices > 1 && (p1 > b || bDoSearch[0] || bDoSearch[1]))
         {
-            int lastRow = 1;
-            for (int cuY = fenc->heightInCU4 - 1; cuY >= 0; cuY--)
+            /* with HME a slice's half-res blocks read quarter-res vectors that another slice's task
+             * writes (:4250-4263, :4450-4453): timing dependent in x265, not restated */
+            if (p->bEnableHME)
+                return -1;
+            for (int i = 0; i < numCoopSlices; i++)
             {
-                for (int cuX = fenc->widthInCU4 - 1; cuX >= 0; cuX--)
-                    estimate_cu(t, p, frames, cuX, cuY, p0, p1, b, bDoSearch, lastRow, 1);
-                lastRow = 0;
+                const int firstY = rowsPerSlice * i;
+                const int lastY = (i == numCoopSlices - 1) ? fenc->heightInCU - 1 : rowsPerSlice * (i + 1) - 1;
+                int lastRow = 1;
+                for (int cuY = lastY; cuY >= firstY; cuY--)
+                {
+                    fenc->rowSatds[b - p0][p1 - b][cuY] = 0;
+                    for (int cuX = fenc->widthInCU - 1; cuX >= 0; cuX--)
+                        estimate_cu(t, p, frames, cuX, cuY, p0, p1, b, bDoSearch, lastRow, 0);
+                    lastRow = 0;
+                }
             }
         }
-        int lastRow = 1;
-        for (int cuY = fenc->heightInCU - 1; cuY >= 0; cuY--)
+        else
         {
-            fenc->rowSatds[b - p0][p1 - b][cuY] = 0;
-            for (int cuX = fenc->widthInCU - 1; cuX >= 0; cuX--)
-                estimate_cu(t, p, frames, cuX, cuY, p0, p1, b, bDoSearch, lastRow, 0);
-            lastRow = 0;
+            if (p->bEnableHME)
+            {
+                int lastRow = 1;
+                for (int cuY = fenc->heightInCU4 - 1; cuY >= 0; cuY--)
+                {
+                    for (int cuX = fenc->widthInCU4 - 1; cuX >= 0; cuX--)
+                        estimate_cu(t, p, frames, cuX, cuY, p0, p1, b, bDoSearch, lastRow, 1);
+                    lastRow = 0;
+                }
+            }
+            int lastRow = 1;
+            for (int cuY = fenc->heightInCU - 1; cuY >= 0; cuY--)
+            {
+                fenc->rowSatds[b - p0][p1 - b][cuY] = 0;
+                for (int cuX = fenc->widthInCU - 1; cuX >= 0; cuX--)
+                    estimate_cu(t, p, frames, cuX, cuY, p0, p1, b, bDoSearch, lastRow, 0);
+                lastRow = 0;
+            }
         }
 
         score = fenc->costEst[b - p0][p1 - b];
@@ -786,6 +829,20 @@ int64_t orc_estimate_frame_cost(orc_tld* t, const orc_param* p, orc_lowres** fra
     if (bIntraPenalty)
         score += score * fenc->intraMbs[b - p0] / (t->ncu * 8);
     return score;
+}
+
+/* a request of a batch (CostEstimateGroup::add / finishBatch), or any request without cooperative slices */
+int64_t orc_estimate_frame_cost(orc_tld* t, const orc_param* p, orc_lowres** frames,
+                                int p0, int p1, int b, int bIntraPenalty)
+{
+    return estimate_frame_cost(t, p, frames, p0, p1, b, bIntraPenalty, 1);
+}
+
+/* CostEstimateGroup::singleCost outside batch mode: split into p->lookaheadSlices cooperative slices */
+int64_t orc_estimate_frame_cost_single(orc_tld* t, const orc_param* p, orc_lowres** frames,
+                                       int p0, int p1, int b, int bIntraPenalty)
+{
+    return estimate_frame_cost(t, p, frames, p0, p1, b, bIntraPenalty, 0);
 }
 
 /* ---------------------------------------------------------------- ctypes accessors */

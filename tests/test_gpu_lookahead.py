@@ -256,3 +256,76 @@ def test_single_launch_search_mode(monkeypatch):
     finally:
         ctx.close()
         ref.close()
+
+
+@pytest.mark.parametrize("depth,slices", [(8, 3), (10, 2), (8, 8)])
+def test_cooperative_slices(depth, slices):
+    """--lookahead-slices: a singleCost outside batch mode runs each slice as its own bottom-up walk
+    (slicetype.cpp:4248-4276, 4312-4343); requests of a batch stay whole-frame."""
+    W, H, N = 448, 528, 5                        # 33 block rows: 3 x 11, 2 x 16 (+1), or 8 -> 10 rows x 3 (+3)
+    clip, ref, ctx, frames = _setup(W, H, N, depth, seed=31, lookahead_slices=slices)
+    whole = orc.Lookahead(depth, orc.make_param(W, H))
+    try:
+        rows = orc.C.c_int()
+        n = ref.L.orc_coop_slices(orc.C.byref(ref.param), ctx.geom.heightInCU, orc.C.byref(rows))
+        assert (ctx.geom.numCoopSlices, ctx.geom.numRowsPerSlice) == (n, rows.value)
+        assert n == {3: 3, 2: 2, 8: 3}[slices]
+        for f in clip:
+            whole.add_frame(f)
+        est = CostEstimateGroup(ctx, frames)
+        differs = False
+        for (p0, p1, b) in [(0, 1, 1), (0, 2, 1), (1, 2, 2), (0, 3, 3), (1, 3, 2), (3, 4, 4)]:
+            assert est.single_cost(p0, p1, b) == ref.frame_cost(p0, p1, b, single=True), (p0, p1, b)
+            _check_request(ref, ctx, frames, p0, p1, b)
+            whole.frame_cost(p0, p1, b)
+            differs |= not np.array_equal(ref.frames[b].mvs(0, b - p0), whole.frames[b].mvs(0, b - p0))
+        assert differs                           # the slice boundaries must actually change some predictors
+        # the same context in batch mode: whole frames
+        batch = CostEstimateGroup(ctx, frames)
+        for r in [(0, 4, 2), (2, 4, 3), (0, 4, 4)]:
+            batch.add(*r)
+        batch.finish_batch()
+        for (p0, p1, b) in [(0, 4, 2), (2, 4, 3), (0, 4, 4)]:
+            assert frames[b].cost_est[(b - p0, p1 - b)] == ref.frame_cost(p0, p1, b), (p0, p1, b)
+            _check_request(ref, ctx, frames, p0, p1, b)
+    finally:
+        ctx.close()
+        ref.close()
+        whole.close()
+
+
+def test_cooperative_slices_single_launch_mode(monkeypatch):
+    monkeypatch.setenv("X265GPU_SEARCH_MODE", "rows")
+    clip, ref, ctx, frames = _setup(448, 528, 4, 8, seed=32, lookahead_slices=3)
+    try:
+        est = CostEstimateGroup(ctx, frames)
+        for (p0, p1, b) in [(0, 1, 1), (0, 2, 1), (1, 3, 2)]:
+            assert est.single_cost(p0, p1, b) == ref.frame_cost(p0, p1, b, single=True), (p0, p1, b)
+            _check_request(ref, ctx, frames, p0, p1, b)
+    finally:
+        ctx.close()
+        ref.close()
+
+
+def test_cooperative_slices_with_hme_refused():
+    """x265's slice tasks read quarter-res vectors across slice boundaries while other tasks write them."""
+    clip, ref, ctx, frames = _setup(640, 528, 2, 8, hme=True, lookahead_slices=3)
+    try:
+        with pytest.raises(api.X265GpuError):
+            CostEstimateGroup(ctx, frames).single_cost(0, 1, 1)
+        assert ref.frame_cost(0, 1, 1, single=True) == -1
+    finally:
+        ctx.close()
+        ref.close()
+
+
+def test_encoder_slices_do_not_change_the_lowres_search():
+    """param->maxSlices > 1: the oracle applies motionEstimate's row clamp (motion.cpp:1654-1659); the device
+    path has none because no lowres search can leave the row range.  Multi-hexagon, small frame: most blocks
+    sit near a border."""
+    clip, ref, ctx, frames = _setup(256, 160, 5, 8, seed=41, search=orc.UMH, max_slices=4)
+    try:
+        _run_sequence(ref, ctx, frames, SEQ[:7])
+    finally:
+        ctx.close()
+        ref.close()

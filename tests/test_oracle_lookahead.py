@@ -127,7 +127,7 @@ class OracleBackedCtx:
 
     def estimate_costs(self, requests):
         out = []
-        for (s0, sb, s1, p0, b, p1, do0, do1, _w) in requests:
+        for (s0, sb, s1, p0, b, p1, do0, do1, _w, _coop) in requests:
             fr = self.la.frames[b]
             assert bool(do0) == (int(fr.mvs(0, b - p0)[0, 0]) == 0x7FFF)
             assert bool(do1) == (p1 > b and int(fr.mvs(1, p1 - b)[0, 0]) == 0x7FFF)

@@ -51,6 +51,7 @@ class Config(C.Structure):
         ("hmeSearchMethod", C.c_int32 * 3), ("hmeRange", C.c_int32 * 3), ("bFrameBias", C.c_int32),
         ("maxSlices", C.c_int32), ("lookaheadLambda", C.c_int32), ("deviceId", C.c_int32),
         ("stream", C.c_void_p), ("bKeepFullRes", C.c_int32), ("bMcstfFilter", C.c_int32),
+        ("lookaheadSlices", C.c_int32),
     ]
 
 
@@ -59,6 +60,7 @@ class Geometry(C.Structure):
         ("width", C.c_int32), ("lines", C.c_int32), ("stride", C.c_int32), ("marginX", C.c_int32),
         ("marginY", C.c_int32), ("widthInCU", C.c_int32), ("heightInCU", C.c_int32), ("cuCount", C.c_int32),
         ("widthInCU4", C.c_int32), ("heightInCU4", C.c_int32), ("planeSize", C.c_int64), ("padOffset", C.c_int64),
+        ("numCoopSlices", C.c_int32), ("numRowsPerSlice", C.c_int32),
     ]
 
 
@@ -66,7 +68,7 @@ class Request(C.Structure):
     _fields_ = [
         ("slotP0", C.c_int32), ("slotB", C.c_int32), ("slotP1", C.c_int32),
         ("p0", C.c_int32), ("b", C.c_int32), ("p1", C.c_int32),
-        ("doSearch", C.c_int32 * 2), ("weightedL0", C.c_int32),
+        ("doSearch", C.c_int32 * 2), ("weightedL0", C.c_int32), ("bCoopSlices", C.c_int32),
     ]
 
 
@@ -164,7 +166,8 @@ class Context:
 
     def __init__(self, width, height, depth=8, bframes=4, num_slots=8, search=HEX_SEARCH, merange=16,
                  ctu=64, hme=False, hme_methods=(HEX_SEARCH, UMH_SEARCH, UMH_SEARCH), hme_range=(16, 32, 48),
-                 bframe_bias=0, device=0, stream=None, keep_full_res=False, mcstf=False, lib_path=None):
+                 bframe_bias=0, device=0, stream=None, keep_full_res=False, mcstf=False, lib_path=None,
+                 lookahead_slices=0, max_slices=1):
         self.L = load_library(lib_path)
         cfg = Config()
         cfg.sourceWidth, cfg.sourceHeight, cfg.internalBitDepth = width, height, depth
@@ -173,7 +176,8 @@ class Context:
         for k in range(3):
             cfg.hmeSearchMethod[k] = hme_methods[k]
             cfg.hmeRange[k] = hme_range[k]
-        cfg.bFrameBias, cfg.maxSlices = bframe_bias, 1
+        cfg.bFrameBias, cfg.maxSlices = bframe_bias, max_slices
+        cfg.lookaheadSlices = lookahead_slices
         cfg.lookaheadLambda = {8: 1, 10: 16, 12: 256}[depth]
         cfg.deviceId = device
         cfg.stream = stream
@@ -247,10 +251,11 @@ class Context:
             arr[k].p0, arr[k].b, arr[k].p1 = r[3], r[4], r[5]
             arr[k].doSearch[0], arr[k].doSearch[1] = int(r[6]), int(r[7])
             arr[k].weightedL0 = int(r[8]) if len(r) > 8 else 0
+            arr[k].bCoopSlices = int(r[9]) if len(r) > 9 else 0
         return arr
 
     def estimate(self, requests):
-        """requests: iterable of (slotP0, slotB, slotP1, p0, b, p1, doSearch0, doSearch1[, weightedL0])."""
+        """requests: iterable of (slotP0, slotB, slotP1, p0, b, p1, doSearch0, doSearch1[, weightedL0[, coopSlices]])."""
         arr = self._pack(requests)
         self._chk(self.L.x265gpu_estimate(self.h, len(arr), arr))
 

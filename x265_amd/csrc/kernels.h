@@ -55,6 +55,8 @@ struct SearchJob
     int level0;               // 1: this job searches the quarter-res planes
     int method;
     int merange;
+    int numSlices;            // cooperative slices this search is split into (1: whole frame)
+    int sliceRows;            // block rows per slice; the last slice also takes the remainder
 };
 
 struct CostJob
@@ -97,8 +99,10 @@ struct SearchStreams
     hipEvent_t fork = nullptr;     // recorded on the main stream, awaited by the side streams
     hipEvent_t join[3] = { nullptr, nullptr, nullptr };
 };
+// slicesMax / sliceHeightMax: the largest numSlices and the tallest slice (in block rows) over the n jobs
 hipError_t launch_search(hipStream_t s, const SearchStreams& aux, const Geometry& g, int bpp, const SearchJob* dJobs, int n,
-                         int level0, int method, const uint16_t* costTab, int maxMvd, int maxSlices, int* launches);
+                         int level0, int method, const uint16_t* costTab, int maxMvd, int slicesMax, int sliceHeightMax,
+                         int* launches);
 // single-launch search (row items with in-launch hand-off); dSync holds search_rows_sync_bytes() bytes,
 // word SEARCH_SYNC_ERROR of it is a sticky error flag (a wait ran out) that the caller zeroes once and reads back
 constexpr int SEARCH_SYNC_ERROR = 64;

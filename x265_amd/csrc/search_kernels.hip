@@ -755,6 +755,10 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
         bqy = bmy * 4;
     }
 
+    // param->maxSlices > 1 would pull a full-pel result whose row left mvmin.y..mvmax.y back into range
+    // here (motion.cpp:1654-1659).  Without extra candidates that cannot happen: the diamond, the hexagon
+    // and every stage of the multi-hexagon search test each candidate's row (COST_MV_X4, the checked
+    // single points of CROSS, the border test of the hexagon grid), and the predictor is clipped.
     if (!bcost)
         bcost = mvcost_u<P>(c, bqx, bqy);
     else
@@ -802,8 +806,9 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
 // and handed back in (rightX,rightY).
 template <typename P, int METHOD, bool ROWS>
 __device__ __forceinline__ void search_block(const SearchJob& job, const Geometry& g, int level0, int cuX, int cuY,
-                                             int lane, const uint16_t* costTab, int maxMvd, XG_LDS uint32_t* lds,
-                                             int& rightX, int& rightY, XG_GLOBAL int* rowCount = nullptr, int done = 0)
+                                             bool lastRow, int lane, const uint16_t* costTab, int maxMvd,
+                                             XG_LDS uint32_t* lds, int& rightX, int& rightY,
+                                             XG_GLOBAL int* rowCount = nullptr, int done = 0)
 {
     const int W = level0 ? g.W4 : g.W, H = level0 ? g.H4 : g.H;
     const int stride = level0 ? g.stride4 : g.stride;
@@ -857,7 +862,6 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
 
     // ---- predictor: lowest-SATD neighbour vector (slicetype.cpp:4438-4476) ----
     const XG_GLOBAL int32_t* mvs = as_global<int32_t>(job.mvs);
-    const bool lastRow = cuY == H - 1;
     const bool v0 = cuX < W - 1, v1 = !lastRow, v2 = !lastRow && cuX > 0, v3 = !lastRow && cuX < W - 1;
     bool v4 = false;
     int hx = 0, hy = 0;
@@ -998,7 +1002,24 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     rightY = my;
 }
 
-// grid: (ceil(blocksOnDiagonal / 4), jobs); 4 waves per workgroup, one block each.
+// Block rows [first, last] of cooperative slice `slice` (slicetype.cpp:4265-4266); one slice: the frame.
+__device__ __forceinline__ void slice_rows(const SearchJob& job, int H, int slice, int& first, int& last)
+{
+    first = job.sliceRows * slice;
+    last = (slice == job.numSlices - 1) ? H - 1 : job.sliceRows * (slice + 1) - 1;
+}
+
+// The block row starts a slice's bottom-up walk: no predictors from the row below (lastRow, slicetype.cpp:4267).
+__device__ __forceinline__ bool slice_bottom_row(const SearchJob& job, int H, int cuY)
+{
+    if (cuY == H - 1)
+        return true;
+    const int below = cuY + 1;
+    return job.numSlices > 1 && below % job.sliceRows == 0 && below / job.sliceRows < job.numSlices;
+}
+
+// grid: (ceil(blocksOnDiagonal / 4), jobs, slices); 4 waves per workgroup, one block each.
+// Every cooperative slice is a wavefront of its own, counted from the slice's bottom row.
 // The search method is a compile-time parameter: every job of a launch shares it,
 // and the hexagon-only kernel stays free of the multi-hexagon code's registers.
 template <typename P, int METHOD>
@@ -1009,14 +1030,19 @@ __global__ void __launch_bounds__(256) search_diag_kernel(const SearchJob* jobs,
     const int W = level0 ? g.W4 : g.W, H = level0 ? g.H4 : g.H;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction
     const int k = blockIdx.x * 4 + wave;
-    const int ylo = max(0, (t - (W - 1) + 1) >> 1), yhi = min(H - 1, t >> 1);
+    const SearchJob job = jobs[blockIdx.y];
+    const int slice = blockIdx.z;
+    if (slice >= job.numSlices)
+        return;
+    int first, last;
+    slice_rows(job, H, slice, first, last);
+    const int ylo = max(0, (t - (W - 1) + 1) >> 1), yhi = min(last - first, t >> 1);
     const int yq = ylo + k;
     if (yq > yhi)
         return;                       // whole wave leaves together
     const int xq = t - 2 * yq;
-    const SearchJob job = jobs[blockIdx.y];
     int rx = 0, ry = 0;
-    search_block<P, METHOD, false>(job, g, level0, W - 1 - xq, H - 1 - yq, threadIdx.x & 63, costTab, maxMvd,
+    search_block<P, METHOD, false>(job, g, level0, W - 1 - xq, last - yq, yq == 0, threadIdx.x & 63, costTab, maxMvd,
                                    (XG_LDS uint32_t*)ldsBuf + wave * WaveLds<P>::TOTAL, rx, ry);
 }
 
@@ -1053,7 +1079,8 @@ __device__ __forceinline__ void search_rows_body(const SearchJob* jobs, int nJob
         const int yq = item / nJobs, jobIdx = item - yq * nJobs;
         const SearchJob job = jobs[jobIdx];
         XG_GLOBAL int* prog = gsync + SYNC_ROWS + jobIdx * H + yq;     // this row's count; the row below is prog[-1]
-        const bool waits = yq > 0;
+        const bool bottom = slice_bottom_row(job, H, H - 1 - yq);
+        const bool waits = !bottom;
         int seen = 0, ahead = 0, rx = 0, ry = 0;
         for (int xq = 0; xq < W; xq++)
         {
@@ -1089,7 +1116,8 @@ __device__ __forceinline__ void search_rows_body(const SearchJob* jobs, int nJob
                 if (seen < W)
                     ahead = __hip_atomic_load(prog - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            search_block<P, METHOD, true>(job, g, level0, W - 1 - xq, H - 1 - yq, lane, costTab, maxMvd, lds, rx, ry, prog, xq);
+            search_block<P, METHOD, true>(job, g, level0, W - 1 - xq, H - 1 - yq, bottom, lane, costTab, maxMvd, lds, rx, ry,
+                                          prog, xq);
         }
         // the last vector's store must have left before the count that announces it
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1186,9 +1214,9 @@ hipError_t launch_search_rows(hipStream_t s, const Geometry& g, int bpp, const S
 }
 
 hipError_t launch_search(hipStream_t s, const SearchStreams& aux, const Geometry& g, int bpp, const SearchJob* dJobs, int n,
-                         int level0, int method, const uint16_t* costTab, int maxMvd, int maxSlices, int* launches)
+                         int level0, int method, const uint16_t* costTab, int maxMvd, int slicesMax, int sliceHeightMax,
+                         int* launches)
 {
-    (void)maxSlices;
     if (n <= 0)
         return hipSuccess;
     // job groups: group 0 on the main stream, the others on side streams.  Jobs of one
@@ -1202,7 +1230,10 @@ hipError_t launch_search(hipStream_t s, const SearchStreams& aux, const Geometry
         if (e != hipSuccess)
             return e;
     }
-    const int W = level0 ? g.W4 : g.W, H = level0 ? g.H4 : g.H;
+    // the diagonals of the tallest slice cover every job's; shorter slices' waves leave at once
+    const int W = level0 ? g.W4 : g.W, Hf = level0 ? g.H4 : g.H;
+    const int H = (sliceHeightMax > 0 && sliceHeightMax < Hf) ? sliceHeightMax : Hf;
+    const int nz = slicesMax > 1 ? slicesMax : 1;
     const int tmax = (W - 1) + 2 * (H - 1);
     for (int t = 0; t <= tmax; t++)
     {
@@ -1215,7 +1246,7 @@ hipError_t launch_search(hipStream_t s, const SearchStreams& aux, const Geometry
         {
             const int j0 = (int)((long long)n * k / groups), j1 = (int)((long long)n * (k + 1) / groups);
             hipStream_t st = k ? aux.side[k - 1] : s;
-            dim3 grid((cnt + 3) / 4, j1 - j0);
+            dim3 grid((cnt + 3) / 4, j1 - j0, nz);
             if (bpp == 1)
                 launch_diag_method<uint8_t>(method, st, grid, dJobs + j0, g, level0, t, costTab, maxMvd);
             else

@@ -46,6 +46,8 @@ struct x265gpu_ctx
     Geometry g;
     int bpp = 1;
     int D = 0;
+    int numCoopSlices = 1;            // Lookahead::m_numCoopSlices / m_numRowsPerSlice (slicetype.cpp:1122-1133)
+    int numRowsPerSlice = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;
     std::vector<Slot> slots;
@@ -344,7 +346,7 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
         (cfg->maxCUSize != 16 && cfg->maxCUSize != 32 && cfg->maxCUSize != 64))
         return X265GPU_ERR_ARG;
     auto methodOk = [](int m) { return m == X265GPU_DIA_SEARCH || m == X265GPU_HEX_SEARCH || m == X265GPU_UMH_SEARCH; };
-    if (!methodOk(cfg->searchMethod) || cfg->maxSlices > 1)
+    if (!methodOk(cfg->searchMethod))
         return X265GPU_ERR_UNSUPPORTED;
     if (cfg->bEnableHME && (!methodOk(cfg->hmeSearchMethod[0]) || !methodOk(cfg->hmeSearchMethod[1]) ||
                             cfg->hmeRange[0] < 4 || cfg->hmeRange[1] < 4))
@@ -375,6 +377,17 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
     ctx->bpp = cfg->internalBitDepth > 8 ? 2 : 1;
     ctx->D = cfg->bframes + 2;
     compute_geometry(*cfg, ctx->g);
+    // cooperative slices: Lookahead::Lookahead, source/encoder/slicetype.cpp:1122-1133
+    ctx->numRowsPerSlice = ctx->g.H;
+    ctx->numCoopSlices = 1;
+    if (cfg->lookaheadSlices > 1)
+    {
+        int rows = ctx->g.H / cfg->lookaheadSlices;
+        rows = rows > 10 ? rows : 10;                   // at least 10 rows per slice
+        rows = rows < ctx->g.H ? rows : ctx->g.H;       // but no more than the full picture
+        ctx->numRowsPerSlice = rows;
+        ctx->numCoopSlices = ctx->g.H / rows;
+    }
     if (cfg->bKeepFullRes)
     {
         const int ctu = cfg->maxCUSize;
@@ -523,6 +536,8 @@ int x265gpu_get_geometry(const x265gpu_ctx* ctx, x265gpu_geometry* o)
     o->heightInCU4 = g.H4;
     o->planeSize = g.planeSize;
     o->padOffset = g.padOffset;
+    o->numCoopSlices = ctx->numCoopSlices;
+    o->numRowsPerSlice = ctx->numRowsPerSlice;
     return X265GPU_OK;
 }
 
@@ -706,9 +721,22 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
     std::vector<SearchJob> sj;      // half-res searches
     std::vector<SearchJob> sj4;     // quarter-res searches (HME level 0), run first
     std::vector<CostJob> cj(n);
+    int slicesMax = 1, sliceHeightMax = 0;
     for (int i = 0; i < n; i++)
     {
         const x265gpu_request& r = reqs[i];
+        const bool coop = r.bCoopSlices && ctx->numCoopSlices > 1;
+        // x265 runs both levels of a slice in one task and a slice's half-res blocks read quarter-res
+        // vectors of rows another slice's task writes (slicetype.cpp:4250-4276, :4450-4453): the
+        // result depends on thread timing there, so there is nothing to be exact against
+        if (coop && hme && (r.doSearch[0] || r.doSearch[1]))
+            return fail(ctx, X265GPU_ERR_UNSUPPORTED, "estimate: cooperative slices with HME");
+        const int sliceHeight = coop ? g.H - ctx->numRowsPerSlice * (ctx->numCoopSlices - 1) : g.H;
+        if (r.doSearch[0] || r.doSearch[1])
+        {
+            slicesMax = coop && ctx->numCoopSlices > slicesMax ? ctx->numCoopSlices : slicesMax;
+            sliceHeightMax = sliceHeight > sliceHeightMax ? sliceHeight : sliceHeightMax;
+        }
         const int d0 = r.b - r.p0, d1 = r.p1 - r.b;
         if (!slot_ok(ctx, r.slotP0) || !slot_ok(ctx, r.slotB) || !slot_ok(ctx, r.slotP1) || d0 < 1 || d0 >= D ||
             d1 < 0 || d1 >= D || (d1 == 0 && r.slotP1 != r.slotB) || (r.doSearch[1] && d1 == 0))
@@ -746,6 +774,8 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
                 j.level0 = 1;
                 j.method = ctx->cfg.hmeSearchMethod[0];
                 j.merange = ctx->cfg.hmeRange[0];
+                j.numSlices = 1;
+                j.sliceRows = g.H4;
                 sj4.push_back(j);
             }
             SearchJob j;
@@ -770,6 +800,8 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
             // slicetype.cpp:4478); without it x265 hard-wires HEX and s_merange
             j.method = hme ? ctx->cfg.hmeSearchMethod[1] : ctx->cfg.searchMethod;
             j.merange = hme ? ctx->cfg.hmeRange[1] : ctx->cfg.merange;
+            j.numSlices = coop ? ctx->numCoopSlices : 1;
+            j.sliceRows = coop ? ctx->numRowsPerSlice : g.H;
             sj.push_back(j);
         }
         CostJob& c = cj[i];
@@ -837,9 +869,9 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
         int launches = 0;
         if (!sj4.empty())
             HIPCHK(launch_search(ctx->stream, ctx->searchAux, g, ctx->bpp, (const SearchJob*)ctx->jobBuf, (int)sj4.size(), 1,
-                                 sj4[0].method, ctx->costCentre, ctx->maxMvd, ctx->cfg.maxSlices, &launches));
+                                 sj4[0].method, ctx->costCentre, ctx->maxMvd, 1, g.H4, &launches));
         HIPCHK(launch_search(ctx->stream, ctx->searchAux, g, ctx->bpp, (const SearchJob*)(ctx->jobBuf + s4Bytes), (int)sj.size(), 0,
-                             sj[0].method, ctx->costCentre, ctx->maxMvd, ctx->cfg.maxSlices, &launches));
+                             sj[0].method, ctx->costCentre, ctx->maxMvd, slicesMax, sliceHeightMax, &launches));
         pt.stop(launches);
     }
     {

@@ -134,6 +134,7 @@ class CostEstimateGroup:
         # LookaheadTLD::ncu = m_8x8Blocks (slicetype.cpp:1065-1066)
         self.ncu = (W * H + 4 - 2 * (W + H)) if (W > 2 and H > 2) else W * H
         self.batch = []
+        self.batch_mode = False         # m_batchMode: set by the first add(), as in the reference
 
     def _request(self, p0, p1, b):
         """Builds the device request for (p0, p1, b) or None when the cost is cached."""
@@ -154,7 +155,9 @@ class CostEstimateGroup:
             if do0:
                 self.tld.weights_analyse(fenc, self.frames[p0])
                 weighted = fenc.weighted[d0]
-        return (self.frames[p0].slot, fenc.slot, self.frames[p1].slot, p0, b, p1, do0, do1, int(weighted))
+        # outside batch mode a request is split into the lookahead's cooperative slices (slicetype.cpp:4312)
+        coop = int(not self.batch_mode)
+        return (self.frames[p0].slot, fenc.slot, self.frames[p1].slot, p0, b, p1, do0, do1, int(weighted), coop)
 
     def _collect(self, b, d0, d1, res=None):
         fenc = self.frames[b]
@@ -178,6 +181,7 @@ class CostEstimateGroup:
         return score
 
     def add(self, p0, p1, b):
+        self.batch_mode = True
         r = self._request(p0, p1, b)
         if r is not None:
             self.batch.append((r, b, b - p0, p1 - b))

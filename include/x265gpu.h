@@ -254,6 +254,25 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
                                int32_t merange, int32_t subpelRefine, int32_t n, const x265gpu_pu_job* jobs,
                                x265gpu_pu_result* out);
 
+/* ---- motion search of the motion-compensated spatio-temporal filter (--mcstf) ----
+ *
+ * What the lookahead runs for a picture that is going to be filtered, for each of its reference pictures:
+ * MotionEstimatorTLD::motionEstimationLuma on the quarter-res, half-res and full-res pictures, then
+ * ::motionEstimationLumaDoubleRes in 1/16 pixel (source/common/temporalfilter.cpp:421-478, 642-897), issued as
+ * 16-line row tasks, one batch per level (source/encoder/slicetype.cpp:2280-2297, 4217-4234).  The context
+ * needs bMcstfFilter and bKeepFullRes; every slot involved must have been through x265gpu_lowres_init with
+ * its unfiltered source picture (x265 searches copies taken before filtering, source/encoder/encoder.cpp:1973).
+ * Outputs follow the arrays of TemporalFilterRefPicInfo (temporalfilter.cpp:397-409), reference after reference,
+ * W x H the source size:
+ *   mvs    : (W/4)*(H/4) x {x,y} per reference, 1/16 pixel per 8x8 block, W/4 entries per block row  (::mvs, ::mvsStride)
+ *   error  : (W/4)*(H/4) per reference, same indexing                                              (::error)
+ *   coarse : optional; 3 x (W/16)*(H/16) x {x,y} per reference: ::mvs0, ::mvs1, ::mvs2, W/16 entries per row
+ * Entries the reference does not write are zero.  At most 16 references (MCSTF_MAX_REFS).  The final error
+ * is formed in double precision with every operation rounded on its own; a reference build whose compiler
+ * regroups that expression under -ffast-math may differ in the last unit there. */
+int x265gpu_mcstf_motion_search(x265gpu_ctx* ctx, int32_t slotCur, int32_t numRefs, const int32_t* slotRefs,
+                                int32_t* mvs, int32_t* error, int32_t* coarse);
+
 /* ---- adaptive-quantisation block energies and weighted-prediction frame sums ----
  *
  * The pixel passes of LookaheadTLD::calcAdaptiveQuantFrame (source/encoder/slicetype.cpp:454-704) for a

@@ -233,6 +233,30 @@ typedef struct orc_hist_stats {
 void orc_collect_picture_statistics(const pixel* lowresPlane0, intptr_t lowresStride, const pixel* y, intptr_t sy,
                                     const pixel* u, const pixel* v, intptr_t sc, int w, int h, orc_hist_stats* out);
 
+/* ---- MCSTF motion search (orc_mcstf.c) ---- */
+typedef struct orc_mcstf_planes {
+    const pixel* lowerRes;    /* Lowres::lowerResPlane[0] (origin) */
+    const pixel* lowres;      /* Lowres::lowresPlane[0] */
+    intptr_t lumaStride;      /* Lowres::lumaStride; the quarter-res planes use half of it */
+    int width, lines;         /* Lowres::width / lines */
+    const pixel* pic;         /* PicYuv::m_picOrg[0] of the border-extended source picture */
+    intptr_t picStride;
+    int picWidth, picHeight;
+} orc_mcstf_planes;
+typedef struct orc_mcstf_mvs {  /* the arrays of one TemporalFilterRefPicInfo (source/common/temporalfilter.h:155-172) */
+    orc_mv *mvs0, *mvs1, *mvs2, *mvs;
+    uint32_t mvsStride0, mvsStride1, mvsStride2, mvsStride;
+    int* error;
+} orc_mcstf_mvs;
+int  orc_mcstf_motion_error(const pixel* src, int stride, const pixel* buf, int x, int y, int dx, int dy, int bs,
+                            int besterror);
+void orc_mcstf_me_luma(orc_mv* mvs, uint32_t mvStride, const pixel* src, int stride, int height, int width,
+                       const pixel* buf, int row, int rowSize, const orc_mv* previous, uint32_t prevMvStride, int factor);
+void orc_mcstf_me_luma_double_res(orc_mv* mvs, uint32_t mvStride, const pixel* orig, int stride, int origWidth,
+                                  int origHeight, const pixel* buffer, const orc_mv* previous, uint32_t prevMvStride,
+                                  int factor, int* minError, int row, int rowSize);
+void orc_mcstf_level(int level, const orc_mcstf_planes* cur, const orc_mcstf_planes* ref, orc_mcstf_mvs* out);
+
 /* field accessors for ctypes */
 void* orc_lowres_ptr(orc_lowres* lr, const char* field, int i, int j);
 int64_t orc_lowres_i64(orc_lowres* lr, const char* field, int i, int j);

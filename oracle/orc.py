@@ -43,6 +43,18 @@ class HistStats(C.Structure):
                 ("picAvgVarianceCb", C.c_uint16), ("picAvgVarianceCr", C.c_uint16), ("pad2", C.c_uint16)]
 
 
+class McstfPlanes(C.Structure):
+    _fields_ = [("lowerRes", C.c_void_p), ("lowres", C.c_void_p), ("lumaStride", C.c_ssize_t), ("width", C.c_int),
+                ("lines", C.c_int), ("pic", C.c_void_p), ("picStride", C.c_ssize_t), ("picWidth", C.c_int),
+                ("picHeight", C.c_int)]
+
+
+class McstfMvs(C.Structure):
+    _fields_ = [("mvs0", C.c_void_p), ("mvs1", C.c_void_p), ("mvs2", C.c_void_p), ("mvs", C.c_void_p),
+                ("mvsStride0", C.c_uint32), ("mvsStride1", C.c_uint32), ("mvsStride2", C.c_uint32),
+                ("mvsStride", C.c_uint32), ("error", C.c_void_p)]
+
+
 class RefPlanes(C.Structure):
     _fields_ = [("plane", C.c_void_p * 4), ("lowerPlane", C.c_void_p * 4), ("stride", C.c_ssize_t),
                 ("isLowres", C.c_int), ("isHMELowres", C.c_int)]
@@ -124,6 +136,8 @@ def lib(depth=8):
     L.orc_motion_estimate.restype = i
     L.orc_diamond_search.argtypes = [vp, C.POINTER(RefPlanes), MV, MV, MV, C.POINTER(MV)]
     L.orc_diamond_search.restype = i
+    L.orc_mcstf_motion_error.argtypes = [vp, i, vp, i, i, i, i, i, i]
+    L.orc_mcstf_level.argtypes = [i, C.POINTER(McstfPlanes), C.POINTER(McstfPlanes), C.POINTER(McstfMvs)]
     L.libc_free = C.CDLL(None).free
     L.libc_free.argtypes = [vp]
     _libs[depth] = L
@@ -374,3 +388,45 @@ def collect_picture_statistics(lowres, y, u, v):
     L.orc_collect_picture_statistics(C.c_void_p(plane0), lowres.i64("stride"), ptr(y), y.strides[0] // item, ptr(u), ptr(v),
                                      u.strides[0] // item, w, h, C.byref(st))
     return st
+
+
+MCSTF_PAD = 64
+
+
+class McstfPicture:
+    """What the --mcstf motion search reads of one frame: the Lowres planes (made with the param's mcstf
+    filter) and the border-extended source picture."""
+
+    def __init__(self, lowres, tight_luma):
+        self.lowres = lowres
+        self.pic = np.ascontiguousarray(np.pad(tight_luma, MCSTF_PAD, mode="edge"))
+        item = self.pic.itemsize
+        h, w = tight_luma.shape
+        p = McstfPlanes()
+        p.lowerRes = lowres.L.orc_lowres_ptr(lowres.h, b"lowerPlane", 0, 0)
+        p.lowres = lowres.L.orc_lowres_ptr(lowres.h, b"plane", 0, 0)
+        p.lumaStride = lowres.i64("stride")
+        p.width, p.lines = lowres.i64("width"), lowres.i64("lines")
+        p.picStride = self.pic.shape[1]
+        p.pic = self.pic.ctypes.data + (MCSTF_PAD * self.pic.shape[1] + MCSTF_PAD) * item
+        p.picWidth, p.picHeight = w, h
+        self.planes = p
+
+
+def mcstf_motion_search(cur, refs):
+    """All four levels for each reference -> (mvs[r, H/4, W/4, 2], error[r, H/4, W/4], coarse[r, 3, H/16, W/16, 2])."""
+    L = cur.lowres.L
+    W, H = cur.planes.picWidth, cur.planes.picHeight
+    n = len(refs)
+    mvs = np.zeros((n, H // 4, W // 4, 2), np.int32)
+    err = np.zeros((n, H // 4, W // 4), np.int32)
+    coarse = np.zeros((n, 3, H // 16, W // 16, 2), np.int32)
+    for r, ref in enumerate(refs):
+        m = McstfMvs()
+        m.mvs0, m.mvs1, m.mvs2 = (coarse[r, k].ctypes.data for k in range(3))
+        m.mvs, m.error = mvs[r].ctypes.data, err[r].ctypes.data
+        m.mvsStride0 = m.mvsStride1 = m.mvsStride2 = W // 16
+        m.mvsStride = W // 4
+        for level in range(4):
+            L.orc_mcstf_level(level, C.byref(cur.planes), C.byref(ref.planes), C.byref(m))
+    return mvs, err, coarse

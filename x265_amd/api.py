@@ -24,7 +24,7 @@ EXPORTS = (
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_weight_cost", "x265gpu_weight_planes",
     "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_interp_luma",
     "x265gpu_cutree_clear", "x265gpu_cutree_swap", "x265gpu_cutree_propagate", "x265gpu_cutree_get_propagate_cost",
-    "x265gpu_cutree_finish", "x265gpu_hist_stats",
+    "x265gpu_cutree_finish", "x265gpu_hist_stats", "x265gpu_mcstf_motion_search",
     "x265gpu_profile_enable", "x265gpu_profile_read",
 )
 
@@ -150,6 +150,7 @@ def load_library(path=None):
     L.x265gpu_cutree_finish.argtypes = [vp, i32, i32, C.c_double, C.c_double, vp, vp]
     L.x265gpu_hist_stats.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp]
     L.x265gpu_aq_frame.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.x265gpu_mcstf_motion_search.argtypes = [vp, i32, i32, vp, vp, vp, vp]
     L.x265gpu_interp_luma.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.x265gpu_profile_enable.argtypes = [vp, i32]
     L.x265gpu_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
@@ -399,6 +400,18 @@ class Context:
         self._chk(self.L.x265gpu_hist_stats(self.h, slot, _ptr(y), y.shape[1], _ptr(u), _ptr(v), u.shape[1], MEM_HOST,
                                             C.byref(st)))
         return hist_stats_dict(st)
+
+    def mcstf_motion_search(self, slot_cur, slot_refs):
+        """--mcstf motion search of the picture in slot_cur against each reference slot ->
+        (mvs[r, H/4, W/4, 2], error[r, H/4, W/4], coarse[r, 3, H/16, W/16, 2]) laid out as TemporalFilterRefPicInfo's arrays."""
+        W, H = self.cfg.sourceWidth, self.cfg.sourceHeight
+        n = len(slot_refs)
+        mvs = np.zeros((n, H // 4, W // 4, 2), np.int32)
+        err = np.zeros((n, H // 4, W // 4), np.int32)
+        coarse = np.zeros((n, 3, H // 16, W // 16, 2), np.int32)
+        refs = (C.c_int32 * n)(*slot_refs)
+        self._chk(self.L.x265gpu_mcstf_motion_search(self.h, slot_cur, n, refs, _ptr(mvs), _ptr(err), _ptr(coarse)))
+        return mvs, err, coarse
 
     # ---- cuTree ----
     def cutree_clear(self, slot):

@@ -205,6 +205,27 @@ namespace xg {
 void hist_finish(int width, int height, const uint32_t* hist, const unsigned long long* sums,
                  const unsigned long long* rowVar, int maxRows, x265gpu_hist_stats_t* out);
 hipError_t launch_cost(hipStream_t s, const Geometry& g, int bpp, const CostJob* dJobs, int n);
+
+// ---- MCSTF motion search: one pyramid level of one picture against numRefs references ----
+struct McstfLevel
+{
+    const void* src;          // the picture's plane of this level, pixel (0,0)
+    int stride;               // shared by the picture and its references
+    int width, height;        // the level's size as the reference passes it (bounds of the coarser-level lookup)
+    int depth;
+    int blocksX, blocksY;     // blocks searched (16x16 on levels 0..2, 8x8 on level 3)
+    int mvStride;             // blocks per row of the vector arrays
+    int prevStride, factor;   // coarser level's vector array stride and scale
+};
+struct McstfRef
+{
+    const void* buf;          // the reference picture's plane of this level, pixel (0,0)
+    int32_t* mvs;             // {x,y} per block, 1/16 pixel
+    const int32_t* prev;      // the coarser level's vectors, or null on level 0
+    int32_t* least;           // running best error per block
+    int32_t* error;           // level 3: the normalised error that the filter reads
+};
+hipError_t launch_mcstf_level(hipStream_t s, int bpp, int level, const McstfLevel& lv, const McstfRef* dRefs, int numRefs);
 hipError_t launch_weight_cost(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJob);
 hipError_t launch_weight_planes(hipStream_t s, const Geometry& g, int bpp, int depth, int nPlanes, const void* src,
                                 void* dst, int w0, int round, int shift, int offset);

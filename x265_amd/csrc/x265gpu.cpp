@@ -81,6 +81,8 @@ struct x265gpu_ctx
     int meMaxMvd = 0;
     char* puBuf = nullptr;            // device staging: jobs, then results
     size_t puBufSize = 0;
+    char* mcstfBuf = nullptr;         // MCSTF motion search: vector / error arrays of every reference
+    size_t mcstfBufSize = 0;
     // single-launch search: row-progress words on the device, and its sticky error word mirrored here
     bool searchRows = false;
     int* searchSync = nullptr;
@@ -511,6 +513,7 @@ void x265gpu_close(x265gpu_ctx* ctx)
     if (ctx->searchAux.fork) (void)hipEventDestroy(ctx->searchAux.fork);
     if (ctx->meCostBuf) (void)hipFree(ctx->meCostBuf);
     if (ctx->puBuf) (void)hipFree(ctx->puBuf);
+    if (ctx->mcstfBuf) (void)hipFree(ctx->mcstfBuf);
     if (ctx->searchSync) (void)hipFree(ctx->searchSync);
     if (ctx->searchErrHost) (void)hipHostFree(ctx->searchErrHost);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1177,6 +1180,131 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
 }
 
 /* ---- cuTree ---- */
+
+int x265gpu_mcstf_motion_search(x265gpu_ctx* ctx, int32_t slotCur, int32_t numRefs, const int32_t* slotRefs, int32_t* mvs,
+                                int32_t* error, int32_t* coarse)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || numRefs < 0 || numRefs > 16 || (numRefs && (!slotRefs || !mvs || !error)))
+        return X265GPU_ERR_ARG;
+    if (!numRefs)
+        return X265GPU_OK;
+    if (!ctx->cfg.bMcstfFilter || !ctx->fullStride)
+        return fail(ctx, X265GPU_ERR_STATE, "mcstf_motion_search: context opened without bMcstfFilter and bKeepFullRes");
+    if (!slot_ok(ctx, slotCur))
+        return fail(ctx, X265GPU_ERR_ARG, "mcstf_motion_search: bad slot");
+    for (int r = 0; r < numRefs; r++)
+        if (!slot_ok(ctx, slotRefs[r]))
+            return fail(ctx, X265GPU_ERR_ARG, "mcstf_motion_search: bad reference slot");
+    const Geometry& g = ctx->g;
+    const int W = g.srcWidth, H = g.srcHeight;
+    // array sizes and strides of TemporalFilter::createRefPicInfo (temporalfilter.cpp:397-409)
+    const size_t n16 = (size_t)(W / 16) * (H / 16), n4 = (size_t)(W / 4) * (H / 4);
+    if (!n16)
+        return fail(ctx, X265GPU_ERR_UNSUPPORTED, "mcstf_motion_search: picture smaller than one block");
+    const size_t perRef = align256(3 * n16 * 2 * sizeof(int32_t)) + align256(n4 * 2 * sizeof(int32_t)) +
+                          2 * align256(n4 * sizeof(int32_t));
+    const size_t total = perRef * numRefs;
+    if (total > ctx->mcstfBufSize)
+    {
+        if (ctx->mcstfBuf)
+        {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipFree(ctx->mcstfBuf));
+            ctx->mcstfBuf = nullptr;
+            ctx->mcstfBufSize = 0;
+        }
+        HIPCHK(hipMalloc((void**)&ctx->mcstfBuf, total));
+        ctx->mcstfBufSize = total;
+    }
+    HIPCHK(hipMemsetAsync(ctx->mcstfBuf, 0, total, ctx->stream));
+    int rc = ensure_job_buf(ctx, 4 * align256(sizeof(McstfRef) * numRefs));
+    if (rc)
+        return rc;
+
+    struct RefArrays { int32_t* coarse[3]; int32_t* mvs; int32_t* error; int32_t* least; };
+    std::vector<RefArrays> arr(numRefs);
+    for (int r = 0; r < numRefs; r++)
+    {
+        char* p = ctx->mcstfBuf + perRef * r;
+        for (int k = 0; k < 3; k++)
+            arr[r].coarse[k] = (int32_t*)p + k * n16 * 2;
+        p += align256(3 * n16 * 2 * sizeof(int32_t));
+        arr[r].mvs = (int32_t*)p;
+        p += align256(n4 * 2 * sizeof(int32_t));
+        arr[r].error = (int32_t*)p;
+        p += align256(n4 * sizeof(int32_t));
+        arr[r].least = (int32_t*)p;
+    }
+    const size_t fullOrigin = ((size_t)ctx->fullMarginY * ctx->fullStride + ctx->fullMarginX) * ctx->bpp;
+    const Slot& sc = ctx->slots[slotCur];
+    const int rowSize = 16;                                        // PARALLEL_ME_ROWSIZE, slicetype.h:67
+    const int levelHeight[4] = { H >> 2, H >> 1, H, H };          // slicetype.cpp:2282
+    for (int level = 0; level < 4; level++)
+    {
+        McstfLevel lv;
+        memset(&lv, 0, sizeof(lv));
+        lv.depth = ctx->cfg.internalBitDepth;
+        const int numBlockRows = (levelHeight[level] + rowSize - 1) / rowSize;
+        // the arguments of slicetype.cpp:4227-4233
+        if (level == 0)
+        {
+            lv.src = plane4_origin(ctx, sc.planes4);
+            lv.stride = g.stride / 2;
+            lv.width = g.width / 2;
+            lv.height = g.lines / 2;
+        }
+        else if (level == 1)
+        {
+            lv.src = plane_origin(ctx, sc.planes);
+            lv.stride = g.stride;
+            lv.width = g.width;
+            lv.height = g.lines;
+        }
+        else
+        {
+            lv.src = sc.full + fullOrigin;
+            lv.stride = ctx->fullStride;
+            lv.width = W;
+            lv.height = H;
+        }
+        const int bs = level == 3 ? 8 : 16;
+        lv.blocksX = lv.width / bs;
+        // a row task starts every 16 lines and holds the blocks that end inside it and inside the picture
+        // (temporalfilter.cpp:653-661, 762-771)
+        const int rowsInPicture = lv.height / bs, rowsInTasks = numBlockRows * (rowSize / bs);
+        lv.blocksY = rowsInPicture < rowsInTasks ? rowsInPicture : rowsInTasks;
+        lv.mvStride = level == 3 ? W / 4 : W / 16;
+        lv.prevStride = W / 16;
+        lv.factor = level == 3 ? 1 : 2;
+        std::vector<McstfRef> refs(numRefs);
+        for (int r = 0; r < numRefs; r++)
+        {
+            const Slot& sr = ctx->slots[slotRefs[r]];
+            refs[r].buf = level == 0 ? plane4_origin(ctx, sr.planes4) : level == 1 ? plane_origin(ctx, sr.planes)
+                                                                                   : sr.full + fullOrigin;
+            refs[r].mvs = level == 3 ? arr[r].mvs : arr[r].coarse[level];
+            refs[r].prev = level == 0 ? nullptr : arr[r].coarse[level - 1];
+            refs[r].least = arr[r].least;
+            refs[r].error = arr[r].error;
+        }
+        const size_t off = level * align256(sizeof(McstfRef) * numRefs);
+        rc = upload_jobs(ctx, off, refs.data(), sizeof(McstfRef) * numRefs, level == 0);
+        if (rc)
+            return rc;
+        HIPCHK(launch_mcstf_level(ctx->stream, ctx->bpp, level, lv, (const McstfRef*)(ctx->jobBuf + off), numRefs));
+    }
+    for (int r = 0; r < numRefs; r++)
+    {
+        HIPCHK(hipMemcpyAsync(mvs + (size_t)r * n4 * 2, arr[r].mvs, n4 * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(error + (size_t)r * n4, arr[r].error, n4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (coarse)
+            HIPCHK(hipMemcpyAsync(coarse + (size_t)r * 3 * n16 * 2, arr[r].coarse[0], 3 * n16 * 2 * sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
 
 int x265gpu_cutree_clear(x265gpu_ctx* ctx, int32_t slot)
 {

@@ -247,7 +247,8 @@ typedef struct x265gpu_pu_result
  * unlike the lookahead's): same meaning as x265gpu_set_mvcost. */
 int x265gpu_me_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd);
 
-/* searchMethod: X265GPU_DIA_SEARCH, _HEX_, _STAR_ or _FULL_SEARCH (param->searchMethod);
+/* searchMethod: X265GPU_DIA_SEARCH, _HEX_, _UMH_, _STAR_ or _FULL_SEARCH (param->searchMethod; SEA, which needs
+ * integral planes of the reference, is X265GPU_ERR_UNSUPPORTED);
  * merange: param->searchRange; subpelRefine: param->subpelRefine (0..7, workload table
  * motion.cpp:48-58).  Results come back in job order; the call returns when they are in `out`. */
 int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t searchMethod,

@@ -71,6 +71,8 @@ def _run(depth, method, merange, subpel, count, seed, size=(416, 240), lam=None)
     (orc.DIA, 16, 1),
     (orc.STAR, 24, 7),
     (orc.HEX, 32, 5),
+    (orc.UMH, 16, 2),         # --me umh, with the adaptive range from the candidate list
+    (orc.UMH, 44, 3),
 ])
 def test_pu_motion_estimate(depth, method, merange, subpel):
     _run(depth, method, merange, subpel, 96, seed=100 + depth + merange)
@@ -93,8 +95,8 @@ def test_pu_rejects_bad_jobs():
                     (0, 0, 8, 8, (0, 0), (-400, -4), (4, 4), [])]:           # vectors leave the padded plane
             with pytest.raises(api.X265GpuError):
                 ctx.pu_motion_estimate(0, 1, api.STAR_SEARCH, 57, 3, [bad])
-        with pytest.raises(api.X265GpuError):                    # UMH is not offered on this path
-            ctx.pu_motion_estimate(0, 1, api.UMH_SEARCH, 16, 2, [(0, 0, 8, 8, (0, 0), (-4, -4), (4, 4), [])])
+        with pytest.raises(api.X265GpuError):                    # SEA (4) is not offered on this path
+            ctx.pu_motion_estimate(0, 1, 4, 16, 2, [(0, 0, 8, 8, (0, 0), (-4, -4), (4, 4), [])])
     finally:
         ctx.close()
 

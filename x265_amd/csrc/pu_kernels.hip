@@ -26,7 +26,7 @@
 
 namespace xg {
 
-constexpr int PU_DIA = 0, PU_HEX = 1, PU_STAR = 3;   // x265gpu search method values (anything else: exhaustive)
+constexpr int PU_DIA = 0, PU_HEX = 1, PU_UMH = 2, PU_STAR = 3;   // x265gpu search method values (anything else: exhaustive)
 constexpr int PU_AREA_DIAMOND = 16;                  // MotionEstimate::diamondSearch instead of motionEstimate
 
 // luma interpolation taps, source/common/constants.cpp:250-256
@@ -95,6 +95,13 @@ template <typename P> __device__ __forceinline__ int mvcost(const PuCtx<P>& c, i
 {
     const int dx = clampi(qx - c.mvpx, c.lo, c.hi), dy = clampi(qy - c.mvpy, c.lo, c.hi);
     return ((int)c.cx[dx + c.mvpx] + (int)c.cy[dy + c.mvpy]) & 0xffff;
+}
+
+// the same two entries added as plain integers (ADD_MVCOST of the multi-hexagon grid, motion.cpp:1273)
+template <typename P> __device__ __forceinline__ int mvcost_sum(const PuCtx<P>& c, int qx, int qy)
+{
+    const int dx = clampi(qx - c.mvpx, c.lo, c.hi), dy = clampi(qy - c.mvpy, c.lo, c.hi);
+    return (int)c.cx[dx + c.mvpx] + (int)c.cy[dy + c.mvpy];
 }
 
 // origin of the block displaced by full-pel (mx,my), clamped into the padded picture
@@ -530,6 +537,170 @@ template <typename P> __device__ __forceinline__ void try_rel(PuCtx<P>& c, int o
     }
 }
 
+// four COST_MV_X4 offsets packed as biased nibbles
+template <typename P> __device__ __forceinline__ void try_x4(PuCtx<P>& c, int ox, int oy, uint32_t px, uint32_t py)
+{
+#pragma unroll 1
+    for (int k = 0; k < 4; k++)
+        try_rel<P>(c, ox, oy, nib(px, k), nib(py, k));
+}
+
+// CROSS(start, x_max, y_max) around (ox,oy): motion.cpp:361-385
+template <typename P> __device__ __forceinline__ void umh_cross(PuCtx<P>& c, int ox, int oy, int start, int x_max, int y_max)
+{
+    int i = (short)start;
+    if (x_max <= min(c.maxx - ox, ox - c.minx))
+        for (; i < x_max - 2; i += 4)
+        {
+            try_rel<P>(c, ox, oy, i, 0);
+            try_rel<P>(c, ox, oy, -i, 0);
+            try_rel<P>(c, ox, oy, i + 2, 0);
+            try_rel<P>(c, ox, oy, -i - 2, 0);
+        }
+    for (; i < x_max; i += 2)
+    {
+        if (ox + i <= c.maxx)
+            try_mv<P>(c, ox + i, oy);
+        if (ox - i >= c.minx)
+            try_mv<P>(c, ox - i, oy);
+    }
+    i = (short)start;
+    if (y_max <= min(c.maxy - oy, oy - c.miny))
+        for (; i < y_max - 2; i += 4)
+        {
+            try_rel<P>(c, ox, oy, 0, i);
+            try_rel<P>(c, ox, oy, 0, -i);
+            try_rel<P>(c, ox, oy, 0, i + 2);
+            try_rel<P>(c, ox, oy, 0, -i - 2);
+        }
+    for (; i < y_max; i += 2)
+    {
+        if (oy + i <= c.maxy)
+            try_mv<P>(c, ox, oy + i);
+        if (oy - i >= c.miny)
+            try_mv<P>(c, ox, oy - i);
+    }
+}
+
+// Uneven multi-hexagon search, motion.cpp:1142-1326; returns true when the hexagon walk must follow.
+// (pfx,pfy): the clipped predictor rounded to full pel.
+template <typename P>
+__device__ __forceinline__ bool umh_search(PuCtx<P>& c, const PuJob& job, int pfx, int pfy, int merange)
+{
+    constexpr uint32_t D1X = 0x00009788u, D1Y = 0x00008897u;     // (0,-1)(0,1)(-1,0)(1,0)
+    const int scale = (c.h * c.h) >> 4;                          // sizeScale[], motion.cpp:123-153
+#define PU_SAD_THRESH(v) (c.bcost < (((v) >> 4) * scale))
+    int cross_start = 1;
+    const int ucost1 = c.bcost;
+    try_x4<P>(c, pfx, pfy, D1X, D1Y);
+    if (pfx | pfy)
+        try_x4<P>(c, 0, 0, D1X, D1Y);
+    const int ucost2 = c.bcost;
+    if ((c.bmx | c.bmy) && (c.bmx != pfx || c.bmy != pfy))
+        try_x4<P>(c, c.bmx, c.bmy, D1X, D1Y);
+    if (c.bcost == ucost2)
+        cross_start = 3;
+
+    int ox = c.bmx, oy = c.bmy;
+    if (c.bcost == ucost2 && PU_SAD_THRESH(2000))
+    {
+        try_x4<P>(c, ox, oy, 0x00006978u, 0x00008776u);          // (0,-2)(-1,-1)(1,-1)(-2,0)
+        try_x4<P>(c, ox, oy, 0x0000897Au, 0x0000A998u);          // (2,0)(-1,1)(1,1)(0,2)
+        if (c.bcost == ucost1 && PU_SAD_THRESH(500))
+            return false;
+        if (c.bcost == ucost2)
+        {
+            const int range = (short)((merange >> 1) | 1);
+            umh_cross<P>(c, ox, oy, 3, range, range);
+            try_x4<P>(c, ox, oy, 0x0000A697u, 0x00007766u);      // (-1,-2)(1,-2)(-2,-1)(2,-1)
+            try_x4<P>(c, ox, oy, 0x000097A6u, 0x0000AA99u);      // (-2,1)(2,1)(-1,2)(1,2)
+            if (c.bcost == ucost2)
+                return false;
+            cross_start = range + 2;
+        }
+    }
+
+    // search range adapted to how well the extra candidates agree (motion.cpp:1184-1236)
+    if (job.numCandidates)
+    {
+        const int n = job.numCandidates;
+        const bool is64 = c.w == 64 && c.h == 64;
+        int mvd, denom = 1;
+        if (n == 1)
+            mvd = is64 ? 25 : abs(c.mvpx - job.mvc[0]) + abs(c.mvpy - job.mvc[1]);
+        else
+        {
+            denom = n - 1;
+            mvd = 0;
+            if (!is64)
+            {
+                mvd = abs(c.mvpx - job.mvc[0]) + abs(c.mvpy - job.mvc[1]);
+                denom++;
+            }
+#pragma unroll 1
+            for (int i = 0; i < n - 1; i++)
+                mvd += abs(job.mvc[2 * i] - job.mvc[2 * i + 2]) + abs(job.mvc[2 * i + 1] - job.mvc[2 * i + 3]);
+        }
+        const int sad_ctx = PU_SAD_THRESH(1000) ? 0 : PU_SAD_THRESH(2000) ? 1 : PU_SAD_THRESH(4000) ? 2 : 3;
+        const int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
+        // range_mul[mvd_ctx][sad_ctx] = {3,3,4,4},{3,4,4,4},{4,4,4,5},{4,4,5,6}, one nibble each
+        const uint32_t mul = mvd_ctx == 0 ? 0x4433u : mvd_ctx == 1 ? 0x4443u : mvd_ctx == 2 ? 0x5444u : 0x6544u;
+        merange = (merange * (int)((mul >> (4 * sad_ctx)) & 15u)) >> 2;
+    }
+
+    // the cross stays centred on (ox,oy) even if the steps above moved the best vector (motion.cpp:1238)
+    umh_cross<P>(c, ox, oy, cross_start, merange, merange >> 1);
+    try_x4<P>(c, ox, oy, 0x0000AA66u, 0x0000A6A6u);              // (-2,-2)(-2,2)(2,-2)(2,2)
+
+    // hexagon grid of growing radius around the best so far: hex4[16], motion.cpp:67-73
+    constexpr uint32_t H4X0 = 0xC4C4A688u, H4Y0 = 0x776655C4u, H4X1 = 0xA6C4C4C4u, H4Y1 = 0xBBAA9988u;
+    ox = c.bmx;
+    oy = c.bmy;
+    int i = 1;
+    do
+    {
+        if (4 * i > min(min(c.maxx - ox, ox - c.minx), min(c.maxy - oy, oy - c.miny)))
+        {
+#pragma unroll 1
+            for (int j = 0; j < 16; j++)
+            {
+                const int mx = ox + nib(j < 8 ? H4X0 : H4X1, j & 7) * i, my = oy + nib(j < 8 ? H4Y0 : H4Y1, j & 7) * i;
+                if (in_range<P>(c, mx, my))
+                    try_mv<P>(c, mx, my);
+            }
+        }
+        else
+        {
+            // all sixteen measured; a point counts when the row of its UNSCALED offset is in range (MIN_MV,
+            // motion.cpp:1274); the two table entries are added without the 16-bit wrap of mvcost()
+            int dirx = 0, diry = 0;
+            bool moved = false;
+#pragma unroll 1
+            for (int j = 0; j < 16; j++)
+            {
+                const int dx = nib(j < 8 ? H4X0 : H4X1, j & 7), dy = nib(j < 8 ? H4Y0 : H4Y1, j & 7);
+                const int mx = ox + dx * i, my = oy + dy * i;
+                const int cost = block_cost<P, false>(c, mx * 4, my * 4) + mvcost_sum<P>(c, mx * 4, my * 4);
+                if (y_ok<P>(c, oy + dy) && cost < c.bcost)
+                {
+                    c.bcost = cost;
+                    dirx = dx;
+                    diry = dy;
+                    moved = true;
+                }
+            }
+            if (moved)
+            {
+                c.bmx = ox + i * dirx;
+                c.bmy = oy + i * diry;
+            }
+        }
+    }
+    while (++i <= (merange >> 2));
+#undef PU_SAD_THRESH
+    return in_range<P>(c, c.bmx, c.bmy);
+}
+
 // MotionEstimate::diamondSearch (motion.cpp:631-788), the coarse search behind an area's
 // starting vector.  Inside the range the reference hands absolute coordinates to the relative
 // COST_MV_X4, so the position measured (and stored) is o + coordinate; try_rel keeps that.
@@ -778,6 +949,11 @@ __global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, int n
             dia_search<P>(c, f.merange);
         else if (f.method == PU_HEX)
             hex_search<P>(c, f.merange);
+        else if (f.method == PU_UMH)
+        {
+            if (umh_search<P>(c, job, (pmvx + 2) >> 2, (pmvy + 2) >> 2, f.merange))
+                hex_search<P>(c, f.merange);
+        }
         else if (f.method == PU_STAR)
             star_search<P>(c, f.merange);
         else

@@ -1142,7 +1142,8 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
         return fail(ctx, X265GPU_ERR_STATE, "pu_motion_estimate: context opened without bKeepFullRes");
     if (!ctx->meCostCentre)
         return fail(ctx, X265GPU_ERR_STATE, "pu_motion_estimate: MV cost table not set");
-    if (searchMethod != X265GPU_DIA_SEARCH && searchMethod != X265GPU_HEX_SEARCH && searchMethod != X265GPU_STAR_SEARCH &&
+    if (searchMethod != X265GPU_DIA_SEARCH && searchMethod != X265GPU_HEX_SEARCH && searchMethod != X265GPU_UMH_SEARCH &&
+        searchMethod != X265GPU_STAR_SEARCH &&
         searchMethod != X265GPU_FULL_SEARCH && searchMethod != X265GPU_AREA_DIAMOND_SEARCH)
         return fail(ctx, X265GPU_ERR_UNSUPPORTED, "pu_motion_estimate: search method");
     if (subpelRefine < 0 || subpelRefine > 7 || merange < 1 || merange > 32767)

@@ -329,3 +329,18 @@ def test_encoder_slices_do_not_change_the_lowres_search():
     finally:
         ctx.close()
         ref.close()
+
+
+def test_intra_on_the_main_stream(monkeypatch):
+    """X265GPU_INTRA_STREAM=0: the intra estimate queued on the context's own stream instead of beside the searches."""
+    monkeypatch.setenv("X265GPU_INTRA_STREAM", "0")
+    clip, ref, ctx, frames = _setup(384, 208, 5, 8, with_aq=True, seed=51)
+    try:
+        for i in range(5):
+            cost, mode = ctx.get_intra(i)
+            np.testing.assert_array_equal(cost, ref.frames[i].intra_cost())
+            np.testing.assert_array_equal(mode, ref.frames[i].intra_mode())
+        _run_sequence(ref, ctx, frames, SEQ[:6])
+    finally:
+        ctx.close()
+        ref.close()

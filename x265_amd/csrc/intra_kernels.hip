@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256) intra_kernel(const IntraJob* jobs, Geomet
 }
 
 // frame totals: costEst[0][0], costEstAq[0][0] (slicetype.cpp:813-814)
-__global__ void intra_finalize_kernel(const IntraJob* jobs, long long* sums, int H)
+__global__ void intra_finalize_kernel(const IntraJob* jobs, int H)
 {
     const IntraJob job = jobs[blockIdx.x];
     long long a = 0, b = 0;
@@ -296,13 +296,12 @@ __global__ void intra_finalize_kernel(const IntraJob* jobs, long long* sums, int
     }
     if (threadIdx.x == 0)
     {
-        sums[2 * blockIdx.x] = a;
-        sums[2 * blockIdx.x + 1] = b;
+        job.sums[0] = a;
+        job.sums[1] = b;
     }
 }
 
-hipError_t launch_intra(hipStream_t s, const Geometry& g, int bpp, int depth, int lambda, const IntraJob* dJobs,
-                        long long* dSums, int n)
+hipError_t launch_intra(hipStream_t s, const Geometry& g, int bpp, int depth, int lambda, const IntraJob* dJobs, int n)
 {
     if (n <= 0)
         return hipSuccess;
@@ -312,7 +311,7 @@ hipError_t launch_intra(hipStream_t s, const Geometry& g, int bpp, int depth, in
         hipLaunchKernelGGL(intra_kernel<uint8_t>, grid, dim3(256), 0, s, dJobs, g, lambda, pixelMax);
     else
         hipLaunchKernelGGL(intra_kernel<uint16_t>, grid, dim3(256), 0, s, dJobs, g, lambda, pixelMax);
-    hipLaunchKernelGGL(intra_finalize_kernel, dim3(n), dim3(64), 0, s, dJobs, dSums, g.H);
+    hipLaunchKernelGGL(intra_finalize_kernel, dim3(n), dim3(64), 0, s, dJobs, g.H);
     return hipGetLastError();
 }
 

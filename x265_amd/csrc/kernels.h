@@ -39,6 +39,7 @@ struct IntraJob
     uint16_t* lowresCosts;    // lowresCosts[0][0]
     int32_t* rowSatds;        // rowSatds[0][0]
     long long* rowPartials;   // [H][2]: costEst, costEstAq partial per block row
+    long long* sums;          // [2] frame totals costEst[0][0], costEstAq[0][0], written by the finalize pass
 };
 
 struct SearchJob
@@ -88,8 +89,7 @@ struct WeightCostJob
 
 // launchers (defined in the .hip files); bytesPerPixel is 1 or 2
 hipError_t launch_lowres_init(hipStream_t s, const Geometry& g, int bpp, const LowresJob* dJobs, int n);
-hipError_t launch_intra(hipStream_t s, const Geometry& g, int bpp, int depth, int lambda, const IntraJob* dJobs,
-                        long long* dSums /* [n][2] */, int n);
+hipError_t launch_intra(hipStream_t s, const Geometry& g, int bpp, int depth, int lambda, const IntraJob* dJobs, int n);
 // Side streams the search may spread independent jobs over so that the drain of
 // one anti-diagonal launch overlaps the body of another job group's launch.
 struct SearchStreams

@@ -83,6 +83,14 @@ struct x265gpu_ctx
     size_t puBufSize = 0;
     char* mcstfBuf = nullptr;         // MCSTF motion search: vector / error arrays of every reference
     size_t mcstfBufSize = 0;
+    // The intra estimate runs on a stream of its own: the motion searches that usually follow it read
+    // nothing it writes, so the two overlap.  Every other entry point first makes the main stream wait.
+    hipStream_t intraStream = nullptr;
+    hipEvent_t intraFork = nullptr, intraDone = nullptr;
+    bool intraPending = false;        // intraDone not yet awaited by the main stream
+    char* intraJobBuf = nullptr;      // job descriptors of the intra launch in flight (device, pinned mirror)
+    char* intraJobHost = nullptr;
+    size_t intraJobBufSize = 0;
     // single-launch search: row-progress words on the device, and its sticky error word mirrored here
     bool searchRows = false;
     int* searchSync = nullptr;
@@ -118,10 +126,11 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // Makes the context's device current for the duration of an entry point and puts the caller's
 // device back afterwards: a process may drive several contexts (one per GPU) from one thread.
+// Unless told otherwise it also orders the main stream behind an intra estimate still running on its side stream.
 struct DeviceScope
 {
     int prev = -1;
-    explicit DeviceScope(const x265gpu_ctx* ctx);
+    explicit DeviceScope(x265gpu_ctx* ctx, bool joinIntra = true);
     ~DeviceScope()
     {
         if (prev >= 0)
@@ -168,11 +177,22 @@ void compute_geometry(const x265gpu_config& cfg, Geometry& g)
     }
 }
 
-DeviceScope::DeviceScope(const x265gpu_ctx* ctx)
+void join_intra(x265gpu_ctx* ctx)
+{
+    if (ctx->intraPending)
+    {
+        (void)hipStreamWaitEvent(ctx->stream, ctx->intraDone, 0);
+        ctx->intraPending = false;
+    }
+}
+
+DeviceScope::DeviceScope(x265gpu_ctx* ctx, bool joinIntra)
 {
     int cur = -1;
     if (ctx && hipGetDevice(&cur) == hipSuccess && cur != ctx->cfg.deviceId && hipSetDevice(ctx->cfg.deviceId) == hipSuccess)
         prev = cur;
+    if (ctx && joinIntra)
+        join_intra(ctx);
 }
 
 int alloc_slot(x265gpu_ctx* ctx, Slot& s)
@@ -459,6 +479,21 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
             rc = X265GPU_ERR_NOMEM;
             break;
         }
+        {
+            // X265GPU_INTRA_STREAM=0 keeps the intra estimate on the main stream
+            const char* e = getenv("X265GPU_INTRA_STREAM");
+            if (!e || atoi(e) != 0)
+            {
+                if (hipStreamCreateWithFlags(&ctx->intraStream, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&ctx->intraFork, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&ctx->intraDone, hipEventDisableTiming) != hipSuccess ||
+                    hipEventRecord(ctx->intraDone, ctx->intraStream) != hipSuccess)
+                {
+                    rc = X265GPU_ERR_DEVICE;
+                    break;
+                }
+            }
+        }
         ctx->slots.resize(cfg->numSlots);
         for (auto& s : ctx->slots)
         {
@@ -514,6 +549,12 @@ void x265gpu_close(x265gpu_ctx* ctx)
     if (ctx->meCostBuf) (void)hipFree(ctx->meCostBuf);
     if (ctx->puBuf) (void)hipFree(ctx->puBuf);
     if (ctx->mcstfBuf) (void)hipFree(ctx->mcstfBuf);
+    if (ctx->intraStream) (void)hipStreamSynchronize(ctx->intraStream);
+    if (ctx->intraJobBuf) (void)hipFree(ctx->intraJobBuf);
+    if (ctx->intraJobHost) (void)hipHostFree(ctx->intraJobHost);
+    if (ctx->intraFork) (void)hipEventDestroy(ctx->intraFork);
+    if (ctx->intraDone) (void)hipEventDestroy(ctx->intraDone);
+    if (ctx->intraStream) (void)hipStreamDestroy(ctx->intraStream);
     if (ctx->searchSync) (void)hipFree(ctx->searchSync);
     if (ctx->searchErrHost) (void)hipHostFree(ctx->searchErrHost);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -679,23 +720,44 @@ int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots)
         jobs[i].lowresCosts = s.lowresCosts;   // [0][0]
         jobs[i].rowSatds = s.rowSatds;         // [0][0]
         jobs[i].rowPartials = s.rowPartials;   // scratch of request (0,0)
+        jobs[i].sums = s.sums;                 // totals of request (0,0)
     }
-    // per-job frame totals land in a scratch array behind the jobs, then are copied into each slot
-    const size_t jobsBytes = align256(sizeof(IntraJob) * n);
-    int rc = ensure_job_buf(ctx, jobsBytes + sizeof(long long) * 2 * n);
+    if (ctx->intraStream && !ctx->prof)
+    {
+        // side stream: starts after everything queued on the main stream so far (planes, AQ factors)
+        const size_t bytes = sizeof(IntraJob) * n;
+        HIPCHK(hipEventSynchronize(ctx->intraDone));        // the previous launch is done with the job buffers
+        if (bytes > ctx->intraJobBufSize)
+        {
+            if (ctx->intraJobBuf) HIPCHK(hipFree(ctx->intraJobBuf));
+            if (ctx->intraJobHost) HIPCHK(hipHostFree(ctx->intraJobHost));
+            ctx->intraJobBuf = ctx->intraJobHost = nullptr;
+            ctx->intraJobBufSize = 0;
+            const size_t sz = align256(bytes * 2);
+            HIPCHK(hipMalloc((void**)&ctx->intraJobBuf, sz));
+            HIPCHK(hipHostMalloc((void**)&ctx->intraJobHost, sz, hipHostMallocDefault));
+            ctx->intraJobBufSize = sz;
+        }
+        memcpy(ctx->intraJobHost, jobs.data(), bytes);
+        HIPCHK(hipEventRecord(ctx->intraFork, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->intraStream, ctx->intraFork, 0));
+        HIPCHK(hipMemcpyAsync(ctx->intraJobBuf, ctx->intraJobHost, bytes, hipMemcpyHostToDevice, ctx->intraStream));
+        HIPCHK(launch_intra(ctx->intraStream, ctx->g, ctx->bpp, ctx->cfg.internalBitDepth, ctx->cfg.lookaheadLambda,
+                            (const IntraJob*)ctx->intraJobBuf, n));
+        HIPCHK(hipEventRecord(ctx->intraDone, ctx->intraStream));
+        ctx->intraPending = true;
+        return X265GPU_OK;
+    }
+    int rc = ensure_job_buf(ctx, sizeof(IntraJob) * n);
     if (rc)
         return rc;
-    long long* dSums = (long long*)(ctx->jobBuf + jobsBytes);
     rc = upload_jobs(ctx, 0, jobs.data(), sizeof(IntraJob) * n, true);
     if (rc)
         return rc;
     PhaseTimer pt(ctx, X265GPU_PHASE_INTRA);
     HIPCHK(launch_intra(ctx->stream, ctx->g, ctx->bpp, ctx->cfg.internalBitDepth, ctx->cfg.lookaheadLambda,
-                        (const IntraJob*)ctx->jobBuf, dSums, n));
+                        (const IntraJob*)ctx->jobBuf, n));
     pt.stop(2);
-    for (int i = 0; i < n; i++)
-        HIPCHK(hipMemcpyAsync(ctx->slots[slots[i]].sums, dSums + 2 * i, sizeof(long long) * 2,
-                              hipMemcpyDeviceToDevice, ctx->stream));
     return X265GPU_OK;
 }
 
@@ -877,6 +939,7 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
                              sj[0].method, ctx->costCentre, ctx->maxMvd, slicesMax, sliceHeightMax, &launches));
         pt.stop(launches);
     }
+    join_intra(ctx);          // the cost pass reads intraCost; the searches above did not have to wait for it
     {
         PhaseTimer pt(ctx, X265GPU_PHASE_COST);
         HIPCHK(launch_cost(ctx->stream, g, ctx->bpp, (const CostJob*)(ctx->jobBuf + s4Bytes + sBytes), n));
@@ -887,13 +950,13 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
 
 int x265gpu_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs)
 {
-    DeviceScope deviceScope(ctx);
+    DeviceScope deviceScope(ctx, false);
     return run_estimate(ctx, n, reqs, false);
 }
 
 int x265gpu_estimate_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, x265gpu_frame_cost* out)
 {
-    DeviceScope deviceScope(ctx);
+    DeviceScope deviceScope(ctx, false);
     if (!out && n)
         return X265GPU_ERR_ARG;
     int rc = run_estimate(ctx, n, reqs, true);

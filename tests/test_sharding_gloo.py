@@ -52,6 +52,71 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _window_costs(requests, lo, hi):
+    """The oracle on frames [lo, hi) of the clip, running `requests` (indices relative to lo)."""
+    sys.path.insert(0, ROOT)
+    from oracle import orc
+    from x265_amd import synth
+    clip = synth.luma_clip(W, H, TOTAL, 8, seed=7)[lo:hi]
+    ref = orc.Lookahead(8, orc.make_param(W, H, bframes=BFRAMES))
+    for f in clip:
+        ref.add_frame(f)
+    rows = []
+    for (p0, p1, b) in requests:
+        ref.frame_cost(p0, p1, b)
+        fr = ref.frames[b]
+        rows.append((fr.i64("costEst", b - p0, p1 - b), fr.i64("costEstAq", b - p0, p1 - b), fr.i64("intraMbs", b - p0)))
+    ref.close()
+    return np.array(rows, np.int64).reshape(-1, 3)
+
+
+def _halo_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import bench
+    import torch.distributed as dist
+    from x265_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b1, b2 = bench.batch_requests(TOTAL, BFRAMES)
+    start, end = sharding.segment_bounds(TOTAL, world, rank)
+    lo, hi = sharding.halo_bounds(TOTAL, world, rank, BFRAMES + 1)
+    pos, mine = sharding.shard_requests(b1 + b2, start, end, origin=lo)
+    parts = sharding.gather_costs(_window_costs(mine, lo, hi))
+    if rank == 0:
+        q.put([p.tolist() for p in parts])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_one_window_sharded_with_halo_matches_single_process(oracle_built):
+    """One lookahead window split by frame b across two ranks, each holding its segment plus a halo of
+    bframes + 1 frames: the gathered per-request scalars, put back in request order, are those of one process."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_halo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    parts = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    import bench
+    from x265_amd import sharding
+    b1, b2 = bench.batch_requests(TOTAL, BFRAMES)
+    want = _window_costs(b1 + b2, 0, TOTAL)
+    merged = np.full_like(want, -1)
+    for r in range(2):
+        s, e = sharding.segment_bounds(TOTAL, 2, r)
+        pos, _ = sharding.shard_requests(b1 + b2, s, e)
+        merged[pos] = np.array(parts[r], np.int64).reshape(-1, 3)
+    np.testing.assert_array_equal(merged, want)
+
+
 def test_segment_bounds_cover_everything():
     sys.path.insert(0, ROOT)
     from x265_amd import sharding

@@ -17,6 +17,24 @@ def segment_bounds(total_frames, world, rank):
     return start, start + base + (1 if rank < extra else 0)
 
 
+def halo_bounds(total_frames, world, rank, reach):
+    """Frames a rank must hold to run every request whose frame b lies in its segment of ONE lookahead
+    window: the segment plus `reach` = bframes + 1 frames either side (a request reads frames b - d0 and
+    b + d1 with distances up to bframes + 1).  Downscaling the halo frames again from their source is
+    cheaper than shipping four planes per frame between GPUs."""
+    start, end = segment_bounds(total_frames, world, rank)
+    return max(0, start - reach), min(total_frames, end + reach)
+
+
+def shard_requests(requests, start, end, origin=0):
+    """The (p0, p1, b) requests of a window that belong to the rank owning frames [start, end), in their
+    original order (all requests of one frame b stay together, so the request-order dependence of the
+    searches is kept), with frame indices relative to `origin` (the first frame the rank holds).
+    Returns (positions in `requests`, shifted requests)."""
+    pos = [k for k, (_, _, b) in enumerate(requests) if start <= b < end]
+    return pos, [(requests[k][0] - origin, requests[k][1] - origin, requests[k][2] - origin) for k in pos]
+
+
 def gather_costs(local, device=None):
     """all_gather of an int64 [n, 3] array; returns one array per rank, in rank order.
 

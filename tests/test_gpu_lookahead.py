@@ -9,9 +9,10 @@ from x265_amd.lookahead import CostEstimateGroup, LowresState, PreLookaheadGroup
 pytestmark = pytest.mark.gpu
 
 
-def _setup(width, height, nframes, depth, with_aq=False, seed=1234, bframes=4, **search):
+def _setup(width, height, nframes, depth, with_aq=False, seed=1234, bframes=4, clip=None, **search):
     """`search` (search=, hme=, hme_methods=, hme_range=) goes to the oracle's param and the context alike."""
-    clip = synth.luma_clip(width, height, nframes, depth, seed=seed)
+    if clip is None:
+        clip = synth.luma_clip(width, height, nframes, depth, seed=seed)
     param = orc.make_param(width, height, bframes=bframes, **search)
     ref = orc.Lookahead(depth, param, with_aq=with_aq)
     aq = None
@@ -341,6 +342,54 @@ def test_intra_on_the_main_stream(monkeypatch):
             np.testing.assert_array_equal(cost, ref.frames[i].intra_cost())
             np.testing.assert_array_equal(mode, ref.frames[i].intra_mode())
         _run_sequence(ref, ctx, frames, SEQ[:6])
+    finally:
+        ctx.close()
+        ref.close()
+
+
+def _hard_clip(width, height, nframes, depth, kind, seed):
+    """Content at the edges of the arithmetic: full-range noise (largest SAD / SATD, long walks), flat extremes
+    (zero residuals, early exits), and a fast pan with a hard luminance step (vectors at the range limits)."""
+    rng = np.random.default_rng(seed)
+    top = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    if kind == "noise":
+        return rng.integers(0, top + 1, (nframes, height, width)).astype(dt)
+    if kind == "flat":
+        vals = [0, top, top, 0, top // 2, 0, top, top]
+        out = np.stack([np.full((height, width), vals[i % len(vals)], dt) for i in range(nframes)])
+        out[:, height // 3:height // 2, width // 4:width // 2] = top     # one patch so that something moves
+        return out
+    base = rng.integers(0, top + 1, (height + 64, width + 40 * nframes + 64)).astype(dt)
+    base[:, ::37] = top
+    base[::29, :] = 0
+    return np.stack([base[(7 * i) % 32:(7 * i) % 32 + height, 23 * i:23 * i + width] for i in range(nframes)])
+
+
+@pytest.mark.parametrize("depth", [8, 10, 12])
+@pytest.mark.parametrize("kind", ["noise", "flat", "pan"])
+def test_extreme_content(depth, kind):
+    W, H, N = 320, 192, 6
+    clip = _hard_clip(W, H, N, depth, kind, seed=depth * 7 + len(kind))
+    _, ref, ctx, frames = _setup(W, H, N, depth, with_aq=True, seed=3, clip=clip)
+    try:
+        for i in range(N):
+            cost, mode = ctx.get_intra(i)
+            np.testing.assert_array_equal(cost, ref.frames[i].intra_cost())
+            np.testing.assert_array_equal(mode, ref.frames[i].intra_mode())
+        _run_sequence(ref, ctx, frames)
+    finally:
+        ctx.close()
+        ref.close()
+
+
+@pytest.mark.parametrize("kind", ["noise", "pan"])
+def test_extreme_content_hme_umh_12bit(kind):
+    W, H, N = 640, 368, 5
+    clip = _hard_clip(W, H, N, 12, kind, seed=19)
+    _, ref, ctx, frames = _setup(W, H, N, 12, seed=3, clip=clip, hme=True)
+    try:
+        _run_sequence(ref, ctx, frames, SEQ[:7])
     finally:
         ctx.close()
         ref.close()

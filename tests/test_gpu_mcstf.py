@@ -25,7 +25,7 @@ def _clip(width, height, n, depth, seed):
     return frames
 
 
-@pytest.mark.parametrize("depth,size", [(8, (384, 208)), (10, (320, 184)), (8, (424, 250))])
+@pytest.mark.parametrize("depth,size", [(8, (384, 208)), (10, (320, 184)), (8, (424, 250)), (12, (256, 144))])
 def test_mcstf_motion_search(depth, size):
     W, H = size
     N = 5

@@ -78,6 +78,11 @@ def test_pu_motion_estimate(depth, method, merange, subpel):
     _run(depth, method, merange, subpel, 96, seed=100 + depth + merange)
 
 
+def test_pu_motion_estimate_12bit():
+    _run(12, orc.STAR, 57, 3, 64, seed=1212)
+    _run(12, orc.UMH, 24, 5, 48, seed=1213)
+
+
 def test_pu_exhaustive_search_and_lambda():
     """--me full on a small range, with a steeper MV cost (higher QP lambda)."""
     _run(8, orc.FULL, 6, 4, 24, seed=7, lam=9.5)

@@ -393,3 +393,24 @@ def test_extreme_content_hme_umh_12bit(kind):
     finally:
         ctx.close()
         ref.close()
+
+
+@pytest.mark.parametrize("width,height,depth,hme", [
+    (1920, 1080, 8, False),      # the benchmark's configuration
+    (3840, 2160, 10, False),
+    (3840, 2160, 10, True),      # 4K Main10 with --hme: hexagon on the quarter-res, multi-hexagon on the half-res planes
+    (7680, 4320, 10, False),
+])
+def test_full_size_against_oracle(width, height, depth, hme):
+    """The benchmark sizes, three frames, against the oracle directly (a request takes it under a second)."""
+    clip, ref, ctx, frames = _setup(width, height, 3, depth, seed=5, hme=hme)
+    try:
+        for p in range(4):
+            np.testing.assert_array_equal(ctx.get_plane(1, p), ref.frames[1].buffer(p), err_msg="plane %d" % p)
+        cost, mode = ctx.get_intra(2)
+        np.testing.assert_array_equal(cost, ref.frames[2].intra_cost())
+        np.testing.assert_array_equal(mode, ref.frames[2].intra_mode())
+        _run_sequence(ref, ctx, frames, [(0, 1, 1), (0, 2, 1), (1, 2, 2), (0, 2, 2)])
+    finally:
+        ctx.close()
+        ref.close()

@@ -82,8 +82,13 @@ orc_lowres* orc_lowres_create(const orc_param* p, int withAq)
             {
                 int aw = ((lr->width / 2) + ORC_CU - 1) >> 3, ah = ((lr->lines / 2) + ORC_CU - 1) >> 3;
                 int n4 = imax(aw, lr->widthInCU4) * imax(ah, lr->heightInCU4);
-                lr->lowerResMvs[l][i] = (orc_mv*)malloc(sizeof(orc_mv) * n4);
-                lr->lowerResMvCosts[l][i] = (int32_t*)malloc(sizeof(int32_t) * n4);
+                /* Zeroed, unlike the reference's CHECKED_MALLOC (source/common/lowres.cpp:214-217): when the
+                 * source height (or width) is 2 or 3 above a multiple of 32, the half-res grid's last block
+                 * row maps to a quarter-res row (cuY / 2) that the quarter-res search never visits
+                 * (m_4x4Height rows, slicetype.cpp:1063-1064), and estimateCUCost reads its cost anyway
+                 * (:4450).  The reference reads uninitialised heap there; zero means "no such candidate". */
+                lr->lowerResMvs[l][i] = (orc_mv*)calloc(n4, sizeof(orc_mv));
+                lr->lowerResMvCosts[l][i] = (int32_t*)calloc(n4, sizeof(int32_t));
             }
         }
     }

@@ -414,3 +414,19 @@ def test_full_size_against_oracle(width, height, depth, hme):
     finally:
         ctx.close()
         ref.close()
+
+
+def test_hme_odd_block_grid_wild_predictor():
+    """39 half-res block columns: the index arithmetic of slicetype.cpp:4397 ((cuY / 2) * widthInCU / 2 against a
+    quarter-res grid 20 wide) hands a block the doubled vector of a block elsewhere in the frame, which can point
+    far past the margin.  The reference measures it unclipped, as a flat offset into its four-plane buffer, and
+    so must the device (found by tests/fuzz_gpu_parity.py, round 314 of seed 1)."""
+    W, H, N, depth = 624, 284, 4, 10
+    clip = _hard_clip(W, H, N, depth, "pan", 997691383)
+    _, ref, ctx, frames = _setup(W, H, N, depth, seed=3, bframes=2, clip=clip, hme=True,
+                                 hme_methods=(orc.UMH, orc.HEX, orc.UMH), hme_range=(24, 16, 48))
+    try:
+        _run_sequence(ref, ctx, frames, [(0, 1, 1), (0, 2, 2), (0, 3, 1), (1, 3, 2), (0, 3, 2)])
+    finally:
+        ctx.close()
+        ref.close()

@@ -146,14 +146,18 @@ template <> __device__ __forceinline__ Row<uint16_t> lds_row<uint16_t>(const XG_
 
 // Row r of the block displaced by the quarter-pel vector (qx,qy), from the
 // half-pel plane that vector selects: ReferencePlanes::lowresMC,
-// source/common/lowres.h:72-93.  Block origins are clamped into the padded
-// buffer; for vectors the reference itself can produce this is a no-op.
+// source/common/lowres.h:72-93.  Addressed the way the reference does, as one
+// offset into the buffer of four planes: a predictor candidate is measured
+// unclipped (slicetype.cpp:4466-4471), and one that points past the margin (the
+// doubled quarter-res vector of a block that the odd-width index arithmetic of
+// :4397 picked from elsewhere in the frame) lands in a neighbouring row or plane
+// there too.  Only an offset outside the whole buffer, where the reference
+// would leave its allocation, is pulled back.
 template <typename P> __device__ __forceinline__ Row<P> fetch_plane_row(const BlockCtx<P>& c, int qx, int qy)
 {
     const int hp = (qy & 2) | ((qx & 2) >> 1);
-    const int X = clampi(c.bx + (qx >> 2), c.minX, c.maxX);
-    const int Y = clampi(c.by + (qy >> 2), c.minY, c.maxY) + c.r;
-    return load_row_g<P>(c.base, c.padOffset + hp * c.planeSize + Y * c.stride + X);
+    const int off = c.padOffset + hp * c.planeSize + (c.by + (qy >> 2) + c.r) * c.stride + c.bx + (qx >> 2);
+    return load_row_g<P>(c.base, clampi(off, 0, 4 * c.planeSize - 8));
 }
 
 constexpr int EV_SAD = 0, EV_SATD = 1;

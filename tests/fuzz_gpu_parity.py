@@ -21,6 +21,8 @@ from oracle import orc  # noqa: E402
 from x265_amd import api, synth  # noqa: E402
 from x265_amd.lookahead import CostEstimateGroup  # noqa: E402
 import test_gpu_lookahead as T  # noqa: E402
+import test_gpu_mcstf as TM  # noqa: E402
+import test_gpu_pu_me as TP  # noqa: E402
 
 
 def draw(rng):
@@ -83,17 +85,62 @@ def one_round(cfg):
         ref.close()
 
 
+def draw_pu(rng):
+    return dict(depth=int(rng.choice([8, 10, 12])), method=int(rng.choice([orc.DIA, orc.HEX, orc.UMH, orc.STAR, orc.FULL])),
+                merange=int(rng.choice([4, 8, 16, 24, 57])), subpel=int(rng.integers(0, 8)),
+                size=(int(rng.integers(20, 70)) * 8 + int(rng.integers(0, 4)) * 2, int(rng.integers(12, 40)) * 8 + int(rng.integers(0, 4)) * 2),
+                lam=float(rng.choice([0, 0, 2.5, 9.5, 40.0])), seed=int(rng.integers(1, 1 << 30)))
+
+
+def pu_round(cfg):
+    merange = min(cfg["merange"], 6) if cfg["method"] == orc.FULL else cfg["merange"]
+    TP._run(cfg["depth"], cfg["method"], merange, cfg["subpel"], 24, cfg["seed"], size=cfg["size"], lam=cfg["lam"] or None)
+
+
+def draw_mcstf(rng):
+    return dict(depth=int(rng.choice([8, 10, 12])), W=int(rng.integers(8, 40)) * 16 + int(rng.integers(0, 8)) * 2,
+                H=int(rng.integers(6, 24)) * 16 + int(rng.integers(0, 8)) * 2, refs=int(rng.integers(1, 5)),
+                seed=int(rng.integers(1, 1 << 30)))
+
+
+def mcstf_round(cfg):
+    depth, W, H = cfg["depth"], cfg["W"], cfg["H"]
+    clip = TM._clip(W, H, 5, depth, seed=cfg["seed"] % 100000)
+    param = orc.make_param(W, H, mcstf=True)
+    L = orc.lib(depth)
+    pics = []
+    for i, f in enumerate(clip):
+        lr = orc.Lowres(L, depth, param)
+        lr.init(f, i)
+        pics.append(orc.McstfPicture(lr, f))
+    ctx = api.Context(W, H, depth=depth, num_slots=5, mcstf=True, keep_full_res=True)
+    try:
+        for i, f in enumerate(clip):
+            ctx.lowres_init(i, f, i)
+        refs = [0, 1, 3, 4][:cfg["refs"]]
+        want = orc.mcstf_motion_search(pics[2], [pics[r] for r in refs])
+        got = ctx.mcstf_motion_search(2, refs)
+        for name, g, w in zip(("mvs", "error", "coarse"), got, want):
+            np.testing.assert_array_equal(g, w, err_msg=name)
+    finally:
+        ctx.close()
+        for p in pics:
+            p.lowres.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--what", default="lookahead", choices=["lookahead", "pu", "mcstf"])
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
+    drawer, runner = {"lookahead": (draw, one_round), "pu": (draw_pu, pu_round), "mcstf": (draw_mcstf, mcstf_round)}[a.what]
     t0, rounds = time.time(), 0
     while time.time() - t0 < a.seconds:
-        cfg = draw(rng)
+        cfg = drawer(rng)
         try:
-            one_round(cfg)
+            runner(cfg)
         except Exception:
             print("MISMATCH in round %d: %r" % (rounds, cfg), flush=True)
             raise

@@ -75,6 +75,17 @@ def one_round(cfg):
             np.testing.assert_array_equal(mode, ref.frames[i].intra_mode())
         est = CostEstimateGroup(ctx, frames)
         single = cfg["mode"] == "slices"
+        if not single and rng.integers(0, 2):
+            # one device batch (CostEstimateGroup::add / finishBatch); the oracle runs the same requests in order
+            reqs = list(dict.fromkeys(requests(rng, cfg["n"], cfg["bframes"], int(rng.integers(2, 40)))))
+            for r in reqs:
+                est.add(*r)
+            est.finish_batch()
+            for (p0, p1, b) in reqs:
+                want = ref.frame_cost(p0, p1, b)
+                assert frames[b].cost_est[(b - p0, p1 - b)] == want, ("batch frame cost", (p0, p1, b))
+            for (p0, p1, b) in reqs:
+                T._check_request(ref, ctx, frames, p0, p1, b)
         for (p0, p1, b) in requests(rng, cfg["n"], cfg["bframes"], 8):
             pen = bool(rng.integers(0, 2))
             got, want = est.single_cost(p0, p1, b, pen), ref.frame_cost(p0, p1, b, pen, single=single)

@@ -76,3 +76,18 @@ def test_null_context_is_an_error(lib):
     assert lib.x265gpu_estimate(None, 0, None) == -1
     assert lib.x265gpu_get_geometry(None, None) == -1
     lib.x265gpu_close(None)
+
+
+def test_host_layer_exports():
+    """The C++ host layer's plain-C face (x265_amd/host/lookahead_host.h) loads beside the library."""
+    from x265_amd import api
+    if not os.path.exists(api.HOST_LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    H = api.load_host_library()
+    text = open(os.path.join(ROOT, "x265_amd", "host", "lookahead_host.h")).read()
+    declared = sorted(set(re.findall(r"\b(xgh_[a-z_]+)\s*\(", text)))
+    assert declared == sorted(api.HOST_EXPORTS)
+    for n in declared:
+        assert hasattr(H, n), "missing export %s" % n
+    assert H.xgh_window_create(None, 4, 0, 8) is None

@@ -1,0 +1,145 @@
+"""GPU parity through the C++ host layer (x265_amd/host): PreLookaheadGroup, CostEstimateGroup, LookaheadTLD and
+CuTree written in x265's own language above the C-ABI, against the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from x265_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+I, P, B, R = 2, 3, 5, 4          # X265_TYPE_I / P / B / BREF
+
+
+class Slots:
+    """What _check_request of the Python-mirror tests expects of a frame: its slot."""
+
+    def __init__(self, slot):
+        self.slot = slot
+
+
+def _check(ref, ctx, p0, p1, b):
+    from test_gpu_lookahead import _check_request
+    _check_request(ref, ctx, [Slots(i) for i in range(len(ref.frames))], p0, p1, b)
+
+
+@pytest.mark.parametrize("depth,slices", [(8, 0), (10, 0), (8, 3)])
+def test_single_costs_and_batches(depth, slices):
+    W, H, N = (448, 528, 6) if slices else (384, 208, 8)
+    clip = synth.luma_clip(W, H, N, depth, seed=71)
+    rng = np.random.default_rng(72)
+    ref = orc.Lookahead(depth, orc.make_param(W, H, lookahead_slices=slices), with_aq=True)
+    ctx = api.Context(W, H, depth=depth, num_slots=N, lookahead_slices=slices)
+    win = api.HostWindow(ctx, N)
+    try:
+        n = ctx.geom.cuCount
+        invs = [rng.integers(128, 513, size=n).astype(np.int32) for _ in range(N)]
+        for f, q in zip(clip, invs):
+            ref.add_frame(f, q)
+        ctx.set_mvcost(ref.table, ref.centre)
+        win.pre_lookahead(list(clip), invs)
+        for i in range(N):
+            assert win.cost_est(i, 0, 0) == ref.frames[i].i64("costEst", 0, 0)
+        seq = [(0, 1, 1), (0, 2, 2), (0, 2, 1), (1, 2, 2), (0, 3, 3), (0, 3, 1), (1, 3, 2), (3, 4, 4), (3, 5, 4), (0, 2, 1)]
+        for (p0, p1, b) in seq:
+            for pen in (False, True):
+                assert win.single_cost(p0, p1, b, pen) == ref.frame_cost(p0, p1, b, pen, single=True), (p0, p1, b, pen)
+            _check(ref, ctx, p0, p1, b)
+            assert win.intra_mbs(b, b - p0) == ref.frames[b].i64("intraMbs", b - p0)
+        batch = [(2, 5, 4), (1, 5, 3), (2, 5, 5), (3, 5, 5), (4, 5, 5)]
+        for r in batch:
+            win.add(*r)
+        win.finish_batch()
+        for (p0, p1, b) in batch:
+            assert win.cost_est(b, b - p0, p1 - b) == ref.frame_cost(p0, p1, b), (p0, p1, b)
+            _check(ref, ctx, p0, p1, b)
+    finally:
+        win.close()
+        ctx.close()
+        ref.close()
+
+
+def test_weights_analyse():
+    W, H, N, depth = 384, 208, 6, 8
+    base = synth.luma_clip(W, H, N, depth, seed=9)[0]
+    rng = np.random.default_rng(3)
+    clip = [np.clip(np.roll(base, i, axis=1).astype(np.int32) * (64 - 6 * i) // 64 + 2 * i + rng.integers(-1, 2, base.shape),
+                    0, 255).astype(np.uint8) for i in range(N)]
+    ref = orc.Lookahead(depth, orc.make_param(W, H, weightp=True))
+    ctx = api.Context(W, H, depth=depth, num_slots=N)
+    win = api.HostWindow(ctx, N, weightp=True)
+    try:
+        for i, f in enumerate(clip):
+            lr = ref.add_frame(f)
+            v = f.astype(np.int64)
+            ssum = int(v.sum())
+            ssd = int((v * v).sum()) - ssum * ssum // v.size
+            wsum, wssd = lr.wp()
+            wsum[0], wssd[0] = ssum, ssd
+        ctx.set_mvcost(ref.table, ref.centre)
+        win.pre_lookahead(clip)
+        for i in range(N):                       # after pre_lookahead: Lowres::init resets the host state
+            wsum, wssd = ref.frames[i].wp()
+            win.set_wp(i, int(wsum[0]), int(wssd[0]))
+        nweighted = 0
+        for (p0, p1, b) in [(0, 1, 1), (0, 2, 2), (0, 2, 1), (1, 3, 3), (1, 3, 2), (0, 5, 5), (2, 5, 3), (3, 4, 4), (2, 4, 4)]:
+            assert win.single_cost(p0, p1, b) == ref.frame_cost(p0, p1, b), (p0, p1, b)
+            _check(ref, ctx, p0, p1, b)
+            want = bool(ref.frames[b].i64("isWeighted", b - p0))
+            assert win.is_weighted(b, b - p0) == want, (p0, p1, b)
+            nweighted += want
+        assert nweighted >= 5
+    finally:
+        win.close()
+        ctx.close()
+        ref.close()
+
+
+@pytest.mark.parametrize("types,kw,b_intra", [
+    ([I, B, B, P, B, B, B, P, B, P], {}, False),
+    ([I, B, B, P, B, R, B, P, B, P], {"b_pyramid": True, "weighted_bipred": True}, False),
+    ([I, B, P, B, B, P, P, B], {"vbv_buffer_size": 1000, "fps_num": 24000, "fps_denom": 1001}, True),
+    ([I, P], {"lookahead_depth": 0}, False),
+])
+def test_cu_tree(types, kw, b_intra):
+    W, H, depth = 384, 208, 8
+    N = len(types)
+    clip = synth.luma_clip(W, H, N, depth, seed=11)
+    rng = np.random.default_rng(11)
+    ref = orc.Lookahead(depth, orc.make_param(W, H), with_aq=True)
+    ctx = api.Context(W, H, depth=depth, num_slots=N)
+    win = api.HostWindow(ctx, N)
+    try:
+        ctx.set_mvcost(ref.table, ref.centre)
+        n = ctx.geom.cuCount
+        invs, cutree = [], []
+        for k, f in enumerate(clip):
+            inv = rng.integers(128, 513, size=n).astype(np.int32)
+            inv[rng.integers(0, n, 8)] = 0
+            invs.append(inv)
+            lr = ref.add_frame(f, inv)
+            lr.set_slice_type(types[k])
+            qa = rng.normal(0, 2, n)
+            lr.qp_aq_offset()[:] = qa
+            lr.qp_cutree_offset()[:] = qa
+            cutree.append((qa.copy(), qa.copy()))
+        win.pre_lookahead(list(clip), invs)
+        for k in range(N):
+            win.set_slice_type(k, types[k])
+            win.set_qp_offsets(k, *cutree[k])
+        cp = orc.CuTreeParam(kw.get("fps_num", 30), kw.get("fps_denom", 1), int(kw.get("b_pyramid", False)),
+                             int(kw.get("weighted_bipred", False)), kw.get("lookahead_depth", 20),
+                             kw.get("vbv_buffer_size", 0), kw.get("q_compress", 0.6))
+        ref.cu_tree(cp, N - 1, b_intra)
+        win.cu_tree(N - 1, b_intra, **kw)
+        touched = 0
+        for k in range(N):
+            want = ref.frames[k].propagate_cost()
+            np.testing.assert_array_equal(ctx.cutree_get_propagate_cost(k), want, err_msg="propagateCost of frame %d" % k)
+            np.testing.assert_array_equal(cutree[k][1], ref.frames[k].qp_cutree_offset(), err_msg="qpCuTreeOffset %d" % k)
+            touched += int(np.any(want))
+        assert touched >= 1
+    finally:
+        win.close()
+        ctx.close()
+        ref.close()

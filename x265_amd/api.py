@@ -455,3 +455,116 @@ class Context:
             self._chk(self.L.x265gpu_profile_read(self.h, k, C.byref(ms), C.byref(n), int(reset)))
             out[name] = (ms.value, n.value)
         return out
+
+
+# ---- the C++ host layer (x265_amd/host/lookahead_host.h) through its plain-C face ----
+HOST_LIB_PATH = os.path.join(_HERE, "libx265gpu_host.so")
+HOST_EXPORTS = (
+    "xgh_window_create", "xgh_window_destroy", "xgh_pre_lookahead", "xgh_set_wp", "xgh_set_slice_type",
+    "xgh_set_qp_offsets", "xgh_single_cost", "xgh_add", "xgh_finish_batch", "xgh_cost_est", "xgh_intra_mbs",
+    "xgh_is_weighted", "xgh_cu_tree", "xgh_status",
+)
+
+
+def load_host_library():
+    if HOST_LIB_PATH in _libs:
+        return _libs[HOST_LIB_PATH]
+    if not os.path.exists(HOST_LIB_PATH):
+        raise X265GpuError("%s not found: build first (python -c 'import __graft_entry__ as g; g.build()')" % HOST_LIB_PATH)
+    load_library()                      # the dependency, from the same directory
+    H = C.CDLL(HOST_LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    H.xgh_window_create.argtypes = [vp, i32, i32, i32]
+    H.xgh_window_create.restype = vp
+    H.xgh_window_destroy.argtypes = [vp]
+    H.xgh_window_destroy.restype = None
+    H.xgh_pre_lookahead.argtypes = [vp, i32, vp, vp, vp, vp]
+    H.xgh_set_wp.argtypes = [vp, i32, C.c_uint64, C.c_uint64]
+    H.xgh_set_wp.restype = None
+    H.xgh_set_slice_type.argtypes = [vp, i32, i32]
+    H.xgh_set_slice_type.restype = None
+    H.xgh_set_qp_offsets.argtypes = [vp, i32, vp, vp]
+    H.xgh_set_qp_offsets.restype = None
+    H.xgh_single_cost.argtypes = [vp, i32, i32, i32, i32]
+    H.xgh_single_cost.restype = i64
+    H.xgh_add.argtypes = [vp, i32, i32, i32]
+    H.xgh_add.restype = None
+    H.xgh_finish_batch.argtypes = [vp]
+    H.xgh_cost_est.argtypes = [vp, i32, i32, i32]
+    H.xgh_cost_est.restype = i64
+    H.xgh_intra_mbs.argtypes = [vp, i32, i32]
+    H.xgh_is_weighted.argtypes = [vp, i32, i32]
+    H.xgh_cu_tree.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.c_double, i32, i32]
+    H.xgh_status.argtypes = [vp]
+    _libs[HOST_LIB_PATH] = H
+    return H
+
+
+class HostWindow:
+    """One lookahead window driven by the C++ host classes (PreLookaheadGroup, CostEstimateGroup, LookaheadTLD,
+    CuTree of x265_amd/host/lookahead_host.h); frame i uses slot i of `ctx`."""
+
+    def __init__(self, ctx, nframes, weightp=False):
+        self.H = load_host_library()
+        self.ctx = ctx
+        self.n = nframes
+        self.h = self.H.xgh_window_create(ctx.h, nframes, int(weightp), ctx.depth)
+        if not self.h:
+            raise X265GpuError("xgh_window_create failed")
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.H.xgh_window_destroy(self.h)
+            self.h = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise X265GpuError("host layer status %d: %s" % (rc, self.ctx.L.x265gpu_last_error(self.ctx.h).decode()))
+
+    def pre_lookahead(self, lumas, inv_qscales=None):
+        n = len(lumas)
+        arrs = [np.ascontiguousarray(a, self.ctx.pix) for a in lumas]
+        invs = None if inv_qscales is None else [np.ascontiguousarray(a, np.int32) for a in inv_qscales]
+        frames = (C.c_int32 * n)(*range(n))
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        strides = (C.c_ssize_t * n)(*[a.shape[1] for a in arrs])
+        iq = None if invs is None else (C.c_void_p * n)(*[a.ctypes.data for a in invs])
+        self._chk(self.H.xgh_pre_lookahead(self.h, n, frames, ptrs, strides, iq))
+
+    def set_wp(self, frame, wp_sum, wp_ssd):
+        self.H.xgh_set_wp(self.h, frame, int(wp_sum), int(wp_ssd))
+
+    def set_slice_type(self, frame, t):
+        self.H.xgh_set_slice_type(self.h, frame, int(t))
+
+    def set_qp_offsets(self, frame, qp_aq, qp_cutree):
+        """float64 contiguous arrays; qp_cutree is updated in place by cu_tree()."""
+        assert qp_aq.dtype == np.float64 and qp_cutree.dtype == np.float64
+        self._keep += [qp_aq, qp_cutree]
+        self.H.xgh_set_qp_offsets(self.h, frame, _ptr(qp_aq), _ptr(qp_cutree))
+
+    def single_cost(self, p0, p1, b, intra_penalty=False):
+        v = self.H.xgh_single_cost(self.h, p0, p1, b, int(intra_penalty))
+        self._chk(self.H.xgh_status(self.h))
+        return v
+
+    def add(self, p0, p1, b):
+        self.H.xgh_add(self.h, p0, p1, b)
+
+    def finish_batch(self):
+        self._chk(self.H.xgh_finish_batch(self.h))
+
+    def cost_est(self, b, d0, d1):
+        return self.H.xgh_cost_est(self.h, b, d0, d1)
+
+    def intra_mbs(self, b, d0):
+        return self.H.xgh_intra_mbs(self.h, b, d0)
+
+    def is_weighted(self, b, d0):
+        return bool(self.H.xgh_is_weighted(self.h, b, d0))
+
+    def cu_tree(self, numframes, b_intra, fps_num=30, fps_denom=1, b_pyramid=False, weighted_bipred=False,
+                lookahead_depth=20, vbv_buffer_size=0, q_compress=0.6):
+        self._chk(self.H.xgh_cu_tree(self.h, fps_num, fps_denom, int(b_pyramid), int(weighted_bipred), lookahead_depth,
+                                     vbv_buffer_size, float(q_compress), numframes, int(b_intra)))

@@ -485,12 +485,28 @@ __device__ __forceinline__ void hex_search(BlockCtx<P>& c, int merange, int& bmx
 // the reference's strict '<' (COST_MV / COST_MV_X4 semantics, motion.cpp:263-323).
 // `mask` (wave-uniform) says which groups hold a candidate that may be accepted;
 // the others are neither loaded nor compared.
+// When every candidate of the pass (block and both MV-cost entries) lies inside what is staged in
+// LDS, the pass reads it there; the long-range steps, which no window covers, go to global memory.
 template <typename P>
 __device__ __forceinline__ void try_points(const BlockCtx<P>& c, int mx, int my, unsigned mask, int& bmx, int& bmy,
                                            int& bcost)
 {
     const bool active = ((mask >> c.g) & 1u) != 0;
-    const int cost = fpel_cost_g<P>(c, mx, my, active);
+    const bool staged = (unsigned)(c.relX + mx) <= (unsigned)(WIN - 8) && (unsigned)(c.relY + my) <= (unsigned)(WIN - 8) &&
+                        (unsigned)(4 * mx + c.tabBiasX) < (unsigned)TAB_N &&
+                        (unsigned)(4 * my + c.tabBiasY - TAB_N) < (unsigned)TAB_N;
+    int cost;
+    if (__builtin_amdgcn_ballot_w64(active && !staged) == 0)
+    {
+        // idle groups read the window's first block: any address inside the slice will do
+        const int wx = active ? mx : -c.relX, wy = active ? my : -c.relY;
+        const Row<P> ref = win_row<P>(c, wx, wy);
+        const int idx = (c.r & 1) ? 4 * wy + c.tabBiasY : 4 * wx + c.tabBiasX;
+        const int t = (active && c.r < 2) ? (int)((const XG_LDS uint16_t*)c.tab)[idx] : 0;
+        cost = reduce_cost<P, EV_SAD>(c, ref, t);
+    }
+    else
+        cost = fpel_cost_g<P>(c, mx, my, active);
     take_winner(wave_min(active ? make_key(cost, c.g + 1, c.g) : KEY_INVALID), mx, my, bmx, bmy, bcost);
 }
 
@@ -579,7 +595,7 @@ constexpr uint32_t H4X0 = 0xC4C4A688u, H4Y0 = 0x776655C4u, H4X1 = 0xA6C4C4C4u, H
 // uneven multi-hexagon search, lowres case (no extra candidates): motion.cpp:1142-1326.
 // Returns true when the hexagon walk must follow.
 template <typename P>
-__device__ __forceinline__ bool umh_search(const BlockCtx<P>& c, int pmx, int pmy, int merange, int& bmx, int& bmy,
+__device__ __forceinline__ bool umh_search(BlockCtx<P>& c, int pmx, int pmy, int merange, int& bmx, int& bmy,
                                            int& bcost)
 {
     const int scale = 4;   // sizeScale[LUMA_8x8] = (8*8) >> 4 (motion.cpp:123-153)
@@ -627,8 +643,10 @@ __device__ __forceinline__ bool umh_search(const BlockCtx<P>& c, int pmx, int pm
     umh_cross<P>(c, ox, oy, cross_start, merange, merange >> 1, bmx, bmy, bcost);
     try_points<P>(c, ox + nib(CORN_X, c.g & 3), oy + nib(CORN_Y, c.g & 3), x4_mask<P>(c, oy, CORN_Y, 0), bmx, bmy, bcost);
 
-    // hexagon grid of growing radius around the best so far
+    // hexagon grid of growing radius around the best so far; its first three radii (up to +-12) fit a
+    // window centred here
     const int hx = bmx, hy = bmy;
+    ensure_window<P>(c, hx, hy, 12);
     unsigned i = 1;
     do
     {

@@ -138,8 +138,16 @@ hipError_t launch_interp_block(hipStream_t s, int bpp, const void* pic, int stri
                                int depth, void* dOut);
 hipError_t launch_pad_picture(hipStream_t s, int bpp, const void* src, long long srcStride, void* dst, int stride, int rows,
                               int width, int height, int marginX, int marginY);
-hipError_t launch_pu_search(hipStream_t s, int bpp, const PuFrame& f, const PuJob* dJobs, int n, const uint16_t* costTab,
-                            int maxMvd, PuResult* dOut);
+// Jobs sorted into size classes: order[] lists job indices class after class (PUs of at most 2, 4, 8 tiles of
+// 8x4 / 4x4 pixels share a wave eight, four, two at a time; the rest own a wave each), count[] the class sizes.
+struct PuClasses
+{
+    const int* order;      // device
+    int count[4];
+    int maxPasses64;       // largest ceil(tiles / 16) in the last class
+};
+hipError_t launch_pu_search(hipStream_t s, int bpp, const PuFrame& f, const PuJob* dJobs, const PuClasses& classes,
+                            const uint16_t* costTab, int maxMvd, PuResult* dOut);
 // AQ block energies: tight (unpadded) planes on the device, 4:2:0
 struct AqJob
 {

@@ -9,7 +9,7 @@
 // check (motion.cpp:1762-1768).  Every PU shape whose width and height are
 // multiples of 4 up to 64x64 is handled.
 //
-// One wave per PU.  The PU is cut into tiles of 8x4 pixels (4x4 when the width
+// One wave per PU, or per 2 / 4 / 8 PUs of at most 8 / 4 / 2 tiles (see pu_search_kernel).  The PU is cut into tiles of 8x4 pixels (4x4 when the width
 // is not a multiple of 8, which is also how the reference tiles its SATD,
 // source/common/pixel.cpp:1148-1172); a quad of lanes holds the four rows of a
 // tile, sixteen tiles are measured per pass and a 64x64 PU takes eight passes.
@@ -67,8 +67,10 @@ struct PuCtx
     int x, y, w, h;                // the PU
     int minX, maxX, minY, maxY;    // legal block origins (inside the padded picture)
     int passes;
-    int lane;
-    const XG_LDS uint32_t* rec;    // this wave's records, [pass][lane][PU_REC_DW]
+    int lane;                      // lane inside the PU's share of the wave
+    int phys;                      // lane inside the wave
+    int lpp;                       // lanes per PU: 64, or 32 / 16 / 8 when several small PUs share a wave
+    const XG_LDS uint32_t* rec;    // this wave's records, [pass][lane of the wave][PU_REC_DW]
     int minx, miny, maxx, maxy;    // full-pel search bounds
     const XG_GLOBAL uint16_t* cx;  // MV-cost table shifted by the predictor: cx[q] = cost[q - mvp.x]
     const XG_GLOBAL uint16_t* cy;
@@ -88,6 +90,24 @@ __device__ __forceinline__ int wave_sum(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
     return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Sum over the lanes of one PU.  A PU that owns the wave gets a wave-uniform scalar back; PUs that share
+// a wave get the total in each of their lanes (and everything decided from it becomes per-lane code, so
+// the PUs of a wave walk their own candidate sequences).  c.lpp is a compile-time constant of the kernel
+// instance once everything is inlined.
+template <typename P> __device__ __forceinline__ int pu_sum(const PuCtx<P>& c, int v)
+{
+    if (c.lpp == 64)
+        return wave_sum(v);
+    v += dpp<DPP_XOR1>(v);
+    v += dpp<DPP_XOR2>(v);
+    v += dpp<DPP_HALF_MIRROR>(v);
+    if (c.lpp >= 16)
+        v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);   // row_ror:8
+    if (c.lpp == 32)
+        v += __builtin_amdgcn_ds_bpermute(4 * (c.phys ^ 16), v);          // the other row of the pair
+    return v;
 }
 
 // BitCost::mvcost (source/encoder/bitcost.h:56): uint16 sum of the two table entries
@@ -201,7 +221,7 @@ template <typename P, bool SATD> __device__ __forceinline__ int block_cost(const
 #pragma unroll 1
     for (int k = 0; k < c.passes; k++)
     {
-        const XG_LDS uint32_t* r = c.rec + (k * 64 + c.lane) * PU_REC_DW;
+        const XG_LDS uint32_t* r = c.rec + (k * 64 + c.phys) * PU_REC_DW;
         const uint32_t f0 = r[0], f1 = r[1], f2 = r[2], f3 = r[3], mask = r[5];
         const int off = (int)r[4];
         Row<P> row;
@@ -227,7 +247,7 @@ template <typename P, bool SATD> __device__ __forceinline__ int block_cost(const
     }
     if (SATD)
         acc = (c.lane & 3) ? 0u : acc;      // every lane of a quad holds its tile's value: count it once
-    return wave_sum((int)acc);
+    return pu_sum<P>(c, (int)acc);
 }
 
 template <typename P> __device__ __forceinline__ int fpel_cost(const PuCtx<P>& c, int mx, int my)
@@ -823,17 +843,18 @@ __device__ __forceinline__ void stage_encode_block(PuCtx<P>& c, const XG_GLOBAL 
 {
     const int segW = (c.w & 7) ? 4 : 8;
     const int tilesX = c.w / segW, ntiles = tilesX * (c.h >> 2);
-    c.passes = (ntiles + 15) >> 4;
+    const int tilesPerPass = c.lpp >> 2;
+    c.passes = (ntiles + tilesPerPass - 1) / tilesPerPass;
     const XG_GLOBAL P* fenc = fencPic + ((long long)c.y * stride + c.x);
     for (int k = 0; k < c.passes; k++)
     {
-        const int t = k * 16 + (c.lane >> 2);
+        const int t = k * tilesPerPass + (c.lane >> 2);
         const bool valid = t < ntiles;
         const int ty = valid ? t / tilesX : 0, tx = valid ? t - ty * tilesX : 0;
         const int off = (ty * 4 + (c.lane & 3)) * stride + tx * segW;
         const uint32_t mask = valid ? (segW == 8 ? 0xffffffffu : 0x0000ffffu) : 0u;
         const Cols fc = pair_cols<P>(load_row_g<P>(fenc, off));
-        XG_LDS uint32_t* r = rec + (k * 64 + c.lane) * PU_REC_DW;
+        XG_LDS uint32_t* r = rec + (k * 64 + c.phys) * PU_REC_DW;
         r[0] = fc.q[0] & mask;
         r[1] = fc.q[1] & mask;
         r[2] = fc.q[2] & mask;
@@ -844,16 +865,24 @@ __device__ __forceinline__ void stage_encode_block(PuCtx<P>& c, const XG_GLOBAL 
     lds_handover();
 }
 
-template <typename P>
-__global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, int n, PuFrame f, const uint16_t* costTab,
-                                                        int maxMvd, PuResult* out)
+// LPP lanes per PU.  64: one PU per wave, `order` unused or a list of job indices.  Smaller: 64 / LPP
+// PUs of at most LPP / 4 tiles share a wave, each in its own lanes with its own control flow; `order`
+// lists the jobs of that size class and results go back to their own places.
+template <typename P, int LPP>
+__global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, const int* order, int n, PuFrame f,
+                                                        const uint16_t* costTab, int maxMvd, PuResult* out)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t puLds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int pu = blockIdx.x * 4 + wave;
-    if (pu >= n)
-        return;
+    const int phys = threadIdx.x & 63;
+    const int lane = phys & (LPP - 1);
+    constexpr int PER_WAVE = 64 / LPP;
+    if ((blockIdx.x * 4 + wave) * PER_WAVE >= n)
+        return;                               // the whole wave has nothing to do
+    int slotIdx = (blockIdx.x * 4 + wave) * PER_WAVE + phys / LPP;
+    const bool live = slotIdx < n;            // a share without a PU repeats the last one and stores nothing
+    slotIdx = live ? slotIdx : n - 1;
+    const int pu = order ? order[slotIdx] : slotIdx;
     const PuJob& job = jobs[pu];      // read in place: indexing mvc[] of a register copy would go through scratch
     XG_LDS uint32_t* rec = (XG_LDS uint32_t*)puLds + wave * (f.maxPasses * 64 * PU_REC_DW);
 
@@ -869,6 +898,8 @@ __global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, int n
     c.minY = -f.marginY + 4;
     c.maxY = f.height + f.marginY - job.h - 5;
     c.lane = lane;
+    c.phys = phys;
+    c.lpp = LPP;
     c.rec = rec;
     c.minx = job.minx;
     c.miny = job.miny;
@@ -887,7 +918,7 @@ __global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, int n
     if (f.method == PU_AREA_DIAMOND)
     {
         area_diamond_search<P>(c);
-        if (lane == 0)
+        if (live && lane == 0)
         {
             PuResult r;
             r.mvx = c.bmx;                 // full-pel, as diamondSearch returns it
@@ -1024,7 +1055,7 @@ __global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, int n
         if (cost <= bcost)
             bqx = bqy = 0;
     }
-    if (lane == 0)
+    if (live && lane == 0)
     {
         PuResult r;
         r.mvx = bqx;
@@ -1104,6 +1135,8 @@ __global__ void __launch_bounds__(256) block_compare_kernel(const BlockJob* jobs
     c.minY = -f.marginY + 4;
     c.maxY = f.height + f.marginY - job.h - 5;
     c.lane = lane;
+    c.phys = lane;
+    c.lpp = 64;
     c.rec = rec;
     c.depth = f.depth;
     int cost;
@@ -1193,17 +1226,42 @@ hipError_t launch_pad_picture(hipStream_t s, int bpp, const void* src, long long
     return hipGetLastError();
 }
 
-hipError_t launch_pu_search(hipStream_t s, int bpp, const PuFrame& f, const PuJob* dJobs, int n, const uint16_t* costTab,
-                            int maxMvd, PuResult* dOut)
+template <typename P, int LPP>
+static void launch_pu_class(hipStream_t s, const PuFrame& f, const PuJob* dJobs, const int* dOrder, int n, int maxPasses,
+                            const uint16_t* costTab, int maxMvd, PuResult* dOut)
 {
     if (n <= 0)
-        return hipSuccess;
-    const size_t lds = (size_t)4 * f.maxPasses * 64 * PU_REC_DW * sizeof(uint32_t);
-    dim3 grid((n + 3) / 4);
+        return;
+    PuFrame fc = f;
+    fc.maxPasses = maxPasses;
+    const size_t lds = (size_t)4 * maxPasses * 64 * PU_REC_DW * sizeof(uint32_t);
+    const int perWave = 64 / LPP;
+    const int waves = (n + perWave - 1) / perWave;
+    hipLaunchKernelGGL((pu_search_kernel<P, LPP>), dim3((waves + 3) / 4), dim3(256), lds, s, dJobs, dOrder, n, fc, costTab,
+                       maxMvd, dOut);
+}
+
+template <typename P>
+static void launch_pu_classes(hipStream_t s, const PuFrame& f, const PuJob* dJobs, const PuClasses& k, const uint16_t* costTab,
+                              int maxMvd, PuResult* dOut)
+{
+    const int* o = k.order;
+    launch_pu_class<P, 8>(s, f, dJobs, o, k.count[0], 1, costTab, maxMvd, dOut);
+    o += k.count[0];
+    launch_pu_class<P, 16>(s, f, dJobs, o, k.count[1], 1, costTab, maxMvd, dOut);
+    o += k.count[1];
+    launch_pu_class<P, 32>(s, f, dJobs, o, k.count[2], 1, costTab, maxMvd, dOut);
+    o += k.count[2];
+    launch_pu_class<P, 64>(s, f, dJobs, o, k.count[3], k.maxPasses64, costTab, maxMvd, dOut);
+}
+
+hipError_t launch_pu_search(hipStream_t s, int bpp, const PuFrame& f, const PuJob* dJobs, const PuClasses& classes,
+                            const uint16_t* costTab, int maxMvd, PuResult* dOut)
+{
     if (bpp == 1)
-        hipLaunchKernelGGL(pu_search_kernel<uint8_t>, grid, dim3(256), lds, s, dJobs, n, f, costTab, maxMvd, dOut);
+        launch_pu_classes<uint8_t>(s, f, dJobs, classes, costTab, maxMvd, dOut);
     else
-        hipLaunchKernelGGL(pu_search_kernel<uint16_t>, grid, dim3(256), lds, s, dJobs, n, f, costTab, maxMvd, dOut);
+        launch_pu_classes<uint16_t>(s, f, dJobs, classes, costTab, maxMvd, dOut);
     return hipGetLastError();
 }
 

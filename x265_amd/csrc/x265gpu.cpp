@@ -1212,6 +1212,12 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
     if (subpelRefine < 0 || subpelRefine > 7 || merange < 1 || merange > 32767)
         return fail(ctx, X265GPU_ERR_ARG, "pu_motion_estimate: subpelRefine or merange");
     int maxPasses = 1;
+    // size classes: PUs of at most 2 / 4 / 8 tiles share a wave (8 / 4 / 2 at a time), the rest own one each;
+    // X265GPU_PU_PACK=0 gives every PU a wave
+    static const bool pack = []() { const char* e = getenv("X265GPU_PU_PACK"); return !e || atoi(e) != 0; }();
+    std::vector<int> cls(n);
+    PuClasses classes;
+    memset(&classes, 0, sizeof(classes));
     for (int i = 0; i < n; i++)
     {
         const x265gpu_pu_job& j = jobs[i];
@@ -1223,23 +1229,40 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
             j.y + j.mvminY < -ctx->fullMarginY + 8 || j.y + j.h + j.mvmaxY > ctx->fullH + ctx->fullMarginY - 8)
             return fail(ctx, X265GPU_ERR_ARG, "pu_motion_estimate: bad job");
         const int segW = (j.w & 7) ? 4 : 8;
-        const int passes = ((j.w / segW) * (j.h / 4) + 15) / 16;
-        maxPasses = passes > maxPasses ? passes : maxPasses;
+        const int tiles = (j.w / segW) * (j.h / 4);
+        cls[i] = !pack ? 3 : tiles <= 2 ? 0 : tiles <= 4 ? 1 : tiles <= 8 ? 2 : 3;
+        classes.count[cls[i]]++;
+        if (cls[i] == 3)
+        {
+            const int passes = (tiles + 15) / 16;
+            maxPasses = passes > maxPasses ? passes : maxPasses;
+        }
     }
-    const size_t jobBytes = align256(sizeof(PuJob) * (size_t)n), outBytes = sizeof(PuResult) * (size_t)n;
-    int rc = ensure_pu_buf(ctx, jobBytes + outBytes);
+    classes.maxPasses64 = maxPasses;
+    std::vector<int> order(n);
+    {
+        int at[4] = { 0, classes.count[0], classes.count[0] + classes.count[1],
+                      classes.count[0] + classes.count[1] + classes.count[2] };
+        for (int i = 0; i < n; i++)
+            order[at[cls[i]]++] = i;
+    }
+    const size_t jobBytes = align256(sizeof(PuJob) * (size_t)n), outBytes = align256(sizeof(PuResult) * (size_t)n);
+    const size_t orderBytes = sizeof(int) * (size_t)n;
+    int rc = ensure_pu_buf(ctx, jobBytes + outBytes + orderBytes);
     if (rc)
         return rc;
     HIPCHK(hipMemcpyAsync(ctx->puBuf, jobs, sizeof(PuJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->puBuf + jobBytes + outBytes, order.data(), orderBytes, hipMemcpyHostToDevice, ctx->stream));
+    classes.order = (const int*)(ctx->puBuf + jobBytes + outBytes);
     PuFrame f = pu_frame(ctx, slotFenc, slotRef);
     f.method = searchMethod;
     f.merange = merange;
     f.subpelRefine = subpelRefine;
     f.maxPasses = maxPasses;
-    HIPCHK(launch_pu_search(ctx->stream, ctx->bpp, f, (const PuJob*)ctx->puBuf, n, ctx->meCostCentre, ctx->meMaxMvd,
+    HIPCHK(launch_pu_search(ctx->stream, ctx->bpp, f, (const PuJob*)ctx->puBuf, classes, ctx->meCostCentre, ctx->meMaxMvd,
                             (PuResult*)(ctx->puBuf + jobBytes)));
-    HIPCHK(hipMemcpyAsync(out, ctx->puBuf + jobBytes, outBytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpyAsync(out, ctx->puBuf + jobBytes, sizeof(PuResult) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));    // also keeps `order` alive until its upload is done
     return X265GPU_OK;
 }
 

@@ -232,6 +232,7 @@ struct McstfRef
     const int32_t* prev;      // the coarser level's vectors, or null on level 0
     int32_t* least;           // running best error per block
     int32_t* error;           // level 3: the normalised error that the filter reads
+    int32_t* spec;            // level 3: per block { own x, own y, error of left's vector, error of above's } (4 ints)
 };
 hipError_t launch_mcstf_level(hipStream_t s, int bpp, int level, const McstfLevel& lv, const McstfRef* dRefs, int numRefs);
 hipError_t launch_weight_cost(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJob);

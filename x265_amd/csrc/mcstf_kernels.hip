@@ -359,8 +359,56 @@ __global__ void __launch_bounds__(256) mcstf_search8_kernel(McstfLevel lv, const
     }
 }
 
-// One wave per 16-line row task: its first block row tries the left vector only, its second
-// also the vector of the block above, before the left one (temporalfilter.cpp:854-881).
+// The closing candidates of the last level are the FINAL vectors of the left block and, inside a
+// row task, of the block above (temporalfilter.cpp:854-881): a chain along the row.  Most of the
+// time a block's final vector is the one its own search found, so this pass measures, for every
+// block at once, the errors of its left and above neighbours' own-search vectors and keeps a copy
+// of those vectors; the chain below then only has to compare numbers unless a neighbour's vector
+// was itself replaced on the way.  spec[4 * idx ..] = { own x, own y, error of left's, error of above's }.
+template <typename P>
+__global__ void __launch_bounds__(256) mcstf_spec8_kernel(McstfLevel lv, const McstfRef* refs)
+{
+    __shared__ Lds8 lds[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = blockIdx.x * 4 + wave;
+    if (blk >= lv.blocksX * lv.blocksY)
+        return;
+    XG_LDS Lds8* l = (XG_LDS Lds8*)&lds[wave];
+    const McstfRef rf = refs[blockIdx.y];
+    const int bxi = blk % lv.blocksX, byi = blk / lv.blocksX;
+    const int idx = byi * lv.mvStride + bxi;
+    const XG_GLOBAL P* src = as_global<P>(lv.src);
+    const XG_GLOBAL P* buf = as_global<P>(rf.buf);
+    const XG_GLOBAL int32_t* mvs = as_global<int32_t>(rf.mvs);
+    const int maxVal = (1 << lv.depth) - 1;
+    const int o = (int)src[(long long)(byi * 8 + (lane >> 3)) * lv.stride + bxi * 8 + (lane & 7)];
+    const int mx = mvs[2 * idx], my = mvs[2 * idx + 1];
+    int eL = -1, eA = -1;
+    if (bxi > 0)
+    {
+        const int vx = mvs[2 * (idx - 1)], vy = mvs[2 * (idx - 1) + 1];
+        if (vx != mx || vy != my)
+            eL = error8<P>(l, buf, lv.stride, bxi * 8, byi * 8, vx, vy, o, maxVal, lane);
+    }
+    if (byi & 1)
+    {
+        const int vx = mvs[2 * (idx - lv.mvStride)], vy = mvs[2 * (idx - lv.mvStride) + 1];
+        if (vx != mx || vy != my)
+            eA = error8<P>(l, buf, lv.stride, bxi * 8, byi * 8, vx, vy, o, maxVal, lane);
+    }
+    if (lane == 0)
+    {
+        rf.spec[4 * idx] = mx;
+        rf.spec[4 * idx + 1] = my;
+        rf.spec[4 * idx + 2] = eL;
+        rf.spec[4 * idx + 3] = eA;
+    }
+}
+
+// One wave per 16-line row task, 64 blocks of its two rows at a time: a lane holds one block's
+// numbers, the walk reads them lane by lane.  A candidate is measured here only when the
+// neighbour's final vector is not the one the pass above measured.
 template <typename P>
 __global__ void __launch_bounds__(64) mcstf_chain8_kernel(McstfLevel lv, const McstfRef* refs)
 {
@@ -370,58 +418,104 @@ __global__ void __launch_bounds__(64) mcstf_chain8_kernel(McstfLevel lv, const M
     const McstfRef rf = refs[blockIdx.y];
     const XG_GLOBAL P* src = as_global<P>(lv.src);
     const XG_GLOBAL P* buf = as_global<P>(rf.buf);
-    const XG_GLOBAL int32_t* mvs = as_global<int32_t>(rf.mvs);
+    const XG_GLOBAL int32_t* spec = as_global<int32_t>(rf.spec);
+    const XG_GLOBAL int32_t* leastIn = as_global<int32_t>(rf.least);
     const int maxVal = (1 << lv.depth) - 1;
-    for (int sub = 0; sub < 2; sub++)
+    const int rows = min(2, lv.blocksY - 2 * (int)blockIdx.x);
+    int leftx[2] = { 0, 0 }, lefty[2] = { 0, 0 };          // final vector of the previous block of each row
+    int leftOwnX[2] = { 0, 0 }, leftOwnY[2] = { 0, 0 };    // and what its own search had found
+    for (int x0 = 0; x0 < lv.blocksX; x0 += 64)
     {
-        const int byi = 2 * blockIdx.x + sub;
-        if (byi >= lv.blocksY)
-            break;
-        const int row = byi * lv.mvStride;
-        int leftx = 0, lefty = 0;
-        for (int bxi = 0; bxi < lv.blocksX; bxi++)
+        const int cnt = min(64, lv.blocksX - x0);
+        int finx0 = 0, finy0 = 0;                           // row 0's final vectors of this chunk, one per lane
+        for (int sub = 0; sub < rows; sub++)
         {
-            const int idx = row + bxi;
-            int mx = mvs[2 * idx], my = mvs[2 * idx + 1];
-            int least = rf.least[idx];
-            bool changed = false;
-            const int o = (int)src[(long long)(byi * 8 + (lane >> 3)) * lv.stride + bxi * 8 + (lane & 7)];
-            if (sub)
+            const int byi = 2 * blockIdx.x + sub;
+            const int idx0 = byi * lv.mvStride + x0;
+            int ownx = 0, owny = 0, eL = -1, eA = -1, least = 0;
+            if (lane < cnt)
             {
-                // written by this wave one row ago: read past the L1 it may still sit in
-                const int ax = __hip_atomic_load(mvs + 2 * (idx - lv.mvStride), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int ay = __hip_atomic_load(mvs + 2 * (idx - lv.mvStride) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (ax != mx || ay != my)
-                {
-                    const int e = error8<P>(l, buf, lv.stride, bxi * 8, byi * 8, ax, ay, o, maxVal, lane);
-                    if (e < least)
+                ownx = spec[4 * (idx0 + lane)];
+                owny = spec[4 * (idx0 + lane) + 1];
+                eL = spec[4 * (idx0 + lane) + 2];
+                eA = spec[4 * (idx0 + lane) + 3];
+                least = leastIn[idx0 + lane];
+            }
+            // what the block above found on its own: valid for eA only if that is still its final vector
+            int aboveOwnX = 0, aboveOwnY = 0;
+            if (sub && lane < cnt)
+            {
+                aboveOwnX = spec[4 * (idx0 - lv.mvStride + lane)];
+                aboveOwnY = spec[4 * (idx0 - lv.mvStride + lane) + 1];
+            }
+            int outx = ownx, outy = owny, outLeast = least;
+            for (int i = 0; i < cnt; i++)
+            {
+                const int bxi = x0 + i;
+                const int ox = __builtin_amdgcn_readlane(ownx, i), oy = __builtin_amdgcn_readlane(owny, i);
+                const int ownLeast = __builtin_amdgcn_readlane(least, i);
+                int mx = ox, my = oy, cur = ownLeast;
+                int o = 0;
+                bool haveO = false;
+                auto measure = [&](int vx, int vy) {
+                    if (!haveO)
                     {
-                        mx = ax;
-                        my = ay;
-                        least = e;
-                        changed = true;
+                        o = (int)src[(long long)(byi * 8 + (lane >> 3)) * lv.stride + bxi * 8 + (lane & 7)];
+                        haveO = true;
+                    }
+                    return error8<P>(l, buf, lv.stride, bxi * 8, byi * 8, vx, vy, o, maxVal, lane);
+                };
+                if (sub)
+                {
+                    const int ax = __builtin_amdgcn_readlane(finx0, i), ay = __builtin_amdgcn_readlane(finy0, i);
+                    if (ax != mx || ay != my)
+                    {
+                        const bool asMeasured = ax == __builtin_amdgcn_readlane(aboveOwnX, i) &&
+                                                ay == __builtin_amdgcn_readlane(aboveOwnY, i);
+                        const int e = asMeasured ? __builtin_amdgcn_readlane(eA, i) : measure(ax, ay);
+                        if (e < cur)
+                        {
+                            mx = ax;
+                            my = ay;
+                            cur = e;
+                        }
                     }
                 }
-            }
-            if (bxi > 0 && (leftx != mx || lefty != my))
-            {
-                const int e = error8<P>(l, buf, lv.stride, bxi * 8, byi * 8, leftx, lefty, o, maxVal, lane);
-                if (e < least)
+                if (bxi > 0 && (leftx[sub] != mx || lefty[sub] != my))
                 {
-                    mx = leftx;
-                    my = lefty;
-                    least = e;
-                    changed = true;
+                    int e;
+                    if (leftx[sub] == ox && lefty[sub] == oy)
+                        e = ownLeast;                        // the block's own vector again (it lost to the one above)
+                    else if (leftx[sub] == leftOwnX[sub] && lefty[sub] == leftOwnY[sub])
+                        e = __builtin_amdgcn_readlane(eL, i);
+                    else
+                        e = measure(leftx[sub], lefty[sub]);
+                    if (e < cur)
+                    {
+                        mx = leftx[sub];
+                        my = lefty[sub];
+                        cur = e;
+                    }
                 }
+                outx = lane == i ? mx : outx;
+                outy = lane == i ? my : outy;
+                outLeast = lane == i ? cur : outLeast;
+                leftx[sub] = mx;
+                lefty[sub] = my;
+                leftOwnX[sub] = ox;
+                leftOwnY[sub] = oy;
             }
-            if (changed && lane == 0)
+            if (lane < cnt)
             {
-                __hip_atomic_store(rf.mvs + 2 * idx, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(rf.mvs + 2 * idx + 1, my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                rf.least[idx] = least;
+                rf.mvs[2 * (idx0 + lane)] = outx;
+                rf.mvs[2 * (idx0 + lane) + 1] = outy;
+                rf.least[idx0 + lane] = outLeast;
             }
-            leftx = mx;
-            lefty = my;
+            if (!sub)
+            {
+                finx0 = outx;
+                finy0 = outy;
+            }
         }
     }
 }
@@ -477,12 +571,14 @@ hipError_t launch_mcstf_level(hipStream_t s, int bpp, int level, const McstfLeve
         if (bpp == 1)
         {
             hipLaunchKernelGGL(mcstf_search8_kernel<uint8_t>, gridBlocks, dim3(256), 0, s, lv, dRefs);
+            hipLaunchKernelGGL(mcstf_spec8_kernel<uint8_t>, gridBlocks, dim3(256), 0, s, lv, dRefs);
             hipLaunchKernelGGL(mcstf_chain8_kernel<uint8_t>, gridTasks, dim3(64), 0, s, lv, dRefs);
             hipLaunchKernelGGL(mcstf_finish8_kernel<uint8_t>, gridBlocks, dim3(256), 0, s, lv, dRefs);
         }
         else
         {
             hipLaunchKernelGGL(mcstf_search8_kernel<uint16_t>, gridBlocks, dim3(256), 0, s, lv, dRefs);
+            hipLaunchKernelGGL(mcstf_spec8_kernel<uint16_t>, gridBlocks, dim3(256), 0, s, lv, dRefs);
             hipLaunchKernelGGL(mcstf_chain8_kernel<uint16_t>, gridTasks, dim3(64), 0, s, lv, dRefs);
             hipLaunchKernelGGL(mcstf_finish8_kernel<uint16_t>, gridBlocks, dim3(256), 0, s, lv, dRefs);
         }

@@ -1290,7 +1290,7 @@ int x265gpu_mcstf_motion_search(x265gpu_ctx* ctx, int32_t slotCur, int32_t numRe
     if (!n16)
         return fail(ctx, X265GPU_ERR_UNSUPPORTED, "mcstf_motion_search: picture smaller than one block");
     const size_t perRef = align256(3 * n16 * 2 * sizeof(int32_t)) + align256(n4 * 2 * sizeof(int32_t)) +
-                          2 * align256(n4 * sizeof(int32_t));
+                          2 * align256(n4 * sizeof(int32_t)) + align256(n4 * 4 * sizeof(int32_t));
     const size_t total = perRef * numRefs;
     if (total > ctx->mcstfBufSize)
     {
@@ -1309,7 +1309,7 @@ int x265gpu_mcstf_motion_search(x265gpu_ctx* ctx, int32_t slotCur, int32_t numRe
     if (rc)
         return rc;
 
-    struct RefArrays { int32_t* coarse[3]; int32_t* mvs; int32_t* error; int32_t* least; };
+    struct RefArrays { int32_t* coarse[3]; int32_t* mvs; int32_t* error; int32_t* least; int32_t* spec; };
     std::vector<RefArrays> arr(numRefs);
     for (int r = 0; r < numRefs; r++)
     {
@@ -1322,6 +1322,8 @@ int x265gpu_mcstf_motion_search(x265gpu_ctx* ctx, int32_t slotCur, int32_t numRe
         arr[r].error = (int32_t*)p;
         p += align256(n4 * sizeof(int32_t));
         arr[r].least = (int32_t*)p;
+        p += align256(n4 * sizeof(int32_t));
+        arr[r].spec = (int32_t*)p;
     }
     const size_t fullOrigin = ((size_t)ctx->fullMarginY * ctx->fullStride + ctx->fullMarginX) * ctx->bpp;
     const Slot& sc = ctx->slots[slotCur];
@@ -1374,6 +1376,7 @@ int x265gpu_mcstf_motion_search(x265gpu_ctx* ctx, int32_t slotCur, int32_t numRe
             refs[r].prev = level == 0 ? nullptr : arr[r].coarse[level - 1];
             refs[r].least = arr[r].least;
             refs[r].error = arr[r].error;
+            refs[r].spec = arr[r].spec;
         }
         const size_t off = level * align256(sizeof(McstfRef) * numRefs);
         rc = upload_jobs(ctx, off, refs.data(), sizeof(McstfRef) * numRefs, level == 0);

@@ -198,6 +198,9 @@ def main():
     gather_buf = None
     if distributed:
         local = torch.zeros((n_cost, 3), dtype=torch.int64, device="cuda")
+        cost_dtype = np.dtype([("costEst", "<i8"), ("costEstAq", "<i8"), ("intraMbs", "<i4"), ("reserved", "<i4")])
+        host = np.zeros((n_cost, 3), np.int64)
+        offs = [0, len(a1), len(a1) + len(a2)]
         gather_buf = [torch.zeros_like(local) for _ in range(world)]
 
     def step():
@@ -206,7 +209,11 @@ def main():
         ctx._chk(ctx.L.x265gpu_estimate_costs(ctx.h, len(a1), a1, o1))
         ctx._chk(ctx.L.x265gpu_estimate_costs(ctx.h, len(a2), a2, o2))
         if distributed:
-            host = np.array([(o.costEst, o.costEstAq, o.intraMbs) for o in list(o1) + list(o2)], np.int64)
+            for k, o in enumerate((o1, o2)):        # x265gpu_frame_cost records viewed in place, no per-record Python work
+                rec = np.frombuffer(o, dtype=cost_dtype)
+                host[offs[k]:offs[k + 1], 0] = rec["costEst"]
+                host[offs[k]:offs[k + 1], 1] = rec["costEstAq"]
+                host[offs[k]:offs[k + 1], 2] = rec["intraMbs"]
             local.copy_(torch.from_numpy(host))
             dist.all_gather(gather_buf, local)
 

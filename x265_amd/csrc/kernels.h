@@ -146,8 +146,10 @@ struct PuClasses
     int count[4];
     int maxPasses64;       // largest ceil(tiles / 16) in the last class
 };
-hipError_t launch_pu_search(hipStream_t s, int bpp, const PuFrame& f, const PuJob* dJobs, const PuClasses& classes,
-                            const uint16_t* costTab, int maxMvd, PuResult* dOut);
+// the shared-wave classes run on aux.side[0] beside the one-PU-per-wave class on s (when aux has a side stream)
+hipError_t launch_pu_search(hipStream_t s, const SearchStreams& aux, int bpp, const PuFrame& f, const PuJob* dJobs,
+                            const PuClasses& classes, const uint16_t* costTab, int maxMvd, PuResult* dOut);
+
 // AQ block energies: tight (unpadded) planes on the device, 4:2:0
 struct AqJob
 {

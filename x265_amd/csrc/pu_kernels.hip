@@ -1241,28 +1241,49 @@ static void launch_pu_class(hipStream_t s, const PuFrame& f, const PuJob* dJobs,
                        maxMvd, dOut);
 }
 
+// the shared-wave classes on `small`, the wave-per-PU class on `big`
 template <typename P>
-static void launch_pu_classes(hipStream_t s, const PuFrame& f, const PuJob* dJobs, const PuClasses& k, const uint16_t* costTab,
-                              int maxMvd, PuResult* dOut)
+static void launch_pu_classes(hipStream_t small, hipStream_t big, const PuFrame& f, const PuJob* dJobs, const PuClasses& k,
+                              const uint16_t* costTab, int maxMvd, PuResult* dOut)
 {
     const int* o = k.order;
-    launch_pu_class<P, 8>(s, f, dJobs, o, k.count[0], 1, costTab, maxMvd, dOut);
+    launch_pu_class<P, 8>(small, f, dJobs, o, k.count[0], 1, costTab, maxMvd, dOut);
     o += k.count[0];
-    launch_pu_class<P, 16>(s, f, dJobs, o, k.count[1], 1, costTab, maxMvd, dOut);
+    launch_pu_class<P, 16>(small, f, dJobs, o, k.count[1], 1, costTab, maxMvd, dOut);
     o += k.count[1];
-    launch_pu_class<P, 32>(s, f, dJobs, o, k.count[2], 1, costTab, maxMvd, dOut);
+    launch_pu_class<P, 32>(small, f, dJobs, o, k.count[2], 1, costTab, maxMvd, dOut);
     o += k.count[2];
-    launch_pu_class<P, 64>(s, f, dJobs, o, k.count[3], k.maxPasses64, costTab, maxMvd, dOut);
+    launch_pu_class<P, 64>(big, f, dJobs, o, k.count[3], k.maxPasses64, costTab, maxMvd, dOut);
 }
 
-hipError_t launch_pu_search(hipStream_t s, int bpp, const PuFrame& f, const PuJob* dJobs, const PuClasses& classes,
-                            const uint16_t* costTab, int maxMvd, PuResult* dOut)
+// The size classes are independent: with a side stream the shared-wave classes run beside the
+// wave-per-PU class and fill each other's tails.
+hipError_t launch_pu_search(hipStream_t s, const SearchStreams& aux, int bpp, const PuFrame& f, const PuJob* dJobs,
+                            const PuClasses& classes, const uint16_t* costTab, int maxMvd, PuResult* dOut)
 {
+    const bool split = aux.count > 0 && classes.count[3] > 0 && classes.count[0] + classes.count[1] + classes.count[2] > 0;
+    hipStream_t small = s;
+    if (split)
+    {
+        hipError_t e = hipEventRecord(aux.fork, s);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(aux.side[0], aux.fork, 0);
+        if (e != hipSuccess)
+            return e;
+        small = aux.side[0];
+    }
     if (bpp == 1)
-        launch_pu_classes<uint8_t>(s, f, dJobs, classes, costTab, maxMvd, dOut);
+        launch_pu_classes<uint8_t>(small, s, f, dJobs, classes, costTab, maxMvd, dOut);
     else
-        launch_pu_classes<uint16_t>(s, f, dJobs, classes, costTab, maxMvd, dOut);
-    return hipGetLastError();
+        launch_pu_classes<uint16_t>(small, s, f, dJobs, classes, costTab, maxMvd, dOut);
+    hipError_t e = hipGetLastError();
+    if (split && e == hipSuccess)
+    {
+        e = hipEventRecord(aux.join[0], aux.side[0]);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(s, aux.join[0], 0);
+    }
+    return e;
 }
 
 hipError_t launch_block_compare(hipStream_t s, int bpp, const PuFrame& f, const BlockJob* dJobs, int n, int* dOut)

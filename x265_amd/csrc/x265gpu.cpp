@@ -1259,7 +1259,7 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
     f.merange = merange;
     f.subpelRefine = subpelRefine;
     f.maxPasses = maxPasses;
-    HIPCHK(launch_pu_search(ctx->stream, ctx->bpp, f, (const PuJob*)ctx->puBuf, classes, ctx->meCostCentre, ctx->meMaxMvd,
+    HIPCHK(launch_pu_search(ctx->stream, ctx->searchAux, ctx->bpp, f, (const PuJob*)ctx->puBuf, classes, ctx->meCostCentre, ctx->meMaxMvd,
                             (PuResult*)(ctx->puBuf + jobBytes)));
     HIPCHK(hipMemcpyAsync(out, ctx->puBuf + jobBytes, sizeof(PuResult) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));    // also keeps `order` alive until its upload is done

@@ -284,16 +284,25 @@ int x265gpu_mcstf_motion_search(x265gpu_ctx* ctx, int32_t slotCur, int32_t numRe
 int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const void* u, const void* v, intptr_t strideC,
                       int32_t memKind, uint32_t* energy, uint64_t wpSum[3], uint64_t wpSsd[3]);
 
-/* The whole of LookaheadTLD::calcAdaptiveQuantFrame (source/encoder/slicetype.cpp:454-686) for a 4:2:0
- * picture with qgSize >= 16 and rc.aqMode NONE / VARIANCE / AUTO_VARIANCE / AUTO_VARIANCE_BIASED: the block
- * energies come from the device pass above, the double-precision mapping to QP offsets (:486-505, :539-643)
- * and x265_exp2fix8 (source/common/common.cpp:96-103) run on the host in this call, in the reference's order
- * of operations.  Arrays hold one entry per 16x16 block, ceil(w/16) per row; they are left untouched when
- * aqMode is NONE (x265 does not allocate them then) or when bSkipOffsets is set (the rc.bStatRead && cuTree
- * && referenced-frame case, :483).  wpSum / wpSsd receive Lowres::wp_sum / wp_ssd as the function leaves
- * them: with bWeightedPred the mean is removed from wp_ssd (:663-686); without it and without AQ no energy
- * pass runs and both are zero.  With slot >= 0 the resulting invQscaleFactor is also installed for that slot
- * (as x265gpu_lowres_set_aq does).  rc.hevcAq and X265_AQ_EDGE are not covered: X265GPU_ERR_UNSUPPORTED. */
+/* The whole of LookaheadTLD::calcAdaptiveQuantFrame (source/encoder/slicetype.cpp:454-704) for a 4:2:0
+ * picture with rc.aqMode NONE / VARIANCE / AUTO_VARIANCE / AUTO_VARIANCE_BIASED: the block energies come from
+ * the device pass above, the double-precision mapping to QP offsets (:486-505, :539-643) and x265_exp2fix8
+ * (source/common/common.cpp:96-103) run on the host in this call, in the reference's order of operations.
+ * qgSize >= 16: arrays hold one entry per 16x16 block, ceil(w/16) per row.  qgSize 8: 8x8 luma + 4x4 chroma
+ * blocks and the constants of :464-466; arrays hold (2*widthInCU) * (2*heightInCU) entries (Lowres's
+ * cuCountFullRes, source/common/lowres.cpp:92-95), the block loop fills the first ceil(w/8) * ceil(h/8) of
+ * them in loop order exactly as the reference's running index does (:571, :641), the rest keep what the
+ * caller put there (the reference allocates them zeroed), and invQscaleFactor8x8 receives the per-lowres-block
+ * means of :647-660 - that array is what the estimate calls use with qgSize 8 (:798-799, :4532-4533), so it is
+ * the one installed for the slot.  Arrays are left untouched when aqMode is NONE (x265 does not allocate them
+ * then) or when bSkipOffsets is set (the rc.bStatRead && cuTree && referenced-frame case, :483).  wpSum /
+ * wpSsd receive Lowres::wp_sum / wp_ssd as the function leaves them: with bWeightedPred the mean is removed
+ * from wp_ssd (:663-686); without it and without AQ no energy pass runs and both are zero.
+ * bBlockVariance (param->bDynamicRefine || param->bEnableFades) runs the tail of :688-703: blockVariance in
+ * loop order over the picture (rounded to the nearest 16 each way when bWeightedPred is set, :674-675) and
+ * frameVariance, with the reference's running row total; as there, that pass adds to wp_sum / wp_ssd a
+ * second time.  With slot >= 0 the resulting scale factors are also installed for that slot (as
+ * x265gpu_lowres_set_aq does).  rc.hevcAq and X265_AQ_EDGE are not covered: X265GPU_ERR_UNSUPPORTED. */
 typedef struct x265gpu_aq_params
 {
     int32_t aqMode;               /* param->rc.aqMode, 0..3 */
@@ -301,6 +310,11 @@ typedef struct x265gpu_aq_params
     int32_t bHDR10Opt;            /* param->bHDR10Opt: luma-average dependent offset (:613-635) */
     int32_t bSkipOffsets;
     double  aqStrength;           /* param->rc.aqStrength */
+    int32_t qgSize;               /* param->rc.qgSize: 8, 16, 32, 64 (0 = 32) */
+    int32_t bBlockVariance;       /* param->bDynamicRefine || param->bEnableFades */
+    int32_t*  invQscaleFactor8x8; /* out, qgSize 8: widthInCU * heightInCU (Lowres::invQscaleFactor8x8) */
+    uint32_t* blockVariance;      /* out, bBlockVariance: Lowres::blockVariance, same size as the offset arrays */
+    double*   frameVariance;      /* out, bBlockVariance: Lowres::frameVariance */
 } x265gpu_aq_params;
 int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t strideY, const void* u, const void* v,
                      intptr_t strideC, int32_t memKind, const x265gpu_aq_params* params,
@@ -325,6 +339,13 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
  *                             Lookahead::m_cuTreeStrength (:1075).  log2 runs on the host (libm).
  *                             qpCuTreeOffset is read-modify-write: blocks with a zero scaled intra
  *                             cost keep their value.
+ *   x265gpu_cutree_finish_qg8 the qgSize 8 loop of cuTreeFinish (:4030-4049): the slot's scale factors are
+ *                             Lowres::invQscaleFactor8x8 (as x265gpu_aq_frame installs them with qgSize 8),
+ *                             intra and propagated costs enter divided by 4, and each lowres block's ratio
+ *                             is applied to the four entries it covers in offset arrays of
+ *                             (2*widthInCU) * (2*heightInCU) doubles.  estimateCUPropagate itself only
+ *                             swaps the scale-factor array with qgSize 8 (:3791-3798), which installing
+ *                             invQscaleFactor8x8 for the slot already does.
  * The uint16 saturation of the reference's CLIP_ADD is order independent (all addends >= 0), so the
  * device adds with atomics into wide cells and clamps on read; results are bit-exact. */
 int x265gpu_cutree_clear(x265gpu_ctx* ctx, int32_t slot);
@@ -334,6 +355,8 @@ int x265gpu_cutree_propagate(x265gpu_ctx* ctx, int32_t slotP0, int32_t slotP1, i
 int x265gpu_cutree_get_propagate_cost(x265gpu_ctx* ctx, int32_t slot, uint16_t* propagateCost);
 int x265gpu_cutree_finish(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, double weightDelta, double cuTreeStrength,
                           const double* qpAqOffset, double* qpCuTreeOffset);
+int x265gpu_cutree_finish_qg8(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, double weightDelta,
+                              double cuTreeStrength, const double* qpAqOffset, double* qpCuTreeOffset);
 
 /* ---- picture statistics for histogram-based scene-cut detection (--hist-scenecut) ----
  *

@@ -74,7 +74,9 @@ int  orc_exp2fix8(double x);
 void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, const pixel* v, intptr_t sc,
                                    int w, int h, int aqMode, double aqStrength, int weightedPred, int hdr10,
                                    int skipOffsets, const float* quantOffsets, double* qpAqOffset,
-                                   double* qpCuTreeOffset, int* invQscaleFactor, uint64_t* wp);
+                                   double* qpCuTreeOffset, int* invQscaleFactor, uint64_t* wp,
+                                   int qgSize, int w8, int h8, int* invQscaleFactor8x8,
+                                   int blockVarianceOn, uint32_t* blockVariance, double* frameVarianceOut);
 
 void orc_intra_filter(int tuSize, const pixel* samples, pixel* filtered);
 void orc_intra_pred(int size, int mode, pixel* dst, intptr_t dstStride, const pixel* srcPix, int bFilter);
@@ -219,6 +221,9 @@ void orc_propagate_cost(int* dst, const uint16_t* propagateIn, const int32_t* in
 void orc_estimate_cu_propagate(const orc_cutree_param* cp, orc_lowres** frames, int* scratch, double averageDuration,
                                int p0, int p1, int b, int referenced);
 void orc_cutree_finish(const orc_cutree_param* cp, orc_lowres* frame, double averageDuration, int ref0Distance);
+void orc_cutree_finish_qg8(int W, int H, const int32_t* intraCost, const int32_t* invQscale8x8,
+                           const uint16_t* propagateCost, int fpsFactor, double weightdelta, double strength,
+                           const double* qpAqOffset, double* qpCuTreeOffset);
 void orc_cutree(orc_tld* t, const orc_param* p, const orc_cutree_param* cp, orc_lowres** frames, int numframes, int bIntra);
 void orc_lowres_set_slice_type(orc_lowres* lr, int sliceType);
 

@@ -122,8 +122,10 @@ def lib(depth=8):
     L.orc_lowres_i64.restype = C.c_int64
     L.orc_aq_energy.argtypes = [vp, ip, vp, vp, ip, i, i, vp, vp]
     L.orc_exp2fix8.argtypes = [C.c_double]
-    L.orc_calc_adaptive_quant_frame.argtypes = [vp, ip, vp, vp, ip, i, i, i, C.c_double, i, i, i, vp, vp, vp, vp, vp]
+    L.orc_calc_adaptive_quant_frame.argtypes = [vp, ip, vp, vp, ip, i, i, i, C.c_double, i, i, i, vp, vp, vp, vp, vp,
+                                                i, i, i, vp, i, vp, vp]
     L.orc_cutree.argtypes = [vp, C.POINTER(Param), C.POINTER(CuTreeParam), C.POINTER(vp), i, i]
+    L.orc_cutree_finish_qg8.argtypes = [i, i, vp, vp, vp, i, C.c_double, C.c_double, vp, vp]
     L.orc_lowres_set_slice_type.argtypes = [vp, i]
     L.orc_propagate_cost.argtypes = [vp, vp, vp, vp, vp, vp, i]
     L.orc_collect_picture_statistics.argtypes = [vp, ip, vp, ip, vp, vp, ip, i, i, C.POINTER(HistStats)]
@@ -362,20 +364,37 @@ FullResME.diamond_search = _frme_diamond
 
 
 def calc_adaptive_quant_frame(depth, y, u, v, aq_mode, strength, weightp=False, hdr10=False, skip_offsets=False,
-                              quant_offsets=None):
-    """calcAdaptiveQuantFrame on tight 4:2:0 planes -> (qpAqOffset, qpCuTreeOffset, invQscaleFactor, wp_sum, wp_ssd)."""
+                              quant_offsets=None, qg_size=32, block_variance=False):
+    """calcAdaptiveQuantFrame on tight 4:2:0 planes -> (qpAqOffset, qpCuTreeOffset, invQscaleFactor, wp_sum, wp_ssd)
+    [+ (invQscaleFactor8x8,) with qg_size 8] [+ (blockVariance, frameVariance) with block_variance]."""
     L = lib(depth)
     h, w = y.shape
-    n = ((w + 15) // 16) * ((h + 15) // 16)
-    qa = np.full(n, np.nan)
-    qc = np.full(n, np.nan)
-    inv = np.full(n, -1, np.int32)
+    w8, h8 = ((w // 2) + 7) >> 3, ((h // 2) + 7) >> 3
+    qg8 = qg_size == 8
+    if qg8:
+        n = 4 * w8 * h8                     # allocated zeroed, as Lowres::create does
+        qa, qc, inv = np.zeros(n), np.zeros(n), np.zeros(n, np.int32)
+    else:
+        n = w8 * h8
+        qa = np.full(n, np.nan)
+        qc = np.full(n, np.nan)
+        inv = np.full(n, -1, np.int32)
+    inv8 = np.full(w8 * h8, -1, np.int32)
+    var = np.zeros(n, np.uint32)
+    fvar = np.full(1, np.nan)
     wp = np.zeros(6, np.uint64)
     qo = None if quant_offsets is None else np.ascontiguousarray(quant_offsets, np.float32)
     L.orc_calc_adaptive_quant_frame(ptr(y), y.strides[0] // y.itemsize, ptr(u), ptr(v), u.strides[0] // u.itemsize,
                                     w, h, aq_mode, float(strength), int(weightp), int(hdr10), int(skip_offsets),
-                                    None if qo is None else ptr(qo), ptr(qa), ptr(qc), ptr(inv), ptr(wp))
-    return qa, qc, inv, wp[:3].copy(), wp[3:].copy()
+                                    None if qo is None else ptr(qo), ptr(qa), ptr(qc), ptr(inv), ptr(wp),
+                                    int(qg_size), w8, h8, ptr(inv8) if qg8 else None, int(block_variance), ptr(var),
+                                    ptr(fvar))
+    out = (qa, qc, inv, wp[:3].copy(), wp[3:].copy())
+    if qg8:
+        out += (inv8,)
+    if block_variance:
+        out += (var, float(fvar[0]))
+    return out
 
 
 def collect_picture_statistics(lowres, y, u, v):

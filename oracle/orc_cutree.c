@@ -3,8 +3,8 @@
  *
  * Follows Lookahead::cuTree, estimateCUPropagate and cuTreeFinish
  * (source/encoder/slicetype.cpp:3665-3874, 4016-4064) and the C primitive
- * estimateCUPropagateCost (source/common/pixel.cpp:906-932), for qgSize >= 16
- * without hevcAq. */
+ * estimateCUPropagateCost (source/common/pixel.cpp:906-932), without hevcAq; the frame walk for
+ * qgSize >= 16, the closing offsets also for qgSize 8 (orc_cutree_finish_qg8). */
 #include "orc.h"
 
 #include <math.h>
@@ -59,6 +59,31 @@ void orc_cutree_finish(const orc_cutree_param* cp, orc_lowres* frame, double ave
             frame->qpCuTreeOffset[i] = frame->qpAqOffset[i] - strength * log2_ratio;
         }
     }
+}
+
+/* source/encoder/slicetype.cpp:4030-4049, the qgSize 8 loop of cuTreeFinish on plain arrays: invQscale8x8
+ * is Lowres::invQscaleFactor8x8 (W x H), the offset arrays hold (2W) x (2H) doubles. */
+void orc_cutree_finish_qg8(int W, int H, const int32_t* intraCost, const int32_t* invQscale8x8,
+                           const uint16_t* propagateCost, int fpsFactor, double weightdelta, double strength,
+                           const double* qpAqOffset, double* qpCuTreeOffset)
+{
+    const int rowFull = W * 2;
+    for (int cuY = 0; cuY < H; cuY++)
+        for (int cuX = 0; cuX < W; cuX++)
+        {
+            const int cuXY = cuX + cuY * W;
+            int intracost = ((intraCost[cuXY]) / 4 * invQscale8x8[cuXY] + 128) >> 8;
+            if (intracost)
+            {
+                int propagate = ((propagateCost[cuXY]) / 4 * fpsFactor + 128) >> 8;
+                double log2_ratio = log2(intracost + propagate) - log2(intracost) + weightdelta;
+                const int at = cuX * 2 + cuY * W * 4;
+                qpCuTreeOffset[at] = qpAqOffset[at] - strength * (log2_ratio);
+                qpCuTreeOffset[at + 1] = qpAqOffset[at + 1] - strength * (log2_ratio);
+                qpCuTreeOffset[at + rowFull] = qpAqOffset[at + rowFull] - strength * (log2_ratio);
+                qpCuTreeOffset[at + rowFull + 1] = qpAqOffset[at + rowFull + 1] - strength * (log2_ratio);
+            }
+        }
 }
 
 /* source/encoder/slicetype.cpp:3768-3874 */

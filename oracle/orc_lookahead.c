@@ -347,23 +347,44 @@ int orc_exp2fix8(double x)
     return (lut[i & 63] + 256) << (i >> 6) >> 8;
 }
 
-/* LookaheadTLD::calcAdaptiveQuantFrame, source/encoder/slicetype.cpp:454-686, for 4:2:0,
- * qgSize >= 16 (16x16 blocks, modeOneConst 14.427f, modeTwoConst 11.f), without hevcAq and
- * the edge mode.  Block by block in the reference's order: acEnergyCu is called from the
- * same places, so wp_sum / wp_ssd accumulate exactly as they do there.  wp[0..2] = wp_sum,
- * wp[3..5] = wp_ssd.  Arrays may be null when the mode does not write them. */
+/* LookaheadTLD::calcAdaptiveQuantFrame, source/encoder/slicetype.cpp:454-704, for 4:2:0, without
+ * hevcAq and the edge mode.  qgSize 8 measures 8x8 luma + 4x4 chroma blocks with modeOneConst 11.427f /
+ * modeTwoConst 8.f, everything else 16x16 + 8x8 with 14.427f / 11.f (:461-474).  Block by block in the
+ * reference's order: acEnergyCu is called from the same places, so wp_sum / wp_ssd accumulate exactly
+ * as they do there, including the second round of the bDynamicRefine / bEnableFades tail (:688-703).
+ * wp[0..2] = wp_sum, wp[3..5] = wp_ssd.  Arrays hold blockCount entries (:463, :470) and are written
+ * through the reference's running index; they may be null when the mode does not write them.
+ * w8 x h8 is the lowres 8x8 grid (Lowres::maxBlocksInRow / maxBlocksInCol). */
 void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, const pixel* v, intptr_t sc,
                                    int w, int h, int aqMode, double aqStrength, int weightedPred, int hdr10,
                                    int skipOffsets, const float* quantOffsets, double* qpAqOffset,
-                                   double* qpCuTreeOffset, int* invQscaleFactor, uint64_t* wp)
+                                   double* qpCuTreeOffset, int* invQscaleFactor, uint64_t* wp,
+                                   int qgSize, int w8, int h8, int* invQscaleFactor8x8,
+                                   int blockVarianceOn, uint32_t* blockVariance, double* frameVarianceOut)
 {
-    const float modeOneConst = 14.427f, modeTwoConst = 11.f;
-    const int bw = (w + 15) >> 4, bh = (h + 15) >> 4, blockCount = bw * bh;
+    int maxCol = w, maxRow = h;
+    int blockCount, loopIncr;
+    float modeOneConst, modeTwoConst;
+    if (qgSize == 8)
+    {
+        blockCount = (w8 * 2) * (h8 * 2);
+        modeOneConst = 11.427f;
+        modeTwoConst = 8.f;
+        loopIncr = 8;
+    }
+    else
+    {
+        blockCount = w8 * h8;
+        modeOneConst = 14.427f;
+        modeTwoConst = 11.f;
+        loopIncr = 16;
+    }
+    const int lumaShift = loopIncr == 8 ? 6 : 8, chromaShift = loopIncr == 8 ? 4 : 6, half = loopIncr >> 1;
     memset(wp, 0, 6 * sizeof(uint64_t));
 #define ORC_ENERGY(bx, by) \
-    (ac_energy_plane(y, sy, w, h, bx, by, 16, 8, &wp[0], &wp[3]) + \
-     ac_energy_plane(u, sc, w >> 1, h >> 1, (bx) >> 1, (by) >> 1, 8, 6, &wp[1], &wp[4]) + \
-     ac_energy_plane(v, sc, w >> 1, h >> 1, (bx) >> 1, (by) >> 1, 8, 6, &wp[2], &wp[5]))
+    (ac_energy_plane(y, sy, w, h, bx, by, loopIncr, lumaShift, &wp[0], &wp[3]) + \
+     ac_energy_plane(u, sc, w >> 1, h >> 1, (bx) >> 1, (by) >> 1, half, chromaShift, &wp[1], &wp[4]) + \
+     ac_energy_plane(v, sc, w >> 1, h >> 1, (bx) >> 1, (by) >> 1, half, chromaShift, &wp[2], &wp[5]))
 
     if (!skipOffsets)
     {
@@ -386,8 +407,8 @@ void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, 
                 }
             }
             if (weightedPred)
-                for (int by = 0; by < h; by += 16)
-                    for (int bx = 0; bx < w; bx += 16)
+                for (int by = 0; by < maxRow; by += loopIncr)
+                    for (int bx = 0; bx < maxCol; bx += loopIncr)
                         (void)ORC_ENERGY(bx, by);
         }
         else
@@ -397,8 +418,8 @@ void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, 
             if (aqMode == 2 || aqMode == 3)
             {
                 double bit_depth_correction = 1.f / (1 << (2 * (ORC_DEPTH - 8)));
-                for (int by = 0; by < h; by += 16)
-                    for (int bx = 0; bx < w; bx += 16)
+                for (int by = 0; by < maxRow; by += loopIncr)
+                    for (int bx = 0; bx < maxCol; bx += loopIncr)
                     {
                         uint32_t energy = ORC_ENERGY(bx, by);
                         qp_adj = pow(energy * bit_depth_correction + 1, 0.1);
@@ -416,8 +437,8 @@ void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, 
                 strength = aqStrength * 1.0397f;
 
             k = 0;
-            for (int by = 0; by < h; by += 16)
-                for (int bx = 0; bx < w; bx += 16, k++)
+            for (int by = 0; by < maxRow; by += loopIncr)
+                for (int bx = 0; bx < maxCol; bx += loopIncr, k++)
                 {
                     if (aqMode == 3)
                     {
@@ -438,8 +459,8 @@ void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, 
                     {
                         /* lumaSumCu (:288-301): the low word of pixel_var over the same padded block */
                         uint64_t s0 = 0, s1 = 0;
-                        (void)ac_energy_plane(y, sy, w, h, bx, by, 16, 8, &s0, &s1);
-                        uint32_t lumaAvg = (uint32_t)s0 / 256;
+                        (void)ac_energy_plane(y, sy, w, h, bx, by, loopIncr, lumaShift, &s0, &s1);
+                        uint32_t lumaAvg = (uint32_t)s0 / (loopIncr * loopIncr);
                         if (lumaAvg < 301) qp_adj += 3;
                         else if (lumaAvg < 367) qp_adj += 2;
                         else if (lumaAvg < 434) qp_adj += 1;
@@ -457,14 +478,27 @@ void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, 
                     invQscaleFactor[k] = orc_exp2fix8(qp_adj);
                 }
         }
+        if (qgSize == 8 && invQscaleFactor && invQscaleFactor8x8)
+        {
+            /* :647-660 */
+            const int rowFull = w8 * 2;
+            for (int cuY = 0; cuY < h8; cuY++)
+                for (int cuX = 0; cuX < w8; cuX++)
+                {
+                    const int at = cuX * 2 + cuY * w8 * 4;
+                    invQscaleFactor8x8[cuX + cuY * w8] = (invQscaleFactor[at] + invQscaleFactor[at + 1] +
+                                                          invQscaleFactor[at + rowFull] + invQscaleFactor[at + rowFull + 1]) / 4;
+                }
+        }
     }
     if (weightedPred)
     {
         if (skipOffsets)
-            for (int by = 0; by < h; by += 16)
-                for (int bx = 0; bx < w; bx += 16)
+            for (int by = 0; by < maxRow; by += loopIncr)
+                for (int bx = 0; bx < maxCol; bx += loopIncr)
                     (void)ORC_ENERGY(bx, by);
-        int maxCol = ((w + 8) >> 4) << 4, maxRow = ((h + 8) >> 4) << 4;
+        maxCol = ((maxCol + 8) >> 4) << 4;
+        maxRow = ((maxRow + 8) >> 4) << 4;
         int width[3] = { maxCol, maxCol >> 1, maxCol >> 1 };
         int height[3] = { maxRow, maxRow >> 1, maxRow >> 1 };
         for (int i = 0; i < 3; i++)
@@ -472,6 +506,24 @@ void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, 
             uint64_t sum = wp[i], ssd = wp[3 + i];
             wp[3 + i] = ssd - (sum * sum + (width[i] * height[i]) / 2) / (width[i] * height[i]);
         }
+    }
+    if (blockVarianceOn)
+    {
+        /* :688-703; maxCol / maxRow are the rounded ones when the weighted-prediction branch ran */
+        uint64_t blockXY = 0, rowVariance = 0;
+        double frameVariance = 0;
+        for (int by = 0; by < maxRow; by += loopIncr)
+        {
+            for (int bx = 0; bx < maxCol; bx += loopIncr)
+            {
+                blockVariance[blockXY] = ORC_ENERGY(bx, by);
+                rowVariance += blockVariance[blockXY];
+                blockXY++;
+            }
+            frameVariance += (rowVariance / maxCol);
+        }
+        frameVariance /= maxRow;
+        *frameVarianceOut = frameVariance;
     }
 #undef ORC_ENERGY
 }

@@ -90,3 +90,92 @@ def test_aq_frame_rejects_uncovered_modes():
     with api.Context(W, H, depth=8, num_slots=1) as ctx:
         with pytest.raises(api.X265GpuError):
             ctx.aq_frame(y, u, v, 4, 1.0)                           # X265_AQ_EDGE
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("mode,strength", [(1, 1.0), (2, 1.2), (3, 0.8), (2, 0.0)])
+@pytest.mark.parametrize("size", [(416, 240), (424, 248), (200, 120)])
+def test_aq_frame_qg_size_8(depth, mode, strength, size):
+    """qgSize 8: 8x8 + 4x4 blocks, its own constants, the running index over a grid that can be narrower than
+    the arrays (424 = 53 blocks against rows of 54), and invQscaleFactor8x8."""
+    W, H = size
+    y, u, v, rng = _picture(W, H, depth, 5 + depth + mode)
+    w8, h8 = ((W // 2) + 7) >> 3, ((H // 2) + 7) >> 3
+    names = ("qpAqOffset", "qpCuTreeOffset", "invQscaleFactor", "wp_sum", "wp_ssd", "invQscaleFactor8x8")
+    for qo in (None, rng.normal(0, 1.5, 4 * w8 * h8).astype(np.float32)):
+        for weightp, hdr in ((False, False), (True, True)):
+            want = orc.calc_adaptive_quant_frame(depth, y, u, v, mode, strength, weightp=weightp, hdr10=hdr,
+                                                 quant_offsets=qo, qg_size=8)
+            with api.Context(W, H, depth=depth, num_slots=1) as ctx:
+                got = ctx.aq_frame(y, u, v, mode, strength, weightp=weightp, hdr10=hdr, quant_offsets=qo, slot=0,
+                                   qg_size=8)
+            assert len(got) == len(want) == 6
+            for g, w_, name in zip(got, want, names):
+                np.testing.assert_array_equal(g, w_, err_msg="%s mode %d hdr %s" % (name, mode, hdr))
+            assert np.all(got[5] >= 0)
+
+
+@pytest.mark.parametrize("qg", [8, 32])
+@pytest.mark.parametrize("weightp", [False, True])
+@pytest.mark.parametrize("size", [(416, 240), (424, 248), (410, 230), (1920, 1080)])
+def test_aq_block_variance_tail(qg, weightp, size):
+    """bDynamicRefine / bEnableFades: blockVariance in loop order over the (possibly rounded) picture, the
+    running-row frameVariance, and wp_sum / wp_ssd after the second energy round."""
+    W, H = size
+    y, u, v, _ = _picture(W, H, 8, 17)
+    for mode in (0, 2):
+        want = orc.calc_adaptive_quant_frame(8, y, u, v, mode, 1.0, weightp=weightp, qg_size=qg, block_variance=True)
+        with api.Context(W, H, depth=8, num_slots=1) as ctx:
+            got = ctx.aq_frame(y, u, v, mode, 1.0, weightp=weightp, qg_size=qg, block_variance=True)
+        np.testing.assert_array_equal(got[-2], want[-2], err_msg="blockVariance")
+        assert got[-1] == want[-1]
+        np.testing.assert_array_equal(got[3], want[3], err_msg="wp_sum")
+        np.testing.assert_array_equal(got[4], want[4], err_msg="wp_ssd")
+        if mode:
+            np.testing.assert_array_equal(got[2], want[2], err_msg="invQscaleFactor")
+        assert np.any(want[-2])
+
+
+def test_qg_size_8_end_to_end_intra_and_cutree_finish():
+    """invQscaleFactor8x8 from aq_frame drives costEstAq, and cuTreeFinish's qgSize 8 loop spreads each lowres
+    block's ratio over its four full-resolution entries."""
+    from x265_amd import synth
+    W, H, depth = 416, 240, 8
+    clip = synth.luma_clip(W, H, 2, depth, seed=5)
+    _, u, v, rng = _picture(W, H, depth, 7)
+    param = orc.make_param(W, H)
+    ref = orc.Lookahead(depth, param, with_aq=True)
+    L = orc.lib(depth)
+    with api.Context(W, H, depth=depth, num_slots=2) as ctx:
+        ctx.set_mvcost(ref.table, ref.centre)
+        w8, h8 = ctx.geom.widthInCU, ctx.geom.heightInCU
+        offs = []
+        for k in range(2):
+            want = orc.calc_adaptive_quant_frame(depth, clip[k], u, v, 2, 1.0, qg_size=8)
+            ref.add_frame(clip[k], want[5])
+            ctx.lowres_init(k, clip[k])
+            got = ctx.aq_frame(clip[k], u, v, 2, 1.0, slot=k, qg_size=8)
+            np.testing.assert_array_equal(got[5], want[5])
+            offs.append(got[0])
+        ctx.intra_estimate([0, 1])
+        _, _, (ce, ceaq, _) = ctx.get_costs(0, 0, 0)
+        assert ceaq == ref.frames[0].i64("costEstAq", 0, 0) and ce != ceaq
+        # P frame 1 from frame 0, then propagate into frame 0 and finish it
+        ref.frame_cost(0, 1, 1)
+        ctx.estimate([(0, 1, 1, 0, 1, 1, 1, 0, 0, 0)])
+        ctx.cutree_clear(0)
+        ctx.cutree_clear(1)
+        ctx.cutree_propagate(0, 1, 1, 1, 0, 1, 1.0, 32)
+        prop = ctx.cutree_get_propagate_cost(0)
+        assert np.any(prop)
+        intra = ctx.get_intra(0)[0]
+        inv8 = orc.calc_adaptive_quant_frame(depth, clip[0], u, v, 2, 1.0, qg_size=8)[5]
+        qa = offs[0].copy()
+        want_qc = qa.copy()
+        got_qc = qa.copy()
+        L.orc_cutree_finish_qg8(w8, h8, orc.ptr(np.ascontiguousarray(intra, np.int32)), orc.ptr(inv8),
+                                orc.ptr(np.ascontiguousarray(prop, np.uint16)), 256, 0.25, 2.0, orc.ptr(qa), orc.ptr(want_qc))
+        ctx.cutree_finish(0, 256, 0.25, 2.0, qa, got_qc, qg8=True)
+        np.testing.assert_array_equal(got_qc, want_qc)
+        assert np.any(got_qc != qa)
+    ref.close()

@@ -270,6 +270,43 @@ def test_adaptive_quant_frame_oracle_pins(oracle_built):
     assert np.all(inv0 == -1) and not wsum0.any()
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+def test_aq_qg_size_8_against_numpy(oracle_built, depth):
+    """qgSize 8 (slicetype.cpp:62-86, 461-474, 647-660, 688-703) against numpy: 8x8 luma + 4x4 chroma energies
+    through blockVariance, the variance-mode offsets with the 11.427f constant, the 2x2 means of
+    invQscaleFactor8x8, and frameVariance with its running row total."""
+    W, H = 96, 64
+    rng = np.random.default_rng(depth + 3)
+    dt = np.uint8 if depth == 8 else np.uint16
+    top = (1 << depth) - 1
+    planes = [rng.integers(0, top + 1, s).astype(dt) for s in ((H, W), (H // 2, W // 2), (H // 2, W // 2))]
+    planes[0][:16] = top // 3
+    bw, bh = W // 8, H // 8
+    energy = np.zeros(bw * bh, np.uint64)
+    for p, size, shift in zip(planes, (8, 4, 4), (6, 4, 4)):
+        q = p.astype(np.uint64)
+        for by in range(bh):
+            for bx in range(bw):
+                blk = q[by * size:(by + 1) * size, bx * size:(bx + 1) * size]
+                s_, q_ = int(blk.sum()), int((blk * blk).sum()) & 0xffffffff
+                energy[by * bw + bx] += (q_ - ((s_ * s_) >> shift)) & 0xffffffff
+    energy = (energy & 0xffffffff).astype(np.uint32)
+    qa, qc, inv, _, _, inv8, var, fvar = orc.calc_adaptive_quant_frame(depth, *planes, 1, 1.0, qg_size=8,
+                                                                      block_variance=True)
+    np.testing.assert_array_equal(var, energy)
+    want = float(np.float32(1.0397)) * (np.log2(np.maximum(energy, 1).astype(np.float64))
+                                        - float(np.float32(np.float32(11.427) + np.float32(2 * (depth - 8)))))
+    np.testing.assert_allclose(qa, want, rtol=0, atol=1e-12)
+    grid = inv.reshape(bh, bw)
+    want8 = (grid[0::2, 0::2] + grid[0::2, 1::2] + grid[1::2, 0::2] + grid[1::2, 1::2]) // 4
+    np.testing.assert_array_equal(inv8.reshape(bh // 2, bw // 2), want8)
+    running, total = 0, 0.0
+    for row in energy.reshape(bh, bw):
+        running += int(row.sum())
+        total += running // W
+    assert fvar == total / H
+
+
 def test_propagate_cost_oracle_pin(oracle_built):
     """estimateCUPropagateCost (pixel.cpp:906-932) against the same arithmetic in numpy float64."""
     L = orc.lib(8)

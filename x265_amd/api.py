@@ -22,7 +22,7 @@ EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_weight_cost", "x265gpu_weight_planes",
-    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_interp_luma",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_cutree_finish_qg8", "x265gpu_interp_luma",
     "x265gpu_cutree_clear", "x265gpu_cutree_swap", "x265gpu_cutree_propagate", "x265gpu_cutree_get_propagate_cost",
     "x265gpu_cutree_finish", "x265gpu_hist_stats", "x265gpu_mcstf_motion_search",
     "x265gpu_profile_enable", "x265gpu_profile_read",
@@ -85,7 +85,9 @@ class PuResult(C.Structure):
 
 class AqParams(C.Structure):
     _fields_ = [("aqMode", C.c_int32), ("bWeightedPred", C.c_int32), ("bHDR10Opt", C.c_int32),
-                ("bSkipOffsets", C.c_int32), ("aqStrength", C.c_double)]
+                ("bSkipOffsets", C.c_int32), ("aqStrength", C.c_double), ("qgSize", C.c_int32),
+                ("bBlockVariance", C.c_int32), ("invQscaleFactor8x8", C.c_void_p), ("blockVariance", C.c_void_p),
+                ("frameVariance", C.c_void_p)]
 
 
 class HistStats(C.Structure):
@@ -148,6 +150,7 @@ def load_library(path=None):
     L.x265gpu_cutree_propagate.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.c_double, i32]
     L.x265gpu_cutree_get_propagate_cost.argtypes = [vp, i32, vp]
     L.x265gpu_cutree_finish.argtypes = [vp, i32, i32, C.c_double, C.c_double, vp, vp]
+    L.x265gpu_cutree_finish_qg8.argtypes = [vp, i32, i32, C.c_double, C.c_double, vp, vp]
     L.x265gpu_hist_stats.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp]
     L.x265gpu_aq_frame.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp, vp, vp, vp, vp, vp, vp]
     L.x265gpu_mcstf_motion_search.argtypes = [vp, i32, i32, vp, vp, vp, vp]
@@ -376,21 +379,37 @@ class Context:
         return energy, wsum, wssd
 
     def aq_frame(self, y, u, v, aq_mode, strength, weightp=False, hdr10=False, skip_offsets=False,
-                 quant_offsets=None, slot=-1):
+                 quant_offsets=None, slot=-1, qg_size=32, block_variance=False):
         """calcAdaptiveQuantFrame of a 4:2:0 picture (host planes) ->
-        (qpAqOffset, qpCuTreeOffset, invQscaleFactor, wp_sum, wp_ssd); arrays the mode leaves unwritten keep NaN / -1."""
+        (qpAqOffset, qpCuTreeOffset, invQscaleFactor, wp_sum, wp_ssd); arrays the mode leaves unwritten keep NaN / -1.
+        With qg_size 8 the arrays have the full-resolution 8x8 grid (entries the block loop does not reach stay 0)
+        and invQscaleFactor8x8 is appended; with block_variance, (blockVariance, frameVariance) are appended."""
         y, u, v = (np.ascontiguousarray(p, self.pix) for p in (y, u, v))
         g = self.cfg
-        blocks = ((g.sourceWidth + 15) >> 4) * ((g.sourceHeight + 15) >> 4)
-        qa, qc = np.full(blocks, np.nan), np.full(blocks, np.nan)
-        inv = np.full(blocks, -1, np.int32)
+        qg8 = qg_size == 8
+        if qg8:
+            blocks = 4 * self.geom.widthInCU * self.geom.heightInCU
+            qa, qc, inv = np.zeros(blocks), np.zeros(blocks), np.zeros(blocks, np.int32)
+        else:
+            blocks = ((g.sourceWidth + 15) >> 4) * ((g.sourceHeight + 15) >> 4)
+            qa, qc = np.full(blocks, np.nan), np.full(blocks, np.nan)
+            inv = np.full(blocks, -1, np.int32)
+        inv8 = np.full(self.geom.widthInCU * self.geom.heightInCU, -1, np.int32)
+        var = np.zeros(blocks, np.uint32)
+        fvar = np.full(1, np.nan)
         wsum, wssd = np.zeros(3, np.uint64), np.zeros(3, np.uint64)
-        prm = AqParams(int(aq_mode), int(weightp), int(hdr10), int(skip_offsets), float(strength))
+        prm = AqParams(int(aq_mode), int(weightp), int(hdr10), int(skip_offsets), float(strength), int(qg_size),
+                       int(block_variance), _ptr(inv8), _ptr(var), _ptr(fvar))
         qo = None if quant_offsets is None else np.ascontiguousarray(quant_offsets, np.float32)
         self._chk(self.L.x265gpu_aq_frame(self.h, slot, _ptr(y), y.shape[1], _ptr(u), _ptr(v), u.shape[1], MEM_HOST,
                                           C.byref(prm), None if qo is None else _ptr(qo), _ptr(qa), _ptr(qc), _ptr(inv),
                                           _ptr(wsum), _ptr(wssd)))
-        return qa, qc, inv, wsum, wssd
+        out = (qa, qc, inv, wsum, wssd)
+        if qg8:
+            out += (inv8,)
+        if block_variance:
+            out += (var, float(fvar[0]))
+        return out
 
     def hist_stats(self, slot, y, u, v):
         """collectPictureStatistics of a 4:2:0 picture whose luma was given to lowres_init(slot, ...) ->
@@ -429,11 +448,15 @@ class Context:
         self._chk(self.L.x265gpu_cutree_get_propagate_cost(self.h, slot, _ptr(out)))
         return out
 
-    def cutree_finish(self, slot, fps_factor, weight_delta, strength, qp_aq_offset, qp_cutree_offset):
-        """qp_cutree_offset (float64, contiguous) is updated in place."""
+    def cutree_finish(self, slot, fps_factor, weight_delta, strength, qp_aq_offset, qp_cutree_offset, qg8=False):
+        """qp_cutree_offset (float64, contiguous) is updated in place; with qg8 both arrays hold the
+        full-resolution 8x8 grid (4 entries per lowres block)."""
         assert qp_aq_offset.dtype == np.float64 and qp_cutree_offset.dtype == np.float64
         assert qp_aq_offset.flags.c_contiguous and qp_cutree_offset.flags.c_contiguous
-        self._chk(self.L.x265gpu_cutree_finish(self.h, slot, int(fps_factor), float(weight_delta), float(strength),
+        n = self.geom.widthInCU * self.geom.heightInCU * (4 if qg8 else 1)
+        assert qp_aq_offset.size == n and qp_cutree_offset.size == n
+        fn = self.L.x265gpu_cutree_finish_qg8 if qg8 else self.L.x265gpu_cutree_finish
+        self._chk(fn(self.h, slot, int(fps_factor), float(weight_delta), float(strength),
                                                _ptr(qp_aq_offset), _ptr(qp_cutree_offset)))
 
     def get_full_plane(self, slot):

@@ -1,7 +1,7 @@
 // Host half of adaptive quantisation: the double-precision mapping from block
 // energies to QP offsets and quantiser scale factors.
 //
-// Follows LookaheadTLD::calcAdaptiveQuantFrame for qgSize >= 16
+// Follows LookaheadTLD::calcAdaptiveQuantFrame
 // (source/encoder/slicetype.cpp:539-643) operation by operation, including where
 // the reference mixes float constants into double expressions, because
 // x265_exp2fix8 truncates and a last-bit difference can move a scale factor.
@@ -33,10 +33,10 @@ struct Exp2Table
 };
 const Exp2Table exp2Table;
 
-// the luma-average steps of the HDR10 option (slicetype.cpp:613-635); block sums are of 16x16 samples
-double hdr10_shift(uint32_t lumaSum)
+// the luma-average steps of the HDR10 option (slicetype.cpp:613-635); block sums are of `samples` pixels
+double hdr10_shift(uint32_t lumaSum, uint32_t samples)
 {
-    const uint32_t avg = lumaSum / 256;
+    const uint32_t avg = lumaSum / samples;
     static const struct { uint32_t below; int add; } steps[] = {
         { 301, 3 }, { 367, 2 }, { 434, 1 }, { 501, 0 }, { 567, -1 }, { 634, -2 }, { 701, -3 }, { 767, -4 }, { 834, -5 } };
     for (const auto& s : steps)
@@ -61,7 +61,8 @@ int aq_exp2fix8(double x)
 void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy, const uint32_t* lumaSum,
                       const float* quantOffsets, double* qpAqOffset, double* qpCuTreeOffset, int32_t* invQscale)
 {
-    const float modeOneConst = 14.427f, modeTwoConst = 11.f;   // the qgSize > 8 constants (slicetype.cpp:470-473)
+    // slicetype.cpp:461-474
+    const float modeOneConst = p.blockSize == 8 ? 11.427f : 14.427f, modeTwoConst = p.blockSize == 8 ? 8.f : 11.f;
     double strength, avg = 0, bias = 0;
     const bool autoVariance = p.aqMode == 2 || p.aqMode == 3;
     if (autoVariance)
@@ -76,8 +77,8 @@ void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy
             sum += a;
             sumSq += a * a;
         }
-        sum /= blocks;
-        sumSq /= blocks;
+        sum /= p.blockCount;
+        sumSq /= p.blockCount;
         strength = p.strength * sum;
         avg = sum - 0.5f * (sumSq - modeTwoConst) / sum;
         bias = p.strength;
@@ -102,7 +103,7 @@ void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy
             q = strength * (log2((double)e) - modeOneOffset);
         }
         if (p.hdr10)
-            q += hdr10_shift(lumaSum[i]);
+            q += hdr10_shift(lumaSum[i], (uint32_t)(p.blockSize * p.blockSize));
         if (quantOffsets)
             q += quantOffsets[i];
         qpAqOffset[i] = q;
@@ -140,6 +141,32 @@ void cutree_finish_offsets(int blocks, const int32_t* intraCost, const int32_t* 
         const double ratio = log2((double)(intra + propagated)) - log2((double)intra) + weightDelta;
         qpCuTreeOffset[i] = qpAqOffset[i] - strength * ratio;
     }
+}
+
+// Lookahead::cuTreeFinish, the qgSize 8 loop (source/encoder/slicetype.cpp:4030-4049): one ratio per lowres
+// 8x8 block from a quarter of its intra and propagated costs, applied to the four full-resolution 8x8 blocks
+// it covers (offset arrays of 2W x 2H entries).
+void cutree_finish_offsets_qg8(int W, int H, const int32_t* intraCost, const int32_t* invQscale8x8,
+                               const unsigned long long* totals, int fpsFactor, double weightDelta, double strength,
+                               const double* qpAqOffset, double* qpCuTreeOffset)
+{
+    const int rowFull = 2 * W;
+    for (int cuY = 0; cuY < H; cuY++)
+        for (int cuX = 0; cuX < W; cuX++)
+        {
+            const int i = cuX + cuY * W;
+            const int intra = (intraCost[i] / 4 * invQscale8x8[i] + 128) >> 8;
+            if (!intra)
+                continue;
+            const int inherited = (int)(totals[i] < 65535 ? totals[i] : 65535);
+            const int propagated = (inherited / 4 * fpsFactor + 128) >> 8;
+            const double ratio = log2((double)(intra + propagated)) - log2((double)intra) + weightDelta;
+            const int at = cuX * 2 + cuY * W * 4;
+            qpCuTreeOffset[at] = qpAqOffset[at] - strength * ratio;
+            qpCuTreeOffset[at + 1] = qpAqOffset[at + 1] - strength * ratio;
+            qpCuTreeOffset[at + rowFull] = qpAqOffset[at + rowFull] - strength * ratio;
+            qpCuTreeOffset[at + rowFull + 1] = qpAqOffset[at + rowFull + 1] - strength * ratio;
+        }
 }
 
 // The arithmetic collectPictureStatistics applies to the raw counts

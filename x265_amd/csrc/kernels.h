@@ -156,8 +156,10 @@ struct AqJob
     const void* luma; const void* u; const void* v;
     long long lumaStride, chromaStride;      // pixels
     int width, height;                       // luma size
-    uint32_t* energy;                        // [ceil(h/16)][ceil(w/16)]
-    uint32_t* lumaSum;                       // same shape: sum of the block's 256 luma samples (lumaSumCu), or null
+    int visitWidth, visitHeight;             // the block loop runs while blockX < visitWidth, blockY < visitHeight
+    int blockSize;                           // 16 (qgSize >= 16) or 8 (qgSize 8)
+    uint32_t* energy;                        // [ceil(visitHeight/blockSize)][ceil(visitWidth/blockSize)]
+    uint32_t* lumaSum;                       // same shape: sum of the block's luma samples (lumaSumCu), or null
     unsigned long long* wp;                  // [0..2] wp_sum Y,U,V; [3..5] wp_ssd Y,U,V (zeroed by the caller)
 };
 hipError_t launch_aq_energy(hipStream_t s, int bpp, const AqJob& job);
@@ -169,6 +171,8 @@ struct AqFrameParams
     int depth;
     int hdr10;
     double strength;     // rc.aqStrength
+    int blockSize;       // 16, or 8 for qgSize 8
+    int blockCount;      // what the activity moments are divided by (can exceed the visited blocks with qgSize 8)
 };
 int aq_exp2fix8(double x);
 void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy, const uint32_t* lumaSum,
@@ -178,6 +182,9 @@ void aq_finish_wp(int width, int height, unsigned long long sum[3], unsigned lon
 void cutree_finish_offsets(int blocks, const int32_t* intraCost, const int32_t* invQscale, const unsigned long long* totals,
                            int fpsFactor, double weightDelta, double strength, const double* qpAqOffset,
                            double* qpCuTreeOffset);
+void cutree_finish_offsets_qg8(int W, int H, const int32_t* intraCost, const int32_t* invQscale8x8,
+                               const unsigned long long* totals, int fpsFactor, double weightDelta, double strength,
+                               const double* qpAqOffset, double* qpCuTreeOffset);
 
 // One estimateCUPropagate(p0, p1, b): frame b's blocks hand their amounts to frames p0 / p1.
 struct PropagateJob

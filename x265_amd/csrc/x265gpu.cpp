@@ -1471,10 +1471,11 @@ int x265gpu_cutree_get_propagate_cost(x265gpu_ctx* ctx, int32_t slot, uint16_t* 
     return X265GPU_OK;
 }
 
-int x265gpu_cutree_finish(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, double weightDelta, double cuTreeStrength,
-                          const double* qpAqOffset, double* qpCuTreeOffset)
+namespace {
+
+int cutree_finish(x265gpu_ctx* ctx, int32_t slot, bool qg8, int32_t fpsFactor, double weightDelta, double cuTreeStrength,
+                  const double* qpAqOffset, double* qpCuTreeOffset)
 {
-    DeviceScope deviceScope(ctx);
     if (!ctx || !slot_ok(ctx, slot) || !qpAqOffset || !qpCuTreeOffset)
         return X265GPU_ERR_ARG;
     Slot& s = ctx->slots[slot];
@@ -1489,9 +1490,29 @@ int x265gpu_cutree_finish(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, dou
     HIPCHK(hipMemcpyAsync(intra.data(), s.intraCost, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(invQ.data(), s.invQscale, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    cutree_finish_offsets((int)nb, intra.data(), invQ.data(), acc.data(), fpsFactor, weightDelta, cuTreeStrength,
-                          qpAqOffset, qpCuTreeOffset);
+    if (qg8)
+        cutree_finish_offsets_qg8(ctx->g.W, ctx->g.H, intra.data(), invQ.data(), acc.data(), fpsFactor, weightDelta,
+                                  cuTreeStrength, qpAqOffset, qpCuTreeOffset);
+    else
+        cutree_finish_offsets((int)nb, intra.data(), invQ.data(), acc.data(), fpsFactor, weightDelta, cuTreeStrength,
+                              qpAqOffset, qpCuTreeOffset);
     return X265GPU_OK;
+}
+
+} // namespace
+
+int x265gpu_cutree_finish(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, double weightDelta, double cuTreeStrength,
+                          const double* qpAqOffset, double* qpCuTreeOffset)
+{
+    DeviceScope deviceScope(ctx);
+    return cutree_finish(ctx, slot, false, fpsFactor, weightDelta, cuTreeStrength, qpAqOffset, qpCuTreeOffset);
+}
+
+int x265gpu_cutree_finish_qg8(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, double weightDelta, double cuTreeStrength,
+                              const double* qpAqOffset, double* qpCuTreeOffset)
+{
+    DeviceScope deviceScope(ctx);
+    return cutree_finish(ctx, slot, true, fpsFactor, weightDelta, cuTreeStrength, qpAqOffset, qpCuTreeOffset);
 }
 
 namespace {
@@ -1530,27 +1551,28 @@ int stage_yuv(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const void* u, 
     return X265GPU_OK;
 }
 
-// One device pass over a 4:2:0 picture: block energies, optional block luma sums
-// and the six frame accumulators, copied to the host.
-int run_aq_energy(x265gpu_ctx* ctx, const char* who, const void* y, intptr_t strideY, const void* u, const void* v,
-                  intptr_t strideC, int32_t memKind, uint32_t* energy, uint32_t* lumaSum, unsigned long long wp[6])
+// One device pass over a staged 4:2:0 picture: block energies (blockSize 16 or 8), optional block luma
+// sums and the six frame accumulators, copied to the host.  The block loop runs while blockX < visitW and
+// blockY < visitH; arrays hold ceil(visitW / blockSize) * ceil(visitH / blockSize) entries in loop order.
+int aq_energy_pass(x265gpu_ctx* ctx, const YuvOnDevice& pic, int blockSize, int visitW, int visitH, uint32_t* energy,
+                   uint32_t* lumaSum, unsigned long long wp[6])
 {
-    const int w = ctx->cfg.sourceWidth, h = ctx->cfg.sourceHeight, cw = w >> 1, ch = h >> 1;
-    if (strideY < w || strideC < cw || cw < 1 || ch < 1)
-        return fail(ctx, X265GPU_ERR_ARG, (std::string(who) + ": bad stride or picture size").c_str());
-    const int blocks = ((w + 15) >> 4) * ((h + 15) >> 4);
+    const int blocks = ((visitW + blockSize - 1) / blockSize) * ((visitH + blockSize - 1) / blockSize);
+    for (int i = 0; i < 6; i++)
+        wp[i] = 0;
+    if (blocks < 1)
+        return X265GPU_OK;
     const size_t arrayBytes = align256(sizeof(uint32_t) * (size_t)blocks);
-    AqJob job;
-    memset(&job, 0, sizeof(job));
-    job.width = w;
-    job.height = h;
     int rc = ensure_pu_buf(ctx, 2 * arrayBytes + 256);
     if (rc)
         return rc;
-    YuvOnDevice pic;
-    rc = stage_yuv(ctx, y, strideY, u, v, strideC, memKind, pic);
-    if (rc)
-        return rc;
+    AqJob job;
+    memset(&job, 0, sizeof(job));
+    job.width = ctx->cfg.sourceWidth;
+    job.height = ctx->cfg.sourceHeight;
+    job.visitWidth = visitW;
+    job.visitHeight = visitH;
+    job.blockSize = blockSize;
     job.luma = pic.y;
     job.u = pic.u;
     job.v = pic.v;
@@ -1569,6 +1591,15 @@ int run_aq_energy(x265gpu_ctx* ctx, const char* who, const void* y, intptr_t str
     return X265GPU_OK;
 }
 
+int stage_aq_picture(x265gpu_ctx* ctx, const char* who, const void* y, intptr_t strideY, const void* u, const void* v,
+                     intptr_t strideC, int32_t memKind, YuvOnDevice& pic)
+{
+    const int w = ctx->cfg.sourceWidth, h = ctx->cfg.sourceHeight, cw = w >> 1, ch = h >> 1;
+    if (strideY < w || strideC < cw || cw < 1 || ch < 1)
+        return fail(ctx, X265GPU_ERR_ARG, (std::string(who) + ": bad stride or picture size").c_str());
+    return stage_yuv(ctx, y, strideY, u, v, strideC, memKind, pic);
+}
+
 } // namespace
 
 int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const void* u, const void* v, intptr_t strideC,
@@ -1578,7 +1609,11 @@ int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const v
     if (!ctx || !y || !u || !v || !energy || !wpSum || !wpSsd)
         return X265GPU_ERR_ARG;
     unsigned long long wp[6];
-    int rc = run_aq_energy(ctx, "aq_energy", y, strideY, u, v, strideC, memKind, energy, nullptr, wp);
+    YuvOnDevice pic;
+    int rc = stage_aq_picture(ctx, "aq_energy", y, strideY, u, v, strideC, memKind, pic);
+    if (rc)
+        return rc;
+    rc = aq_energy_pass(ctx, pic, 16, ctx->cfg.sourceWidth, ctx->cfg.sourceHeight, energy, nullptr, wp);
     if (rc)
         return rc;
     for (int i = 0; i < 3; i++)
@@ -1599,25 +1634,44 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
         return X265GPU_ERR_ARG;
     if (params->aqMode < 0 || params->aqMode > 3)
         return fail(ctx, X265GPU_ERR_UNSUPPORTED, "aq_frame: aqMode must be 0..3 (edge-based and HEVC AQ are not covered)");
+    if (params->qgSize != 0 && params->qgSize != 8 && params->qgSize != 16 && params->qgSize != 32 && params->qgSize != 64)
+        return fail(ctx, X265GPU_ERR_ARG, "aq_frame: qgSize must be 8, 16, 32 or 64 (0 = 32)");
     if (slot >= 0 && !slot_ok(ctx, slot))
         return fail(ctx, X265GPU_ERR_ARG, "aq_frame: bad slot");
     const int w = ctx->cfg.sourceWidth, h = ctx->cfg.sourceHeight;
-    const int blocks = ((w + 15) >> 4) * ((h + 15) >> 4);
+    const bool qg8 = params->qgSize == 8;
+    const int B = qg8 ? 8 : 16;                                   // loopIncr (slicetype.cpp:461-474)
+    const int cols = (w + B - 1) / B, rows = (h + B - 1) / B, visited = cols * rows;
+    // blockCount (:463, :470): with qgSize 8 the full-resolution grid is twice the lowres grid each way, which
+    // can be one column / row more than the block loop visits; averages divide by it all the same
+    const int fullCols = 2 * ctx->g.W, fullRows = 2 * ctx->g.H;
+    const int blockCount = qg8 ? fullCols * fullRows : visited;
     const bool offsets = !params->bSkipOffsets && params->aqMode != 0;
     const bool mapped = offsets && params->aqStrength != 0;     // slicetype.cpp:486: the energy-driven modes
     if (offsets && (!qpAqOffset || !qpCuTreeOffset || !invQscaleFactor))
         return X265GPU_ERR_ARG;
-    if (slot >= 0 && blocks != ctx->g.cuCount)
+    if (qg8 && offsets && !params->invQscaleFactor8x8)
+        return fail(ctx, X265GPU_ERR_ARG, "aq_frame: qgSize 8 needs the invQscaleFactor8x8 output");
+    if (params->bBlockVariance && (!params->blockVariance || !params->frameVariance))
+        return fail(ctx, X265GPU_ERR_ARG, "aq_frame: bBlockVariance needs the blockVariance and frameVariance outputs");
+    if (slot >= 0 && !qg8 && visited != ctx->g.cuCount)
         return fail(ctx, X265GPU_ERR_ARG, "aq_frame: 16x16 block grid differs from the slot's 8x8 lowres grid");
 
     unsigned long long wp[6] = { 0, 0, 0, 0, 0, 0 };
+    YuvOnDevice pic;
+    bool staged = false;
+    std::vector<uint32_t> energy;
     // acEnergyCu runs once per block when a mode maps energies (:547, :609) or weighted prediction wants the
     // frame sums (:508-513, :665-670); otherwise not at all
     if (mapped || params->bWeightedPred)
     {
-        std::vector<uint32_t> energy((size_t)blocks), lumaSum(params->bHDR10Opt && mapped ? (size_t)blocks : 0);
-        int rc = run_aq_energy(ctx, "aq_frame", y, strideY, u, v, strideC, memKind, energy.data(),
-                               lumaSum.empty() ? nullptr : lumaSum.data(), wp);
+        energy.resize((size_t)visited);
+        std::vector<uint32_t> lumaSum(params->bHDR10Opt && mapped ? (size_t)visited : 0);
+        int rc = stage_aq_picture(ctx, "aq_frame", y, strideY, u, v, strideC, memKind, pic);
+        if (rc)
+            return rc;
+        staged = true;
+        rc = aq_energy_pass(ctx, pic, B, w, h, energy.data(), lumaSum.empty() ? nullptr : lumaSum.data(), wp);
         if (rc)
             return rc;
         if (mapped)
@@ -1627,29 +1681,77 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
             p.depth = ctx->cfg.internalBitDepth;
             p.hdr10 = params->bHDR10Opt != 0;
             p.strength = params->aqStrength;
-            aq_frame_offsets(p, blocks, energy.data(), lumaSum.empty() ? nullptr : lumaSum.data(), quantOffsets,
+            p.blockSize = B;
+            p.blockCount = blockCount;
+            aq_frame_offsets(p, visited, energy.data(), lumaSum.empty() ? nullptr : lumaSum.data(), quantOffsets,
                              qpAqOffset, qpCuTreeOffset, invQscaleFactor);
         }
     }
     if (offsets && !mapped)
     {
         // aqMode on with zero strength (:488-505): the caller's offsets alone, or none
-        for (int i = 0; i < blocks; i++)
+        for (int i = 0; i < blockCount; i++)
         {
             const double q = quantOffsets ? quantOffsets[i] : 0.0;
             qpAqOffset[i] = qpCuTreeOffset[i] = q;
             invQscaleFactor[i] = quantOffsets ? aq_exp2fix8(q) : 256;
         }
     }
+    if (qg8 && offsets)
+    {
+        // :647-660: the lowres 8x8 block's factor is the mean of its four full-resolution 8x8 blocks
+        const int W8 = ctx->g.W, H8 = ctx->g.H;
+        for (int cuY = 0; cuY < H8; cuY++)
+            for (int cuX = 0; cuX < W8; cuX++)
+            {
+                const int* q = invQscaleFactor + cuX * 2 + cuY * W8 * 4;
+                params->invQscaleFactor8x8[cuX + cuY * W8] = (q[0] + q[1] + q[fullCols] + q[fullCols + 1]) / 4;
+            }
+    }
+    int visitW = w, visitH = h;
     if (params->bWeightedPred)
+    {
         aq_finish_wp(w, h, wp, wp + 3);
+        visitW = ((w + 8) >> 4) << 4;                            // :674-675: the tail below inherits these bounds
+        visitH = ((h + 8) >> 4) << 4;
+    }
+    if (params->bBlockVariance)
+    {
+        // :688-703: acEnergyCu once more per block (adding to wp_sum / wp_ssd again, as the reference does)
+        const int tcols = (visitW + B - 1) / B, trows = (visitH + B - 1) / B;
+        std::vector<uint32_t> var((size_t)tcols * trows);
+        unsigned long long twp[6];
+        if (!staged)
+        {
+            int rc = stage_aq_picture(ctx, "aq_frame", y, strideY, u, v, strideC, memKind, pic);
+            if (rc)
+                return rc;
+        }
+        int rc = aq_energy_pass(ctx, pic, B, visitW, visitH, var.data(), nullptr, twp);
+        if (rc)
+            return rc;
+        for (int i = 0; i < 6; i++)
+            wp[i] += twp[i];
+        unsigned long long rowVariance = 0;                       // not reset between rows in the reference either
+        double frameVariance = 0;
+        for (int r = 0; r < trows; r++)
+        {
+            for (int c = 0; c < tcols; c++)
+            {
+                params->blockVariance[(size_t)r * tcols + c] = var[(size_t)r * tcols + c];
+                rowVariance += var[(size_t)r * tcols + c];
+            }
+            frameVariance += (double)(rowVariance / (unsigned long long)visitW);
+        }
+        *params->frameVariance = trows ? frameVariance / visitH : 0.0 / visitH;
+    }
     for (int i = 0; i < 3; i++)
     {
         wpSum[i] = wp[i];
         wpSsd[i] = wp[3 + i];
     }
     if (slot >= 0 && offsets)
-        return x265gpu_lowres_set_aq(ctx, slot, invQscaleFactor);
+        return x265gpu_lowres_set_aq(ctx, slot, qg8 ? params->invQscaleFactor8x8 : invQscaleFactor);
     return X265GPU_OK;
 }
 

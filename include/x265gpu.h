@@ -302,7 +302,24 @@ int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const v
  * loop order over the picture (rounded to the nearest 16 each way when bWeightedPred is set, :674-675) and
  * frameVariance, with the reference's running row total; as there, that pass adds to wp_sum / wp_ssd a
  * second time.  With slot >= 0 the resulting scale factors are also installed for that slot (as
- * x265gpu_lowres_set_aq does).  rc.hevcAq and X265_AQ_EDGE are not covered: X265GPU_ERR_UNSUPPORTED. */
+ * x265gpu_lowres_set_aq does).
+ * bHevcAq (param->rc.hevcAq, :517-521): xPreanalyze (:339-452) replaces the energy mapping.  For every layer the
+ * caller lists (the enabled depths of aqLayerDepth, source/common/lowres.h:120-139, with the part sizes and part
+ * counts Lowres::create gave them, source/common/lowres.cpp:128-155) the device sums each part's four quadrants,
+ * the host forms dActivity = 1 + the smallest quadrant variance, dAvgActivity, and xPreanalyzeQp's dQpOffset /
+ * dCuTreeOffset (:303-337) with qpAdaptationRange.  The LAST layer listed is the one of minAQDepth: its
+ * dQpOffset becomes invQscaleFactor through x265_exp2fix8 in visiting order (:441-447), and acEnergyCu runs
+ * once per block for wp_sum / wp_ssd (:449).  qpAqOffset / qpCuTreeOffset are not written in this mode.
+ * X265_AQ_EDGE is not covered: X265GPU_ERR_UNSUPPORTED. */
+typedef struct x265gpu_hevc_aq_layer
+{
+    int32_t aqPartWidth, aqPartHeight;            /* PicQPAdaptationLayer's fields of the same names */
+    int32_t numAQPartInWidth, numAQPartInHeight;
+    double* dActivity;                            /* out, numAQPartInWidth * numAQPartInHeight each; the parts the */
+    double* dQpOffset;                            /* loops visit, ceil(w / aqPartWidth) * ceil(h / aqPartHeight), */
+    double* dCuTreeOffset;                        /* are written in visiting order                                */
+    double  dAvgActivity;                         /* out */
+} x265gpu_hevc_aq_layer;
 typedef struct x265gpu_aq_params
 {
     int32_t aqMode;               /* param->rc.aqMode, 0..3 */
@@ -315,6 +332,10 @@ typedef struct x265gpu_aq_params
     int32_t*  invQscaleFactor8x8; /* out, qgSize 8: widthInCU * heightInCU (Lowres::invQscaleFactor8x8) */
     uint32_t* blockVariance;      /* out, bBlockVariance: Lowres::blockVariance, same size as the offset arrays */
     double*   frameVariance;      /* out, bBlockVariance: Lowres::frameVariance */
+    int32_t bHevcAq;              /* param->rc.hevcAq */
+    int32_t numLayers;            /* bHevcAq: entries of layers[], 1..4, in increasing depth */
+    double  qpAdaptationRange;    /* param->rc.qpAdaptationRange */
+    x265gpu_hevc_aq_layer* layers;
 } x265gpu_aq_params;
 int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t strideY, const void* u, const void* v,
                      intptr_t strideC, int32_t memKind, const x265gpu_aq_params* params,

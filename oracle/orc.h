@@ -71,6 +71,9 @@ uint64_t orc_pixel_var(int size, const pixel* pix, intptr_t stride);
 void orc_aq_energy(const pixel* y, intptr_t sy, const pixel* u, const pixel* v, intptr_t sc, int w, int h,
                    uint32_t* energy, uint64_t* wp);
 int  orc_exp2fix8(double x);
+double orc_hevc_aq_layer(const pixel* src, intptr_t stride, int width, int height, int aqPartWidth, int aqPartHeight,
+                         int numW, int numH, double qpAdaptationRange, double* dActivity, double* dQpOffset,
+                         double* dCuTreeOffset);
 void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, const pixel* v, intptr_t sc,
                                    int w, int h, int aqMode, double aqStrength, int weightedPred, int hdr10,
                                    int skipOffsets, const float* quantOffsets, double* qpAqOffset,

@@ -122,6 +122,9 @@ def lib(depth=8):
     L.orc_lowres_i64.restype = C.c_int64
     L.orc_aq_energy.argtypes = [vp, ip, vp, vp, ip, i, i, vp, vp]
     L.orc_exp2fix8.argtypes = [C.c_double]
+    L.orc_hevc_aq_layer.argtypes = [vp, ip, i, i, i, i, i, i, C.c_double, vp, vp, vp]
+    L.orc_hevc_aq_layer.restype = C.c_double
+    L.orc_exp2fix8.argtypes = [C.c_double]
     L.orc_calc_adaptive_quant_frame.argtypes = [vp, ip, vp, vp, ip, i, i, i, C.c_double, i, i, i, vp, vp, vp, vp, vp,
                                                 i, i, i, vp, i, vp, vp]
     L.orc_cutree.argtypes = [vp, C.POINTER(Param), C.POINTER(CuTreeParam), C.POINTER(vp), i, i]

@@ -528,6 +528,72 @@ void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, 
 #undef ORC_ENERGY
 }
 
+/* One layer of LookaheadTLD::xPreanalyze (source/encoder/slicetype.cpp:352-428) followed by
+ * xPreanalyzeQp for that layer (:315-335): quadrant variances of every part straight from the
+ * pixels, activity = 1 + the smallest, the layer mean over numW * numH parts, then the QP offsets.
+ * Returns dAvgActivity. */
+double orc_hevc_aq_layer(const pixel* src, intptr_t stride, int width, int height, int aqPartWidth, int aqPartHeight,
+                         int numW, int numH, double qpAdaptationRange, double* dActivity, double* dQpOffset,
+                         double* dCuTreeOffset)
+{
+    double* pcAQU = dActivity;
+    double dSumAct = 0.0;
+    for (uint32_t y = 0; y < (uint32_t)height; y += aqPartHeight)
+    {
+        const uint32_t currAQPartHeight = imin(aqPartHeight, height - y);
+        for (uint32_t x = 0; x < (uint32_t)width; x += aqPartWidth, pcAQU++)
+        {
+            const uint32_t currAQPartWidth = imin(aqPartWidth, width - x);
+            const pixel* pBlkY = &src[x];
+            uint64_t sum[4] = { 0, 0, 0, 0 };
+            uint64_t sumSq[4] = { 0, 0, 0, 0 };
+            uint32_t by = 0;
+            for (; by < currAQPartHeight; by++)
+            {
+                const int lower = by >= (currAQPartHeight >> 1) ? 2 : 0;
+                for (uint32_t bx = 0; bx < currAQPartWidth; bx++)
+                {
+                    const int q = lower + (bx >= (currAQPartWidth >> 1) ? 1 : 0);
+                    sum[q] += pBlkY[bx];
+                    sumSq[q] += pBlkY[bx] * pBlkY[bx];
+                }
+                pBlkY += stride;
+            }
+            const uint32_t numPixInAQPart = (currAQPartWidth >> 1) * (currAQPartHeight >> 1);
+            double dMinVar = 1.7e+308;
+            if (numPixInAQPart != 0)
+            {
+                for (int i = 0; i < 4; i++)
+                {
+                    const double dAverage = (double)(sum[i]) / numPixInAQPart;
+                    const double dVariance = (double)(sumSq[i]) / numPixInAQPart - dAverage * dAverage;
+                    dMinVar = dMinVar < dVariance ? dMinVar : dVariance;
+                }
+            }
+            else
+                dMinVar = 0.0;
+            double dAct = 1.0 + dMinVar;
+            *pcAQU = dAct;
+            dSumAct += dAct;
+        }
+        src += stride * currAQPartHeight;
+    }
+    const double dAvgAct = dSumAct / (numW * numH);
+
+    pcAQU = dActivity;
+    for (uint32_t y = 0; y < (uint32_t)height; y += aqPartHeight)
+        for (uint32_t x = 0; x < (uint32_t)width; x += aqPartWidth, pcAQU++, dQpOffset++, dCuTreeOffset++)
+        {
+            double dMaxQScale = pow(2.0, qpAdaptationRange / 6.0);
+            double dCUAct = *pcAQU;
+            double dNormAct = (dMaxQScale * dCUAct + dAvgAct) / (dCUAct + dMaxQScale * dAvgAct);
+            double dQp = (log2(dNormAct) / log2(2.0)) * 6.0;
+            *dQpOffset = dQp;
+            *dCuTreeOffset = dQp;
+        }
+    return dAvgAct;
+}
+
 /* ---------------------------------------------------------------- weighted prediction */
 
 /* source/encoder/slicetype.cpp:817-850 */

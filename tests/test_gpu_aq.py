@@ -179,3 +179,48 @@ def test_qg_size_8_end_to_end_intra_and_cutree_finish():
         np.testing.assert_array_equal(got_qc, want_qc)
         assert np.any(got_qc != qa)
     ref.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,qg", [((416, 240), 32), ((424, 250), 16), ((416, 240), 8), ((1920, 1080), 64)])
+def test_hevc_aq_layers(depth, size, qg):
+    """rc.hevcAq: per-layer quadrant activities, dAvgActivity and QP offsets, invQscaleFactor from the finest
+    layer, and the wp sums of the closing acEnergyCu round - against the oracle's xPreanalyze."""
+    W, H = size
+    y, u, v, _ = _picture(W, H, depth, 31 + depth)
+    y[H // 2:, : W // 2] = (np.arange(W // 2) % 7 + 5).astype(y.dtype)       # low-variance quadrants
+    w8, h8 = ((W // 2) + 7) >> 3, ((H // 2) + 7) >> 3
+    # CTU 64: the depths aqLayerDepth enables for this qgSize (lowres.h:120-126); the finest one has the
+    # 2 * lowres grid, the others ceil(picture / part) parts (lowres.cpp:139-150)
+    depths = {64: (0, 2), 32: (0, 1, 2), 16: (0, 1, 2), 8: (0, 1, 2, 3)}[qg]
+    parts = []
+    for d in depths:
+        s = 64 >> d
+        if d == 3:
+            parts.append((s, 2 * w8, 2 * h8))
+        else:
+            parts.append((s, (W + s - 1) // s, (H + s - 1) // s))
+    L = orc.lib(depth)
+    want_layers = []
+    for (s, nw, nh) in parts:
+        arrs = [np.full(nw * nh, np.nan) for _ in range(3)]
+        avg = L.orc_hevc_aq_layer(orc.ptr(y), W, W, H, s, s, nw, nh, 1.5, *(orc.ptr(a) for a in arrs))
+        want_layers.append(tuple(arrs) + (avg,))
+    with api.Context(W, H, depth=depth, num_slots=1) as ctx:
+        got = ctx.aq_frame(y, u, v, 2, 1.0, weightp=True, qg_size=qg, hevc_aq_parts=parts, qp_adaptation_range=1.5)
+    for k, (g, w_) in enumerate(zip(got[-1], want_layers)):
+        for a, b, name in zip(g, w_, ("dActivity", "dQpOffset", "dCuTreeOffset", "dAvgActivity")):
+            np.testing.assert_array_equal(a, b, err_msg="layer %d %s" % (k, name))
+    B = 8 if qg == 8 else 16
+    visited = ((W + B - 1) // B) * ((H + B - 1) // B)
+    want_inv = np.array([L.orc_exp2fix8(float(q)) for q in want_layers[-1][1][:visited]], np.int32)
+    np.testing.assert_array_equal(got[2][:visited], want_inv)
+    assert len(set(want_inv.tolist())) > 3
+    # the energy round feeds wp_sum / wp_ssd exactly as in the other modes
+    ref = orc.calc_adaptive_quant_frame(depth, y, u, v, 2, 1.0, weightp=True, qg_size=qg)
+    np.testing.assert_array_equal(got[3], ref[3])
+    np.testing.assert_array_equal(got[4], ref[4])
+    if qg == 8:
+        grid = got[2].reshape(2 * h8, 2 * w8)
+        np.testing.assert_array_equal(got[5].reshape(h8, w8),
+                                      (grid[0::2, 0::2] + grid[0::2, 1::2] + grid[1::2, 0::2] + grid[1::2, 1::2]) // 4)

@@ -307,6 +307,33 @@ def test_aq_qg_size_8_against_numpy(oracle_built, depth):
     assert fvar == total / H
 
 
+def test_hevc_aq_layer_against_numpy(oracle_built):
+    """xPreanalyze / xPreanalyzeQp for one layer (slicetype.cpp:303-428) against a numpy statement: activity =
+    1 + min quadrant variance (population variance in float64), QP offset = 6 * log2 of the normalised activity."""
+    W, H, S = 96, 80, 32                          # the bottom row of parts is clipped to 16 lines
+    rng = np.random.default_rng(4)
+    y = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    y[:40, :40] = 77
+    nw, nh = 3, 3
+    arrs = [np.full(nw * nh, np.nan) for _ in range(3)]
+    avg = orc.lib(8).orc_hevc_aq_layer(_p(y), W, W, H, S, S, nw, nh, 2.0, *(_p(a) for a in arrs))
+    act = []
+    for py in range(0, H, S):
+        for px in range(0, W, S):
+            blk = y[py:py + S, px:px + S].astype(np.float64)
+            hh, hw = blk.shape[0] // 2, blk.shape[1] // 2
+            quads = (blk[:hh, :hw], blk[:hh, hw:], blk[hh:, :hw], blk[hh:, hw:])
+            act.append(1.0 + min((q * q).sum() / q.size - (q.sum() / q.size) ** 2 for q in quads))
+    act = np.array(act)
+    np.testing.assert_allclose(arrs[0], act, rtol=1e-12)
+    assert avg == pytest.approx(act.sum() / (nw * nh), rel=1e-12)
+    scale = 2.0 ** (2.0 / 6.0)
+    want = 6.0 * np.log2((scale * act + avg) / (act + scale * avg))
+    np.testing.assert_allclose(arrs[1], want, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(arrs[1], arrs[2])
+    assert arrs[0][0] == 1.0                      # a flat quadrant
+
+
 def test_propagate_cost_oracle_pin(oracle_built):
     """estimateCUPropagateCost (pixel.cpp:906-932) against the same arithmetic in numpy float64."""
     L = orc.lib(8)

@@ -87,7 +87,14 @@ class AqParams(C.Structure):
     _fields_ = [("aqMode", C.c_int32), ("bWeightedPred", C.c_int32), ("bHDR10Opt", C.c_int32),
                 ("bSkipOffsets", C.c_int32), ("aqStrength", C.c_double), ("qgSize", C.c_int32),
                 ("bBlockVariance", C.c_int32), ("invQscaleFactor8x8", C.c_void_p), ("blockVariance", C.c_void_p),
-                ("frameVariance", C.c_void_p)]
+                ("frameVariance", C.c_void_p), ("bHevcAq", C.c_int32), ("numLayers", C.c_int32),
+                ("qpAdaptationRange", C.c_double), ("layers", C.c_void_p)]
+
+
+class HevcAqLayer(C.Structure):
+    _fields_ = [("aqPartWidth", C.c_int32), ("aqPartHeight", C.c_int32), ("numAQPartInWidth", C.c_int32),
+                ("numAQPartInHeight", C.c_int32), ("dActivity", C.c_void_p), ("dQpOffset", C.c_void_p),
+                ("dCuTreeOffset", C.c_void_p), ("dAvgActivity", C.c_double)]
 
 
 class HistStats(C.Structure):
@@ -379,11 +386,14 @@ class Context:
         return energy, wsum, wssd
 
     def aq_frame(self, y, u, v, aq_mode, strength, weightp=False, hdr10=False, skip_offsets=False,
-                 quant_offsets=None, slot=-1, qg_size=32, block_variance=False):
+                 quant_offsets=None, slot=-1, qg_size=32, block_variance=False, hevc_aq_parts=None,
+                 qp_adaptation_range=1.0):
         """calcAdaptiveQuantFrame of a 4:2:0 picture (host planes) ->
         (qpAqOffset, qpCuTreeOffset, invQscaleFactor, wp_sum, wp_ssd); arrays the mode leaves unwritten keep NaN / -1.
         With qg_size 8 the arrays have the full-resolution 8x8 grid (entries the block loop does not reach stay 0)
-        and invQscaleFactor8x8 is appended; with block_variance, (blockVariance, frameVariance) are appended."""
+        and invQscaleFactor8x8 is appended; with block_variance, (blockVariance, frameVariance) are appended.
+        hevc_aq_parts = [(partSize, numPartsInWidth, numPartsInHeight), ...] switches to rc.hevcAq; a list of
+        (dActivity, dQpOffset, dCuTreeOffset, dAvgActivity) per layer is appended last."""
         y, u, v = (np.ascontiguousarray(p, self.pix) for p in (y, u, v))
         g = self.cfg
         qg8 = qg_size == 8
@@ -398,8 +408,17 @@ class Context:
         var = np.zeros(blocks, np.uint32)
         fvar = np.full(1, np.nan)
         wsum, wssd = np.zeros(3, np.uint64), np.zeros(3, np.uint64)
+        layers, layer_arrays = None, []
+        if hevc_aq_parts:
+            layers = (HevcAqLayer * len(hevc_aq_parts))()
+            for k, (size, nw, nh) in enumerate(hevc_aq_parts):
+                arrs = [np.full(nw * nh, np.nan) for _ in range(3)]
+                layer_arrays.append(arrs)
+                layers[k] = HevcAqLayer(size, size, nw, nh, _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), 0.0)
         prm = AqParams(int(aq_mode), int(weightp), int(hdr10), int(skip_offsets), float(strength), int(qg_size),
-                       int(block_variance), _ptr(inv8), _ptr(var), _ptr(fvar))
+                       int(block_variance), _ptr(inv8), _ptr(var), _ptr(fvar), int(bool(hevc_aq_parts)),
+                       len(hevc_aq_parts or ()), float(qp_adaptation_range),
+                       C.cast(layers, C.c_void_p) if layers is not None else None)
         qo = None if quant_offsets is None else np.ascontiguousarray(quant_offsets, np.float32)
         self._chk(self.L.x265gpu_aq_frame(self.h, slot, _ptr(y), y.shape[1], _ptr(u), _ptr(v), u.shape[1], MEM_HOST,
                                           C.byref(prm), None if qo is None else _ptr(qo), _ptr(qa), _ptr(qc), _ptr(inv),
@@ -409,6 +428,8 @@ class Context:
             out += (inv8,)
         if block_variance:
             out += (var, float(fvar[0]))
+        if hevc_aq_parts:
+            out += ([tuple(a) + (layers[k].dAvgActivity,) for k, a in enumerate(layer_arrays)],)
         return out
 
     def hist_stats(self, slot, y, u, v):

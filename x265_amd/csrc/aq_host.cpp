@@ -112,6 +112,51 @@ void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy
     }
 }
 
+// LookaheadTLD::xPreanalyze for one layer (source/encoder/slicetype.cpp:358-428) from the device's quadrant
+// sums, then xPreanalyzeQp for it (:322-335).  Parts are visited in raster order and written through a running
+// pointer, as there; the mean divides by the layer's allocated part count.
+double hevc_aq_layer(int width, int height, int partW, int partH, int numPartInWidth, int numPartInHeight,
+                     double qpAdaptationRange, const unsigned long long* quadrants, double* dActivity, double* dQpOffset,
+                     double* dCuTreeOffset)
+{
+    double dSumAct = 0.0;
+    int k = 0;
+    for (int y = 0; y < height; y += partH)
+    {
+        const int ch = partH < height - y ? partH : height - y;
+        for (int x = 0; x < width; x += partW, k++)
+        {
+            const int cw = partW < width - x ? partW : width - x;
+            const uint32_t numPix = (uint32_t)(cw >> 1) * (uint32_t)(ch >> 1);
+            double dMinVar = 1.7e+308;                      // MAX_DOUBLE (source/common/common.h:157)
+            if (numPix != 0)
+            {
+                for (int i = 0; i < 4; i++)
+                {
+                    const double dAverage = double(quadrants[(size_t)k * 8 + i]) / numPix;
+                    const double dVariance = double(quadrants[(size_t)k * 8 + 4 + i]) / numPix - dAverage * dAverage;
+                    dMinVar = dMinVar < dVariance ? dMinVar : dVariance;
+                }
+            }
+            else
+                dMinVar = 0.0;
+            const double dAct = 1.0 + dMinVar;
+            dActivity[k] = dAct;
+            dSumAct += dAct;
+        }
+    }
+    const double dAvgAct = dSumAct / (numPartInWidth * numPartInHeight);
+    const double dMaxQScale = pow(2.0, qpAdaptationRange / 6.0);
+    for (int i = 0; i < k; i++)
+    {
+        const double dNormAct = (dMaxQScale * dActivity[i] + dAvgAct) / (dActivity[i] + dMaxQScale * dAvgAct);
+        const double dQp = (log2(dNormAct) / log2(2.0)) * 6.0;
+        dQpOffset[i] = dQp;
+        dCuTreeOffset[i] = dQp;
+    }
+    return dAvgAct;
+}
+
 // wp_ssd with the mean removed over the picture rounded to the nearest multiple
 // of 16 each way, 4:2:0 (slicetype.cpp:672-685)
 void aq_finish_wp(int width, int height, unsigned long long sum[3], unsigned long long ssd[3])

@@ -110,6 +110,69 @@ __global__ void __launch_bounds__(256) aq_energy_kernel(AqJob job)
     }
 }
 
+// Quadrant statistics of LookaheadTLD::xPreanalyze (source/encoder/slicetype.cpp:359-398): the picture is cut
+// into parts of partW x partH luma samples (clipped at the right / bottom edge), each part into four quadrants
+// at half its clipped width and height, and every quadrant gets its sum and sum of squares.  One wave per part;
+// out[part * 8 + q] = sum, out[part * 8 + 4 + q] = sum of squares, q = 2 * (lower half) + (right half).
+template <typename P>
+__global__ void __launch_bounds__(256) aq_quadrant_kernel(const P* luma, long long stride, int width, int height, int partW,
+                                                          int partH, int partsX, int parts, unsigned long long* out)
+{
+    const int lane = threadIdx.x & 63;
+    const int part = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (part >= parts)
+        return;
+    const int x0 = (part % partsX) * partW, y0 = (part / partsX) * partH;
+    const int cw = min(partW, width - x0), ch = min(partH, height - y0);
+    const int halfW = cw >> 1, halfH = ch >> 1;
+    uint32_t sum[4] = { 0, 0, 0, 0 };
+    unsigned long long sq[4] = { 0, 0, 0, 0 };
+    for (int i = lane; i < cw * ch; i += 64)
+    {
+        const int r = i / cw, c = i - r * cw;
+        const uint32_t v = luma[(long long)(y0 + r) * stride + x0 + c];
+        const int q = (r >= halfH ? 2 : 0) + (c >= halfW ? 1 : 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            sum[k] += q == k ? v : 0u;
+            sq[k] += q == k ? (unsigned long long)(v * v) : 0ull;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        unsigned long long s = sum[k], t = sq[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+        {
+            s += __shfl_xor(s, m, 64);
+            t += __shfl_xor(t, m, 64);
+        }
+        if (lane == 0)
+        {
+            out[(long long)part * 8 + k] = s;
+            out[(long long)part * 8 + 4 + k] = t;
+        }
+    }
+}
+
+hipError_t launch_aq_quadrants(hipStream_t s, int bpp, const void* luma, long long stride, int width, int height, int partW,
+                               int partH, unsigned long long* out)
+{
+    const int partsX = (width + partW - 1) / partW, partsY = (height + partH - 1) / partH, parts = partsX * partsY;
+    if (parts < 1)
+        return hipSuccess;
+    dim3 grid((parts + 3) / 4);
+    if (bpp == 1)
+        hipLaunchKernelGGL(aq_quadrant_kernel<uint8_t>, grid, dim3(256), 0, s, (const uint8_t*)luma, stride, width, height,
+                           partW, partH, partsX, parts, out);
+    else
+        hipLaunchKernelGGL(aq_quadrant_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)luma, stride, width, height,
+                           partW, partH, partsX, parts, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_aq_energy(hipStream_t s, int bpp, const AqJob& job)
 {
     const int B = job.blockSize == 8 ? 8 : 16;

@@ -163,6 +163,13 @@ struct AqJob
     unsigned long long* wp;                  // [0..2] wp_sum Y,U,V; [3..5] wp_ssd Y,U,V (zeroed by the caller)
 };
 hipError_t launch_aq_energy(hipStream_t s, int bpp, const AqJob& job);
+// xPreanalyze's quadrant sums: out holds 8 values per part (4 sums, 4 sums of squares), parts in raster order
+hipError_t launch_aq_quadrants(hipStream_t s, int bpp, const void* luma, long long stride, int width, int height, int partW,
+                               int partH, unsigned long long* out);
+// xPreanalyze / xPreanalyzeQp for one layer from those sums (aq_host.cpp); returns dAvgActivity
+double hevc_aq_layer(int width, int height, int partW, int partH, int numPartInWidth, int numPartInHeight,
+                     double qpAdaptationRange, const unsigned long long* quadrants, double* dActivity, double* dQpOffset,
+                     double* dCuTreeOffset);
 
 // Host half of calcAdaptiveQuantFrame: block energies -> QP offsets (aq_host.cpp).
 struct AqFrameParams

@@ -1633,7 +1633,7 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
     if (!ctx || !params || !y || !u || !v || !wpSum || !wpSsd)
         return X265GPU_ERR_ARG;
     if (params->aqMode < 0 || params->aqMode > 3)
-        return fail(ctx, X265GPU_ERR_UNSUPPORTED, "aq_frame: aqMode must be 0..3 (edge-based and HEVC AQ are not covered)");
+        return fail(ctx, X265GPU_ERR_UNSUPPORTED, "aq_frame: aqMode must be 0..3 (the edge-based mode is not covered)");
     if (params->qgSize != 0 && params->qgSize != 8 && params->qgSize != 16 && params->qgSize != 32 && params->qgSize != 64)
         return fail(ctx, X265GPU_ERR_ARG, "aq_frame: qgSize must be 8, 16, 32 or 64 (0 = 32)");
     if (slot >= 0 && !slot_ok(ctx, slot))
@@ -1648,8 +1648,26 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
     const int blockCount = qg8 ? fullCols * fullRows : visited;
     const bool offsets = !params->bSkipOffsets && params->aqMode != 0;
     const bool mapped = offsets && params->aqStrength != 0;     // slicetype.cpp:486: the energy-driven modes
-    if (offsets && (!qpAqOffset || !qpCuTreeOffset || !invQscaleFactor))
+    const bool hevcAq = mapped && params->bHevcAq;              // :517: only inside the energy-driven branch
+    if (offsets && (!invQscaleFactor || (!hevcAq && (!qpAqOffset || !qpCuTreeOffset))))
         return X265GPU_ERR_ARG;
+    if (hevcAq)
+    {
+        if (params->numLayers < 1 || params->numLayers > 4 || !params->layers)
+            return fail(ctx, X265GPU_ERR_ARG, "aq_frame: bHevcAq needs 1..4 layers");
+        for (int i = 0; i < params->numLayers; i++)
+        {
+            const x265gpu_hevc_aq_layer& l = params->layers[i];
+            if (l.aqPartWidth < 2 || l.aqPartHeight < 2 || l.aqPartWidth > 64 || l.aqPartHeight > 64 || !l.dActivity ||
+                !l.dQpOffset || !l.dCuTreeOffset ||
+                (long long)l.numAQPartInWidth * l.numAQPartInHeight <
+                    (long long)((w + l.aqPartWidth - 1) / l.aqPartWidth) * ((h + l.aqPartHeight - 1) / l.aqPartHeight))
+                return fail(ctx, X265GPU_ERR_ARG, "aq_frame: bad HEVC AQ layer");
+        }
+        const x265gpu_hevc_aq_layer& last = params->layers[params->numLayers - 1];
+        if (last.aqPartWidth != B || last.aqPartHeight != B)
+            return fail(ctx, X265GPU_ERR_ARG, "aq_frame: the last HEVC AQ layer must have parts of the AQ block size");
+    }
     if (qg8 && offsets && !params->invQscaleFactor8x8)
         return fail(ctx, X265GPU_ERR_ARG, "aq_frame: qgSize 8 needs the invQscaleFactor8x8 output");
     if (params->bBlockVariance && (!params->blockVariance || !params->frameVariance))
@@ -1674,7 +1692,30 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
         rc = aq_energy_pass(ctx, pic, B, w, h, energy.data(), lumaSum.empty() ? nullptr : lumaSum.data(), wp);
         if (rc)
             return rc;
-        if (mapped)
+        if (hevcAq)
+        {
+            for (int i = 0; i < params->numLayers; i++)
+            {
+                x265gpu_hevc_aq_layer& l = params->layers[i];
+                const size_t parts = (size_t)((w + l.aqPartWidth - 1) / l.aqPartWidth) * ((h + l.aqPartHeight - 1) / l.aqPartHeight);
+                rc = ensure_pu_buf(ctx, parts * 8 * sizeof(unsigned long long));
+                if (rc)
+                    return rc;
+                std::vector<unsigned long long> quadrants(parts * 8);
+                HIPCHK(launch_aq_quadrants(ctx->stream, ctx->bpp, pic.y, pic.strideY, w, h, l.aqPartWidth, l.aqPartHeight,
+                                           (unsigned long long*)ctx->puBuf));
+                HIPCHK(hipMemcpyAsync(quadrants.data(), ctx->puBuf, parts * 8 * sizeof(unsigned long long),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                l.dAvgActivity = hevc_aq_layer(w, h, l.aqPartWidth, l.aqPartHeight, l.numAQPartInWidth, l.numAQPartInHeight,
+                                               params->qpAdaptationRange, quadrants.data(), l.dActivity, l.dQpOffset,
+                                               l.dCuTreeOffset);
+            }
+            const x265gpu_hevc_aq_layer& last = params->layers[params->numLayers - 1];
+            for (int i = 0; i < visited; i++)                     // :441-447
+                invQscaleFactor[i] = aq_exp2fix8(last.dQpOffset[i]);
+        }
+        else if (mapped)
         {
             AqFrameParams p;
             p.aqMode = params->aqMode;

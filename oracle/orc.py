@@ -342,7 +342,7 @@ class FullResME:
             self.L.orc_me_destroy(self.me)
             self.me = None
 
-    def estimate(self, x, y, w, h, mvp, mvmin, mvmax, method, merange, subpel, mvc=()):
+    def estimate(self, x, y, w, h, mvp, mvmin, mvmax, method, merange, subpel, mvc=(), max_slices=1):
         """-> ((mvx, mvy), cost)"""
         L = self.L
         L.orc_me_set_source(self.me, C.c_void_p(self.fenc_org), self.stride, y * self.stride + x, w, h,
@@ -350,7 +350,7 @@ class FullResME:
         arr = (MV * max(1, len(mvc)))(*[MV(int(a), int(b)) for a, b in mvc])
         out = MV()
         cost = L.orc_motion_estimate(self.me, C.byref(self.rp), MV(*mvmin), MV(*mvmax), MV(*mvp), len(mvc), arr,
-                                     merange, C.byref(out), 1, 0)
+                                     merange, C.byref(out), max_slices, 0)
         return (out.x, out.y), cost
 
 

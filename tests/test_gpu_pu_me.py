@@ -88,6 +88,44 @@ def test_pu_exhaustive_search_and_lambda():
     _run(8, orc.FULL, 6, 4, 24, seed=7, lam=9.5)
 
 
+@pytest.mark.parametrize("method,merange", [(orc.STAR, 57), (orc.HEX, 24), (orc.UMH, 24), (orc.DIA, 16)])
+def test_pu_slice_bounded_vertical_range(method, merange):
+    """param->maxSlices > 1: Search::setSearchRange keeps vectors inside the slice, so the vertical range is a
+    few rows and often excludes 0.  Every candidate row is range-checked, which leaves the closing clamp of
+    motionEstimate (motion.cpp:1654-1659) nothing to do: the oracle run with maxSlices = 4 gives what the
+    library gives with the caller's bounds alone."""
+    depth, W, H, ctu = 8, 416, 256, 64
+    clip, pads, mx, my, fw, fh = _pictures(W, H, depth, ctu, 77)
+    table, centre = orc.bitcost_table(depth)
+    ref = orc.FullResME(depth, table, centre, pads[1], pads[0], mx, my)
+    rng = np.random.default_rng(merange)
+    jobs = []
+    while len(jobs) < 64:
+        w, h = PU_SHAPES[rng.integers(len(PU_SHAPES))]
+        x = int(rng.integers(0, (fw - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (fh - h) // 4 + 1)) * 4
+        top, bottom = (y // 64) * 64, (y // 64) * 64 + 64                   # slices of one CTU row
+        mvp = (int(rng.integers(-40, 41)), int(rng.integers(-120, 121)))
+        lo = (max((mvp[0] >> 2) - merange, -x - mx + 24), max((mvp[1] >> 2) - merange, top - y))
+        hi = (min((mvp[0] >> 2) + merange, fw - x - w + mx - 24), min((mvp[1] >> 2) + merange, bottom - y - h))
+        if lo[0] > hi[0] or lo[1] > hi[1]:
+            continue
+        mvc = [(int(rng.integers(-60, 61)), int(rng.integers(-200, 201))) for _ in range(int(rng.integers(0, 4)))]
+        jobs.append((x, y, w, h, mvp, lo, hi, mvc))
+    assert sum(1 for j in jobs if j[5][1] > 0 or j[6][1] < 0) > 5           # ranges that exclude the zero row
+    with api.Context(W, H, depth=depth, num_slots=2, ctu=ctu, keep_full_res=True) as ctx:
+        ctx.lowres_init(0, clip[0])
+        ctx.lowres_init(1, clip[1])
+        ctx.me_set_mvcost(table, centre)
+        got = ctx.pu_motion_estimate(1, 0, method, merange, 3, jobs)
+    for j, g in zip(jobs, got):
+        want = ref.estimate(j[0], j[1], j[2], j[3], j[4], j[5], j[6], method, merange, 3, j[7], max_slices=4)
+        assert g == want, (j, g, want)
+        # (the fork's closing zero-vector override, motion.cpp:1762-1768, is the one step that ignores the range)
+        assert g[0] == (0, 0) or j[5][1] * 4 <= g[0][1] <= j[6][1] * 4
+    ref.close()
+
+
 def test_pu_rejects_bad_jobs():
     ctx = api.Context(416, 240, num_slots=2, keep_full_res=True)
     try:

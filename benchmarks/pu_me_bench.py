@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--merange", type=int, default=57)
     ap.add_argument("--subme", type=int, default=3)
     ap.add_argument("--cpu-pus", type=int, default=400)
+    ap.add_argument("--pageable", action="store_true")
     a = ap.parse_args()
     W, H, ctu = a.width, a.height, 64
     clip = synth.luma_clip(W, H, 2, a.depth, seed=1234)
@@ -54,7 +55,8 @@ def main():
     ctx.pu_motion_estimate(1, 0, api.STAR_SEARCH, a.merange, a.subme, jobs[:1024])      # warm-up
     # the job array is packed once, outside the timed region: a C++ caller fills x265gpu_pu_job structs directly
     import ctypes as C
-    arr = (api.PuJob * len(jobs))()
+    # ... into page-locked arrays from x265gpu_host_alloc (--pageable: plain host memory instead)
+    arr = (api.PuJob * len(jobs))() if a.pageable else ctx.host_alloc(api.PuJob, len(jobs))
     for k, (x, y, w, h, mvp, mvmin, mvmax, mvc) in enumerate(jobs):
         j = arr[k]
         j.x, j.y, j.w, j.h = x, y, w, h
@@ -62,7 +64,7 @@ def main():
         j.mvminX, j.mvminY = mvmin
         j.mvmaxX, j.mvmaxY = mvmax
         j.numCandidates = 0
-    out_arr = (api.PuResult * len(jobs))()
+    out_arr = (api.PuResult * len(jobs))() if a.pageable else ctx.host_alloc(api.PuResult, len(jobs))
     times = []
     for _ in range(a.reps):
         t0 = time.perf_counter()
@@ -73,7 +75,8 @@ def main():
     out = {"metric": "full-res PU motion estimations per second (star, merange %d, subme %d)" % (a.merange, a.subme),
            "value": len(jobs) / dt, "unit": "PU/s", "pus": len(jobs), "seconds": dt,
            "config": {"workload": "%dx%d %d-bit, square PUs 64/32/16/8 of one frame" % (W, H, a.depth)},
-           "note": "wall time of x265gpu_pu_motion_estimate: job upload, kernel and result download"}
+           "note": "wall time of x265gpu_pu_motion_estimate: job upload, kernels and result download; job and "
+                   "result arrays in %s host memory" % ("pageable" if a.pageable else "page-locked")}
     if a.cpu_pus:
         pads = [np.pad(f, ((my, my + fh - H), (mx, mx + fw - W)), mode="edge") for f in clip]
         ref = orc.FullResME(a.depth, table, centre, pads[1], pads[0], mx, my)
@@ -85,6 +88,9 @@ def main():
         assert want == res[::step], "GPU result differs from the oracle"
         out["cpu_baseline"] = {"value": len(sample) / cdt, "unit": "PU/s", "cores": 1, "kind": "port",
                                "sample": "every %dth PU (%d PUs), checked equal to the GPU result" % (step, len(sample))}
+    if not a.pageable:
+        ctx.host_free(arr)
+        ctx.host_free(out_arr)
     ctx.close()
     print(json.dumps(out))
 

@@ -134,6 +134,12 @@ int x265gpu_get_geometry(const x265gpu_ctx* ctx, x265gpu_geometry* out);
 const char* x265gpu_last_error(const x265gpu_ctx* ctx);
 /* Waits for all work queued by this context. */
 int x265gpu_sync(x265gpu_ctx* ctx);
+/* Page-locked host memory for the arrays the caller hands over with X265GPU_MEM_HOST (source frames, PU job
+ * and result arrays): transfers from pageable memory are staged by the driver at a fraction of the PCIe
+ * rate.  Stands where x265 allocates the same buffers with x265_malloc (source/common/common.cpp:150-170);
+ * any host pointer is still accepted everywhere. */
+int x265gpu_host_alloc(x265gpu_ctx* ctx, size_t bytes, void** out);
+int x265gpu_host_free(x265gpu_ctx* ctx, void* p);
 
 /* Uploads the host-built BitCost table (source/encoder/bitcost.cpp:31-56):
  * `centre` points at the MVD-0 entry, valid for [-maxMvd, +maxMvd]. */

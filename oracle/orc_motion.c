@@ -134,8 +134,15 @@ typedef struct {
 static inline int mvcost_q(const srch* s, int qx, int qy) { return (uint16_t)(s->cx[qx] + s->cy[qy]); }
 static inline int mvcost_f(const srch* s, int fx, int fy) { return mvcost_q(s, fx * 4, fy * 4); }
 
+/* compare counters for workload analysis (tests / benchmarks read them through orc.py):
+ * [0] full-pel SADs, [1] those inside the star search's raster pass, [2] sub-pel compares */
+long long orc_me_counters[3];
+static int g_inRaster;
+
 static inline int fpel_sad(srch* s, int mx, int my)
 {
+    orc_me_counters[0]++;
+    orc_me_counters[1] += g_inRaster;
     return cmp_sad(s->me, s->fref + mx + my * s->stride, s->stride);
 }
 static inline int fpel_cost(srch* s, int mx, int my) { return fpel_sad(s, mx, my) + mvcost_f(s, mx, my); }
@@ -596,6 +603,7 @@ static void star_search(srch* s, int merange)
     const int raster = 5;
     if (sb.dist > raster)
     {
+        g_inRaster = 1;
         for (int ty = s->mvmin.y; ty <= s->mvmax.y; ty += raster)
             for (int tx = s->mvmin.x; tx <= s->mvmax.x; tx += raster)
             {
@@ -622,6 +630,7 @@ static void star_search(srch* s, int merange)
                 else
                     try_mv(s, tx, ty);
             }
+        g_inRaster = 0;
     }
 
     while (sb.dist > 0)
@@ -668,6 +677,7 @@ static int subpel_compare(srch* s, orc_mv qmv, int useSatd)
     intptr_t rs = s->ref->stride;
     const pixel* fref = s->ref->plane[0] + me->blockOffset + (qmv.x >> 2) + (qmv.y >> 2) * rs;
     int xf = qmv.x & 3, yf = qmv.y & 3;
+    orc_me_counters[2]++;
     if (!(xf | yf))
         return useSatd ? cmp_satd(me, fref, rs) : cmp_sad(me, fref, rs);
     pixel buf[64 * 64];

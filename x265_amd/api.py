@@ -22,7 +22,7 @@ EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_weight_cost", "x265gpu_weight_planes",
-    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_cutree_finish_qg8", "x265gpu_interp_luma",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_cutree_finish_qg8", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
     "x265gpu_cutree_clear", "x265gpu_cutree_swap", "x265gpu_cutree_propagate", "x265gpu_cutree_get_propagate_cost",
     "x265gpu_cutree_finish", "x265gpu_hist_stats", "x265gpu_mcstf_motion_search",
     "x265gpu_profile_enable", "x265gpu_profile_read",
@@ -157,6 +157,8 @@ def load_library(path=None):
     L.x265gpu_cutree_propagate.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.c_double, i32]
     L.x265gpu_cutree_get_propagate_cost.argtypes = [vp, i32, vp]
     L.x265gpu_cutree_finish.argtypes = [vp, i32, i32, C.c_double, C.c_double, vp, vp]
+    L.x265gpu_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.x265gpu_host_free.argtypes = [vp, vp]
     L.x265gpu_cutree_finish_qg8.argtypes = [vp, i32, i32, C.c_double, C.c_double, vp, vp]
     L.x265gpu_hist_stats.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp]
     L.x265gpu_aq_frame.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp, vp, vp, vp, vp, vp, vp]
@@ -288,6 +290,17 @@ class Context:
 
     def sync(self):
         self._chk(self.L.x265gpu_sync(self.h))
+
+    def host_alloc(self, ctype, count):
+        """A page-locked ctypes array of `count` `ctype`s (x265gpu_host_alloc); release with host_free(array)."""
+        p = C.c_void_p()
+        self._chk(self.L.x265gpu_host_alloc(self.h, C.sizeof(ctype) * count, C.byref(p)))
+        arr = (ctype * count).from_address(p.value)
+        arr._x265gpu_base = p.value
+        return arr
+
+    def host_free(self, arr):
+        self._chk(self.L.x265gpu_host_free(self.h, C.c_void_p(arr._x265gpu_base)))
 
     # ---- results ----
     def get_plane(self, slot, idx):

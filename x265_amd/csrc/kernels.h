@@ -131,6 +131,7 @@ struct PuFrame
     int depth;
     int method, merange, subpelRefine;
     int maxPasses;                     // largest ceil(tiles / 16) over the batch: sizes the LDS per wave
+    int rowForm;                       // 1: SAD stages read the encode block in row form (pu_kernels.hip)
 };
 struct BlockJob { int x, y, w, h; int qmvx, qmvy; int op; int reserved; };   // same layout as x265gpu_block_job
 hipError_t launch_block_compare(hipStream_t s, int bpp, const PuFrame& f, const BlockJob* dJobs, int n, int* dOut);
@@ -139,12 +140,13 @@ hipError_t launch_interp_block(hipStream_t s, int bpp, const void* pic, int stri
 hipError_t launch_pad_picture(hipStream_t s, int bpp, const void* src, long long srcStride, void* dst, int stride, int rows,
                               int width, int height, int marginX, int marginY);
 // Jobs sorted into size classes: order[] lists job indices class after class (PUs of at most 2, 4, 8 tiles of
-// 8x4 / 4x4 pixels share a wave eight, four, two at a time; the rest own a wave each), count[] the class sizes.
+// 8x4 / 4x4 pixels share a wave eight, four, two at a time; the rest own a wave each: those of at most 32 tiles,
+// then the larger ones), count[] the class sizes.
 struct PuClasses
 {
     const int* order;      // device
-    int count[4];
-    int maxPasses64;       // largest ceil(tiles / 16) in the last class
+    int count[5];
+    int maxPasses[2];      // largest ceil(tiles / 16) in each of the two wave-per-PU classes
 };
 // the shared-wave classes run on aux.side[0] beside the one-PU-per-wave class on s (when aux has a side stream)
 hipError_t launch_pu_search(hipStream_t s, const SearchStreams& aux, int bpp, const PuFrame& f, const PuJob* dJobs,

@@ -78,6 +78,8 @@ struct PuCtx
     int mvpx, mvpy;
     int depth;
     int bmx, bmy, bcost;           // running best of the integer search
+    const XG_GLOBAL P* fencPic;    // encode picture, pixel (0,0) (same stride as the reference)
+    bool tileForm;                 // lane layout of the staged encode block (stage_encode_block)
 };
 
 // sum over the wave of per-lane values; the total comes back as a wave-uniform scalar
@@ -218,6 +220,33 @@ template <typename P, bool SATD> __device__ __forceinline__ int block_cost(const
     const XG_GLOBAL P* base = block_at<P>(c, qx >> 2, qy >> 2);
     const int xf = qx & 3, yf = qy & 3;
     uint32_t acc = 0;
+    if (!SATD && !(xf | yf))
+    {
+        // full-pel SAD, the bulk of a search: the row loads of up to four passes are issued together
+#pragma unroll 1
+        for (int k = 0; k < c.passes; k += 4)
+        {
+            Row<P> rows[4];
+            const XG_LDS uint32_t* r = c.rec + (k * 64 + c.phys) * PU_REC_DW;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (k + i < c.passes)
+                    rows[i] = load_row_g<P>(base, (int)r[i * 64 * PU_REC_DW + 4]);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (k + i < c.passes)
+                {
+                    const XG_LDS uint32_t* ri = r + i * 64 * PU_REC_DW;
+                    const uint32_t mask = ri[5];
+                    const Cols d = pair_cols<P>(rows[i]);
+                    acc = __builtin_amdgcn_sad_u16(ri[0], d.q[0] & mask, acc);
+                    acc = __builtin_amdgcn_sad_u16(ri[1], d.q[1] & mask, acc);
+                    acc = __builtin_amdgcn_sad_u16(ri[2], d.q[2] & mask, acc);
+                    acc = __builtin_amdgcn_sad_u16(ri[3], d.q[3] & mask, acc);
+                }
+        }
+        return pu_sum<P>(c, (int)acc);
+    }
 #pragma unroll 1
     for (int k = 0; k < c.passes; k++)
     {
@@ -255,8 +284,11 @@ template <typename P> __device__ __forceinline__ int fpel_cost(const PuCtx<P>& c
     return block_cost<P, false>(c, mx * 4, my * 4) + mvcost<P>(c, mx * 4, my * 4);
 }
 
-template <typename P> __device__ __forceinline__ int subpel_cost(const PuCtx<P>& c, int qx, int qy, bool satd)
+template <typename P> __device__ __forceinline__ void ensure_tile_form(PuCtx<P>& c);
+template <typename P> __device__ __forceinline__ int subpel_cost(PuCtx<P>& c, int qx, int qy, bool satd)
 {
+    if (satd)
+        ensure_tile_form<P>(c);
     return (satd ? block_cost<P, true>(c, qx, qy) : block_cost<P, false>(c, qx, qy)) + mvcost<P>(c, qx, qy);
 }
 
@@ -837,21 +869,37 @@ template <typename P> __device__ __forceinline__ void area_diamond_search(PuCtx<
 }
 
 // The encode block into LDS (MotionEstimate::setSourcePU, motion.cpp:167-191): per pass and lane the
-// row's column pairs (masked), the row's pixel offset inside the block, and the mask.
+// row's column pairs (masked), the row's pixel offset inside the block, and the mask.  Two lane layouts:
+// tile form (a quad of lanes holds the four rows of an 8x4 / 4x4 tile, what the SATD needs) and row form
+// (consecutive lanes hold consecutive segments of one row, so the lanes of a row read neighbouring bytes of
+// the reference and share cache lines; a SAD only sums over lanes and takes either).  A lane reads back
+// only its own records, so switching layouts needs no agreement between the lanes of a wave.
 template <typename P>
-__device__ __forceinline__ void stage_encode_block(PuCtx<P>& c, const XG_GLOBAL P* fencPic, int stride, XG_LDS uint32_t* rec)
+__device__ __forceinline__ void stage_encode_block(PuCtx<P>& c, const XG_GLOBAL P* fencPic, int stride, XG_LDS uint32_t* rec,
+                                                   bool tileForm = true)
 {
     const int segW = (c.w & 7) ? 4 : 8;
-    const int tilesX = c.w / segW, ntiles = tilesX * (c.h >> 2);
-    const int tilesPerPass = c.lpp >> 2;
-    c.passes = (ntiles + tilesPerPass - 1) / tilesPerPass;
+    const int segsX = c.w / segW, nsegs = segsX * c.h;
+    c.passes = (nsegs + c.lpp - 1) / c.lpp;
     const XG_GLOBAL P* fenc = fencPic + ((long long)c.y * stride + c.x);
     for (int k = 0; k < c.passes; k++)
     {
-        const int t = k * tilesPerPass + (c.lane >> 2);
-        const bool valid = t < ntiles;
-        const int ty = valid ? t / tilesX : 0, tx = valid ? t - ty * tilesX : 0;
-        const int off = (ty * 4 + (c.lane & 3)) * stride + tx * segW;
+        bool valid;
+        int off;
+        if (tileForm)
+        {
+            const int t = k * (c.lpp >> 2) + (c.lane >> 2);
+            valid = t < (nsegs >> 2);
+            const int ty = valid ? t / segsX : 0, tx = valid ? t - ty * segsX : 0;
+            off = (ty * 4 + (c.lane & 3)) * stride + tx * segW;
+        }
+        else
+        {
+            const int i = k * c.lpp + c.lane;
+            valid = i < nsegs;
+            const int row = valid ? i / segsX : 0, sx = valid ? i - row * segsX : 0;
+            off = row * stride + sx * segW;
+        }
         const uint32_t mask = valid ? (segW == 8 ? 0xffffffffu : 0x0000ffffu) : 0u;
         const Cols fc = pair_cols<P>(load_row_g<P>(fenc, off));
         XG_LDS uint32_t* r = rec + (k * 64 + c.phys) * PU_REC_DW;
@@ -862,7 +910,15 @@ __device__ __forceinline__ void stage_encode_block(PuCtx<P>& c, const XG_GLOBAL 
         r[4] = (uint32_t)off;
         r[5] = mask;
     }
+    c.tileForm = tileForm;
     lds_handover();
+}
+
+// SATD compares want the tile form; the integer search and the SAD stages run in row form
+template <typename P> __device__ __forceinline__ void ensure_tile_form(PuCtx<P>& c)
+{
+    if (!c.tileForm)
+        stage_encode_block<P>(c, c.fencPic, c.stride, (XG_LDS uint32_t*)c.rec, true);
 }
 
 // LPP lanes per PU.  64: one PU per wave, `order` unused or a list of job indices.  Smaller: 64 / LPP
@@ -913,7 +969,8 @@ __global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, const
     c.hi = maxMvd;
     c.depth = f.depth;
 
-    stage_encode_block<P>(c, as_global<P>(f.fenc), f.stride, rec);
+    c.fencPic = as_global<P>(f.fenc);
+    stage_encode_block<P>(c, c.fencPic, f.stride, rec, f.method == PU_AREA_DIAMOND || !f.rowForm);
 
     if (f.method == PU_AREA_DIAMOND)
     {
@@ -1241,47 +1298,49 @@ static void launch_pu_class(hipStream_t s, const PuFrame& f, const PuJob* dJobs,
                        maxMvd, dOut);
 }
 
-// the shared-wave classes on `small`, the wave-per-PU class on `big`
+// Stream plan: the wave-per-PU classes on `big` (the longest-running waves first), the eight- and four-per-wave
+// classes on `small`, the two-per-wave class on `third`.
 template <typename P>
-static void launch_pu_classes(hipStream_t small, hipStream_t big, const PuFrame& f, const PuJob* dJobs, const PuClasses& k,
-                              const uint16_t* costTab, int maxMvd, PuResult* dOut)
+static void launch_pu_classes(hipStream_t small, hipStream_t big, hipStream_t third, const PuFrame& f, const PuJob* dJobs,
+                              const PuClasses& k, const uint16_t* costTab, int maxMvd, PuResult* dOut)
 {
-    const int* o = k.order;
-    launch_pu_class<P, 8>(small, f, dJobs, o, k.count[0], 1, costTab, maxMvd, dOut);
-    o += k.count[0];
-    launch_pu_class<P, 16>(small, f, dJobs, o, k.count[1], 1, costTab, maxMvd, dOut);
-    o += k.count[1];
-    launch_pu_class<P, 32>(small, f, dJobs, o, k.count[2], 1, costTab, maxMvd, dOut);
-    o += k.count[2];
-    launch_pu_class<P, 64>(big, f, dJobs, o, k.count[3], k.maxPasses64, costTab, maxMvd, dOut);
+    const int* o0 = k.order;
+    const int* o1 = o0 + k.count[0];
+    const int* o2 = o1 + k.count[1];
+    const int* o3 = o2 + k.count[2];
+    const int* o4 = o3 + k.count[3];
+    launch_pu_class<P, 64>(big, f, dJobs, o4, k.count[4], k.maxPasses[1], costTab, maxMvd, dOut);
+    launch_pu_class<P, 8>(small, f, dJobs, o0, k.count[0], 1, costTab, maxMvd, dOut);
+    launch_pu_class<P, 32>(third, f, dJobs, o2, k.count[2], 1, costTab, maxMvd, dOut);
+    launch_pu_class<P, 16>(small, f, dJobs, o1, k.count[1], 1, costTab, maxMvd, dOut);
+    launch_pu_class<P, 64>(big, f, dJobs, o3, k.count[3], k.maxPasses[0], costTab, maxMvd, dOut);
 }
 
-// The size classes are independent: with a side stream the shared-wave classes run beside the
-// wave-per-PU class and fill each other's tails.
+// The size classes are independent: on side streams the shared-wave classes run beside the
+// wave-per-PU classes and fill each other's tails.
 hipError_t launch_pu_search(hipStream_t s, const SearchStreams& aux, int bpp, const PuFrame& f, const PuJob* dJobs,
                             const PuClasses& classes, const uint16_t* costTab, int maxMvd, PuResult* dOut)
 {
-    const bool split = aux.count > 0 && classes.count[3] > 0 && classes.count[0] + classes.count[1] + classes.count[2] > 0;
-    hipStream_t small = s;
-    if (split)
+    const int sides = aux.count > 2 ? 2 : aux.count;
+    hipStream_t small = sides > 0 ? aux.side[0] : s, third = sides > 1 ? aux.side[1] : s;
+    for (int k = 0; k < sides; k++)
     {
-        hipError_t e = hipEventRecord(aux.fork, s);
+        hipError_t e = k ? hipSuccess : hipEventRecord(aux.fork, s);
         if (e == hipSuccess)
-            e = hipStreamWaitEvent(aux.side[0], aux.fork, 0);
+            e = hipStreamWaitEvent(aux.side[k], aux.fork, 0);
         if (e != hipSuccess)
             return e;
-        small = aux.side[0];
     }
     if (bpp == 1)
-        launch_pu_classes<uint8_t>(small, s, f, dJobs, classes, costTab, maxMvd, dOut);
+        launch_pu_classes<uint8_t>(small, s, third, f, dJobs, classes, costTab, maxMvd, dOut);
     else
-        launch_pu_classes<uint16_t>(small, s, f, dJobs, classes, costTab, maxMvd, dOut);
+        launch_pu_classes<uint16_t>(small, s, third, f, dJobs, classes, costTab, maxMvd, dOut);
     hipError_t e = hipGetLastError();
-    if (split && e == hipSuccess)
+    for (int k = 0; k < sides && e == hipSuccess; k++)
     {
-        e = hipEventRecord(aux.join[0], aux.side[0]);
+        e = hipEventRecord(aux.join[k], aux.side[k]);
         if (e == hipSuccess)
-            e = hipStreamWaitEvent(s, aux.join[0], 0);
+            e = hipStreamWaitEvent(s, aux.join[k], 0);
     }
     return e;
 }

@@ -9,6 +9,7 @@
 #include <new>
 #include <string>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 using namespace xg;
@@ -587,6 +588,26 @@ int x265gpu_get_geometry(const x265gpu_ctx* ctx, x265gpu_geometry* o)
 
 const char* x265gpu_last_error(const x265gpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+int x265gpu_host_alloc(x265gpu_ctx* ctx, size_t bytes, void** out)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || !out || !bytes)
+        return X265GPU_ERR_ARG;
+    *out = nullptr;
+    HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return X265GPU_OK;
+}
+
+int x265gpu_host_free(x265gpu_ctx* ctx, void* p)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx)
+        return X265GPU_ERR_ARG;
+    if (p)
+        HIPCHK(hipHostFree(p));
+    return X265GPU_OK;
+}
+
 int x265gpu_sync(x265gpu_ctx* ctx)
 {
     DeviceScope deviceScope(ctx);
@@ -1149,6 +1170,8 @@ PuFrame pu_frame(const x265gpu_ctx* ctx, int slotFenc, int slotRef)
     f.marginY = ctx->fullMarginY;
     f.depth = ctx->cfg.internalBitDepth;
     f.maxPasses = 1;
+    static const bool rowForm = !getenv("X265GPU_PU_ROWFORM") || atoi(getenv("X265GPU_PU_ROWFORM")) != 0;
+    f.rowForm = rowForm;
     return f;
 }
 
@@ -1211,11 +1234,12 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
         return fail(ctx, X265GPU_ERR_UNSUPPORTED, "pu_motion_estimate: search method");
     if (subpelRefine < 0 || subpelRefine > 7 || merange < 1 || merange > 32767)
         return fail(ctx, X265GPU_ERR_ARG, "pu_motion_estimate: subpelRefine or merange");
-    int maxPasses = 1;
-    // size classes: PUs of at most 2 / 4 / 8 tiles share a wave (8 / 4 / 2 at a time), the rest own one each;
-    // X265GPU_PU_PACK=0 gives every PU a wave
+    int maxPasses = 1, midPasses = 1;
+    // size classes: PUs of at most 2 / 4 / 8 tiles share a wave (8 / 4 / 2 at a time), the rest own one each, split
+    // into those of at most 32 tiles (two passes, a small LDS record) and the large ones, which are started first,
+    // largest first; X265GPU_PU_PACK=0 gives every PU a wave
     static const bool pack = []() { const char* e = getenv("X265GPU_PU_PACK"); return !e || atoi(e) != 0; }();
-    std::vector<int> cls(n);
+    std::vector<int> cls(n), passesOf(n);
     PuClasses classes;
     memset(&classes, 0, sizeof(classes));
     for (int i = 0; i < n; i++)
@@ -1230,22 +1254,31 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
             return fail(ctx, X265GPU_ERR_ARG, "pu_motion_estimate: bad job");
         const int segW = (j.w & 7) ? 4 : 8;
         const int tiles = (j.w / segW) * (j.h / 4);
-        cls[i] = !pack ? 3 : tiles <= 2 ? 0 : tiles <= 4 ? 1 : tiles <= 8 ? 2 : 3;
+        const int passes = (tiles + 15) / 16;
+        passesOf[i] = passes;
+        cls[i] = !pack ? 4 : tiles <= 2 ? 0 : tiles <= 4 ? 1 : tiles <= 8 ? 2 : tiles <= 32 ? 3 : 4;
         classes.count[cls[i]]++;
         if (cls[i] == 3)
-        {
-            const int passes = (tiles + 15) / 16;
+            midPasses = passes > midPasses ? passes : midPasses;
+        if (cls[i] == 4)
             maxPasses = passes > maxPasses ? passes : maxPasses;
-        }
     }
-    classes.maxPasses64 = maxPasses;
+    classes.maxPasses[0] = midPasses;
+    classes.maxPasses[1] = maxPasses;
     std::vector<int> order(n);
     {
-        int at[4] = { 0, classes.count[0], classes.count[0] + classes.count[1],
-                      classes.count[0] + classes.count[1] + classes.count[2] };
+        int at[5], sum = 0;
+        for (int k = 0; k < 5; k++)
+        {
+            at[k] = sum;
+            sum += classes.count[k];
+        }
+        const int bigAt = at[4];
         for (int i = 0; i < n; i++)
             order[at[cls[i]]++] = i;
+        std::stable_sort(order.begin() + bigAt, order.end(), [&](int a, int b) { return passesOf[a] > passesOf[b]; });
     }
+    maxPasses = maxPasses > midPasses ? maxPasses : midPasses;
     const size_t jobBytes = align256(sizeof(PuJob) * (size_t)n), outBytes = align256(sizeof(PuResult) * (size_t)n);
     const size_t orderBytes = sizeof(int) * (size_t)n;
     int rc = ensure_pu_buf(ctx, jobBytes + outBytes + orderBytes);

@@ -279,6 +279,51 @@ template <typename P, bool SATD> __device__ __forceinline__ int block_cost(const
     return pu_sum<P>(c, (int)acc);
 }
 
+// SADs of four blocks at full-pel vectors (mx[k], my[k]) (what sad_x4 does for the reference,
+// source/common/pixel.cpp:113-136): the four row loads of a pass are in flight together and the four sums
+// reduce side by side, which is what a wave that owns its candidates one after the other otherwise lacks.
+template <typename P, int N>
+__device__ __forceinline__ void sad_pts(const PuCtx<P>& c, const int mx[N], const int my[N], int out[N])
+{
+    const XG_GLOBAL P* base[N];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        base[k] = block_at<P>(c, mx[k], my[k]);
+    uint32_t acc[N];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        acc[k] = 0;
+#pragma unroll 1
+    for (int p = 0; p < c.passes; p++)
+    {
+        const XG_LDS uint32_t* r = c.rec + (p * 64 + c.phys) * PU_REC_DW;
+        const uint32_t f0 = r[0], f1 = r[1], f2 = r[2], f3 = r[3], mask = r[5];
+        const int off = (int)r[4];
+        Row<P> rows[N];
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            rows[k] = load_row_g<P>(base[k], off);
+#pragma unroll
+        for (int k = 0; k < N; k++)
+        {
+            const Cols d = pair_cols<P>(rows[k]);
+            acc[k] = __builtin_amdgcn_sad_u16(f0, d.q[0] & mask, acc[k]);
+            acc[k] = __builtin_amdgcn_sad_u16(f1, d.q[1] & mask, acc[k]);
+            acc[k] = __builtin_amdgcn_sad_u16(f2, d.q[2] & mask, acc[k]);
+            acc[k] = __builtin_amdgcn_sad_u16(f3, d.q[3] & mask, acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        out[k] = pu_sum<P>(c, (int)acc[k]);
+}
+
+template <typename P>
+__device__ __forceinline__ void sad_pts4(const PuCtx<P>& c, const int mx[4], const int my[4], int out[4])
+{
+    sad_pts<P, 4>(c, mx, my, out);
+}
+
 template <typename P> __device__ __forceinline__ int fpel_cost(const PuCtx<P>& c, int mx, int my)
 {
     return block_cost<P, false>(c, mx * 4, my * 4) + mvcost<P>(c, mx * 4, my * 4);
@@ -434,38 +479,41 @@ __device__ __forceinline__ void star_pattern(PuCtx<P>& c, int earlyExitIters, in
     for (int dist = 1; dist < 16 || dist <= last; dist <<= 1)
     {
         const int saved = c.bcost;
-        if (dist < 16)
-        {
-            const int h = dist >> 1;
+        // A round's points are measured four at a time (their costs do not depend on each other) and then
+        // offered in the reference's order; a point outside the range is measured at its clamped place and dropped.
+        const int npts = dist < 16 ? 8 : 16;
+        const int h = dist >> 1, q = dist >> 2;
 #pragma unroll 1
-            for (int k = 0; k < 8; k++)
-            {
-                const int sx = k_star8[k][0], sy = k_star8[k][1], half = k_star8[k][2], point = k_star8[k][3];
-                if (half && dist == 1)
-                    continue;                       // the first round has only the four axis points
-                const int d = half ? h : dist;
-                const int mx = ox + sx * d, my = oy + sy * d;
-                // the reference tests only the side a point can leave the range on
-                const bool ok = (sx >= 0 || mx >= c.minx) && (sx <= 0 || mx <= c.maxx) &&
-                                (sy >= 0 || my >= c.miny) && (sy <= 0 || my <= c.maxy);
-                if (ok)
-                    star_try<P>(c, mx, my, point, d, bPoint, bDist);
-            }
-        }
-        else
+        for (int k0 = 0; k0 < npts; k0 += 4)
         {
-            const int q = dist >> 2;
-#pragma unroll 1
-            for (int k = 0; k < 16; k++)
+            int mxs[4], mys[4], pts[4], ds[4], sad[4], mc[4];
+            bool ok[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
             {
-                int sx, sy, mx, my;
-                if (k < 4)
+                const int k = k0 + i;
+                int sx, sy;
+                bool take = true;
+                if (dist < 16)
+                {
+                    sx = k_star8[k][0];
+                    sy = k_star8[k][1];
+                    const int half = k_star8[k][2];
+                    pts[i] = k_star8[k][3];
+                    take = !(half && dist == 1);    // the first round has only the four axis points
+                    ds[i] = half ? h : dist;
+                    mxs[i] = ox + sx * ds[i];
+                    mys[i] = oy + sy * ds[i];
+                }
+                else if (k < 4)
                 {
                     // top, left, right, bottom
                     sx = (k == 1) ? -1 : (k == 2) ? 1 : 0;
                     sy = (k == 0) ? -1 : (k == 3) ? 1 : 0;
-                    mx = ox + sx * dist;
-                    my = oy + sy * dist;
+                    pts[i] = 0;
+                    ds[i] = dist;
+                    mxs[i] = ox + sx * dist;
+                    mys[i] = oy + sy * dist;
                 }
                 else
                 {
@@ -473,14 +521,33 @@ __device__ __forceinline__ void star_pattern(PuCtx<P>& c, int earlyExitIters, in
                     const int idx = ((k - 4) >> 2) + 1, corner = (k - 4) & 3;
                     sx = (corner & 1) ? 1 : -1;
                     sy = (corner & 2) ? 1 : -1;
-                    mx = ox + sx * q * idx;
-                    my = oy + sy * (dist - q * idx);
+                    pts[i] = 0;
+                    ds[i] = dist;
+                    mxs[i] = ox + sx * q * idx;
+                    mys[i] = oy + sy * (dist - q * idx);
                 }
-                const bool ok = (sx >= 0 || mx >= c.minx) && (sx <= 0 || mx <= c.maxx) &&
-                                (sy >= 0 || my >= c.miny) && (sy <= 0 || my <= c.maxy);
-                if (ok)
-                    star_try<P>(c, mx, my, 0, dist, bPoint, bDist);
+                // the reference tests only the side a point can leave the range on
+                ok[i] = take && (sx >= 0 || mxs[i] >= c.minx) && (sx <= 0 || mxs[i] <= c.maxx) &&
+                        (sy >= 0 || mys[i] >= c.miny) && (sy <= 0 || mys[i] <= c.maxy);
+                mc[i] = mvcost<P>(c, mxs[i] * 4, mys[i] * 4);
             }
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                any |= ok[i];
+            if (!any)
+                continue;
+            sad_pts4<P>(c, mxs, mys, sad);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (ok[i] && sad[i] + mc[i] < c.bcost)
+                {
+                    c.bcost = sad[i] + mc[i];
+                    c.bmx = mxs[i];
+                    c.bmy = mys[i];
+                    bPoint = pts[i];
+                    bDist = ds[i];
+                }
         }
         if (c.bcost < saved)
             rounds = 0;
@@ -539,20 +606,24 @@ template <typename P> __device__ __forceinline__ void star_search(PuCtx<P>& c, i
                     {
                         if (tx + raster * 3 <= c.maxx)
                         {
-#pragma unroll 1
+                            int mxs[4], mys[4], sad[4], mc[4];
+#pragma unroll
                             for (int k = 0; k < 4; k++)
                             {
-                                const int mx = tx + raster * k;
+                                mxs[k] = tx + raster * k;
+                                mys[k] = ty;
                                 // the fourth point is priced with the vector scaled by 8 instead of 4 (motion.cpp:1392)
-                                const int mc = k < 3 ? mvcost<P>(c, mx * 4, ty * 4) : mvcost<P>(c, mx * 8, ty * 8);
-                                const int cost = block_cost<P, false>(c, mx * 4, ty * 4) + mc;
-                                if (cost < c.bcost)
+                                mc[k] = k < 3 ? mvcost<P>(c, mxs[k] * 4, ty * 4) : mvcost<P>(c, mxs[k] * 8, ty * 8);
+                            }
+                            sad_pts4<P>(c, mxs, mys, sad);
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                                if (sad[k] + mc[k] < c.bcost)
                                 {
-                                    c.bcost = cost;
-                                    c.bmx = mx;
+                                    c.bcost = sad[k] + mc[k];
+                                    c.bmx = mxs[k];
                                     c.bmy = ty;
                                 }
-                            }
                             tx += raster * 3;
                         }
                         else

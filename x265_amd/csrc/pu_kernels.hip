@@ -189,7 +189,7 @@ __device__ __forceinline__ Row<P> interp_row(const XG_GLOBAL P* p, int stride, i
         const int shiftV = 6 + headRoom;
         const int offV = (1 << (shiftV - 1)) + (8192 << 6);
         int acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll 1
+#pragma unroll 4
         for (int k = 0; k < 8; k++)
         {
             int in[16];

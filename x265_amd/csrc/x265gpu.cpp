@@ -1234,6 +1234,13 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
         return fail(ctx, X265GPU_ERR_UNSUPPORTED, "pu_motion_estimate: search method");
     if (subpelRefine < 0 || subpelRefine > 7 || merange < 1 || merange > 32767)
         return fail(ctx, X265GPU_ERR_ARG, "pu_motion_estimate: subpelRefine or merange");
+    // the jobs go up while the host checks and sorts them
+    const size_t jobBytes = align256(sizeof(PuJob) * (size_t)n), outBytes = align256(sizeof(PuResult) * (size_t)n);
+    const size_t orderBytes = sizeof(int) * (size_t)n;
+    int rc = ensure_pu_buf(ctx, jobBytes + outBytes + orderBytes);
+    if (rc)
+        return rc;
+    HIPCHK(hipMemcpyAsync(ctx->puBuf, jobs, sizeof(PuJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     int maxPasses = 1, midPasses = 1;
     // size classes: PUs of at most 2 / 4 / 8 tiles share a wave (8 / 4 / 2 at a time), the rest own one each, split
     // into those of at most 32 tiles (two passes, a small LDS record) and the large ones, which are started first,
@@ -1251,7 +1258,10 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
             j.mvminX > j.mvmaxX || j.mvminY > j.mvmaxY ||
             j.x + j.mvminX < -ctx->fullMarginX + 8 || j.x + j.w + j.mvmaxX > ctx->fullW + ctx->fullMarginX - 16 ||
             j.y + j.mvminY < -ctx->fullMarginY + 8 || j.y + j.h + j.mvmaxY > ctx->fullH + ctx->fullMarginY - 8)
+        {
+            (void)hipStreamSynchronize(ctx->stream);      // the upload reads the caller's array
             return fail(ctx, X265GPU_ERR_ARG, "pu_motion_estimate: bad job");
+        }
         const int segW = (j.w & 7) ? 4 : 8;
         const int tiles = (j.w / segW) * (j.h / 4);
         const int passes = (tiles + 15) / 16;
@@ -1279,12 +1289,6 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
         std::stable_sort(order.begin() + bigAt, order.end(), [&](int a, int b) { return passesOf[a] > passesOf[b]; });
     }
     maxPasses = maxPasses > midPasses ? maxPasses : midPasses;
-    const size_t jobBytes = align256(sizeof(PuJob) * (size_t)n), outBytes = align256(sizeof(PuResult) * (size_t)n);
-    const size_t orderBytes = sizeof(int) * (size_t)n;
-    int rc = ensure_pu_buf(ctx, jobBytes + outBytes + orderBytes);
-    if (rc)
-        return rc;
-    HIPCHK(hipMemcpyAsync(ctx->puBuf, jobs, sizeof(PuJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->puBuf + jobBytes + outBytes, order.data(), orderBytes, hipMemcpyHostToDevice, ctx->stream));
     classes.order = (const int*)(ctx->puBuf + jobBytes + outBytes);
     PuFrame f = pu_frame(ctx, slotFenc, slotRef);

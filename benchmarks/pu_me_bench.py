@@ -39,8 +39,10 @@ def main():
     ap.add_argument("--subme", type=int, default=3)
     ap.add_argument("--cpu-pus", type=int, default=400)
     ap.add_argument("--pageable", action="store_true")
+    ap.add_argument("--method", default="star", choices=["dia", "hex", "umh", "star"])
     a = ap.parse_args()
     W, H, ctu = a.width, a.height, 64
+    method = {"dia": api.DIA_SEARCH, "hex": api.HEX_SEARCH, "umh": api.UMH_SEARCH, "star": api.STAR_SEARCH}[a.method]
     clip = synth.luma_clip(W, H, 2, a.depth, seed=1234)
     mx, my = ctu + 32, ctu + 16
     fw, fh = -(-W // ctu) * ctu, -(-H // ctu) * ctu
@@ -52,7 +54,7 @@ def main():
     ctx.lowres_init(0, clip[0])
     ctx.lowres_init(1, clip[1])
     ctx.me_set_mvcost(table, centre)
-    ctx.pu_motion_estimate(1, 0, api.STAR_SEARCH, a.merange, a.subme, jobs[:1024])      # warm-up
+    ctx.pu_motion_estimate(1, 0, method, a.merange, a.subme, jobs[:1024])      # warm-up
     # the job array is packed once, outside the timed region: a C++ caller fills x265gpu_pu_job structs directly
     import ctypes as C
     # ... into page-locked arrays from x265gpu_host_alloc (--pageable: plain host memory instead)
@@ -68,11 +70,11 @@ def main():
     times = []
     for _ in range(a.reps):
         t0 = time.perf_counter()
-        ctx._chk(ctx.L.x265gpu_pu_motion_estimate(ctx.h, 1, 0, api.STAR_SEARCH, a.merange, a.subme, len(jobs), arr, out_arr))
+        ctx._chk(ctx.L.x265gpu_pu_motion_estimate(ctx.h, 1, 0, method, a.merange, a.subme, len(jobs), arr, out_arr))
         times.append(time.perf_counter() - t0)
     res = [((o.mvX, o.mvY), o.cost) for o in out_arr]
     dt = sorted(times)[len(times) // 2]
-    out = {"metric": "full-res PU motion estimations per second (star, merange %d, subme %d)" % (a.merange, a.subme),
+    out = {"metric": "full-res PU motion estimations per second (%s, merange %d, subme %d)" % (a.method, a.merange, a.subme),
            "value": len(jobs) / dt, "unit": "PU/s", "pus": len(jobs), "seconds": dt,
            "config": {"workload": "%dx%d %d-bit, square PUs 64/32/16/8 of one frame" % (W, H, a.depth)},
            "note": "wall time of x265gpu_pu_motion_estimate: job upload, kernels and result download; job and "
@@ -83,7 +85,7 @@ def main():
         step = max(1, len(jobs) // a.cpu_pus)
         sample = jobs[::step]
         t0 = time.perf_counter()
-        want = [ref.estimate(j[0], j[1], j[2], j[3], j[4], j[5], j[6], orc.STAR, a.merange, a.subme, j[7]) for j in sample]
+        want = [ref.estimate(j[0], j[1], j[2], j[3], j[4], j[5], j[6], method, a.merange, a.subme, j[7]) for j in sample]
         cdt = time.perf_counter() - t0
         assert want == res[::step], "GPU result differs from the oracle"
         out["cpu_baseline"] = {"value": len(sample) / cdt, "unit": "PU/s", "cores": 1, "kind": "port",

@@ -329,6 +329,20 @@ template <typename P> __device__ __forceinline__ int fpel_cost(const PuCtx<P>& c
     return block_cost<P, false>(c, mx * 4, my * 4) + mvcost<P>(c, mx * 4, my * 4);
 }
 
+// fpel_cost of N vectors at once (sad_pts plus the vector costs)
+template <typename P, int N>
+__device__ __forceinline__ void fpel_costs(const PuCtx<P>& c, const int mx[N], const int my[N], int cost[N])
+{
+    int mc[N];
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        mc[k] = mvcost<P>(c, mx[k] * 4, my[k] * 4);
+    sad_pts<P, N>(c, mx, my, cost);
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        cost[k] += mc[k];
+}
+
 template <typename P> __device__ __forceinline__ void ensure_tile_form(PuCtx<P>& c);
 template <typename P> __device__ __forceinline__ int subpel_cost(PuCtx<P>& c, int qx, int qy, bool satd)
 {
@@ -360,17 +374,21 @@ template <typename P> __device__ __forceinline__ void square_refine(PuCtx<P>& c)
 {
     const int ox = c.bmx, oy = c.bmy;
     int dir = 0;
-#pragma unroll 1
-    for (int k = 1; k <= 8; k++)
+    int mxs[8], mys[8], cost[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
     {
-        const int dx = k_square1[k][0], dy = k_square1[k][1];
-        const int cost = fpel_cost<P>(c, ox + dx, oy + dy);
-        if ((dy == 0 || y_ok<P>(c, oy + dy)) && cost < c.bcost)
-        {
-            c.bcost = cost;
-            dir = k;
-        }
+        mxs[k] = ox + k_square1[k + 1][0];
+        mys[k] = oy + k_square1[k + 1][1];
     }
+    fpel_costs<P, 8>(c, mxs, mys, cost);
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if ((mys[k] == oy || y_ok<P>(c, mys[k])) && cost[k] < c.bcost)
+        {
+            c.bcost = cost[k];
+            dir = k + 1;
+        }
     c.bmx = ox + k_square1[dir][0];
     c.bmy = oy + k_square1[dir][1];
 }
@@ -380,14 +398,20 @@ template <typename P> __device__ __forceinline__ void hex_search(PuCtx<P>& c, in
 {
     int bx = c.bmx, by = c.bmy;
     int bc = c.bcost << 3;
-#pragma unroll 1
-    for (int k = 0; k < 6; k++)
     {
-        // (-2,0) (-1,2) (1,2) (2,0) (1,-2) (-1,-2) = hex2[1..6], direction values 2..7
-        const int dx = k_hex2[k + 1][0], dy = k_hex2[k + 1][1];
-        const int cost = fpel_cost<P>(c, bx + dx, by + dy);
-        if (y_ok<P>(c, by + dy))
-            bc = min(bc, (cost << 3) + k + 2);
+        // (-2,0) (-1,2) (1,2) (2,0) (1,-2) (-1,-2) = hex2[1..6], direction values 2..7; measured together
+        int mxs[6], mys[6], cost[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+        {
+            mxs[k] = bx + k_hex2[k + 1][0];
+            mys[k] = by + k_hex2[k + 1][1];
+        }
+        fpel_costs<P, 6>(c, mxs, mys, cost);
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            if (y_ok<P>(c, mys[k]))
+                bc = min(bc, (cost[k] << 3) + k + 2);
     }
     if (bc & 7)
     {
@@ -400,14 +424,18 @@ template <typename P> __device__ __forceinline__ void hex_search(PuCtx<P>& c, in
             for (int i = (merange >> 1) - 1; i > 0 && in_range<P>(c, bx, by); i--)
             {
                 bc &= ~7;
-#pragma unroll 1
+                int mxs[3], mys[3], cost[3];
+#pragma unroll
                 for (int k = 0; k < 3; k++)
                 {
-                    const int dx = k_hex2[dir + k][0], dy = k_hex2[dir + k][1];
-                    const int cost = fpel_cost<P>(c, bx + dx, by + dy);
-                    if (y_ok<P>(c, by + dy))
-                        bc = min(bc, (cost << 3) + k + 1);
+                    mxs[k] = bx + k_hex2[dir + k][0];
+                    mys[k] = by + k_hex2[dir + k][1];
                 }
+                fpel_costs<P, 3>(c, mxs, mys, cost);
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    if (y_ok<P>(c, mys[k]))
+                        bc = min(bc, (cost[k] << 3) + k + 1);
                 if (!(bc & 7))
                     break;
                 dir += (bc & 7) - 2;
@@ -431,14 +459,20 @@ template <typename P> __device__ __forceinline__ void dia_search(PuCtx<P>& c, in
     int i = merange;
     do
     {
-#pragma unroll 1
+        int mxs[4], mys[4], cost[4];
+#pragma unroll
         for (int k = 0; k < 4; k++)
         {
-            const int dx = k_square1[k + 1][0], dy = k_square1[k + 1][1];
-            const int cost = fpel_cost<P>(c, bx + dx, by + dy);
+            mxs[k] = bx + k_square1[k + 1][0];
+            mys[k] = by + k_square1[k + 1][1];
+        }
+        fpel_costs<P, 4>(c, mxs, mys, cost);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
             const int step = (0xC431 >> (4 * k)) & 15;            // 1, 3, 4, 12
-            if (dy == 0 || y_ok<P>(c, by + dy))
-                bc = min(bc, (cost << 4) + step);
+            if (mys[k] == by || y_ok<P>(c, mys[k]))
+                bc = min(bc, (cost[k] << 4) + step);
         }
         if (!(bc & 15))
             break;
@@ -663,9 +697,41 @@ template <typename P> __device__ __forceinline__ void try_rel(PuCtx<P>& c, int o
 // four COST_MV_X4 offsets packed as biased nibbles
 template <typename P> __device__ __forceinline__ void try_x4(PuCtx<P>& c, int ox, int oy, uint32_t px, uint32_t py)
 {
-#pragma unroll 1
+    // measured together, offered in order
+    int mxs[4], mys[4], cost[4];
+#pragma unroll
     for (int k = 0; k < 4; k++)
-        try_rel<P>(c, ox, oy, nib(px, k), nib(py, k));
+    {
+        mxs[k] = ox + nib(px, k);
+        mys[k] = oy + nib(py, k);
+    }
+    fpel_costs<P, 4>(c, mxs, mys, cost);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (y_ok<P>(c, mys[k]) && cost[k] < c.bcost)
+        {
+            c.bcost = cost[k];
+            c.bmx = mxs[k];
+            c.bmy = mys[k];
+        }
+}
+
+// four COST_MV_X4 offsets given one by one
+template <typename P>
+__device__ __forceinline__ void try_rel4(PuCtx<P>& c, int ox, int oy, int dx0, int dy0, int dx1, int dy1, int dx2, int dy2,
+                                         int dx3, int dy3)
+{
+    const int mxs[4] = { ox + dx0, ox + dx1, ox + dx2, ox + dx3 }, mys[4] = { oy + dy0, oy + dy1, oy + dy2, oy + dy3 };
+    int cost[4];
+    fpel_costs<P, 4>(c, mxs, mys, cost);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (y_ok<P>(c, mys[k]) && cost[k] < c.bcost)
+        {
+            c.bcost = cost[k];
+            c.bmx = mxs[k];
+            c.bmy = mys[k];
+        }
 }
 
 // CROSS(start, x_max, y_max) around (ox,oy): motion.cpp:361-385
@@ -675,10 +741,7 @@ template <typename P> __device__ __forceinline__ void umh_cross(PuCtx<P>& c, int
     if (x_max <= min(c.maxx - ox, ox - c.minx))
         for (; i < x_max - 2; i += 4)
         {
-            try_rel<P>(c, ox, oy, i, 0);
-            try_rel<P>(c, ox, oy, -i, 0);
-            try_rel<P>(c, ox, oy, i + 2, 0);
-            try_rel<P>(c, ox, oy, -i - 2, 0);
+            try_rel4<P>(c, ox, oy, i, 0, -i, 0, i + 2, 0, -i - 2, 0);
         }
     for (; i < x_max; i += 2)
     {
@@ -691,10 +754,7 @@ template <typename P> __device__ __forceinline__ void umh_cross(PuCtx<P>& c, int
     if (y_max <= min(c.maxy - oy, oy - c.miny))
         for (; i < y_max - 2; i += 4)
         {
-            try_rel<P>(c, ox, oy, 0, i);
-            try_rel<P>(c, ox, oy, 0, -i);
-            try_rel<P>(c, ox, oy, 0, i + 2);
-            try_rel<P>(c, ox, oy, 0, -i - 2);
+            try_rel4<P>(c, ox, oy, 0, i, 0, -i, 0, i + 2, 0, -i - 2);
         }
     for (; i < y_max; i += 2)
     {
@@ -799,18 +859,29 @@ __device__ __forceinline__ bool umh_search(PuCtx<P>& c, const PuJob& job, int pf
             int dirx = 0, diry = 0;
             bool moved = false;
 #pragma unroll 1
-            for (int j = 0; j < 16; j++)
+            for (int j0 = 0; j0 < 16; j0 += 4)
             {
-                const int dx = nib(j < 8 ? H4X0 : H4X1, j & 7), dy = nib(j < 8 ? H4Y0 : H4Y1, j & 7);
-                const int mx = ox + dx * i, my = oy + dy * i;
-                const int cost = block_cost<P, false>(c, mx * 4, my * 4) + mvcost_sum<P>(c, mx * 4, my * 4);
-                if (y_ok<P>(c, oy + dy) && cost < c.bcost)
+                int dxs[4], dys[4], mxs[4], mys[4], sad[4], mc[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
                 {
-                    c.bcost = cost;
-                    dirx = dx;
-                    diry = dy;
-                    moved = true;
+                    const int j = j0 + k;
+                    dxs[k] = nib(j < 8 ? H4X0 : H4X1, j & 7);
+                    dys[k] = nib(j < 8 ? H4Y0 : H4Y1, j & 7);
+                    mxs[k] = ox + dxs[k] * i;
+                    mys[k] = oy + dys[k] * i;
+                    mc[k] = mvcost_sum<P>(c, mxs[k] * 4, mys[k] * 4);
                 }
+                sad_pts<P, 4>(c, mxs, mys, sad);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (y_ok<P>(c, oy + dys[k]) && sad[k] + mc[k] < c.bcost)
+                    {
+                        c.bcost = sad[k] + mc[k];
+                        dirx = dxs[k];
+                        diry = dys[k];
+                        moved = true;
+                    }
             }
             if (moved)
             {

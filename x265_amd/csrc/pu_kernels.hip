@@ -57,6 +57,9 @@ __constant__ signed char k_workload[8][5] = {
     { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 },
 };
 
+#ifndef XG_PU_WAVES
+#define XG_PU_WAVES 4
+#endif
 constexpr int PU_REC_DW = 8;   // LDS record per lane and pass: 4 dwords encode column pairs, pixel offset, mask, 2 spare
 
 template <typename P>
@@ -1067,7 +1070,7 @@ template <typename P> __device__ __forceinline__ void ensure_tile_form(PuCtx<P>&
 // PUs of at most LPP / 4 tiles share a wave, each in its own lanes with its own control flow; `order`
 // lists the jobs of that size class and results go back to their own places.
 template <typename P, int LPP>
-__global__ void __launch_bounds__(256) pu_search_kernel(const PuJob* jobs, const int* order, int n, PuFrame f,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XG_PU_WAVES))) pu_search_kernel(const PuJob* jobs, const int* order, int n, PuFrame f,
                                                         const uint16_t* costTab, int maxMvd, PuResult* out)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t puLds[];

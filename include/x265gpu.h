@@ -300,7 +300,8 @@ int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const v
  * them in loop order exactly as the reference's running index does (:571, :641), the rest keep what the
  * caller put there (the reference allocates them zeroed), and invQscaleFactor8x8 receives the per-lowres-block
  * means of :647-660 - that array is what the estimate calls use with qgSize 8 (:798-799, :4532-4533), so it is
- * the one installed for the slot.  Arrays are left untouched when aqMode is NONE (x265 does not allocate them
+ * the one installed for the slot (it is formed whenever qgSize is 8, offsets are not skipped and both arrays are
+ * given, as the reference does even with aqMode NONE).  Arrays are otherwise left untouched when aqMode is NONE (x265 does not allocate them
  * then) or when bSkipOffsets is set (the rc.bStatRead && cuTree && referenced-frame case, :483).  wpSum /
  * wpSsd receive Lowres::wp_sum / wp_ssd as the function leaves them: with bWeightedPred the mean is removed
  * from wp_ssd (:663-686); without it and without AQ no energy pass runs and both are zero.

@@ -139,14 +139,77 @@ def mcstf_round(cfg):
             p.lowres.close()
 
 
+def draw_aq(rng):
+    return dict(depth=int(rng.choice([8, 10, 12])), W=int(rng.integers(16, 140)) * 4 + int(rng.integers(0, 2)) * 2,
+                H=int(rng.integers(16, 90)) * 4 + int(rng.integers(0, 2)) * 2, mode=int(rng.integers(0, 4)),
+                strength=float(rng.choice([0.0, 0.4, 1.0, 1.7])), qg=int(rng.choice([8, 16, 32, 64])),
+                weightp=bool(rng.integers(0, 2)), hdr=bool(rng.integers(0, 2)), qo=bool(rng.integers(0, 2)),
+                var=bool(rng.integers(0, 2)), hevc=bool(rng.integers(0, 3) == 0), skip=bool(rng.integers(0, 8) == 0),
+                kind=str(rng.choice(["noise", "mixed", "flat"])), seed=int(rng.integers(1, 1 << 30)))
+
+
+def aq_round(cfg):
+    """calcAdaptiveQuantFrame in every covered mode: all arrays, the wp sums, the variance tail, the HEVC AQ layers."""
+    depth, W, H = cfg["depth"], cfg["W"], cfg["H"]
+    rng = np.random.default_rng(cfg["seed"])
+    dt = np.uint8 if depth == 8 else np.uint16
+    top = (1 << depth) - 1
+    if cfg["kind"] == "flat":
+        y = np.full((H, W), int(rng.integers(0, top + 1)), dt)
+        y[H // 2:, W // 3:] = int(rng.integers(0, top + 1))
+    else:
+        y = rng.integers(0, top + 1, (H, W)).astype(dt)
+        if cfg["kind"] == "mixed":
+            y[: H // 3] = (np.arange(W) * top // W).astype(dt)
+            y[H // 3: H // 2] = top // 5
+    u = rng.integers(0, top + 1, (H // 2, W // 2)).astype(dt)
+    v = rng.integers(top // 3, top // 2 + 1, (H // 2, W // 2)).astype(dt)
+    w8, h8 = ((W // 2) + 7) >> 3, ((H // 2) + 7) >> 3
+    qg8 = cfg["qg"] == 8
+    nblocks = 4 * w8 * h8 if qg8 else w8 * h8
+    qo = rng.normal(0, 1.5, nblocks).astype(np.float32) if cfg["qo"] else None
+    hevc = cfg["hevc"] and cfg["mode"] != 0 and cfg["strength"] != 0 and not cfg["skip"]
+    kw = dict(weightp=cfg["weightp"], hdr10=cfg["hdr"], skip_offsets=cfg["skip"], quant_offsets=qo, qg_size=cfg["qg"],
+              block_variance=cfg["var"])
+    with api.Context(W, H, depth=depth, num_slots=1) as ctx:
+        if hevc:
+            depths = {64: (0, 2), 32: (0, 1, 2), 16: (0, 1, 2), 8: (0, 1, 2, 3)}[cfg["qg"]]
+            parts = [((64 >> d), 2 * w8, 2 * h8) if d == 3 else ((64 >> d), (W + (64 >> d) - 1) // (64 >> d),
+                                                                  (H + (64 >> d) - 1) // (64 >> d)) for d in depths]
+            got = ctx.aq_frame(y, u, v, cfg["mode"], cfg["strength"], hevc_aq_parts=parts, qp_adaptation_range=1.25, **kw)
+            L = orc.lib(depth)
+            for (s_, nw, nh), g in zip(parts, got[-1]):
+                arrs = [np.full(nw * nh, np.nan) for _ in range(3)]
+                avg = L.orc_hevc_aq_layer(orc.ptr(y), W, W, H, s_, s_, nw, nh, 1.25, *(orc.ptr(a) for a in arrs))
+                for a, b in zip(g, tuple(arrs) + (avg,)):
+                    np.testing.assert_array_equal(a, b)
+            B = 8 if qg8 else 16
+            visited = ((W + B - 1) // B) * ((H + B - 1) // B)
+            want_inv = np.array([L.orc_exp2fix8(float(q)) for q in got[-1][-1][1][:visited]], np.int32)
+            np.testing.assert_array_equal(got[2][:visited], want_inv)
+            want = orc.calc_adaptive_quant_frame(depth, y, u, v, cfg["mode"], cfg["strength"], **kw)
+            np.testing.assert_array_equal(got[3], want[3])
+            np.testing.assert_array_equal(got[4], want[4])
+            if cfg["var"]:
+                np.testing.assert_array_equal(got[-3], want[-2])
+                assert got[-2] == want[-1]
+        else:
+            got = ctx.aq_frame(y, u, v, cfg["mode"], cfg["strength"], **kw)
+            want = orc.calc_adaptive_quant_frame(depth, y, u, v, cfg["mode"], cfg["strength"], **kw)
+            assert len(got) == len(want)
+            for k, (g, w_) in enumerate(zip(got, want)):
+                np.testing.assert_array_equal(g, w_, err_msg="output %d" % k)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--what", default="lookahead", choices=["lookahead", "pu", "mcstf"])
+    ap.add_argument("--what", default="lookahead", choices=["lookahead", "pu", "mcstf", "aq"])
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
-    drawer, runner = {"lookahead": (draw, one_round), "pu": (draw_pu, pu_round), "mcstf": (draw_mcstf, mcstf_round)}[a.what]
+    drawer, runner = {"lookahead": (draw, one_round), "pu": (draw_pu, pu_round), "mcstf": (draw_mcstf, mcstf_round),
+                      "aq": (draw_aq, aq_round)}[a.what]
     t0, rounds = time.time(), 0
     while time.time() - t0 < a.seconds:
         cfg = drawer(rng)

@@ -1775,9 +1775,10 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
             invQscaleFactor[i] = quantOffsets ? aq_exp2fix8(q) : 256;
         }
     }
-    if (qg8 && offsets)
+    if (qg8 && !params->bSkipOffsets && invQscaleFactor && params->invQscaleFactor8x8)
     {
-        // :647-660: the lowres 8x8 block's factor is the mean of its four full-resolution 8x8 blocks
+        // :647-660: the lowres 8x8 block's factor is the mean of its four full-resolution 8x8 blocks (also with AQ off,
+        // when the arrays exist only for weighted prediction and hold what the caller put there)
         const int W8 = ctx->g.W, H8 = ctx->g.H;
         for (int cuY = 0; cuY < H8; cuY++)
             for (int cuX = 0; cuX < W8; cuX++)

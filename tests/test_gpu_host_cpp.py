@@ -143,3 +143,42 @@ def test_cu_tree(types, kw, b_intra):
         win.close()
         ctx.close()
         ref.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_pre_lookahead_with_adaptive_quant(depth):
+    """PreLookaheadGroup::processTasks in full: Lowres::init, calcAdaptiveQuantFrame and the intra estimate in
+    one host-layer call; scale factors, offsets, wp sums and the AQ frame costs against the oracle, then a
+    weighted-prediction analysis that starts from those wp sums."""
+    W, H, N = 384, 208, 3
+    clip = synth.luma_clip(W, H, N, depth, seed=81)
+    rng = np.random.default_rng(82)
+    dt = clip[0].dtype
+    top = (1 << depth) - 1
+    chroma = [(rng.integers(0, top + 1, (H // 2, W // 2)).astype(dt), rng.integers(0, top + 1, (H // 2, W // 2)).astype(dt))
+              for _ in range(N)]
+    ref = orc.Lookahead(depth, orc.make_param(W, H), with_aq=True)
+    ctx = api.Context(W, H, depth=depth, num_slots=N)
+    win = api.HostWindow(ctx, N)
+    try:
+        n = ctx.geom.cuCount
+        want = [orc.calc_adaptive_quant_frame(depth, clip[i], chroma[i][0], chroma[i][1], 2, 1.0, weightp=True) for i in range(N)]
+        for i in range(N):
+            ref.add_frame(clip[i], want[i][2])
+        ctx.set_mvcost(ref.table, ref.centre)
+        offs = [(np.full(n, np.nan), np.full(n, np.nan)) for _ in range(N)]
+        for i in range(N):
+            win.set_qp_offsets(i, *offs[i])
+        invs = win.pre_lookahead_aq([(clip[i],) + chroma[i] for i in range(N)], 2, 1.0, weightp=True)
+        for i in range(N):
+            np.testing.assert_array_equal(invs[i], want[i][2])
+            np.testing.assert_array_equal(offs[i][0], want[i][0])
+            np.testing.assert_array_equal(offs[i][1], want[i][1])
+            assert win.get_wp(i) == (int(want[i][3][0]), int(want[i][4][0]))
+            assert win.cost_est(i, 0, 0) == ref.frames[i].i64("costEst", 0, 0)
+        assert win.single_cost(0, 1, 1) == ref.frame_cost(0, 1, 1, single=True)
+        _check(ref, ctx, 0, 1, 1)
+    finally:
+        win.close()
+        ctx.close()
+        ref.close()

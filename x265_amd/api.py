@@ -517,7 +517,7 @@ class Context:
 # ---- the C++ host layer (x265_amd/host/lookahead_host.h) through its plain-C face ----
 HOST_LIB_PATH = os.path.join(_HERE, "libx265gpu_host.so")
 HOST_EXPORTS = (
-    "xgh_window_create", "xgh_window_destroy", "xgh_pre_lookahead", "xgh_set_wp", "xgh_set_slice_type",
+    "xgh_window_create", "xgh_window_destroy", "xgh_pre_lookahead", "xgh_pre_lookahead_aq", "xgh_get_wp", "xgh_set_wp", "xgh_set_slice_type",
     "xgh_set_qp_offsets", "xgh_single_cost", "xgh_add", "xgh_finish_batch", "xgh_cost_est", "xgh_intra_mbs",
     "xgh_is_weighted", "xgh_cu_tree", "xgh_status",
 )
@@ -536,6 +536,9 @@ def load_host_library():
     H.xgh_window_destroy.argtypes = [vp]
     H.xgh_window_destroy.restype = None
     H.xgh_pre_lookahead.argtypes = [vp, i32, vp, vp, vp, vp]
+    H.xgh_pre_lookahead_aq.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    H.xgh_get_wp.argtypes = [vp, i32, vp, vp]
+    H.xgh_get_wp.restype = None
     H.xgh_set_wp.argtypes = [vp, i32, C.c_uint64, C.c_uint64]
     H.xgh_set_wp.restype = None
     H.xgh_set_slice_type.argtypes = [vp, i32, i32]
@@ -588,6 +591,29 @@ class HostWindow:
         strides = (C.c_ssize_t * n)(*[a.shape[1] for a in arrs])
         iq = None if invs is None else (C.c_void_p * n)(*[a.ctypes.data for a in invs])
         self._chk(self.H.xgh_pre_lookahead(self.h, n, frames, ptrs, strides, iq))
+
+    def pre_lookahead_aq(self, pictures, aq_mode, strength, weightp=False, qg_size=32):
+        """The whole pre-lookahead task for 4:2:0 pictures [(y, u, v), ...] -> the frames' invQscaleFactor arrays
+        (offsets go to the arrays given with set_qp_offsets, wp sums are kept in the window: get_wp)."""
+        n = len(pictures)
+        pics = [[np.ascontiguousarray(p, self.ctx.pix) for p in pic] for pic in pictures]
+        blocks = self.ctx.geom.cuCount
+        invs = [np.full(blocks, -1, np.int32) for _ in range(n)]
+        self._keep += invs
+        frames = (C.c_int32 * n)(*range(n))
+        vpn = C.c_void_p * n
+        ys, us, vs = (vpn(*[pic[k].ctypes.data for pic in pics]) for k in range(3))
+        sy = (C.c_ssize_t * n)(*[pic[0].shape[1] for pic in pics])
+        sc = (C.c_ssize_t * n)(*[pic[1].shape[1] for pic in pics])
+        prm = AqParams(int(aq_mode), int(weightp), 0, 0, float(strength), int(qg_size), 0, None, None, None, 0, 0, 0.0, None)
+        iq = vpn(*[a.ctypes.data for a in invs])
+        self._chk(self.H.xgh_pre_lookahead_aq(self.h, n, frames, ys, us, vs, sy, sc, C.byref(prm), iq))
+        return invs
+
+    def get_wp(self, frame):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.H.xgh_get_wp(self.h, frame, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def set_wp(self, frame, wp_sum, wp_ssd):
         self.H.xgh_set_wp(self.h, frame, int(wp_sum), int(wp_ssd))

@@ -133,6 +133,45 @@ int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const void* co
     return X265GPU_OK;
 }
 
+int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const Picture* pics, const x265gpu_aq_params& aq,
+                                    const float* const* quantOffsets)
+{
+    std::vector<int32_t> slots(n);
+    for (int i = 0; i < n; i++)
+    {
+        Lowres& fr = *frames[i];
+        const Picture& p = pics[i];
+        int rc = x265gpu_lowres_init(m_ctx, fr.slot, p.y, p.strideY, X265GPU_MEM_HOST, fr.frameNum);
+        if (rc != X265GPU_OK)
+            return rc;
+        fr.reset();
+        // tld.calcAdaptiveQuantFrame(preFrame, param) when the lookahead has AQ or weighted prediction
+        // (slicetype.cpp:1849-1850); the call installs the scale factors for the slot as well
+        uint64_t wpSum[3], wpSsd[3];
+        rc = x265gpu_aq_frame(m_ctx, fr.slot, p.y, p.strideY, p.u, p.v, p.strideC, X265GPU_MEM_HOST, &aq,
+                              quantOffsets ? quantOffsets[i] : nullptr, fr.qpAqOffset, fr.qpCuTreeOffset, fr.invQscaleFactor,
+                              wpSum, wpSsd);
+        if (rc != X265GPU_OK)
+            return rc;
+        fr.wp_sum = wpSum[0];
+        fr.wp_ssd = wpSsd[0];
+        slots[i] = fr.slot;
+    }
+    int rc = x265gpu_intra_estimate(m_ctx, n, slots.data());
+    if (rc != X265GPU_OK)
+        return rc;
+    for (int i = 0; i < n; i++)
+    {
+        x265gpu_frame_cost fc;
+        rc = x265gpu_get_costs(m_ctx, frames[i]->slot, 0, 0, nullptr, nullptr, &fc);
+        if (rc != X265GPU_OK)
+            return rc;
+        frames[i]->costEst[0][0] = fc.costEst;
+        frames[i]->costEstAq[0][0] = fc.costEstAq;
+    }
+    return X265GPU_OK;
+}
+
 // ---- CostEstimateGroup ----
 CostEstimateGroup::CostEstimateGroup(x265gpu_ctx* ctx, Lowres* const* frames, bool bEnableWeightedPred, int bitDepth)
     : m_ctx(ctx), m_frames(frames), m_tld(ctx), m_weightp(bEnableWeightedPred), m_bitDepth(bitDepth)
@@ -427,6 +466,27 @@ int xgh_pre_lookahead(xgh_window* w, int32_t n, const int32_t* frames, const voi
     for (int i = 0; i < n; i++)
         fr[i] = w->frames[frames[i]];
     return PreLookaheadGroup(w->ctx).processTasks(n, fr.data(), lumas, strides, invQscale);
+}
+
+int xgh_pre_lookahead_aq(xgh_window* w, int32_t n, const int32_t* frames, const void* const* y, const void* const* u,
+                         const void* const* v, const intptr_t* strideY, const intptr_t* strideC,
+                         const x265gpu_aq_params* aq, int32_t* const* invQscale)
+{
+    std::vector<Lowres*> fr(n);
+    std::vector<PreLookaheadGroup::Picture> pics(n);
+    for (int i = 0; i < n; i++)
+    {
+        fr[i] = w->frames[frames[i]];
+        fr[i]->invQscaleFactor = invQscale ? invQscale[i] : nullptr;
+        pics[i] = { y[i], u[i], v[i], strideY[i], strideC[i] };
+    }
+    return PreLookaheadGroup(w->ctx).processTasks(n, fr.data(), pics.data(), *aq, nullptr);
+}
+
+void xgh_get_wp(const xgh_window* w, int32_t frame, uint64_t* sum, uint64_t* ssd)
+{
+    *sum = w->frames[frame]->wp_sum;
+    *ssd = w->frames[frame]->wp_ssd;
 }
 
 void xgh_set_wp(xgh_window* w, int32_t frame, uint64_t sum, uint64_t ssd)

@@ -45,6 +45,7 @@ struct Lowres
     double weightedCostDelta[MAX_D];
     double* qpAqOffset = nullptr;     // caller-owned, one entry per 8x8 lowres block (16x16 source block)
     double* qpCuTreeOffset = nullptr;
+    int32_t* invQscaleFactor = nullptr;   // caller-owned, same shape; filled by the AQ form of processTasks
 
     Lowres() { reset(); }
     void reset();                     // the host half of Lowres::init
@@ -69,6 +70,13 @@ public:
     // invQscale[i] the frame's AQ factors or null
     int processTasks(int n, Lowres* const* frames, const void* const* lumas, const intptr_t* strides,
                      const int32_t* const* invQscale);
+    // The whole of PreLookaheadGroup::processTasks (slicetype.cpp:1836-1861): Lowres::init,
+    // calcAdaptiveQuantFrame (block energies on the device, offsets into the frame's qpAqOffset /
+    // qpCuTreeOffset / invQscaleFactor arrays, wp_sum / wp_ssd of plane 0 into the frame) and
+    // lowresIntraEstimate, for 4:2:0 host pictures.
+    struct Picture { const void* y; const void* u; const void* v; intptr_t strideY, strideC; };
+    int processTasks(int n, Lowres* const* frames, const Picture* pics, const x265gpu_aq_params& aq,
+                     const float* const* quantOffsets);
 
 private:
     x265gpu_ctx* m_ctx;
@@ -139,6 +147,12 @@ xgh_window* xgh_window_create(x265gpu_ctx* ctx, int32_t nframes, int32_t bEnable
 void xgh_window_destroy(xgh_window* w);
 int xgh_pre_lookahead(xgh_window* w, int32_t n, const int32_t* frames, const void* const* lumas, const intptr_t* strides,
                       const int32_t* const* invQscale);
+/* the AQ form: 4:2:0 pictures; invQscale[i] receives the frame's scale factors (qgSize >= 16), the offsets go to the
+ * arrays given with xgh_set_qp_offsets, wp_sum / wp_ssd of the luma plane are kept for weightsAnalyse */
+int xgh_pre_lookahead_aq(xgh_window* w, int32_t n, const int32_t* frames, const void* const* y, const void* const* u,
+                         const void* const* v, const intptr_t* strideY, const intptr_t* strideC,
+                         const x265gpu_aq_params* aq, int32_t* const* invQscale);
+void xgh_get_wp(const xgh_window* w, int32_t frame, uint64_t* sum, uint64_t* ssd);
 void xgh_set_wp(xgh_window* w, int32_t frame, uint64_t sum, uint64_t ssd);
 void xgh_set_slice_type(xgh_window* w, int32_t frame, int32_t sliceType);
 void xgh_set_qp_offsets(xgh_window* w, int32_t frame, double* qpAqOffset, double* qpCuTreeOffset);

@@ -36,6 +36,51 @@ struct DownscaleArgs
 template <bool MEAN> __device__ __forceinline__ int vpart(int a, int b) { return MEAN ? a + b : ravg(a, b); }
 template <bool MEAN> __device__ __forceinline__ int hpart(int a, int b) { return MEAN ? (a + b + 2) >> 2 : ravg(a, b); }
 
+// ---- packed arithmetic for the interior of the lookahead filter ------------------------------
+// (a + b + 1) >> 1 on every pixel of a dword: v_lerp_u8 with a rounding bit per byte for 8-bit pixels,
+// packed 16-bit adds for deeper ones (two 12-bit samples and the rounding bit stay inside 16 bits)
+template <typename P> __device__ __forceinline__ uint32_t pavg(uint32_t a, uint32_t b);
+template <> __device__ __forceinline__ uint32_t pavg<uint8_t>(uint32_t a, uint32_t b)
+{
+    return __builtin_amdgcn_lerp(a, b, 0x01010101u);
+}
+template <> __device__ __forceinline__ uint32_t pavg<uint16_t>(uint32_t a, uint32_t b)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 one = { 1, 1 };
+    const u16x2 r = (__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b) + one) >> one;
+    return __builtin_bit_cast(uint32_t, r);
+}
+// the even / the odd pixels of two consecutive dwords, as one dword
+template <typename P> __device__ __forceinline__ uint32_t evens(uint32_t lo, uint32_t hi)
+{
+    return __builtin_amdgcn_perm(hi, lo, sizeof(P) == 1 ? 0x06040200u : 0x05040100u);
+}
+template <typename P> __device__ __forceinline__ uint32_t odds(uint32_t lo, uint32_t hi)
+{
+    return __builtin_amdgcn_perm(hi, lo, sizeof(P) == 1 ? 0x07050301u : 0x07060302u);
+}
+// dword k of a row moved left by two pixels
+template <typename P> __device__ __forceinline__ uint32_t shift2(const uint32_t* d, int k)
+{
+    return sizeof(P) == 1 ? __builtin_amdgcn_alignbyte(d[k + 1], d[k], 2) : d[k + 1];
+}
+
+// One output row of two planes from the vertical partials `v` of 16 (+1) source columns:
+// plane A = avg(even, odd), plane B = avg(odd, next even)  (source/common/pixel.cpp:607-616)
+template <typename P> __device__ __forceinline__ void hpair(const uint32_t* v, Row<P>& a, Row<P>& b)
+{
+    constexpr int NW = PixT<P>::NW;
+#pragma unroll
+    for (int k = 0; k < NW; k++)
+    {
+        const uint32_t e = evens<P>(v[2 * k], v[2 * k + 1]), o = odds<P>(v[2 * k], v[2 * k + 1]);
+        const uint32_t e1 = evens<P>(shift2<P>(v, 2 * k), shift2<P>(v, 2 * k + 1));
+        a.w[k] = pavg<P>(e, o);
+        b.w[k] = pavg<P>(o, e1);
+    }
+}
+
 // One thread: 8 consecutive output positions of one padded row, all 4 planes.
 template <typename P, bool MEAN>
 __device__ void downscale_span(const DownscaleArgs<P>& a, int span, int prow)
@@ -49,8 +94,44 @@ __device__ void downscale_span(const DownscaleArgs<P>& a, int span, int prow)
     const P* s1 = a.src + (long long)r1 * a.srcStride;
     const P* s2 = a.src + (long long)r2 * a.srcStride;
 
+    P* d = a.dst0 + (long long)py * a.dstStride + px0;
     int o0[8], oh[8], ov[8], oc[8];
     const bool interior = px0 >= 0 && px0 + 8 <= a.width;
+    if (!MEAN && interior && 2 * px0 + 23 < a.srcWidth)
+    {
+        // the bulk of the picture, on packed pixels: 24 source columns of three rows, two vertical averages
+        // per dword, then the even / odd split for the four planes
+        constexpr int NW = PixT<P>::NW;
+        uint32_t t0[3 * NW], t1[3 * NW], t2[3 * NW];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+            const Row<P> r0 = load_row<P>(s0 + 2 * px0 + 8 * k), r1 = load_row<P>(s1 + 2 * px0 + 8 * k),
+                         r2 = load_row<P>(s2 + 2 * px0 + 8 * k);
+#pragma unroll
+            for (int j = 0; j < NW; j++)
+            {
+                t0[k * NW + j] = r0.w[j];
+                t1[k * NW + j] = r1.w[j];
+                t2[k * NW + j] = r2.w[j];
+            }
+        }
+        uint32_t v01[2 * NW + 1], v12[2 * NW + 1];
+#pragma unroll
+        for (int j = 0; j <= 2 * NW; j++)
+        {
+            v01[j] = pavg<P>(t0[j], t1[j]);
+            v12[j] = pavg<P>(t1[j], t2[j]);
+        }
+        Row<P> p0, ph, pv, pc;
+        hpair<P>(v01, p0, ph);
+        hpair<P>(v12, pv, pc);
+        store_row<P>(d, p0);
+        store_row<P>(d + a.planeSize, ph);
+        store_row<P>(d + 2 * a.planeSize, pv);
+        store_row<P>(d + 3 * a.planeSize, pc);
+        return;
+    }
     if (interior && 2 * px0 + 23 < a.srcWidth)
     {
         // 18 source columns per row, fetched as three 8-pixel rows
@@ -109,7 +190,6 @@ __device__ void downscale_span(const DownscaleArgs<P>& a, int span, int prow)
         }
     }
 
-    P* d = a.dst0 + (long long)py * a.dstStride + px0;
     store_row<P>(d, pack_row<P>(o0));
     store_row<P>(d + a.planeSize, pack_row<P>(oh));
     store_row<P>(d + 2 * a.planeSize, pack_row<P>(ov));

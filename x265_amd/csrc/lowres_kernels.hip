@@ -97,17 +97,22 @@ __device__ void downscale_span(const DownscaleArgs<P>& a, int span, int prow)
     P* d = a.dst0 + (long long)py * a.dstStride + px0;
     int o0[8], oh[8], ov[8], oc[8];
     const bool interior = px0 >= 0 && px0 + 8 <= a.width;
-    if (!MEAN && interior && 2 * px0 + 23 < a.srcWidth)
+    // A span inside the left / right border repeats one pixel of the first / last picture span (margins and
+    // widths are multiples of 8, so a span never straddles); the stride-rounding slack is left to the slow path.
+    const bool left = px0 + 8 <= 0, right = px0 >= a.width && px0 + 8 <= a.width + a.marginX;
+    const int pxc = left ? 0 : right ? a.width - 8 : px0;
+    if (!MEAN && (interior || left || right) && a.width >= 8 && 2 * pxc + 15 < a.srcWidth)
     {
-        // the bulk of the picture, on packed pixels: 24 source columns of three rows, two vertical averages
-        // per dword, then the even / odd split for the four planes
+        // the bulk of the picture, on packed pixels: 16 source columns of three rows plus the one column
+        // behind them (the last column of the picture repeats, as the reference's source padding has it),
+        // two vertical averages per dword, then the even / odd split for the four planes
         constexpr int NW = PixT<P>::NW;
-        uint32_t t0[3 * NW], t1[3 * NW], t2[3 * NW];
+        uint32_t t0[2 * NW + 1], t1[2 * NW + 1], t2[2 * NW + 1];
 #pragma unroll
-        for (int k = 0; k < 3; k++)
+        for (int k = 0; k < 2; k++)
         {
-            const Row<P> r0 = load_row<P>(s0 + 2 * px0 + 8 * k), r1 = load_row<P>(s1 + 2 * px0 + 8 * k),
-                         r2 = load_row<P>(s2 + 2 * px0 + 8 * k);
+            const Row<P> r0 = load_row<P>(s0 + 2 * pxc + 8 * k), r1 = load_row<P>(s1 + 2 * pxc + 8 * k),
+                         r2 = load_row<P>(s2 + 2 * pxc + 8 * k);
 #pragma unroll
             for (int j = 0; j < NW; j++)
             {
@@ -116,6 +121,10 @@ __device__ void downscale_span(const DownscaleArgs<P>& a, int span, int prow)
                 t2[k * NW + j] = r2.w[j];
             }
         }
+        const int last = min(2 * pxc + 16, a.srcWidth - 1);
+        t0[2 * NW] = s0[last];
+        t1[2 * NW] = s1[last];
+        t2[2 * NW] = s2[last];
         uint32_t v01[2 * NW + 1], v12[2 * NW + 1];
 #pragma unroll
         for (int j = 0; j <= 2 * NW; j++)
@@ -126,6 +135,20 @@ __device__ void downscale_span(const DownscaleArgs<P>& a, int span, int prow)
         Row<P> p0, ph, pv, pc;
         hpair<P>(v01, p0, ph);
         hpair<P>(v12, pv, pc);
+        if (left | right)
+        {
+            Row<P>* planes[4] = { &p0, &ph, &pv, &pc };
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                constexpr int TOP = PixT<P>::NW - 1, BITS = 8 * (int)sizeof(P);
+                const uint32_t px = left ? planes[q]->w[0] & ((1u << BITS) - 1) : planes[q]->w[TOP] >> (32 - BITS);
+                const uint32_t rep = sizeof(P) == 1 ? px * 0x01010101u : px * 0x00010001u;
+#pragma unroll
+                for (int j = 0; j <= TOP; j++)
+                    planes[q]->w[j] = rep;
+            }
+        }
         store_row<P>(d, p0);
         store_row<P>(d + a.planeSize, ph);
         store_row<P>(d + 2 * a.planeSize, pv);

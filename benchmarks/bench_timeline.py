@@ -1,3 +1,6 @@
+"""Kernel timeline of the last lookahead step in a rocprofv3 --kernel-trace csv of bench.py (start / end of each kernel
+run, same-named consecutive launches folded): python benchmarks/bench_timeline.py "<dir>/*_kernel_trace.csv"
+(the last step of a bench.py run is its untimed per-phase pass; the gaps between runs are the host round trips)."""
 import csv, sys, glob
 f = glob.glob(sys.argv[1])[0]
 rows = list(csv.DictReader(open(f)))

@@ -374,6 +374,14 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
  *                             (2*widthInCU) * (2*heightInCU) doubles.  estimateCUPropagate itself only
  *                             swaps the scale-factor array with qgSize 8 (:3791-3798), which installing
  *                             invQscaleFactor8x8 for the slot already does.
+ *   x265gpu_cutree_finish_hevc cuTreeFinish with rc.hevcAq = computeCUTreeQpOffset (:3876-4014): for every
+ *                             layer listed (fields as for x265gpu_aq_frame; dQpOffset is read, dCuTreeOffset
+ *                             written for all numAQPartInWidth * numAQPartInHeight parts) the mean log2 ratio
+ *                             of the AQ blocks a part covers.  With qgSize 8 the per-block ratios go through
+ *                             dCuTreeOffset8x8 ((2*widthInCU) * (2*heightInCU) doubles, read-modify-write as
+ *                             PicQPAdaptationLayer::dCuTreeOffset8x8 is) and the slot's scale factors are
+ *                             invQscaleFactor8x8.  Every part must reach into the picture (a part without
+ *                             a block divides by zero in the reference).
  * The uint16 saturation of the reference's CLIP_ADD is order independent (all addends >= 0), so the
  * device adds with atomics into wide cells and clamps on read; results are bit-exact. */
 int x265gpu_cutree_clear(x265gpu_ctx* ctx, int32_t slot);
@@ -385,6 +393,9 @@ int x265gpu_cutree_finish(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, dou
                           const double* qpAqOffset, double* qpCuTreeOffset);
 int x265gpu_cutree_finish_qg8(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, double weightDelta,
                               double cuTreeStrength, const double* qpAqOffset, double* qpCuTreeOffset);
+int x265gpu_cutree_finish_hevc(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, double weightDelta,
+                               double cuTreeStrength, int32_t qgSize, int32_t numLayers,
+                               x265gpu_hevc_aq_layer* layers, double* dCuTreeOffset8x8);
 
 /* ---- picture statistics for histogram-based scene-cut detection (--hist-scenecut) ----
  *

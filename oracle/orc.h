@@ -224,6 +224,13 @@ void orc_propagate_cost(int* dst, const uint16_t* propagateIn, const int32_t* in
 void orc_estimate_cu_propagate(const orc_cutree_param* cp, orc_lowres** frames, int* scratch, double averageDuration,
                                int p0, int p1, int b, int referenced);
 void orc_cutree_finish(const orc_cutree_param* cp, orc_lowres* frame, double averageDuration, int ref0Distance);
+void orc_cutree_hevc_layer(int qg8, int maxCols, int widthFullRes, int heightFullRes, int aqPartWidth, int aqPartHeight,
+                           int numAQPartInWidth, int numAQPartInHeight, const int32_t* intraCost,
+                           const int32_t* invQscaleFactor, const uint16_t* propagateCostArr, int fpsFactor,
+                           double weightdelta, double strength, const double* pcCuTree8x8, const double* pcQP,
+                           double* pcCuTree);
+void orc_cutree_ratio8x8(int W, int H, const int32_t* intraCost, const int32_t* invQscale8x8, const uint16_t* propagateCostArr,
+                         int fpsFactor, double weightdelta, double* pcCuTree8x8);
 void orc_cutree_finish_qg8(int W, int H, const int32_t* intraCost, const int32_t* invQscale8x8,
                            const uint16_t* propagateCost, int fpsFactor, double weightdelta, double strength,
                            const double* qpAqOffset, double* qpCuTreeOffset);

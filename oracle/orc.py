@@ -128,6 +128,8 @@ def lib(depth=8):
     L.orc_calc_adaptive_quant_frame.argtypes = [vp, ip, vp, vp, ip, i, i, i, C.c_double, i, i, i, vp, vp, vp, vp, vp,
                                                 i, i, i, vp, i, vp, vp]
     L.orc_cutree.argtypes = [vp, C.POINTER(Param), C.POINTER(CuTreeParam), C.POINTER(vp), i, i]
+    L.orc_cutree_hevc_layer.argtypes = [i, i, i, i, i, i, i, i, vp, vp, vp, i, C.c_double, C.c_double, vp, vp, vp]
+    L.orc_cutree_ratio8x8.argtypes = [i, i, vp, vp, vp, i, C.c_double, vp]
     L.orc_cutree_finish_qg8.argtypes = [i, i, vp, vp, vp, i, C.c_double, C.c_double, vp, vp]
     L.orc_lowres_set_slice_type.argtypes = [vp, i]
     L.orc_propagate_cost.argtypes = [vp, vp, vp, vp, vp, vp, i]

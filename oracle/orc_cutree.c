@@ -86,6 +86,62 @@ void orc_cutree_finish_qg8(int W, int H, const int32_t* intraCost, const int32_t
         }
 }
 
+/* Lookahead::computeCUTreeQpOffset (source/encoder/slicetype.cpp:3876-4014) for ONE layer, on plain arrays.
+ * qg8: pcCuTree8x8 holds the per-block ratios the caller formed with orc_cutree_ratio8x8. */
+void orc_cutree_hevc_layer(int qg8, int maxCols, int widthFullRes, int heightFullRes, int aqPartWidth, int aqPartHeight,
+                           int numAQPartInWidth, int numAQPartInHeight, const int32_t* intraCost,
+                           const int32_t* invQscaleFactor, const uint16_t* propagateCostArr, int fpsFactor,
+                           double weightdelta, double strength, const double* pcCuTree8x8, const double* pcQP,
+                           double* pcCuTree)
+{
+    const uint32_t loopIncr = qg8 ? 8 : 16;
+    for (uint32_t y = 0; y < (uint32_t)numAQPartInHeight; y++)
+        for (uint32_t x = 0; x < (uint32_t)numAQPartInWidth; x++, pcQP++, pcCuTree++)
+        {
+            uint32_t block_x = x * aqPartWidth, block_y = y * aqPartHeight;
+            uint32_t blockXY = 0;
+            double log2_ratio = 0;
+            for (uint32_t block_yy = block_y; block_yy < block_y + aqPartHeight && block_yy < (uint32_t)heightFullRes; block_yy += loopIncr)
+                for (uint32_t block_xx = block_x; block_xx < block_x + aqPartWidth && block_xx < (uint32_t)widthFullRes; block_xx += loopIncr)
+                {
+                    uint32_t idx = ((block_yy / loopIncr) * (maxCols)) + (block_xx / loopIncr);
+                    if (qg8)
+                        log2_ratio += *(pcCuTree8x8 + idx);
+                    else
+                    {
+                        int intra = (intraCost[idx] * invQscaleFactor[idx] + 128) >> 8;
+                        int propagate = (propagateCostArr[idx] * fpsFactor + 128) >> 8;
+                        log2_ratio += (log2(intra + propagate) - log2(intra) + weightdelta);
+                    }
+                    blockXY++;
+                }
+            double qp_offset = (strength * log2_ratio) / blockXY;
+            *pcCuTree = *pcQP - qp_offset;
+        }
+}
+
+/* the first loop of computeCUTreeQpOffset's qgSize 8 branch (:3895-3912) */
+void orc_cutree_ratio8x8(int W, int H, const int32_t* intraCost, const int32_t* invQscale8x8, const uint16_t* propagateCostArr,
+                         int fpsFactor, double weightdelta, double* pcCuTree8x8)
+{
+    const int rowFull = W * 2;
+    for (int cuY = 0; cuY < H; cuY++)
+        for (int cuX = 0; cuX < W; cuX++)
+        {
+            const int cuXY = cuX + cuY * W;
+            int intracost = ((intraCost[cuXY] / 4) * invQscale8x8[cuXY] + 128) >> 8;
+            if (intracost)
+            {
+                int propagate = ((propagateCostArr[cuXY] / 4) * fpsFactor + 128) >> 8;
+                double log2_ratio = log2(intracost + propagate) - log2(intracost) + weightdelta;
+                pcCuTree8x8[cuX * 2 + cuY * W * 4] = log2_ratio;
+                pcCuTree8x8[cuX * 2 + cuY * W * 4 + 1] = log2_ratio;
+                pcCuTree8x8[cuX * 2 + cuY * W * 4 + rowFull] = log2_ratio;
+                pcCuTree8x8[cuX * 2 + cuY * W * 4 + rowFull + 1] = log2_ratio;
+            }
+        }
+}
+
 /* source/encoder/slicetype.cpp:3768-3874 */
 void orc_estimate_cu_propagate(const orc_cutree_param* cp, orc_lowres** frames, int* scratch, double averageDuration,
                                int p0, int p1, int b, int referenced)

@@ -119,3 +119,59 @@ def test_cutree_saturates_like_uint16():
             saturated += int(np.sum(want == 65535))
         assert saturated > 0
     ref.close()
+
+
+@pytest.mark.parametrize("qg", [8, 32])
+def test_cutree_finish_with_hevc_aq_layers(qg):
+    """cuTreeFinish with rc.hevcAq (computeCUTreeQpOffset): per-layer dCuTreeOffset from the device's propagate
+    totals, intra costs and scale factors, against the oracle's statement of the layer loop."""
+    W, H, depth = 416, 240, 8
+    clip = synth.luma_clip(W, H, 2, depth, seed=9)
+    rng = np.random.default_rng(10)
+    param = orc.make_param(W, H)
+    ref = orc.Lookahead(depth, param, with_aq=True)
+    L = orc.lib(depth)
+    with api.Context(W, H, depth=depth, num_slots=2) as ctx:
+        ctx.set_mvcost(ref.table, ref.centre)
+        w8, h8 = ctx.geom.widthInCU, ctx.geom.heightInCU
+        n = w8 * h8
+        invs = []
+        for k in range(2):
+            inv = rng.integers(128, 513, size=n).astype(np.int32)
+            inv[rng.integers(0, n, 6)] = 0
+            invs.append(inv)
+            ref.add_frame(clip[k], inv)
+            ctx.lowres_init(k, clip[k])
+            ctx.set_aq(k, inv)
+        ctx.intra_estimate([0, 1])
+        ref.frame_cost(0, 1, 1)
+        ctx.estimate([(0, 1, 1, 0, 1, 1, 1, 0)])
+        ctx.cutree_clear(0)
+        ctx.cutree_clear(1)
+        ctx.cutree_propagate(0, 1, 1, 1, 0, 1, 1.0, 32)
+        prop = np.ascontiguousarray(ctx.cutree_get_propagate_cost(0), np.uint16)
+        intra = np.ascontiguousarray(ctx.get_intra(0)[0], np.int32)
+        assert np.any(prop)
+        depths = (0, 1, 2, 3) if qg == 8 else (0, 1, 2)
+        layers = []
+        for d in depths:
+            s = 64 >> d
+            nw, nh = (2 * w8, 2 * h8) if d == 3 else ((W + s - 1) // s, (H + s - 1) // s)
+            layers.append((s, nw, nh, rng.normal(0, 2, nw * nh)))
+        qg8 = qg == 8
+        fps, wd, strength = 300, 0.125, 2.4
+        ratio_want = rng.normal(0, 1, 4 * n) if qg8 else None
+        ratio_got = None if ratio_want is None else ratio_want.copy()
+        if qg8:
+            L.orc_cutree_ratio8x8(w8, h8, orc.ptr(intra), orc.ptr(invs[0]), orc.ptr(prop), fps, wd, orc.ptr(ratio_want))
+        got = ctx.cutree_finish_hevc(0, fps, wd, strength, qg, layers, ratio_got)
+        for (s, nw, nh, qp), g in zip(layers, got):
+            want = np.full(nw * nh, np.nan)
+            qp = np.ascontiguousarray(qp)
+            L.orc_cutree_hevc_layer(int(qg8), 2 * w8 if qg8 else w8, W, H, s, s, nw, nh, orc.ptr(intra), orc.ptr(invs[0]),
+                                    orc.ptr(prop), fps, wd, strength, orc.ptr(ratio_want) if qg8 else None, orc.ptr(qp),
+                                    orc.ptr(want))
+            np.testing.assert_array_equal(g, want, err_msg="layer of %d" % s)
+        if qg8:
+            np.testing.assert_array_equal(ratio_got, ratio_want)
+    ref.close()

@@ -22,7 +22,7 @@ EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_weight_cost", "x265gpu_weight_planes",
-    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_cutree_finish_qg8", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
     "x265gpu_cutree_clear", "x265gpu_cutree_swap", "x265gpu_cutree_propagate", "x265gpu_cutree_get_propagate_cost",
     "x265gpu_cutree_finish", "x265gpu_hist_stats", "x265gpu_mcstf_motion_search",
     "x265gpu_profile_enable", "x265gpu_profile_read",
@@ -160,6 +160,7 @@ def load_library(path=None):
     L.x265gpu_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(C.c_void_p)]
     L.x265gpu_host_free.argtypes = [vp, vp]
     L.x265gpu_cutree_finish_qg8.argtypes = [vp, i32, i32, C.c_double, C.c_double, vp, vp]
+    L.x265gpu_cutree_finish_hevc.argtypes = [vp, i32, i32, C.c_double, C.c_double, i32, i32, vp, vp]
     L.x265gpu_hist_stats.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp]
     L.x265gpu_aq_frame.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp, vp, vp, vp, vp, vp, vp]
     L.x265gpu_mcstf_motion_search.argtypes = [vp, i32, i32, vp, vp, vp, vp]
@@ -492,6 +493,23 @@ class Context:
         fn = self.L.x265gpu_cutree_finish_qg8 if qg8 else self.L.x265gpu_cutree_finish
         self._chk(fn(self.h, slot, int(fps_factor), float(weight_delta), float(strength),
                                                _ptr(qp_aq_offset), _ptr(qp_cutree_offset)))
+
+    def cutree_finish_hevc(self, slot, fps_factor, weight_delta, strength, qg_size, layers, ratio8x8=None):
+        """cuTreeFinish with rc.hevcAq.  layers: [(partSize, numW, numH, dQpOffset), ...] -> list of dCuTreeOffset arrays;
+        ratio8x8 (float64, (2W)*(2H), qg_size 8) is updated in place."""
+        n = len(layers)
+        arr = (HevcAqLayer * n)()
+        outs, keep = [], []
+        for k, (size, nw, nh, qp) in enumerate(layers):
+            qp = np.ascontiguousarray(qp, np.float64)
+            out = np.full(nw * nh, np.nan)
+            keep.append(qp)
+            outs.append(out)
+            arr[k] = HevcAqLayer(size, size, nw, nh, None, _ptr(qp), _ptr(out), 0.0)
+        self._chk(self.L.x265gpu_cutree_finish_hevc(self.h, slot, int(fps_factor), float(weight_delta), float(strength),
+                                                    int(qg_size), n, C.cast(arr, C.c_void_p),
+                                                    None if ratio8x8 is None else _ptr(ratio8x8)))
+        return outs
 
     def get_full_plane(self, slot):
         """-> (padded plane as a 2-D array, originX, originY)"""

@@ -214,6 +214,64 @@ void cutree_finish_offsets_qg8(int W, int H, const int32_t* intraCost, const int
         }
 }
 
+// Lookahead::computeCUTreeQpOffset (source/encoder/slicetype.cpp:3876-4014), what cuTreeFinish runs with
+// rc.hevcAq: for every AQ layer, dCuTreeOffset = dQpOffset - strength * (mean log2 ratio of the AQ blocks the
+// part covers).  With qgSize 8 the ratios are first spread over the full-resolution 8x8 grid (ratio8x8, read-
+// modify-write: blocks with a zero scaled intra cost keep what is there); otherwise they are formed per 16x16
+// block inside the layer loop.
+void cutree_finish_hevc(int W, int H, int widthFullRes, int heightFullRes, bool qg8, const int32_t* intraCost,
+                        const int32_t* invQscale, const unsigned long long* totals, int fpsFactor, double weightDelta,
+                        double strength, int numLayers, const int* partW, const int* partH, const int* numW, const int* numH,
+                        const double* const* dQpOffset, double* const* dCuTreeOffset, double* ratio8x8)
+{
+    const int loopIncr = qg8 ? 8 : 16;
+    const int maxCols = qg8 ? 2 * W : W;
+    if (qg8)
+    {
+        for (int cuY = 0; cuY < H; cuY++)
+            for (int cuX = 0; cuX < W; cuX++)
+            {
+                const int i = cuX + cuY * W;
+                const int intra = ((intraCost[i] / 4) * invQscale[i] + 128) >> 8;
+                if (!intra)
+                    continue;
+                const int inherited = (int)(totals[i] < 65535 ? totals[i] : 65535);
+                const int propagated = ((inherited / 4) * fpsFactor + 128) >> 8;
+                const double ratio = log2((double)(intra + propagated)) - log2((double)intra) + weightDelta;
+                const int at = cuX * 2 + cuY * W * 4;
+                ratio8x8[at] = ratio8x8[at + 1] = ratio8x8[at + maxCols] = ratio8x8[at + maxCols + 1] = ratio;
+            }
+    }
+    for (int d = 0; d < numLayers; d++)
+    {
+        const double* qp = dQpOffset[d];
+        double* out = dCuTreeOffset[d];
+        for (int y = 0; y < numH[d]; y++)
+            for (int x = 0; x < numW[d]; x++, qp++, out++)
+            {
+                const uint32_t bx0 = (uint32_t)x * partW[d], by0 = (uint32_t)y * partH[d];
+                uint32_t count = 0;
+                double sum = 0;
+                for (uint32_t by = by0; by < by0 + partH[d] && by < (uint32_t)heightFullRes; by += loopIncr)
+                    for (uint32_t bx = bx0; bx < bx0 + partW[d] && bx < (uint32_t)widthFullRes; bx += loopIncr)
+                    {
+                        const uint32_t idx = (by / loopIncr) * maxCols + bx / loopIncr;
+                        if (qg8)
+                            sum += ratio8x8[idx];
+                        else
+                        {
+                            const int intra = (intraCost[idx] * invQscale[idx] + 128) >> 8;
+                            const int inherited = (int)(totals[idx] < 65535 ? totals[idx] : 65535);
+                            const int propagated = (inherited * fpsFactor + 128) >> 8;
+                            sum += (log2((double)(intra + propagated)) - log2((double)intra) + weightDelta);
+                        }
+                        count++;
+                    }
+                *out = *qp - (strength * sum) / count;
+            }
+    }
+}
+
 // The arithmetic collectPictureStatistics applies to the raw counts
 // (source/encoder/slicetype.cpp:1688-1831): every bin starts at 1 and is scaled by 16 afterwards, chroma
 // sums are scaled by 16 for the 4x4 subsampling, and the per-segment means are rounded divisions whose

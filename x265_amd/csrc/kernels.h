@@ -191,6 +191,10 @@ void aq_finish_wp(int width, int height, unsigned long long sum[3], unsigned lon
 void cutree_finish_offsets(int blocks, const int32_t* intraCost, const int32_t* invQscale, const unsigned long long* totals,
                            int fpsFactor, double weightDelta, double strength, const double* qpAqOffset,
                            double* qpCuTreeOffset);
+void cutree_finish_hevc(int W, int H, int widthFullRes, int heightFullRes, bool qg8, const int32_t* intraCost,
+                        const int32_t* invQscale, const unsigned long long* totals, int fpsFactor, double weightDelta,
+                        double strength, int numLayers, const int* partW, const int* partH, const int* numW, const int* numH,
+                        const double* const* dQpOffset, double* const* dCuTreeOffset, double* ratio8x8);
 void cutree_finish_offsets_qg8(int W, int H, const int32_t* intraCost, const int32_t* invQscale8x8,
                                const unsigned long long* totals, int fpsFactor, double weightDelta, double strength,
                                const double* qpAqOffset, double* qpCuTreeOffset);

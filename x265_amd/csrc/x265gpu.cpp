@@ -1552,6 +1552,51 @@ int x265gpu_cutree_finish_qg8(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor,
     return cutree_finish(ctx, slot, true, fpsFactor, weightDelta, cuTreeStrength, qpAqOffset, qpCuTreeOffset);
 }
 
+int x265gpu_cutree_finish_hevc(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, double weightDelta, double cuTreeStrength,
+                               int32_t qgSize, int32_t numLayers, x265gpu_hevc_aq_layer* layers, double* dCuTreeOffset8x8)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || !slot_ok(ctx, slot) || numLayers < 1 || numLayers > 4 || !layers)
+        return X265GPU_ERR_ARG;
+    const bool qg8 = qgSize == 8;
+    if (qg8 && !dCuTreeOffset8x8)
+        return fail(ctx, X265GPU_ERR_ARG, "cutree_finish_hevc: qgSize 8 needs the dCuTreeOffset8x8 array");
+    Slot& s = ctx->slots[slot];
+    if (!s.hasAq)
+        return fail(ctx, X265GPU_ERR_STATE, "cutree_finish_hevc: the frame has no invQscaleFactor (x265gpu_lowres_set_aq)");
+    int partW[4], partH[4], numW[4], numH[4];
+    const double* qp[4];
+    double* out[4];
+    for (int d = 0; d < numLayers; d++)
+    {
+        const x265gpu_hevc_aq_layer& l = layers[d];
+        if (l.aqPartWidth < (qg8 ? 8 : 16) || l.aqPartHeight < (qg8 ? 8 : 16) || l.numAQPartInWidth < 1 || l.numAQPartInHeight < 1 ||
+            !l.dQpOffset || !l.dCuTreeOffset ||
+            // every part must cover at least one AQ block of the picture
+            (long long)(l.numAQPartInWidth - 1) * l.aqPartWidth >= ctx->cfg.sourceWidth ||
+            (long long)(l.numAQPartInHeight - 1) * l.aqPartHeight >= ctx->cfg.sourceHeight)
+            return fail(ctx, X265GPU_ERR_ARG, "cutree_finish_hevc: bad layer");
+        partW[d] = l.aqPartWidth;
+        partH[d] = l.aqPartHeight;
+        numW[d] = l.numAQPartInWidth;
+        numH[d] = l.numAQPartInHeight;
+        qp[d] = l.dQpOffset;
+        out[d] = l.dCuTreeOffset;
+    }
+    const size_t nb = ctx->g.cuCount;
+    std::vector<unsigned long long> acc;
+    std::vector<int32_t> intra(nb), invQ(nb);
+    int rc = fetch_propagate(ctx, slot, acc);
+    if (rc)
+        return rc;
+    HIPCHK(hipMemcpyAsync(intra.data(), s.intraCost, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(invQ.data(), s.invQscale, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    cutree_finish_hevc(ctx->g.W, ctx->g.H, ctx->cfg.sourceWidth, ctx->cfg.sourceHeight, qg8, intra.data(), invQ.data(), acc.data(),
+                       fpsFactor, weightDelta, cuTreeStrength, numLayers, partW, partH, numW, numH, qp, out, dCuTreeOffset8x8);
+    return X265GPU_OK;
+}
+
 namespace {
 
 // A caller's 4:2:0 source picture as the kernels read it: device planes are used in place,

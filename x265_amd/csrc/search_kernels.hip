@@ -1045,7 +1045,7 @@ __device__ __forceinline__ bool slice_bottom_row(const SearchJob& job, int H, in
 // The search method is a compile-time parameter: every job of a launch shares it,
 // and the hexagon-only kernel stays free of the multi-hexagon code's registers.
 template <typename P, int METHOD>
-__global__ void __launch_bounds__(256) search_diag_kernel(const SearchJob* jobs, Geometry g, int level0, int t,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) search_diag_kernel(const SearchJob* jobs, Geometry g, int level0, int t,
                                                           const uint16_t* costTab, int maxMvd)
 {
     __shared__ uint32_t ldsBuf[4 * WaveLds<P>::TOTAL];

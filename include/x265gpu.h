@@ -189,6 +189,18 @@ int x265gpu_estimate_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* r
  * unweighted reference.  The result is written to *cost after a sync. */
 int x265gpu_weight_cost(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t wtPresent,
                         int32_t scale, int32_t log2Denom, int32_t offset, uint32_t* cost);
+/* x265gpu_weight_cost for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
+ * arguments and result as x265gpu_weight_cost; the accumulator and the weighted copy of plane 0 live in a
+ * fixed 8 MiB array inside the library's device image (one copy per GPU, held until the process ends)
+ * instead of buffers the context allocates or grows, and the call itself performs no hipMalloc / hipFree.
+ * Limit: with wtPresent the padded half-res plane (stride x (lines + 2 marginY) pixels) plus 256 bytes
+ * must fit the array - up to 3840x2160 at 10 bit; larger pictures return X265GPU_ERR_ARG with a message
+ * in x265gpu_last_error.  Every context on one GPU shares that GPU's array and the array keeps the last
+ * call's contents (the call clears what must start at zero): calls that overlap on one GPU race, so
+ * serialise them. */
+int x265gpu_weight_cost_static(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t wtPresent,
+                               int32_t scale, int32_t log2Denom, int32_t offset, uint32_t* cost);
 /* weight_pp over all four padded planes of slotRef (slicetype.cpp:957-969);
  * the result becomes the L0 reference of requests with weightedL0 set, for
  * (slotFenc, dist) until replaced. */

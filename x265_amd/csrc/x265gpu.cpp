@@ -39,7 +39,18 @@ struct Slot
     int poc = 0;
 };
 
+// Scratch of x265gpu_weight_cost_static: a fixed array in the library's device image instead of an
+// allocation.  Each GPU holds its own copy at its own address; the name below is only the host-side
+// handle of the symbol, so host code resolves the address once per device (resolve_static_scratch) and
+// uses that pointer everywhere.  Layout: [0, 256) the cost accumulator, [256, ...) weighted plane 0.
+constexpr size_t STATIC_SCRATCH_BYTES = (size_t)8 << 20;
+constexpr size_t STATIC_SCRATCH_PLANE = 256;
+constexpr int STATIC_SCRATCH_MAX_DEVICES = 64;
+void* g_scratchPtr[STATIC_SCRATCH_MAX_DEVICES];
+
 } // namespace
+
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 
 struct x265gpu_ctx
 {
@@ -63,6 +74,7 @@ struct x265gpu_ctx
     char* srcStage = nullptr;
     size_t srcStageSize = 0;
     unsigned int* scalar = nullptr;   // small device scratch for weight_cost
+    char* staticScratch = nullptr;    // this device's copy of the library's static scratch array
     long long* batchSums = nullptr;   // [n][3] frame totals of the latest batch (device)
     long long* batchSumsHost = nullptr;
     size_t batchSumsCap = 0;
@@ -354,6 +366,23 @@ inline char* plane4_origin(const x265gpu_ctx* ctx, char* planes4)
 
 bool slot_ok(const x265gpu_ctx* ctx, int s) { return s >= 0 && s < (int)ctx->slots.size(); }
 
+// Address of the static scratch array on the context's device (which must be current), looked up once
+// per device and process.
+int resolve_static_scratch(x265gpu_ctx* ctx)
+{
+    const int dev = ctx->cfg.deviceId;
+    if (dev < 0 || dev >= STATIC_SCRATCH_MAX_DEVICES)
+        return X265GPU_OK;              // no static scratch on such a device: weight_cost_static reports it
+    if (!g_scratchPtr[dev])
+    {
+        void* p = nullptr;
+        HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_scratchPtr[dev] = p;
+    }
+    ctx->staticScratch = (char*)g_scratchPtr[dev];
+    return X265GPU_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -480,6 +509,9 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
             rc = X265GPU_ERR_NOMEM;
             break;
         }
+        rc = resolve_static_scratch(ctx);
+        if (rc != X265GPU_OK)
+            break;
         {
             // X265GPU_INTRA_STREAM=0 keeps the intra estimate on the main stream
             const char* e = getenv("X265GPU_INTRA_STREAM");
@@ -1035,6 +1067,50 @@ int x265gpu_weight_cost(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int
     HIPCHK(hipMemsetAsync(ctx->scalar, 0, sizeof(unsigned int), ctx->stream));
     HIPCHK(launch_weight_cost(ctx->stream, g, ctx->bpp, &job));
     HIPCHK(hipMemcpyAsync(cost, ctx->scalar, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
+int x265gpu_weight_cost_static(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t wtPresent, int32_t scale,
+                               int32_t log2Denom, int32_t offset, uint32_t* cost)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || !slot_ok(ctx, slotFenc) || !slot_ok(ctx, slotRef) || !cost)
+        return X265GPU_ERR_ARG;
+    if (!ctx->staticScratch)
+        return fail(ctx, X265GPU_ERR_STATE, "weight_cost_static: no static scratch on this device");
+    const Geometry& g = ctx->g;
+    const size_t planeBytes = (size_t)g.planeSize * ctx->bpp;
+    if (wtPresent && STATIC_SCRATCH_PLANE + planeBytes > STATIC_SCRATCH_BYTES)
+    {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "weight_cost_static: a padded plane of %zu bytes does not fit the %zu-byte static scratch",
+                 planeBytes, STATIC_SCRATCH_BYTES - STATIC_SCRATCH_PLANE);
+        return fail(ctx, X265GPU_ERR_ARG, msg);
+    }
+    Slot& sf = ctx->slots[slotFenc];
+    Slot& sr = ctx->slots[slotRef];
+    const int depth = ctx->cfg.internalBitDepth;
+    unsigned int* acc = (unsigned int*)ctx->staticScratch;
+    char* plane = ctx->staticScratch + STATIC_SCRATCH_PLANE;
+    WeightCostJob job;
+    job.fencPlane0 = plane_origin(ctx, sf.planes);
+    job.refPlane0 = plane_origin(ctx, sr.planes);
+    job.intraCost = sf.intraCost;
+    job.out = acc;
+    if (wtPresent)
+    {
+        const int corr = 14 - depth;
+        const int round = log2Denom ? 1 << (log2Denom - 1) : 0;
+        HIPCHK(launch_weight_planes(ctx->stream, g, ctx->bpp, depth, 1, sr.planes, plane, scale, round << corr,
+                                    log2Denom + corr, offset * (1 << (depth - 8))));
+        job.refPlane0 = plane_origin(ctx, plane);
+    }
+    // the array keeps the previous call's contents: the accumulator must start at zero (the plane is
+    // overwritten in full by the pass above before it is read)
+    HIPCHK(hipMemsetAsync(acc, 0, sizeof(unsigned int), ctx->stream));
+    HIPCHK(launch_weight_cost(ctx->stream, g, ctx->bpp, &job));
+    HIPCHK(hipMemcpyAsync(cost, acc, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return X265GPU_OK;
 }

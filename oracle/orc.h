@@ -39,6 +39,7 @@ typedef uint8_t pixel;
 #define ORC_FENC_STRIDE 64           /* source/common/common.h:71 */
 #define ORC_CU 8                     /* X265_LOWRES_CU_SIZE, source/common/common.h:225 */
 #define ORC_BFRAME_MAX 16            /* X265_BFRAME_MAX, source/x265.h:599 */
+#define ORC_LOOKAHEAD_MAX 250        /* X265_LOOKAHEAD_MAX, source/x265.h:103 */
 #define ORC_COST_MAX (1 << 28)       /* MotionEstimate::COST_MAX, source/encoder/motion.h:65 */
 #define ORC_LOWRES_COST_MASK ((1 << 14) - 1)  /* source/encoder/slicetype.h:42 */
 #define ORC_LOWRES_COST_SHIFT 14
@@ -179,7 +180,16 @@ typedef struct orc_lowres {
     uint16_t* propagateCost;
     double*  qpAqOffset;
     double*  qpCuTreeOffset;
-    int      sliceType;       /* X265_TYPE_* (source/x265.h): only B (5) is told apart by cuTree */
+    int      sliceType;       /* X265_TYPE_* (source/x265.h) */
+    /* what the slice-type decision keeps per frame (source/common/lowres.h:166-213) */
+    int      sliceTypeReq;
+    int      bScenecut, bKeyframe, bLastMiniGopBFrame, leadingBframes;
+    int      indB;
+    int64_t  plannedSatd[ORC_LOOKAHEAD_MAX + 1];
+    int      plannedType[ORC_LOOKAHEAD_MAX + 1];
+    int32_t* recalcRowSatds;  /* not in the reference: frameCostRecalculate's row sums are kept apart from the
+                                 request's rowSatds (which the reference overwrites in place) so that tests can
+                                 compare both */
 } orc_lowres;
 
 typedef struct orc_tld {
@@ -236,6 +246,40 @@ void orc_cutree_finish_qg8(int W, int H, const int32_t* intraCost, const int32_t
                            const double* qpAqOffset, double* qpCuTreeOffset);
 void orc_cutree(orc_tld* t, const orc_param* p, const orc_cutree_param* cp, orc_lowres** frames, int numframes, int bIntra);
 void orc_lowres_set_slice_type(orc_lowres* lr, int sliceType);
+
+/* ---- slice-type decision (orc_slicetype.c): Lookahead::slicetypeDecide and what it calls ---- */
+enum { ORC_TYPE_AUTO = 0, ORC_TYPE_IDR = 1, ORC_TYPE_I = 2, ORC_TYPE_P = 3, ORC_TYPE_BREF = 4 };
+typedef struct orc_la_param {
+    int lookaheadDepth;           /* the x265_param fields of the same names */
+    int bFrameAdaptive;           /* 0 none, 1 fast, 2 trellis */
+    int bBPyramid;
+    int scenecutThreshold;
+    double scenecutBias;          /* as Encoder::configure leaves it: the command-line percentage / 100 */
+    int keyframeMin, keyframeMax; /* keyframeMin after Encoder::configure (never 0) */
+    int bOpenGOP;
+    int bIntraRefresh;
+    int radl;
+    int gopLookahead;
+    int cuTree;                   /* rc.cuTree */
+    int aqMode;                   /* rc.aqMode */
+    int vbvBufferSize, vbvMaxBitrate;
+    int bCqp;                     /* rc.rateControlMode == X265_RC_CQP */
+    int bEnableTemporalSubLayers; /* 0..2 */
+    int maxNumReferences;
+    int poolWorkers;              /* ThreadPool::m_numWorkers of the lookahead's pool, 0: no pool */
+} orc_la_param;
+typedef struct orc_la orc_la;
+orc_la* orc_la_create(const orc_param* p, const orc_la_param* lp, const orc_cutree_param* cp, orc_tld* tld);
+void orc_la_destroy(orc_la* la);
+void orc_la_add_picture(orc_la* la, orc_lowres* frame, int sliceType, int sliceTypeReq);
+void orc_la_flush(orc_la* la);
+orc_lowres* orc_la_get_decided_picture(orc_la* la);
+/* requests in the order estimateFrameCost computed them (cached ones are not listed): 6 ints each,
+ * { frameNum p0, frameNum p1, frameNum b, bDoSearch[0], bDoSearch[1], batch mode } */
+int orc_la_trace(const orc_la* la, const int32_t** out);
+int64_t orc_frame_cost_recalculate(orc_lowres** frames, int p0, int p1, int b);
+typedef void (*orc_request_hook)(void* user, orc_lowres** frames, int p0, int p1, int b, const int* bDoSearch, int batchMode);
+void orc_set_request_hook(orc_request_hook hook, void* user);
 
 /* ---- histogram scene-cut statistics (orc_scenecut.c) ---- */
 typedef struct orc_hist_stats {

@@ -37,6 +37,16 @@ class CuTreeParam(C.Structure):
                 ("lookaheadDepth", C.c_int), ("vbvBufferSize", C.c_int), ("qCompress", C.c_double)]
 
 
+class LaParam(C.Structure):
+    """orc_la_param (defaults: preset medium as Encoder::configure leaves it)."""
+    _fields_ = [("lookaheadDepth", C.c_int), ("bFrameAdaptive", C.c_int), ("bBPyramid", C.c_int),
+                ("scenecutThreshold", C.c_int), ("scenecutBias", C.c_double), ("keyframeMin", C.c_int),
+                ("keyframeMax", C.c_int), ("bOpenGOP", C.c_int), ("bIntraRefresh", C.c_int), ("radl", C.c_int),
+                ("gopLookahead", C.c_int), ("cuTree", C.c_int), ("aqMode", C.c_int), ("vbvBufferSize", C.c_int),
+                ("vbvMaxBitrate", C.c_int), ("bCqp", C.c_int), ("bEnableTemporalSubLayers", C.c_int),
+                ("maxNumReferences", C.c_int), ("poolWorkers", C.c_int)]
+
+
 class HistStats(C.Structure):
     _fields_ = [("picHistogram", C.c_uint32 * 256 * 3 * 4 * 4), ("averageIntensityPerSegment", C.c_uint64 * 3 * 4 * 4),
                 ("averageIntensity", C.c_uint8 * 3), ("pad", C.c_uint8 * 5), ("picAvgVariance", C.c_uint16),
@@ -145,6 +155,16 @@ def lib(depth=8):
     L.orc_diamond_search.restype = i
     L.orc_mcstf_motion_error.argtypes = [vp, i, vp, i, i, i, i, i, i]
     L.orc_mcstf_level.argtypes = [i, C.POINTER(McstfPlanes), C.POINTER(McstfPlanes), C.POINTER(McstfMvs)]
+    L.orc_la_create.argtypes = [C.POINTER(Param), C.POINTER(LaParam), C.POINTER(CuTreeParam), vp]
+    L.orc_la_create.restype = vp
+    L.orc_la_destroy.argtypes = [vp]
+    L.orc_la_add_picture.argtypes = [vp, vp, i, i]
+    L.orc_la_flush.argtypes = [vp]
+    L.orc_la_get_decided_picture.argtypes = [vp]
+    L.orc_la_get_decided_picture.restype = vp
+    L.orc_la_trace.argtypes = [vp, C.POINTER(C.POINTER(C.c_int32))]
+    L.orc_frame_cost_recalculate.argtypes = [C.POINTER(vp), i, i, i]
+    L.orc_frame_cost_recalculate.restype = C.c_int64
     L.libc_free = C.CDLL(None).free
     L.libc_free.argtypes = [vp]
     _libs[depth] = L
@@ -316,6 +336,52 @@ class Lookahead:
         if self.tld:
             self.L.orc_tld_destroy(self.tld)
             self.tld = None
+
+
+class SliceDecider:
+    """The oracle's Lookahead::slicetypeDecide driver over an orc.Lookahead's frames (oracle/orc_slicetype.c).
+
+    p: dict with the fields of api.LookaheadParam (the x265_param names); frames are those of `look`
+    (already pre-analysed: Lowres::init, scale factors, intra estimate), added in order with add_picture()."""
+
+    def __init__(self, look, p):
+        self.look = look
+        L = self.L = look.L
+        lp = LaParam(p["lookaheadDepth"], p["bFrameAdaptive"], p["bBPyramid"], p["scenecutThreshold"], p["scenecutBias"],
+                     p["keyframeMin"], p["keyframeMax"], p["bOpenGOP"], p["bIntraRefresh"], p["radl"], p["gopLookahead"],
+                     p["cuTree"], p["aqMode"] if p["bAdaptiveQuant"] else 0, p["vbvBufferSize"], p["vbvMaxBitrate"],
+                     p["bCqp"], p["bEnableTemporalSubLayers"], p["maxNumReferences"], p["poolWorkers"])
+        cp = CuTreeParam(p["fpsNum"], p["fpsDenom"], p["bBPyramid"], p["bEnableWeightedBiPred"], p["lookaheadDepth"],
+                         p["vbvBufferSize"], p["qCompress"])
+        assert look.param.bframes == p["bframes"] and look.param.bEnableWeightedPred == p["bEnableWeightedPred"]
+        assert look.param.bFrameBias == p["bFrameBias"]
+        self.h = L.orc_la_create(C.byref(look.param), C.byref(lp), C.byref(cp), look.tld)
+        self.by_handle = {}
+
+    def close(self):
+        if self.h:
+            self.L.orc_la_destroy(self.h)
+            self.h = None
+
+    def add_picture(self, index, slice_type=0, slice_type_req=0):
+        lr = self.look.frames[index]
+        self.by_handle[lr.h] = index
+        self.L.orc_la_add_picture(self.h, lr.h, slice_type, slice_type_req)
+
+    def flush(self):
+        self.L.orc_la_flush(self.h)
+
+    def get_decided(self):
+        """-> frame index or None"""
+        h = self.L.orc_la_get_decided_picture(self.h)
+        return None if not h else self.by_handle[h]
+
+    def trace(self):
+        p = C.POINTER(C.c_int32)()
+        n = self.L.orc_la_trace(self.h, C.byref(p))
+        if not n:
+            return np.zeros((0, 6), np.int32)
+        return np.ctypeslib.as_array(p, shape=(n, 6)).copy()
 
 
 class FullResME:

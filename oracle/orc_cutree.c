@@ -262,13 +262,13 @@ void orc_cutree(orc_tld* t, const orc_param* p, const orc_cutree_param* cp, orc_
         if (curnonb < idx)
             break;
 
-        orc_estimate_frame_cost(t, p, frames, curnonb, lastnonb, lastnonb, 0);
+        orc_estimate_frame_cost_single(t, p, frames, curnonb, lastnonb, lastnonb, 0);
         memset(frames[curnonb]->propagateCost, 0, cuCount * sizeof(uint16_t));
         bframes = lastnonb - curnonb - 1;
         if (cp->bBPyramid && bframes > 1)
         {
             int middle = (bframes + 1) / 2 + curnonb;
-            orc_estimate_frame_cost(t, p, frames, curnonb, lastnonb, middle, 0);
+            orc_estimate_frame_cost_single(t, p, frames, curnonb, lastnonb, middle, 0);
             memset(frames[middle]->propagateCost, 0, cuCount * sizeof(uint16_t));
             while (i > curnonb)
             {
@@ -276,7 +276,7 @@ void orc_cutree(orc_tld* t, const orc_param* p, const orc_cutree_param* cp, orc_
                 int p1 = i < middle ? middle : lastnonb;
                 if (i != middle)
                 {
-                    orc_estimate_frame_cost(t, p, frames, p0, p1, i, 0);
+                    orc_estimate_frame_cost_single(t, p, frames, p0, p1, i, 0);
                     orc_estimate_cu_propagate(cp, frames, scratch, averageDuration, p0, p1, i, 0);
                 }
                 i--;
@@ -287,7 +287,7 @@ void orc_cutree(orc_tld* t, const orc_param* p, const orc_cutree_param* cp, orc_
         {
             while (i > curnonb)
             {
-                orc_estimate_frame_cost(t, p, frames, curnonb, lastnonb, i, 0);
+                orc_estimate_frame_cost_single(t, p, frames, curnonb, lastnonb, i, 0);
                 orc_estimate_cu_propagate(cp, frames, scratch, averageDuration, curnonb, lastnonb, i, 0);
                 i--;
             }
@@ -298,7 +298,7 @@ void orc_cutree(orc_tld* t, const orc_param* p, const orc_cutree_param* cp, orc_
 
     if (!cp->lookaheadDepth)
     {
-        orc_estimate_frame_cost(t, p, frames, 0, lastnonb, lastnonb, 0);
+        orc_estimate_frame_cost_single(t, p, frames, 0, lastnonb, lastnonb, 0);
         orc_estimate_cu_propagate(cp, frames, scratch, averageDuration, 0, lastnonb, lastnonb, 1);
         swap_propagate(frames[lastnonb], frames[0]);
     }

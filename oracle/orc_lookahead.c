@@ -107,6 +107,7 @@ void orc_lowres_destroy(orc_lowres* lr)
     free(lr->qpCuTreeOffset);
     free(lr->intraCost);
     free(lr->intraMode);
+    free(lr->recalcRowSatds);
     for (int i = 0; i < ORC_BFRAME_MAX + 2; i++)
     {
         for (int j = 0; j < ORC_BFRAME_MAX + 2; j++)
@@ -157,6 +158,12 @@ pixel* orc_picyuv_pad(const orc_param* p, const pixel* tight, pixel** origin, in
 void orc_lowres_init(orc_lowres* lr, const orc_param* p, const pixel* luma, intptr_t stride, int poc)
 {
     lr->frameNum = poc;
+    lr->bLastMiniGopBFrame = 0;
+    lr->bKeyframe = 0;
+    lr->leadingBframes = 0;
+    lr->indB = 0;
+    for (int i = 0; i <= ORC_LOOKAHEAD_MAX; i++)
+        lr->plannedType[i] = ORC_TYPE_AUTO;
     memset(lr->costEst, -1, sizeof(lr->costEst));
     memset(lr->weightedCostDelta, 0, sizeof(lr->weightedCostDelta));
     if (lr->invQscaleFactor)
@@ -875,6 +882,15 @@ int orc_coop_slices(const orc_param* p, int heightInCU, int* numRowsPerSlice)
     return slices;
 }
 
+/* test instrumentation: called for every request that is computed rather than found cached */
+static orc_request_hook g_requestHook;
+static void* g_requestHookUser;
+void orc_set_request_hook(orc_request_hook hook, void* user)
+{
+    g_requestHook = hook;
+    g_requestHookUser = user;
+}
+
 /* source/encoder/slicetype.cpp:4284-4383.  batchMode: CostEstimateGroup::m_batchMode; outside it a
  * lookahead with cooperative slices splits the block loop (:4312-4343, the slice tasks of
  * processTasks :4248-4276 run here one after the other; their sums are order independent). */
@@ -891,6 +907,8 @@ static int64_t estimate_frame_cost(orc_tld* t, const orc_param* p, orc_lowres** 
         int bDoSearch[2];
         bDoSearch[0] = fenc->lowresMvs[0][b - p0][0].x == 0x7FFF;
         bDoSearch[1] = p1 > b && fenc->lowresMvs[1][p1 - b][0].x == 0x7FFF;
+        if (g_requestHook)
+            g_requestHook(g_requestHookUser, frames, p0, p1, b, bDoSearch, batchMode);
 
         fenc->weightedRefIsWeighted[b - p0] = 0;
         if (p->bEnableWeightedPred && bDoSearch[0])
@@ -993,6 +1011,9 @@ void* orc_lowres_ptr(orc_lowres* lr, const char* f, int i, int j)
     if (!strcmp(f, "wp_sum")) return lr->wp_sum;
     if (!strcmp(f, "wp_ssd")) return lr->wp_ssd;
     if (!strcmp(f, "weightedPlane")) return lr->weightedRef[i].plane[j];
+    if (!strcmp(f, "plannedSatd")) return lr->plannedSatd;
+    if (!strcmp(f, "plannedType")) return lr->plannedType;
+    if (!strcmp(f, "recalcRowSatds")) return lr->recalcRowSatds;
     return NULL;
 }
 
@@ -1014,5 +1035,12 @@ int64_t orc_lowres_i64(orc_lowres* lr, const char* f, int i, int j)
     if (!strcmp(f, "padoffset")) return (int64_t)lr->padoffset;
     if (!strcmp(f, "isWeighted")) return lr->weightedRefIsWeighted[i];
     if (!strcmp(f, "frameNum")) return lr->frameNum;
+    if (!strcmp(f, "sliceType")) return lr->sliceType;
+    if (!strcmp(f, "bScenecut")) return lr->bScenecut;
+    if (!strcmp(f, "bKeyframe")) return lr->bKeyframe;
+    if (!strcmp(f, "bLastMiniGopBFrame")) return lr->bLastMiniGopBFrame;
+    if (!strcmp(f, "leadingBframes")) return lr->leadingBframes;
+    if (!strcmp(f, "indB")) return lr->indB;
+    if (!strcmp(f, "weightedCostDelta")) return (int64_t)lr->weightedCostDelta[i];
     return -1;
 }

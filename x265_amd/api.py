@@ -546,7 +546,41 @@ HOST_EXPORTS = (
     "xgh_window_create", "xgh_window_destroy", "xgh_pre_lookahead", "xgh_pre_lookahead_aq", "xgh_get_wp", "xgh_set_wp", "xgh_set_slice_type",
     "xgh_set_qp_offsets", "xgh_single_cost", "xgh_add", "xgh_finish_batch", "xgh_cost_est", "xgh_intra_mbs",
     "xgh_is_weighted", "xgh_cu_tree", "xgh_status",
+    "xgh_lookahead_create", "xgh_lookahead_destroy", "xgh_lookahead_add_picture", "xgh_lookahead_flush",
+    "xgh_lookahead_get_decided", "xgh_lookahead_trace", "xgh_lookahead_cost_est", "xgh_lookahead_cost_est_aq",
+    "xgh_lookahead_intra_mbs", "xgh_lookahead_slot", "xgh_lookahead_qp_offsets", "xgh_lookahead_inv_qscale",
+    "xgh_lookahead_planned_satd", "xgh_lookahead_recalc_row_satds", "xgh_lookahead_decide_calls",
 )
+
+
+class LookaheadParam(C.Structure):
+    """xgh_lookahead_param: the x265_param fields the slice-type decision reads (defaults: preset medium)."""
+    _fields_ = [("bframes", C.c_int32), ("lookaheadDepth", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bBPyramid", C.c_int32),
+                ("scenecutThreshold", C.c_int32), ("scenecutBias", C.c_double), ("keyframeMin", C.c_int32),
+                ("keyframeMax", C.c_int32), ("bOpenGOP", C.c_int32), ("bIntraRefresh", C.c_int32), ("radl", C.c_int32),
+                ("gopLookahead", C.c_int32), ("cuTree", C.c_int32), ("bFrameBias", C.c_int32), ("vbvBufferSize", C.c_int32),
+                ("vbvMaxBitrate", C.c_int32), ("bCqp", C.c_int32), ("bEnableTemporalSubLayers", C.c_int32),
+                ("maxNumReferences", C.c_int32), ("bEnableWeightedPred", C.c_int32), ("bEnableWeightedBiPred", C.c_int32),
+                ("fpsNum", C.c_int32), ("fpsDenom", C.c_int32), ("qCompress", C.c_double), ("bitDepth", C.c_int32),
+                ("poolWorkers", C.c_int32), ("bAdaptiveQuant", C.c_int32), ("aqMode", C.c_int32), ("aqStrength", C.c_double)]
+
+    MEDIUM = dict(bframes=4, lookaheadDepth=20, bFrameAdaptive=2, bBPyramid=1, scenecutThreshold=40, scenecutBias=0.05,
+                  keyframeMin=25, keyframeMax=250, bOpenGOP=1, bIntraRefresh=0, radl=0, gopLookahead=0, cuTree=1,
+                  bFrameBias=0, vbvBufferSize=0, vbvMaxBitrate=0, bCqp=0, bEnableTemporalSubLayers=0, maxNumReferences=3,
+                  bEnableWeightedPred=1, bEnableWeightedBiPred=0, fpsNum=30, fpsDenom=1, qCompress=0.6, bitDepth=8,
+                  poolWorkers=0, bAdaptiveQuant=1, aqMode=2, aqStrength=1.0)
+
+    def __init__(self, **kw):
+        super().__init__()
+        for k, v in dict(self.MEDIUM, **kw).items():
+            if k not in self.MEDIUM:
+                raise KeyError(k)
+            setattr(self, k, v)
+
+
+class Decided(C.Structure):
+    _fields_ = [("frame", C.c_int32), ("sliceType", C.c_int32), ("bScenecut", C.c_int32), ("bKeyframe", C.c_int32),
+                ("bLastMiniGopBFrame", C.c_int32), ("leadingBframes", C.c_int32)]
 
 
 def load_host_library():
@@ -582,6 +616,29 @@ def load_host_library():
     H.xgh_is_weighted.argtypes = [vp, i32, i32]
     H.xgh_cu_tree.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.c_double, i32, i32]
     H.xgh_status.argtypes = [vp]
+    H.xgh_lookahead_create.argtypes = [vp, C.POINTER(LookaheadParam)]
+    H.xgh_lookahead_create.restype = vp
+    H.xgh_lookahead_destroy.argtypes = [vp]
+    H.xgh_lookahead_destroy.restype = None
+    H.xgh_lookahead_add_picture.argtypes = [vp, vp, vp, vp, C.c_ssize_t, C.c_ssize_t, i32, i32, i32]
+    H.xgh_lookahead_flush.argtypes = [vp]
+    H.xgh_lookahead_flush.restype = None
+    H.xgh_lookahead_get_decided.argtypes = [vp, C.POINTER(Decided)]
+    H.xgh_lookahead_trace.argtypes = [vp, C.POINTER(C.POINTER(i32))]
+    for f in (H.xgh_lookahead_cost_est, H.xgh_lookahead_cost_est_aq):
+        f.argtypes = [vp, i32, i32, i32]
+        f.restype = i64
+    H.xgh_lookahead_intra_mbs.argtypes = [vp, i32, i32]
+    H.xgh_lookahead_slot.argtypes = [vp, i32]
+    H.xgh_lookahead_qp_offsets.argtypes = [vp, i32, i32]
+    H.xgh_lookahead_qp_offsets.restype = C.POINTER(C.c_double)
+    H.xgh_lookahead_inv_qscale.argtypes = [vp, i32]
+    H.xgh_lookahead_inv_qscale.restype = C.POINTER(i32)
+    H.xgh_lookahead_planned_satd.argtypes = [vp, i32, C.POINTER(C.POINTER(i32)), C.POINTER(i32)]
+    H.xgh_lookahead_planned_satd.restype = C.POINTER(i64)
+    H.xgh_lookahead_recalc_row_satds.argtypes = [vp, i32]
+    H.xgh_lookahead_recalc_row_satds.restype = C.POINTER(i32)
+    H.xgh_lookahead_decide_calls.argtypes = [vp]
     _libs[HOST_LIB_PATH] = H
     return H
 
@@ -677,3 +734,106 @@ class HostWindow:
                 lookahead_depth=20, vbv_buffer_size=0, q_compress=0.6):
         self._chk(self.H.xgh_cu_tree(self.h, fps_num, fps_denom, int(b_pyramid), int(weighted_bipred), lookahead_depth,
                                      vbv_buffer_size, float(q_compress), numframes, int(b_intra)))
+
+
+class HostLookahead:
+    """The C++ host layer's Lookahead (queue interface + x265's slice-type decision over device-side costs).
+    Frame i (in order of add_picture) owns slot i of `ctx`, so the context needs one slot per frame added."""
+
+    def __init__(self, ctx, param=None, **kw):
+        self.H = load_host_library()
+        self.ctx = ctx
+        self.param = param if param is not None else LookaheadParam(bitDepth=ctx.depth, **kw)
+        self.h = self.H.xgh_lookahead_create(ctx.h, C.byref(self.param))
+        if not self.h:
+            raise X265GpuError("xgh_lookahead_create failed (unsupported parameters?)")
+        self._keep = []
+        self.count = 0
+
+    def close(self):
+        if self.h:
+            self.H.xgh_lookahead_destroy(self.h)
+            self.h = None
+
+    def add_picture(self, y, u=None, v=None, slice_type=0, slice_type_req=0):
+        """Host planes (numpy); they are kept alive here until close()."""
+        planes = [None if a is None else np.ascontiguousarray(a, self.ctx.pix) for a in (y, u, v)]
+        self._keep.append(planes)
+        py, pu, pv = (None if a is None else _ptr(a) for a in planes)
+        sc = planes[1].shape[1] if planes[1] is not None else 0
+        rc = self.H.xgh_lookahead_add_picture(self.h, py, pu, pv, planes[0].shape[1], sc, MEM_HOST, slice_type, slice_type_req)
+        if rc < 0:
+            raise X265GpuError("xgh_lookahead_add_picture: status %d" % rc)
+        self.count += 1
+        return rc
+
+    def add_device_picture(self, y_ptr, u_ptr, v_ptr, stride_y, stride_c, slice_type=0, slice_type_req=0):
+        rc = self.H.xgh_lookahead_add_picture(self.h, y_ptr, u_ptr, v_ptr, stride_y, stride_c, MEM_DEVICE, slice_type,
+                                              slice_type_req)
+        if rc < 0:
+            raise X265GpuError("xgh_lookahead_add_picture: status %d" % rc)
+        self.count += 1
+        return rc
+
+    def flush(self):
+        self.H.xgh_lookahead_flush(self.h)
+
+    def get_decided(self):
+        """-> Decided or None"""
+        d = Decided()
+        rc = self.H.xgh_lookahead_get_decided(self.h, C.byref(d))
+        if rc < 0:
+            raise X265GpuError("host lookahead status %d: %s" % (rc, self.ctx.L.x265gpu_last_error(self.ctx.h).decode()))
+        return d if rc == 1 else None
+
+    def trace(self):
+        """(n, 6) int32: frame numbers p0, p1, b, bDoSearch[0], bDoSearch[1], batch mode, in issue order."""
+        p = C.POINTER(C.c_int32)()
+        n = self.H.xgh_lookahead_trace(self.h, C.byref(p))
+        if not n:
+            return np.zeros((0, 6), np.int32)
+        return np.ctypeslib.as_array(p, shape=(n, 6)).copy()
+
+    def cost_est(self, frame, d0, d1):
+        return self.H.xgh_lookahead_cost_est(self.h, frame, d0, d1)
+
+    def cost_est_aq(self, frame, d0, d1):
+        return self.H.xgh_lookahead_cost_est_aq(self.h, frame, d0, d1)
+
+    def intra_mbs(self, frame, d0):
+        return self.H.xgh_lookahead_intra_mbs(self.h, frame, d0)
+
+    def slot(self, frame):
+        return self.H.xgh_lookahead_slot(self.h, frame)
+
+    def qp_offsets(self, frame, cutree=False):
+        n = self.ctx.geom.cuCount
+        return np.ctypeslib.as_array(self.H.xgh_lookahead_qp_offsets(self.h, frame, int(cutree)), shape=(n,)).copy()
+
+    def inv_qscale(self, frame):
+        n = self.ctx.geom.cuCount
+        return np.ctypeslib.as_array(self.H.xgh_lookahead_inv_qscale(self.h, frame), shape=(n,)).copy()
+
+    def planned(self, frame):
+        """-> (plannedSatd list, plannedType list) up to the AUTO terminator, indB; empty without a VBV lookahead"""
+        types = C.POINTER(C.c_int32)()
+        ind_b = C.c_int32()
+        satd = self.H.xgh_lookahead_planned_satd(self.h, frame, C.byref(types), C.byref(ind_b))
+        if not satd:
+            return [], [], ind_b.value
+        out_s, out_t = [], []
+        for k in range(251):
+            if types[k] == 0:
+                break
+            out_s.append(satd[k])
+            out_t.append(types[k])
+        return out_s, out_t, ind_b.value
+
+    def recalc_row_satds(self, frame):
+        p = self.H.xgh_lookahead_recalc_row_satds(self.h, frame)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(p, shape=(self.ctx.geom.heightInCU,)).copy()
+
+    def decide_calls(self):
+        return self.H.xgh_lookahead_decide_calls(self.h)

@@ -856,8 +856,11 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
             sliceHeightMax = sliceHeight > sliceHeightMax ? sliceHeight : sliceHeightMax;
         }
         const int d0 = r.b - r.p0, d1 = r.p1 - r.b;
-        if (!slot_ok(ctx, r.slotP0) || !slot_ok(ctx, r.slotB) || !slot_ok(ctx, r.slotP1) || d0 < 1 || d0 >= D ||
-            d1 < 0 || d1 >= D || (d1 == 0 && r.slotP1 != r.slotB) || (r.doSearch[1] && d1 == 0))
+        // d0 == 0 with d1 > 0 is a request x265 does issue: a leading B frame after a closed-GOP keyframe has no
+        // past reference and is measured with p0 = b (slicetype.cpp:2647-2660), i.e. against itself in list 0
+        if (!slot_ok(ctx, r.slotP0) || !slot_ok(ctx, r.slotB) || !slot_ok(ctx, r.slotP1) || d0 < 0 || d0 >= D ||
+            d1 < 0 || d1 >= D || (d0 == 0 && d1 == 0) || (d0 == 0 && r.slotP0 != r.slotB) ||
+            (d1 == 0 && r.slotP1 != r.slotB) || (r.doSearch[1] && d1 == 0))
             return fail(ctx, X265GPU_ERR_ARG, "estimate: bad request");
         if ((r.doSearch[0] || r.doSearch[1]) && !ctx->costCentre)
             return fail(ctx, X265GPU_ERR_STATE, "estimate: MV cost table not set");

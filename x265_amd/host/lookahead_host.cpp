@@ -4,6 +4,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
+
 namespace x265gpu_host {
 
 void Lowres::reset()
@@ -22,10 +24,17 @@ void Lowres::reset()
         weighted[i] = false;
         weightedCostDelta[i] = 0;
     }
+    bLastMiniGopBFrame = false;
+    bKeyframe = false;
+    leadingBframes = 0;
+    indB = 0;
+    if (!plannedType.empty())
+        plannedType.assign(plannedType.size(), TYPE_AUTO);
 }
 
-// ---- LookaheadTLD::weightsAnalyse: the float guess stays here, in single precision as in the reference;
-//      weightCostLuma and weight_pp run on the device ----
+// ---- LookaheadTLD::weightsAnalyse (slicetype.cpp:870-971) with two substitutions: weightCostLuma ->
+//      x265gpu_weight_cost, the weight_pp loop -> x265gpu_weight_planes.  The guess arithmetic is x265's own, in
+//      single precision, so that the same pictures give the same scale / offset / denominator. ----
 int LookaheadTLD::weightsAnalyse(Lowres& fenc, Lowres& ref, int bitDepth)
 {
     static const float epsilon = 1.f / 128.f;
@@ -40,7 +49,7 @@ int LookaheadTLD::weightsAnalyse(Lowres& fenc, Lowres& ref, int bitDepth)
     fencMean = (float)fenc.wp_sum / (m_geom.lines * m_geom.width) / (1 << (bitDepth - 8));
     refMean = (float)ref.wp_sum / (m_geom.lines * m_geom.width) / (1 << (bitDepth - 8));
 
-    /* Early termination */
+    // nothing to gain when means and spread already agree (:906)
     if (fabsf(refMean - fencMean) < 0.5f && fabsf(1.f - guessScale) < epsilon)
         return X265GPU_OK;
 
@@ -82,7 +91,7 @@ int LookaheadTLD::weightsAnalyse(Lowres& fenc, Lowres& ref, int bitDepth)
         found = true;
     }
 
-    /* Use a smaller denominator if possible */
+    // drop common factors of two from scale and denominator (:943-950)
     if (mindenom > 0 && minscale && !(minscale & 1))
     {
         int idx = __builtin_ctz((unsigned)minscale);
@@ -141,14 +150,14 @@ int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const Picture*
     {
         Lowres& fr = *frames[i];
         const Picture& p = pics[i];
-        int rc = x265gpu_lowres_init(m_ctx, fr.slot, p.y, p.strideY, X265GPU_MEM_HOST, fr.frameNum);
+        int rc = x265gpu_lowres_init(m_ctx, fr.slot, p.y, p.strideY, p.memKind, fr.frameNum);
         if (rc != X265GPU_OK)
             return rc;
         fr.reset();
         // tld.calcAdaptiveQuantFrame(preFrame, param) when the lookahead has AQ or weighted prediction
         // (slicetype.cpp:1849-1850); the call installs the scale factors for the slot as well
         uint64_t wpSum[3], wpSsd[3];
-        rc = x265gpu_aq_frame(m_ctx, fr.slot, p.y, p.strideY, p.u, p.v, p.strideC, X265GPU_MEM_HOST, &aq,
+        rc = x265gpu_aq_frame(m_ctx, fr.slot, p.y, p.strideY, p.u, p.v, p.strideC, p.memKind, &aq,
                               quantOffsets ? quantOffsets[i] : nullptr, fr.qpAqOffset, fr.qpCuTreeOffset, fr.invQscaleFactor,
                               wpSum, wpSsd);
         if (rc != X265GPU_OK)
@@ -173,8 +182,9 @@ int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const Picture*
 }
 
 // ---- CostEstimateGroup ----
-CostEstimateGroup::CostEstimateGroup(x265gpu_ctx* ctx, Lowres* const* frames, bool bEnableWeightedPred, int bitDepth)
-    : m_ctx(ctx), m_frames(frames), m_tld(ctx), m_weightp(bEnableWeightedPred), m_bitDepth(bitDepth)
+CostEstimateGroup::CostEstimateGroup(x265gpu_ctx* ctx, Lowres* const* frames, bool bEnableWeightedPred, int bitDepth,
+                                     std::vector<RequestTrace>* trace)
+    : m_ctx(ctx), m_frames(frames), m_tld(ctx), m_weightp(bEnableWeightedPred), m_bitDepth(bitDepth), m_trace(trace)
 {
     x265gpu_geometry g;
     x265gpu_get_geometry(ctx, &g);
@@ -196,6 +206,8 @@ bool CostEstimateGroup::makeRequest(int p0, int p1, int b, Pending& out)
     if (do1)
         fenc.searched[1][d1] = true;
     fenc.pending[d0][d1] = true;
+    if (m_trace)
+        m_trace->push_back({ m_frames[p0]->frameNum, m_frames[p1]->frameNum, fenc.frameNum, { do0, do1 }, m_batchMode });
     bool weighted = false;
     if (m_weightp)
     {
@@ -319,7 +331,9 @@ void CuTree::estimateCUPropagate(Lowres* const* frames, double averageDuration, 
         cuTreeFinish(*frames[b], averageDuration, b == p1 ? b - p0 : 0);
 }
 
-// Lookahead::cuTree, slicetype.cpp:3665-3766
+// Lookahead::cuTree (slicetype.cpp:3665-3766) with these substitutions: memset of propagateCost ->
+// x265gpu_cutree_clear, std::swap of two frames' propagateCost -> x265gpu_cutree_swap, estimateCUPropagate and
+// cuTreeFinish -> the members above (x265gpu_cutree_propagate / _finish).  The walk is x265's.
 int CuTree::cuTree(Lowres* const* frames, int numframes, bool bIntra)
 {
     const int idx = !bIntra;
@@ -336,8 +350,7 @@ int CuTree::cuTree(Lowres* const* frames, int numframes, bool bIntra)
         i--;
     lastnonb = i;
 
-    /* Lookaheadless MB-tree is not a theoretically distinct case; the same extrapolation could
-     * be applied to the end of a lookahead buffer of any size. */
+    // without a lookahead the previous non-B frame's totals are carried over instead (:3690-3704)
     if (!m_p.lookaheadDepth)
     {
         if (bIntra)
@@ -358,7 +371,7 @@ int CuTree::cuTree(Lowres* const* frames, int numframes, bool bIntra)
         note(x265gpu_cutree_clear(m_ctx, frames[lastnonb]->slot));
     }
 
-    CostEstimateGroup estGroup(m_ctx, frames);
+    CostEstimateGroup estGroup(m_ctx, frames, m_p.bEnableWeightedPred, m_p.bitDepth, m_p.trace);
 
     while (i-- > idx)
     {
@@ -414,6 +427,817 @@ int CuTree::cuTree(Lowres* const* frames, int numframes, bool bIntra)
         cuTreeFinish(*frames[lastnonb + (bframes + 1) / 2], averageDuration, 0);
     note(estGroup.status());
     return m_status;
+}
+
+
+// ---- Lookahead: queue interface and slice-type decision ----
+//
+// The decision logic below is x265's (slicetype.cpp, lines cited per member) and has to stay so: which cost
+// requests are issued, and in which order, decides which motion searches run inside a bidirectional request
+// (the skip shortcut of estimateCUCost makes an L0 vector depend on that), so any other order gives other
+// vectors.  What differs from x265 is only where a request is computed: CostEstimateGroup sends it to the device.
+// Not covered (unsupported() says so): zones, fades, analysis load, histogram scene cuts, --aq-motion, --mcstf
+// batches, more than two temporal sub-layers, qgSize 8 and rc.hevcAq in frameCostRecalculate.
+
+// x265_exp2fix8 (source/common/common.cpp:96-103) over x265_exp2_lut (source/common/constants.cpp:552-558),
+// whose entries are round(256 * (2^(i/64) - 1)); inside x265 this is the function itself
+static int exp2fix8(double x)
+{
+    static int lut[64];
+    static bool ready = false;
+    if (!ready)
+    {
+        for (int k = 0; k < 64; k++)
+            lut[k] = (int)lround(256.0 * (exp2(k / 64.0) - 1.0));
+        ready = true;
+    }
+    const int i = (int)(x * (-64.f / 6.f) + 512.5f);
+    if (i < 0)
+        return 0;
+    if (i > 1023)
+        return 0xffff;
+    return (lut[i & 63] + 256) << (i >> 6) >> 8;
+}
+
+static inline bool isTypeI(int t) { return t == TYPE_I || t == TYPE_IDR; }
+static inline bool isTypeB(int t) { return t == TYPE_B || t == TYPE_BREF; }
+
+LookaheadParam::LookaheadParam()
+{
+    memset(&aq, 0, sizeof(aq));
+    aq.aqMode = 2;                 // X265_AQ_AUTO_VARIANCE (param.cpp:310)
+    aq.aqStrength = 1.0;
+    aq.qgSize = 32;
+    aq.bWeightedPred = 1;
+}
+
+Lookahead::Lookahead(x265gpu_ctx* ctx, const LookaheadParam& param) : m_ctx(ctx), m_param(param)
+{
+    x265gpu_get_geometry(ctx, &m_geom);
+    const int W = m_geom.widthInCU, H = m_geom.heightInCU;
+    m_8x8Blocks = (W > 2 && H > 2) ? W * H + 4 - 2 * (W + H) : W * H;      // :1066
+    m_lastKeyframe = -param.keyframeMax;                                   // :1077
+    m_fullQueueSize = (size_t)(param.lookaheadDepth > 1 ? param.lookaheadDepth : 1);
+    m_bBatchMotionSearch = param.poolWorkers > 0 && param.bFrameAdaptive == 2;   // :1091
+    m_bBatchFrameCosts = m_bBatchMotionSearch;                             // :1100
+}
+
+int Lookahead::unsupported() const
+{
+    const LookaheadParam& p = m_param;
+    if (p.bEnableTemporalSubLayers > 2 || p.bframes > X265GPU_BFRAME_MAX || p.lookaheadDepth > LOOKAHEAD_MAX ||
+        (p.bAdaptiveQuant && (p.aq.qgSize == 8 || p.aq.bHevcAq)) || p.keyframeMin < 1 ||
+        (p.cuTree && !p.lookaheadDepth))          // Encoder::configure turns cuTree off without a lookahead (encoder.cpp:4103)
+        return X265GPU_ERR_UNSUPPORTED;
+    return X265GPU_OK;
+}
+
+int64_t Lookahead::cost(Lowres** frames, int p0, int p1, int b, bool bIntraPenalty)
+{
+    CostEstimateGroup est(m_ctx, frames, m_param.bEnableWeightedPred, m_param.bitDepth, &m_trace);
+    const int64_t c = est.singleCost(p0, p1, b, bIntraPenalty);
+    note(est.status());
+    return c;
+}
+
+void Lookahead::cuTree(Lowres** frames, int numframes, bool bIntra)
+{
+    CuTreeParam cp;
+    cp.fpsNum = m_param.fpsNum;
+    cp.fpsDenom = m_param.fpsDenom;
+    cp.bBPyramid = m_param.bBPyramid;
+    cp.bEnableWeightedBiPred = m_param.bEnableWeightedBiPred;
+    cp.lookaheadDepth = m_param.lookaheadDepth;
+    cp.vbvBufferSize = m_param.vbvBufferSize;
+    cp.qCompress = m_param.qCompress;
+    cp.bEnableWeightedPred = m_param.bEnableWeightedPred;
+    cp.bitDepth = m_param.bitDepth;
+    cp.trace = &m_trace;
+    note(CuTree(m_ctx, cp).cuTree(frames, numframes, bIntra));
+}
+
+// addPicture + checkLookaheadQueue (:1299-1342); no pool to wake here
+void Lookahead::addPicture(Lowres& frame, int sliceType)
+{
+    if (!m_filled)
+    {
+        if (!m_param.bframes && !m_param.lookaheadDepth)
+            m_filled = true;
+        else if (m_inputCount >= m_param.lookaheadDepth + 2 + m_param.bframes)
+            m_filled = true;
+    }
+    frame.sliceType = sliceType;
+    frame.bScenecut = false;
+    frame.lowresInit = false;
+    m_inputQueue.push_back(&frame);
+    m_inputCount++;
+}
+
+void Lookahead::flush()                      // :1345-1352
+{
+    m_fullQueueSize = 1;
+    m_filled = true;
+}
+
+Lowres* Lookahead::getDecidedPicture()       // :1396-1431 with findJob (:1360-1393) run in place
+{
+    if (!m_filled)
+        return nullptr;
+    if (m_outputQueue.empty() && m_inputQueue.size() >= m_fullQueueSize)
+        slicetypeDecide();
+    if (m_outputQueue.empty())
+        return nullptr;
+    Lowres* out = m_outputQueue.front();
+    m_outputQueue.pop_front();
+    m_inputCount--;
+    return out;
+}
+
+// :4068-4145 for qgSize > 8 without hevcAq.  The per-block costs come back from the device once; the row sums
+// go to the frame's recalcRowSatds (x265 overwrites rowSatds of the request in place: consumers read
+// recalcRowSatds where x265's rate control reads rowSatds after this call)
+int64_t Lookahead::frameCostRecalculate(Lowres* const* frames, int p0, int p1, int b)
+{
+    Lowres& f = *frames[b];
+    const int d0 = b - p0, d1 = p1 - b;
+    if (f.sliceType == TYPE_B)
+        return f.costEstAq[d0][d1];
+    const int W = m_geom.widthInCU, H = m_geom.heightInCU;
+    std::vector<uint16_t> costs((size_t)W * H);
+    int rc = x265gpu_get_costs(m_ctx, f.slot, d0, d1, costs.data(), nullptr, nullptr);
+    if (rc != X265GPU_OK)
+    {
+        note(rc);
+        return -1;
+    }
+    f.recalcRowSatds.assign(H, 0);
+    int64_t score = 0;
+    const bool tiny = W <= 2 || H <= 2;
+    for (int y = H - 1; y >= 0; y--)
+        for (int x = W - 1; x >= 0; x--)
+        {
+            const int i = x + y * W;
+            int c = costs[i] & 0x3FFF;                                  // LOWRES_COST_MASK
+            c = (c * exp2fix8(f.qpCuTreeOffset[i]) + 128) >> 8;
+            f.recalcRowSatds[y] += c;
+            if (tiny || (y > 0 && y < H - 1 && x > 0 && x < W - 1))
+                score += c;
+        }
+    return score;
+}
+
+int64_t Lookahead::vbvFrameCost(Lowres** frames, int p0, int p1, int b)   // :2830-2844
+{
+    const int64_t c = cost(frames, p0, p1, b);
+    if (!(m_param.bAdaptiveQuant && m_param.aq.aqMode))
+        return c;
+    return m_param.cuTree ? frameCostRecalculate(frames, p0, p1, b) : frames[b]->costEstAq[b - p0][p1 - b];
+}
+
+// :2753-2828.  Fills plannedSatd / plannedType of the next non-B frame (and of the B frames of the current
+// mini-GOP) with the costs of the frames that follow in coded order.
+void Lookahead::vbvLookahead(Lowres** frames, int numFrames, bool keyframe)
+{
+    auto ensure = [](Lowres* f) {
+        if (f->plannedSatd.empty())
+        {
+            f->plannedSatd.assign(LOOKAHEAD_MAX + 1, 0);
+            f->plannedType.assign(LOOKAHEAD_MAX + 1, TYPE_AUTO);
+        }
+    };
+    auto plan = [&](Lowres* f, int at, int64_t satd, int type) {
+        ensure(f);
+        f->plannedSatd[at] = satd;
+        f->plannedType[at] = type;
+    };
+    auto nextNonBAfter = [&](int from) {
+        int k = from;
+        while (k <= numFrames && isTypeB(frames[k]->sliceType))
+            k++;
+        return k;
+    };
+    int prevNonB = 0, idx = 0;
+    int curNonB = 1;
+    while (curNonB < numFrames && isTypeB(frames[curNonB]->sliceType))
+        curNonB++;
+    const int nextNonB = keyframe ? prevNonB : curNonB;
+    const int miniGopEnd = nextNonB;
+    const int nextB = prevNonB + 1;
+    const int curBRef = (m_param.bBPyramid && curNonB - prevNonB > 1) ? (prevNonB + curNonB + 1) / 2 : 0;
+    int nextBRef = 0;
+    for (; curNonB <= numFrames; prevNonB = curNonB, curNonB = nextNonBAfter(curNonB + 1))
+    {
+        if (nextNonB != curNonB)
+        {
+            // the P / I frame that closes this mini-GOP (not nextNonB itself)
+            const int p0 = isTypeI(frames[curNonB]->sliceType) ? curNonB : prevNonB;
+            const int64_t satd = vbvFrameCost(frames, p0, curNonB, curNonB);
+            const int type = frames[curNonB]->sliceType;
+            plan(frames[nextNonB], idx, satd, type);
+            if (curNonB > miniGopEnd)
+                for (int j = nextB; j < miniGopEnd; j++)
+                    plan(frames[j], frames[j]->indB++, satd, type);
+            idx++;
+        }
+        if (m_param.bBPyramid && curNonB - prevNonB > 1)
+            nextBRef = (prevNonB + curNonB + 1) / 2;
+        for (int i = prevNonB + 1; i < curNonB; i++, idx++)
+        {
+            int type = TYPE_B;
+            int64_t satd;
+            if (!nextBRef)
+                satd = vbvFrameCost(frames, prevNonB, curNonB, i);
+            else if (i == nextBRef)
+            {
+                satd = vbvFrameCost(frames, prevNonB, curNonB, nextBRef);
+                type = TYPE_BREF;
+            }
+            else if (i < nextBRef)
+                satd = vbvFrameCost(frames, prevNonB, nextBRef, i);
+            else
+                satd = vbvFrameCost(frames, nextBRef, curNonB, i);
+            plan(frames[nextNonB], idx, satd, type);
+            for (int j = nextB; j < miniGopEnd; j++)
+            {
+                if (curBRef && curBRef == i)
+                    break;
+                if (j >= i && j != nextBRef)
+                    continue;
+                plan(frames[j], frames[j]->indB++, satd, type);
+            }
+        }
+    }
+    ensure(frames[nextNonB]);
+    frames[nextNonB]->plannedType[idx] = TYPE_AUTO;          // end of the plan
+}
+
+// :3281-3321
+bool Lookahead::scenecutInternal(Lowres** frames, int p0, int p1, bool bRealScenecut)
+{
+    Lowres& frame = *frames[p1];
+    cost(frames, p0, p1, p1);
+    const int64_t icost = frame.costEst[0][0];
+    const int64_t pcost = frame.costEst[p1 - p0][0];
+    const int gopSize = (frame.frameNum - m_lastKeyframe) % m_param.keyframeMax;
+    // single precision thresholds, double bias: the mix is x265's and decides borderline frames
+    const float threshMax = (float)(m_param.scenecutThreshold / 100.0);
+    float threshMin = (float)(threshMax * 0.25);
+    double bias = m_param.scenecutBias;
+    if (bRealScenecut)
+    {
+        const int kmin = m_param.keyframeMin, kmax = m_param.keyframeMax;
+        if (kmin == kmax)
+            threshMin = threshMax;
+        if (gopSize <= kmin / 4 || m_param.bIntraRefresh)
+            bias = threshMin / 4;
+        else if (gopSize <= kmin)
+            bias = threshMin * gopSize / kmin;
+        else
+            bias = threshMin + (threshMax - threshMin) * (gopSize - kmin) / (kmax - kmin);
+    }
+    const bool res = pcost >= (1.0 - bias) * icost;
+    if (res && bRealScenecut)
+        frame.bScenecut = true;
+    return res;
+}
+
+// :3186-3279
+bool Lookahead::scenecut(Lowres** frames, int p0, int p1, bool bRealScenecut, int numFrames)
+{
+    const int bf = m_param.bframes;
+    if (bRealScenecut && bf)
+    {
+        // look past p1 so that a flash shorter than a mini-GOP is not taken for a cut
+        const int maxp1 = std::min(p0 + 1 + bf, numFrames);
+        bool fluctuate = false, noScenecuts = false;
+        int64_t avgSatdCost = frames[p0]->costEst[p1 - p0][0] > -1 ? frames[p0]->costEst[p1 - p0][0] : 0;
+        int cnt = 1;
+        for (int cp1 = p1; cp1 <= maxp1; cp1++, cnt++)
+        {
+            if (!scenecutInternal(frames, p0, cp1, false))
+            {
+                for (int i = cp1; i > p0; i--)
+                    frames[i]->bScenecut = false;
+                if (cp1 > p0)
+                    noScenecuts = false;
+            }
+            else if (scenecutInternal(frames, cp1 - 1, cp1, false))
+            {
+                frames[cp1]->bScenecut = true;
+                noScenecuts = true;
+            }
+            avgSatdCost += frames[cp1]->costEst[cp1 - p0][0];
+        }
+        if (noScenecuts)
+        {
+            avgSatdCost /= cnt;
+            for (int i = p1; i <= maxp1; i++)
+            {
+                const int64_t cur = frames[i]->costEst[i - p0][0];
+                const int64_t prev = frames[i - 1]->costEst[i - 1 - p0][0];
+                if (fabs((double)(cur - avgSatdCost)) > 0.1 * avgSatdCost || fabs((double)(cur - prev)) > 0.1 * prev)
+                {
+                    fluctuate = true;
+                    if (!m_isSceneTransition && frames[i]->bScenecut)
+                    {
+                        // only the first change of a transition counts as the cut
+                        m_isSceneTransition = true;
+                        for (int j = i + 1; j <= maxp1; j++)
+                            frames[j]->bScenecut = false;
+                        break;
+                    }
+                }
+                frames[i]->bScenecut = false;
+            }
+        }
+        if (!fluctuate && !noScenecuts)
+            m_isSceneTransition = false;
+    }
+    if (!frames[p1]->bScenecut && bf)
+        return false;
+    return scenecutInternal(frames, p0, p1, bRealScenecut);
+}
+
+// :3534-3579.  path[k] is the type of frame k + 1.
+int64_t Lookahead::slicetypePathCost(Lowres** frames, const std::string& path, int64_t threshold)
+{
+    int64_t total = 0;
+    int cur_p = 0;
+    const int n = (int)path.size();
+    for (int loc = 1; loc <= n;)
+    {
+        int next_p = loc;
+        while (path[next_p - 1] != 'P')
+            next_p++;
+        total += cost(frames, cur_p, next_p, next_p);
+        if (total > threshold)
+            break;
+        if (m_param.bBPyramid && next_p - cur_p > 2)
+        {
+            const int middle = cur_p + (next_p - cur_p) / 2;
+            total += cost(frames, cur_p, next_p, middle);
+            for (int b = loc; b < middle && total < threshold; b++)
+                total += cost(frames, cur_p, middle, b);
+            for (int b = middle + 1; b < next_p && total < threshold; b++)
+                total += cost(frames, middle, next_p, b);
+        }
+        else
+            for (int b = loc; b < next_p && total < threshold; b++)
+                total += cost(frames, cur_p, next_p, b);
+        loc = next_p + 1;
+        cur_p = next_p;
+    }
+    return total;
+}
+
+// :3484-3511.  bestPaths[k % (BFRAME_MAX + 1)] holds the best type string for the first k frames.
+void Lookahead::slicetypePath(Lowres** frames, int length, std::vector<std::string>& bestPaths)
+{
+    const int ring = X265GPU_BFRAME_MAX + 1;
+    const int numPaths = std::min(m_param.bframes + 1, length);
+    int64_t bestCost = 1LL << 62;
+    std::string best;
+    for (int nb = 0; nb < numPaths; nb++)
+    {
+        const int len = length - (nb + 1);
+        std::string cand = bestPaths[len % ring].substr(0, len);
+        cand.resize(len, '\0');
+        cand.append(nb, 'B');
+        cand.push_back('P');
+        const int64_t c = slicetypePathCost(frames, cand, bestCost);
+        if (c < bestCost)
+        {
+            bestCost = c;
+            best.swap(cand);
+        }
+    }
+    bestPaths[length % ring] = best;
+}
+
+// :2846-3184
+void Lookahead::slicetypeAnalyse(Lowres** frames, bool bKeyframe)
+{
+    const LookaheadParam& P = m_param;
+    const int maxSearch = std::min(P.lookaheadDepth, LOOKAHEAD_MAX);
+    const bool bIsVbvLookahead = P.vbvBufferSize && P.lookaheadDepth;
+
+    int framecnt = 0;                              // undecided frames ahead
+    while (framecnt < maxSearch && frames[framecnt + 1] && frames[framecnt + 1]->sliceType == TYPE_AUTO)
+        framecnt++;
+    if (!framecnt)
+    {
+        if (P.cuTree)
+            cuTree(frames, 0, bKeyframe);
+        return;
+    }
+    frames[framecnt + 1] = nullptr;
+
+    const int keyFrameLimit = P.keyframeMax + m_lastKeyframe - frames[0]->frameNum - 1;
+    const bool nearKeyint = P.gopLookahead && keyFrameLimit <= P.bframes + 1;
+    int keyintLimit = nearKeyint ? keyFrameLimit + P.gopLookahead : keyFrameLimit;
+    int numFrames = P.bIntraRefresh ? framecnt : std::min(framecnt, keyintLimit);
+    const int origNumFrames = numFrames;
+
+    if (bIsVbvLookahead)
+        numFrames = framecnt;
+    else if (P.bOpenGOP && numFrames < framecnt)
+        numFrames++;
+    else if (numFrames == 0)
+    {
+        frames[1]->sliceType = TYPE_I;
+        return;
+    }
+
+    if (m_bBatchMotionSearch)
+    {
+        // every motion search the trellis can ask for, in one device batch (:2920-2947) ...
+        CostEstimateGroup est(m_ctx, frames, P.bEnableWeightedPred, P.bitDepth, &m_trace);
+        for (int b = 2; b < numFrames; b++)
+            for (int d = 1; d <= P.bframes + 1; d++)
+            {
+                if (b - d < 0 || frames[b]->searched[0][d])
+                    continue;
+                const bool both = b + d < numFrames && !frames[b]->searched[1][d];
+                est.add(b - d, both ? b + d : b, b);
+            }
+        m_bBatchMotionSearch = m_bBatchMotionSearch && P.poolWorkers >= 4;
+        est.finishBatch();
+        if (m_bBatchFrameCosts)
+        {
+            // ... then every frame cost those searches allow (:2949-2988)
+            for (int b = 2; b < numFrames; b++)
+                for (int d0 = 1; d0 <= P.bframes + 1; d0++)
+                {
+                    if (b < d0 || !frames[b]->searched[0][d0])
+                        continue;
+                    for (int d1 = 0; d1 <= P.bframes && b + d1 < numFrames; d1++)
+                    {
+                        if (d1 && !frames[b]->searched[1][d1])
+                            continue;
+                        if (frames[b]->costEst[d0][d1] >= 0)
+                            continue;
+                        est.add(b - d0, b + d1, b);
+                    }
+                }
+            m_bBatchFrameCosts = m_bBatchFrameCosts && P.poolWorkers > 12;
+            est.finishBatch();
+        }
+        note(est.status());
+    }
+
+    int numBFrames = 0, numAnalyzed = numFrames, resetStart;
+    const bool isScenecut = scenecut(frames, 0, 1, true, origNumFrames);
+    if (P.scenecutThreshold && isScenecut)
+    {
+        frames[1]->sliceType = TYPE_I;
+        return;
+    }
+    const bool gopExtension = P.gopLookahead && keyFrameLimit >= 0 && keyFrameLimit <= P.bframes + 1;
+    if (gopExtension)
+    {
+        // a cut shortly after the keyframe that is due pushes that keyframe back to the cut (:3006-3026)
+        const bool keep = m_isSceneTransition;
+        m_extendGopBoundary = false;
+        for (int i = P.bframes + 1; i < origNumFrames && !m_extendGopBoundary; i += P.bframes + 1)
+        {
+            scenecut(frames, i, i + 1, true, origNumFrames);
+            for (int j = i + 1; j <= std::min(i + P.bframes + 1, origNumFrames); j++)
+                if (frames[j]->bScenecut && scenecutInternal(frames, j - 1, j, true))
+                {
+                    m_extendGopBoundary = true;
+                    break;
+                }
+        }
+        m_isSceneTransition = keep;
+    }
+
+    if (P.bframes)
+    {
+        if (P.bFrameAdaptive == 2)
+        {
+            if (numFrames > 1)
+            {
+                std::vector<std::string> bestPaths(X265GPU_BFRAME_MAX + 1);
+                bestPaths[1] = "P";
+                for (int len = 2; len <= numFrames; len++)
+                    slicetypePath(frames, len, bestPaths);
+                const std::string& best = bestPaths[numFrames % (X265GPU_BFRAME_MAX + 1)];
+                numBFrames = 0;
+                while (numBFrames < (int)best.size() && best[numBFrames] == 'B')
+                    numBFrames++;
+                for (int j = 1; j < numFrames; j++)
+                    frames[j]->sliceType = best[j - 1] == 'B' ? TYPE_B : TYPE_P;
+            }
+            frames[numFrames]->sliceType = TYPE_P;
+        }
+        else if (P.bFrameAdaptive == 1)
+        {
+            // pairwise comparison, then extension of the B run while P frames stay cheap (:3048-3098)
+            const int interThresh = 300, pSensBias = 50 - P.bFrameBias;
+            for (int i = 0; i <= numFrames - 2;)
+            {
+                const int64_t cost2p1 = cost(frames, i, i + 2, i + 2, true);
+                if (frames[i + 2]->intraMbs[2] > m_8x8Blocks / 2)
+                {
+                    frames[i + 1]->sliceType = frames[i + 2]->sliceType = TYPE_P;
+                    i += 2;
+                    continue;
+                }
+                const int64_t cost1b1 = cost(frames, i, i + 2, i + 1);
+                const int64_t cost1p0 = cost(frames, i, i + 1, i + 1);
+                const int64_t cost2p0 = cost(frames, i + 1, i + 2, i + 2);
+                if (cost1p0 + cost2p0 < cost1b1 + cost2p1)
+                {
+                    frames[i + 1]->sliceType = TYPE_P;
+                    i += 1;
+                    continue;
+                }
+                frames[i + 1]->sliceType = TYPE_B;
+                int j = i + 2;
+                for (; j <= std::min(i + P.bframes, numFrames - 1); j++)
+                {
+                    const int64_t pthresh = std::max(interThresh - pSensBias * (j - i - 1), interThresh / 10);
+                    const int64_t pcost = cost(frames, i, j + 1, j + 1, true);
+                    if (pcost > pthresh * m_8x8Blocks || frames[j + 1]->intraMbs[j - i + 1] > m_8x8Blocks / 3)
+                        break;
+                    frames[j]->sliceType = TYPE_B;
+                }
+                frames[j]->sliceType = TYPE_P;
+                i = j;
+            }
+            frames[numFrames]->sliceType = TYPE_P;
+            numBFrames = 0;
+            while (numBFrames < numFrames && frames[numBFrames + 1]->sliceType == TYPE_B)
+                numBFrames++;
+        }
+        else
+        {
+            numBFrames = std::min(numFrames - 1, P.bframes);
+            for (int j = 1; j < numFrames; j++)
+                frames[j]->sliceType = (j % (numBFrames + 1)) ? TYPE_B : TYPE_P;
+            frames[numFrames]->sliceType = TYPE_P;
+        }
+
+        const bool bForceRADL = P.radl && P.keyframeMax == P.keyframeMin;
+        const bool bLastMiniGop = framecnt < P.bframes + 1;
+        const int preRADL = m_lastKeyframe + P.keyframeMax - P.radl - 1;     // frame before the RADL pictures
+        if (bForceRADL && frames[0]->frameNum == preRADL && !bLastMiniGop)
+        {
+            numBFrames = P.radl;
+            for (int j = 1; j <= numBFrames; j++)
+                frames[j]->sliceType = TYPE_B;
+            frames[numBFrames + 1]->sliceType = TYPE_I;
+        }
+        else
+            for (int j = 1; j < numBFrames + 1; j++)
+                if (scenecut(frames, j, j + 1, false, origNumFrames) || (bForceRADL && frames[j]->frameNum == preRADL))
+                {
+                    frames[j]->sliceType = TYPE_P;
+                    numAnalyzed = j;
+                    break;
+                }
+        resetStart = bKeyframe ? 1 : std::min(numBFrames + 2, numAnalyzed + 1);
+    }
+    else
+    {
+        for (int j = 1; j <= numFrames; j++)
+            frames[j]->sliceType = TYPE_P;
+        resetStart = bKeyframe ? 1 : 2;
+    }
+
+    if (P.cuTree)
+        cuTree(frames, std::min(numFrames, P.keyframeMax), bKeyframe);
+
+    if (gopExtension && !m_extendGopBoundary)
+        keyintLimit = keyFrameLimit;
+    if (!P.bIntraRefresh)
+        for (int j = keyintLimit + 1; j <= numFrames; j += P.keyframeMax)
+        {
+            frames[j]->sliceType = TYPE_I;
+            resetStart = std::min(resetStart, j + 1);
+        }
+
+    if (bIsVbvLookahead)
+        vbvLookahead(frames, numFrames, bKeyframe);
+
+    // frames beyond the first mini-GOP go back to undecided (:3163-3171)
+    const int maxp1 = std::min(P.bframes + 1, origNumFrames);
+    for (int j = resetStart; j <= numFrames; j++)
+    {
+        frames[j]->sliceType = TYPE_AUTO;
+        if (j <= maxp1 && frames[j]->bScenecut && m_isSceneTransition)
+            m_isSceneTransition = false;
+    }
+}
+
+void Lookahead::placeBref(Lowres** list, int start, int end, int num, int& brefs)      // :1864-1886
+{
+    const int avg = (start + end) / 2;
+    if (m_param.bEnableTemporalSubLayers >= 2 && num <= 2)
+        return;
+    list[avg]->sliceType = TYPE_BREF;
+    brefs++;
+    if (m_param.bEnableTemporalSubLayers >= 2)
+    {
+        placeBref(list, start, avg, avg - start, brefs);
+        placeBref(list, avg + 1, end, end - avg, brefs);
+    }
+}
+
+void Lookahead::compCostBref(Lowres** frames, int start, int end, int num)              // :1889-1908
+{
+    if (num <= 2)
+    {
+        for (int i = start; i < end; i++)
+            cost(frames, start, end + 1, i + 1);
+        return;
+    }
+    const int avg = (start + end) / 2;
+    cost(frames, start, end + 1, avg + 1);
+    compCostBref(frames, start, avg, avg - start);
+    compCostBref(frames, avg + 1, end, end - avg);
+}
+
+// :1982-2751 without zones, fades, analysis load, MCSTF and the temporal-layer GOP tables
+void Lookahead::slicetypeDecide()
+{
+    const LookaheadParam& P = m_param;
+    m_decideCalls++;
+    std::vector<Lowres*> framesV(LOOKAHEAD_MAX + X265GPU_BFRAME_MAX + 4, nullptr);
+    std::vector<Lowres*> listV(X265GPU_BFRAME_MAX + 4, nullptr);
+    Lowres** frames = framesV.data();
+    Lowres** list = listV.data();
+    int maxSearch = std::max(1, std::min(P.lookaheadDepth, LOOKAHEAD_MAX));
+
+    const int queued = (int)m_inputQueue.size();
+    for (int j = 0; j < P.bframes + 2 && j < queued; j++)
+        list[j] = m_inputQueue[j];
+    frames[0] = m_lastNonB;
+    maxSearch = std::min(maxSearch, queued);
+    std::vector<Lowres*> pre;
+    for (int j = 0; j < maxSearch; j++)
+    {
+        frames[j + 1] = m_inputQueue[j];
+        if (!frames[j + 1]->lowresInit)
+            pre.push_back(frames[j + 1]);
+    }
+
+    // pre-analysis of the frames that entered the window: PreLookaheadGroup::processTasks (:2033-2040)
+    if (!pre.empty())
+    {
+        PreLookaheadGroup group(m_ctx);
+        std::vector<Picture> pics(pre.size());
+        for (size_t i = 0; i < pre.size(); i++)
+            pics[i] = pre[i]->pic;
+        if (P.bAdaptiveQuant)
+            note(group.processTasks((int)pre.size(), pre.data(), pics.data(), P.aq, nullptr));
+        else
+        {
+            if (pics[0].memKind != X265GPU_MEM_HOST)
+                note(X265GPU_ERR_UNSUPPORTED);     // the plain form takes host planes
+            std::vector<const void*> lumas(pre.size());
+            std::vector<intptr_t> strides(pre.size());
+            for (size_t i = 0; i < pre.size(); i++)
+            {
+                lumas[i] = pics[i].y;
+                strides[i] = pics[i].strideY;
+            }
+            note(group.processTasks((int)pre.size(), pre.data(), lumas.data(), strides.data(), nullptr));
+        }
+        for (Lowres* f : pre)
+            f->lowresInit = true;
+    }
+
+    if (m_lastNonB && ((P.bFrameAdaptive && P.bframes) || P.cuTree || P.scenecutThreshold ||
+                       (P.lookaheadDepth && P.vbvBufferSize)))
+        slicetypeAnalyse(frames, false);
+
+    // fix-ups of the first mini-GOP: forced types, keyframe interval, B-frame limit (:2111-2223)
+    const bool isClosedGopRadl = P.radl && P.keyframeMax != P.keyframeMin;
+    int bframes = 0, brefs = 0;
+    for (;; bframes++)
+    {
+        Lowres& frm = *list[bframes];
+        if (frm.sliceTypeReq != TYPE_AUTO && frm.sliceTypeReq != frm.sliceType)
+            frm.sliceType = frm.sliceTypeReq;
+        if (frm.sliceType == TYPE_BREF)
+        {
+            // a B-ref needs the pyramid, and with several of them enough references to keep the P frame
+            const bool noPyramid = !P.bBPyramid && brefs == (int)P.bBPyramid;
+            const bool fewRefs = P.bBPyramid && brefs && P.maxNumReferences <= brefs + 3;
+            if (noPyramid || fewRefs)
+                frm.sliceType = TYPE_B;
+        }
+        const int sinceKey = frm.frameNum - m_lastKeyframe;
+        // chunkStart / chunkEnd at their defaults (0) only ever match frame 0, which this test already catches
+        if ((!P.bIntraRefresh || frm.frameNum == 0) && sinceKey >= P.keyframeMax &&
+            (!m_extendGopBoundary || sinceKey >= P.keyframeMax + P.gopLookahead))
+        {
+            const int keyType = P.bOpenGOP && m_lastKeyframe >= 0 ? TYPE_I : TYPE_IDR;
+            if (frm.sliceType == TYPE_AUTO || frm.sliceType == TYPE_I)
+                frm.sliceType = keyType;
+            const bool compatible = frm.sliceType == TYPE_IDR || (P.bOpenGOP && frm.sliceType == TYPE_I);
+            if (!compatible)
+                frm.sliceType = keyType;
+        }
+        if (frm.sliceType == TYPE_I && sinceKey >= P.keyframeMin)
+        {
+            if (P.bOpenGOP)
+            {
+                m_lastKeyframe = frm.frameNum;
+                frm.bKeyframe = true;
+            }
+            else
+                frm.sliceType = TYPE_IDR;
+        }
+        if (frm.sliceType == TYPE_IDR && frm.bScenecut && isClosedGopRadl)
+        {
+            for (int i = bframes; i < bframes + P.radl; i++)
+                list[i]->sliceType = TYPE_B;
+            list[bframes + P.radl]->sliceType = TYPE_IDR;
+        }
+        if (frm.sliceType == TYPE_IDR)
+        {
+            m_lastKeyframe = frm.frameNum;
+            frm.bKeyframe = true;
+            if (bframes > 0 && !P.radl)
+            {
+                // a closed GOP cannot end on B frames
+                list[bframes - 1]->sliceType = TYPE_P;
+                bframes--;
+            }
+        }
+        // (after the step back above frm is still the IDR frame, which ends the loop below)
+        if (bframes == P.bframes || !list[bframes + 1])
+            if (frm.sliceType == TYPE_AUTO || isTypeB(frm.sliceType))
+                frm.sliceType = TYPE_P;
+        if (frm.sliceType == TYPE_BREF)
+            brefs++;
+        if (frm.sliceType == TYPE_AUTO)
+            frm.sliceType = TYPE_B;
+        else if (!isTypeB(frm.sliceType))
+            break;
+    }
+
+    if (bframes)
+        list[bframes - 1]->bLastMiniGopBFrame = true;
+    list[bframes]->leadingBframes = bframes;
+    m_lastNonB = list[bframes];
+
+    if (P.bBPyramid && bframes > 1 && !brefs)
+        placeBref(list, 0, bframes, bframes + 1, brefs);
+
+    // the costs rate control will ask for, while the frames are still in the window (:2620-2670)
+    if (!P.bCqp)
+    {
+        if (!maxSearch)
+            for (int i = 0; i <= bframes; i++)
+                frames[i + 1] = list[i];
+        const int nonB = bframes + 1;
+        cost(frames, isTypeI(frames[nonB]->sliceType) ? nonB : 0, nonB, nonB);
+        if (P.bEnableTemporalSubLayers > 1 && bframes)
+            compCostBref(frames, 0, bframes, bframes + 1);
+        else
+        {
+            int p0 = 0;
+            bool p0Available = frames[nonB]->sliceType != TYPE_IDR;
+            for (int b = 1; b <= bframes; b++)
+            {
+                if (!p0Available)
+                    p0 = b;
+                int p1 = nonB;
+                if (frames[b]->sliceType == TYPE_B)
+                    for (p1 = b; frames[p1]->sliceType == TYPE_B; p1++)
+                        ;                                       // next non-B or B-ref
+                cost(frames, p0, p1, b);
+                if (frames[b]->sliceType == TYPE_BREF)
+                {
+                    p0 = b;
+                    p0Available = true;
+                }
+            }
+        }
+    }
+
+    // hand the mini-GOP over in coded order: the non-B frame, B-refs, then the plain B frames (:2672-2715)
+    m_inputQueue.erase(m_inputQueue.begin(), m_inputQueue.begin() + bframes + 1);
+    maxSearch -= bframes + 1;
+    m_outputQueue.push_back(list[bframes]);
+    for (int pass = 0; pass < 2; pass++)
+        for (int i = 0; i < bframes; i++)
+            if ((list[i]->sliceType == TYPE_BREF) == (pass == 0) && (pass == 1 || brefs))
+                m_outputQueue.push_back(list[i]);
+
+    // after a keyframe, run the analysis again from it so that cuTree / VBV planning start there (:2718-2747)
+    if ((P.cuTree || (P.vbvBufferSize && P.lookaheadDepth)) && isTypeI(m_lastNonB->sliceType))
+    {
+        frames[0] = m_lastNonB;
+        int j = 0;
+        for (; j < maxSearch; j++)
+            frames[j + 1] = m_inputQueue[j];
+        frames[j + 1] = nullptr;
+        slicetypeAnalyse(frames, true);
+    }
 }
 
 } // namespace x265gpu_host
@@ -535,5 +1359,159 @@ int xgh_cu_tree(xgh_window* w, int32_t fpsNum, int32_t fpsDenom, int32_t bBPyram
 }
 
 int xgh_status(const xgh_window* w) { return w->est->status(); }
+
+struct LaFrame
+{
+    Lowres lowres;
+    std::vector<double> qpAq, qpCuTree;
+    std::vector<int32_t> invQ;
+};
+
+struct xgh_lookahead
+{
+    x265gpu_ctx* ctx;
+    Lookahead* la;
+    std::deque<LaFrame> frames;           // stable addresses: frames are only appended
+    int cuCount;
+};
+
+xgh_lookahead* xgh_lookahead_create(x265gpu_ctx* ctx, const xgh_lookahead_param* p)
+{
+    if (!ctx || !p)
+        return nullptr;
+    LookaheadParam q;
+    q.bframes = p->bframes;
+    q.lookaheadDepth = p->lookaheadDepth;
+    q.bFrameAdaptive = p->bFrameAdaptive;
+    q.bBPyramid = p->bBPyramid != 0;
+    q.scenecutThreshold = p->scenecutThreshold;
+    q.scenecutBias = p->scenecutBias;
+    q.keyframeMin = p->keyframeMin;
+    q.keyframeMax = p->keyframeMax;
+    q.bOpenGOP = p->bOpenGOP != 0;
+    q.bIntraRefresh = p->bIntraRefresh != 0;
+    q.radl = p->radl;
+    q.gopLookahead = p->gopLookahead;
+    q.cuTree = p->cuTree != 0;
+    q.bFrameBias = p->bFrameBias;
+    q.vbvBufferSize = p->vbvBufferSize;
+    q.vbvMaxBitrate = p->vbvMaxBitrate;
+    q.bCqp = p->bCqp != 0;
+    q.bEnableTemporalSubLayers = p->bEnableTemporalSubLayers;
+    q.maxNumReferences = p->maxNumReferences;
+    q.bEnableWeightedPred = p->bEnableWeightedPred != 0;
+    q.bEnableWeightedBiPred = p->bEnableWeightedBiPred != 0;
+    q.fpsNum = p->fpsNum;
+    q.fpsDenom = p->fpsDenom;
+    q.qCompress = p->qCompress;
+    q.bitDepth = p->bitDepth;
+    q.poolWorkers = p->poolWorkers;
+    q.bAdaptiveQuant = p->bAdaptiveQuant != 0;
+    q.aq.aqMode = p->aqMode;
+    q.aq.aqStrength = p->aqStrength;
+    q.aq.bWeightedPred = q.bEnableWeightedPred || q.bEnableWeightedBiPred;
+    xgh_lookahead* h = new xgh_lookahead;
+    h->ctx = ctx;
+    h->la = new Lookahead(ctx, q);
+    if (h->la->unsupported() != X265GPU_OK)
+    {
+        xgh_lookahead_destroy(h);
+        return nullptr;
+    }
+    x265gpu_geometry g;
+    x265gpu_get_geometry(ctx, &g);
+    h->cuCount = g.cuCount;
+    return h;
+}
+
+void xgh_lookahead_destroy(xgh_lookahead* h)
+{
+    if (!h)
+        return;
+    delete h->la;
+    delete h;
+}
+
+int xgh_lookahead_add_picture(xgh_lookahead* h, const void* y, const void* u, const void* v, intptr_t strideY,
+                              intptr_t strideC, int32_t memKind, int32_t sliceType, int32_t sliceTypeReq)
+{
+    if (!h || !y)
+        return X265GPU_ERR_ARG;
+    const int idx = (int)h->frames.size();
+    h->frames.emplace_back();
+    LaFrame& f = h->frames.back();
+    f.qpAq.assign(h->cuCount, 0.0);
+    f.qpCuTree.assign(h->cuCount, 0.0);
+    f.invQ.assign(h->cuCount, 0);
+    f.lowres.slot = idx;
+    f.lowres.frameNum = idx;
+    f.lowres.qpAqOffset = f.qpAq.data();
+    f.lowres.qpCuTreeOffset = f.qpCuTree.data();
+    f.lowres.invQscaleFactor = f.invQ.data();
+    f.lowres.sliceTypeReq = sliceTypeReq;
+    f.lowres.pic.y = y;
+    f.lowres.pic.u = u;
+    f.lowres.pic.v = v;
+    f.lowres.pic.strideY = strideY;
+    f.lowres.pic.strideC = strideC;
+    f.lowres.pic.memKind = memKind;
+    h->la->addPicture(f.lowres, sliceType);
+    return idx;
+}
+
+void xgh_lookahead_flush(xgh_lookahead* h) { h->la->flush(); }
+
+int xgh_lookahead_get_decided(xgh_lookahead* h, xgh_decided* out)
+{
+    Lowres* f = h->la->getDecidedPicture();
+    if (h->la->status() != X265GPU_OK)
+        return h->la->status();
+    if (!f)
+        return 0;
+    out->frame = f->frameNum;
+    out->sliceType = f->sliceType;
+    out->bScenecut = f->bScenecut;
+    out->bKeyframe = f->bKeyframe;
+    out->bLastMiniGopBFrame = f->bLastMiniGopBFrame;
+    out->leadingBframes = f->leadingBframes;
+    return 1;
+}
+
+int xgh_lookahead_trace(const xgh_lookahead* h, const int32_t** out)
+{
+    static_assert(sizeof(RequestTrace) == 6 * sizeof(int32_t), "RequestTrace is read as 6 ints");
+    const std::vector<RequestTrace>& t = h->la->trace();
+    *out = t.empty() ? nullptr : &t[0].p0;
+    return (int)t.size();
+}
+
+int64_t xgh_lookahead_cost_est(const xgh_lookahead* h, int32_t frame, int32_t d0, int32_t d1)
+{
+    return h->frames[frame].lowres.costEst[d0][d1];
+}
+int64_t xgh_lookahead_cost_est_aq(const xgh_lookahead* h, int32_t frame, int32_t d0, int32_t d1)
+{
+    return h->frames[frame].lowres.costEstAq[d0][d1];
+}
+int32_t xgh_lookahead_intra_mbs(const xgh_lookahead* h, int32_t frame, int32_t d0) { return h->frames[frame].lowres.intraMbs[d0]; }
+int32_t xgh_lookahead_slot(const xgh_lookahead* h, int32_t frame) { return h->frames[frame].lowres.slot; }
+const double* xgh_lookahead_qp_offsets(const xgh_lookahead* h, int32_t frame, int32_t which)
+{
+    return which ? h->frames[frame].qpCuTree.data() : h->frames[frame].qpAq.data();
+}
+const int32_t* xgh_lookahead_inv_qscale(const xgh_lookahead* h, int32_t frame) { return h->frames[frame].invQ.data(); }
+const int64_t* xgh_lookahead_planned_satd(const xgh_lookahead* h, int32_t frame, const int32_t** types, int32_t* indB)
+{
+    const Lowres& f = h->frames[frame].lowres;
+    *types = f.plannedType.empty() ? nullptr : f.plannedType.data();
+    *indB = f.indB;
+    return f.plannedSatd.empty() ? nullptr : f.plannedSatd.data();
+}
+const int32_t* xgh_lookahead_recalc_row_satds(const xgh_lookahead* h, int32_t frame)
+{
+    const Lowres& f = h->frames[frame].lowres;
+    return f.recalcRowSatds.empty() ? nullptr : f.recalcRowSatds.data();
+}
+int xgh_lookahead_decide_calls(const xgh_lookahead* h) { return h->la->decideCalls(); }
 
 } // extern "C"

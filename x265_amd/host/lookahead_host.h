@@ -9,6 +9,10 @@
 //   LookaheadTLD::weightsAnalyse        source/encoder/slicetype.cpp:870-971
 //   Lookahead::cuTree / estimateCUPropagate / cuTreeFinish
 //                                       source/encoder/slicetype.cpp:3665-3874, 4016-4064
+//   Lookahead::addPicture / flush / getDecidedPicture, slicetypeDecide, slicetypeAnalyse, scenecut,
+//   scenecutInternal, slicetypePath, slicetypePathCost, vbvLookahead, vbvFrameCost, frameCostRecalculate
+//                                       source/encoder/slicetype.cpp:1299-1431, 1982-2751, 2753-3321,
+//                                       3484-3579, 4068-4145
 //
 // What stays here is what x265 keeps on the host: the cost cache and the bDoSearch decision from the
 // 0x7FFF sentinel, request order, the B-frame bias and the intra penalty, the single-precision weight
@@ -20,6 +24,8 @@
 #include "../../include/x265gpu.h"
 
 #include <stdint.h>
+#include <deque>
+#include <string>
 #include <vector>
 
 namespace x265gpu_host {
@@ -28,6 +34,26 @@ namespace x265gpu_host {
 enum { TYPE_AUTO = 0, TYPE_IDR = 1, TYPE_I = 2, TYPE_P = 3, TYPE_BREF = 4, TYPE_B = 5 };
 
 constexpr int MAX_D = X265GPU_BFRAME_MAX + 2;
+constexpr int LOOKAHEAD_MAX = 250;    // X265_LOOKAHEAD_MAX (source/x265.h:103)
+
+// a 4:2:0 source picture; planes point at pixel (0,0), strides in pixels.  memKind says where the planes
+// live (X265GPU_MEM_HOST / X265GPU_MEM_DEVICE); u and v may be null when no AQ pass reads them
+struct Picture
+{
+    const void* y = nullptr;
+    const void* u = nullptr;
+    const void* v = nullptr;
+    intptr_t strideY = 0, strideC = 0;
+    int memKind = X265GPU_MEM_HOST;
+};
+
+// one computed (not cached) cost request, in issue order: what a test compares against the oracle's order
+struct RequestTrace
+{
+    int32_t p0, p1, b;                // frame numbers
+    int32_t doSearch[2];
+    int32_t batchMode;
+};
 
 // What x265 keeps in Lowres besides pixels (source/common/lowres.h:164-258)
 struct Lowres
@@ -46,6 +72,17 @@ struct Lowres
     double* qpAqOffset = nullptr;     // caller-owned, one entry per 8x8 lowres block (16x16 source block)
     double* qpCuTreeOffset = nullptr;
     int32_t* invQscaleFactor = nullptr;   // caller-owned, same shape; filled by the AQ form of processTasks
+
+    // what the slice-type decision keeps per frame (source/common/lowres.h:166-213)
+    int sliceTypeReq = TYPE_AUTO;
+    bool bScenecut = false, bKeyframe = false, bLastMiniGopBFrame = false;
+    int leadingBframes = 0;
+    int indB = 0;
+    std::vector<int64_t> plannedSatd;     // [LOOKAHEAD_MAX + 1] once the VBV lookahead has run
+    std::vector<int32_t> plannedType;
+    std::vector<int32_t> recalcRowSatds;  // row sums of frameCostRecalculate (the reference overwrites rowSatds in place)
+    Picture pic;                          // Frame::m_fencPic: read when the frame is pre-analysed
+    bool lowresInit = false;              // Frame::m_lowresInit
 
     Lowres() { reset(); }
     void reset();                     // the host half of Lowres::init
@@ -74,7 +111,7 @@ public:
     // calcAdaptiveQuantFrame (block energies on the device, offsets into the frame's qpAqOffset /
     // qpCuTreeOffset / invQscaleFactor arrays, wp_sum / wp_ssd of plane 0 into the frame) and
     // lowresIntraEstimate, for 4:2:0 host pictures.
-    struct Picture { const void* y; const void* u; const void* v; intptr_t strideY, strideC; };
+    typedef x265gpu_host::Picture Picture;
     int processTasks(int n, Lowres* const* frames, const Picture* pics, const x265gpu_aq_params& aq,
                      const float* const* quantOffsets);
 
@@ -86,7 +123,8 @@ class CostEstimateGroup
 {
 public:
     // frames: the window, indexed like x265's frames[]; bitDepth only matters with weightp
-    CostEstimateGroup(x265gpu_ctx* ctx, Lowres* const* frames, bool bEnableWeightedPred = false, int bitDepth = 8);
+    CostEstimateGroup(x265gpu_ctx* ctx, Lowres* const* frames, bool bEnableWeightedPred = false, int bitDepth = 8,
+                      std::vector<RequestTrace>* trace = nullptr);
 
     int64_t singleCost(int p0, int p1, int b, bool bIntraPenalty = false);
     void add(int p0, int p1, int b);
@@ -107,6 +145,7 @@ private:
     int m_ncu;                                    // LookaheadTLD::ncu (slicetype.cpp:1065-1066)
     int m_status = X265GPU_OK;
     std::vector<Pending> m_batch;
+    std::vector<RequestTrace>* m_trace;
 };
 
 // The subset of x265_param that cuTree reads
@@ -118,6 +157,9 @@ struct CuTreeParam
     int lookaheadDepth = 20;
     int vbvBufferSize = 0;
     double qCompress = 0.6;
+    bool bEnableWeightedPred = false;             // cuTree's own requests analyse weights like any other
+    int bitDepth = 8;
+    std::vector<RequestTrace>* trace = nullptr;
 };
 
 class CuTree
@@ -136,6 +178,89 @@ private:
     double m_frameDuration;
     double m_cuTreeStrength;                      // slicetype.cpp:1075
     int m_status = X265GPU_OK;
+};
+
+// The subset of x265_param the slice-type decision reads (fields named as there; values as
+// Encoder::configure leaves them: keyframeMin never 0, scenecutBias already divided by 100).
+struct LookaheadParam
+{
+    int bframes = 4;
+    int lookaheadDepth = 20;
+    int bFrameAdaptive = 2;                       // X265_B_ADAPT_NONE / FAST / TRELLIS
+    bool bBPyramid = true;
+    int scenecutThreshold = 40;
+    double scenecutBias = 0.05;
+    int keyframeMin = 25, keyframeMax = 250;
+    bool bOpenGOP = true;
+    bool bIntraRefresh = false;
+    int radl = 0;
+    int gopLookahead = 0;
+    bool cuTree = true;                           // rc.cuTree
+    int bFrameBias = 0;
+    int vbvBufferSize = 0, vbvMaxBitrate = 0;
+    bool bCqp = false;                            // rc.rateControlMode == X265_RC_CQP
+    int bEnableTemporalSubLayers = 0;             // 0..2
+    int maxNumReferences = 3;
+    bool bEnableWeightedPred = true;
+    bool bEnableWeightedBiPred = false;
+    int fpsNum = 30, fpsDenom = 1;
+    double qCompress = 0.6;
+    int bitDepth = 8;
+    int poolWorkers = 0;                          // ThreadPool::m_numWorkers of the lookahead's pool; 0: no pool, so
+                                                  // requests are issued one by one in the order the decision needs them;
+                                                  // > 0 with trellis B-adapt: the two batches of slicetypeAnalyse
+    bool bAdaptiveQuant = true;                   // Lookahead::m_bAdaptiveQuant: pre-analysis runs calcAdaptiveQuantFrame
+    x265gpu_aq_params aq;                         // its parameters (aqMode, strength, qgSize >= 16, ...)
+    LookaheadParam();
+};
+
+// Lookahead: the queue interface and the serial decision logic, over device-side cost estimation.
+// Frames are the caller's Lowres objects (x265: Frame::m_lowres), each with a device slot of its own for as
+// long as it is inside the lookahead or referenced as the last non-B frame, and with qpAqOffset /
+// qpCuTreeOffset / invQscaleFactor arrays when AQ or cuTree is on.
+class Lookahead
+{
+public:
+    Lookahead(x265gpu_ctx* ctx, const LookaheadParam& param);
+    int  unsupported() const;                     // X265GPU_ERR_UNSUPPORTED when param asks for what is not covered
+    void addPicture(Lowres& frame, int sliceType);
+    void flush();
+    Lowres* getDecidedPicture();
+    int64_t frameCostRecalculate(Lowres* const* frames, int p0, int p1, int b);
+    int status() const { return m_status; }
+    const std::vector<RequestTrace>& trace() const { return m_trace; }
+    int decideCalls() const { return m_decideCalls; }
+
+private:
+    void slicetypeDecide();
+    void slicetypeAnalyse(Lowres** frames, bool bKeyframe);
+    bool scenecut(Lowres** frames, int p0, int p1, bool bRealScenecut, int numFrames);
+    bool scenecutInternal(Lowres** frames, int p0, int p1, bool bRealScenecut);
+    void slicetypePath(Lowres** frames, int length, std::vector<std::string>& bestPaths);
+    int64_t slicetypePathCost(Lowres** frames, const std::string& path, int64_t threshold);
+    void vbvLookahead(Lowres** frames, int numFrames, bool keyframe);
+    int64_t vbvFrameCost(Lowres** frames, int p0, int p1, int b);
+    void placeBref(Lowres** list, int start, int end, int num, int& brefs);
+    void compCostBref(Lowres** frames, int start, int end, int num);
+    void cuTree(Lowres** frames, int numframes, bool bIntra);
+    int64_t cost(Lowres** frames, int p0, int p1, int b, bool bIntraPenalty = false);
+    void note(int rc) { if (rc != X265GPU_OK && m_status == X265GPU_OK) m_status = rc; }
+
+    x265gpu_ctx* m_ctx;
+    LookaheadParam m_param;
+    x265gpu_geometry m_geom;
+    int m_8x8Blocks;
+    Lowres* m_lastNonB = nullptr;
+    int m_lastKeyframe;
+    bool m_isSceneTransition = false, m_extendGopBoundary = false;
+    bool m_bBatchMotionSearch, m_bBatchFrameCosts;
+    bool m_filled = false;
+    size_t m_fullQueueSize;
+    int m_inputCount = 0;
+    std::deque<Lowres*> m_inputQueue, m_outputQueue;
+    std::vector<RequestTrace> m_trace;
+    int m_status = X265GPU_OK;
+    int m_decideCalls = 0;
 };
 
 } // namespace x265gpu_host
@@ -165,6 +290,45 @@ int32_t xgh_is_weighted(const xgh_window* w, int32_t b, int32_t d0);
 int xgh_cu_tree(xgh_window* w, int32_t fpsNum, int32_t fpsDenom, int32_t bBPyramid, int32_t bEnableWeightedBiPred,
                 int32_t lookaheadDepth, int32_t vbvBufferSize, double qCompress, int32_t numframes, int32_t bIntra);
 int xgh_status(const xgh_window* w);
+
+/* the whole lookahead: queue in, decided frames out.  Every frame gets a device slot of its own (the context
+ * needs as many slots as frames are alive at once: here, as frames are added in total). */
+typedef struct xgh_lookahead xgh_lookahead;
+typedef struct xgh_lookahead_param
+{
+    int32_t bframes, lookaheadDepth, bFrameAdaptive, bBPyramid, scenecutThreshold;
+    double  scenecutBias;
+    int32_t keyframeMin, keyframeMax, bOpenGOP, bIntraRefresh, radl, gopLookahead, cuTree, bFrameBias;
+    int32_t vbvBufferSize, vbvMaxBitrate, bCqp, bEnableTemporalSubLayers, maxNumReferences;
+    int32_t bEnableWeightedPred, bEnableWeightedBiPred, fpsNum, fpsDenom;
+    double  qCompress;
+    int32_t bitDepth, poolWorkers, bAdaptiveQuant, aqMode;
+    double  aqStrength;
+} xgh_lookahead_param;
+typedef struct xgh_decided
+{
+    int32_t frame;                /* index in order of xgh_lookahead_add_picture */
+    int32_t sliceType, bScenecut, bKeyframe, bLastMiniGopBFrame, leadingBframes;
+} xgh_decided;
+xgh_lookahead* xgh_lookahead_create(x265gpu_ctx* ctx, const xgh_lookahead_param* p);
+void xgh_lookahead_destroy(xgh_lookahead* la);
+/* planes stay the caller's and must live until the frame comes out; returns the frame's index or a negative status */
+int xgh_lookahead_add_picture(xgh_lookahead* la, const void* y, const void* u, const void* v, intptr_t strideY,
+                              intptr_t strideC, int32_t memKind, int32_t sliceType, int32_t sliceTypeReq);
+void xgh_lookahead_flush(xgh_lookahead* la);
+/* 1: *out filled; 0: nothing decided yet (or the lookahead is empty); < 0: status */
+int xgh_lookahead_get_decided(xgh_lookahead* la, xgh_decided* out);
+int xgh_lookahead_trace(const xgh_lookahead* la, const int32_t** out);    /* 6 ints per request, as RequestTrace */
+int64_t xgh_lookahead_cost_est(const xgh_lookahead* la, int32_t frame, int32_t d0, int32_t d1);
+int64_t xgh_lookahead_cost_est_aq(const xgh_lookahead* la, int32_t frame, int32_t d0, int32_t d1);
+int32_t xgh_lookahead_intra_mbs(const xgh_lookahead* la, int32_t frame, int32_t d0);
+int32_t xgh_lookahead_slot(const xgh_lookahead* la, int32_t frame);
+const double* xgh_lookahead_qp_offsets(const xgh_lookahead* la, int32_t frame, int32_t which /*0 aq, 1 cuTree*/);
+const int32_t* xgh_lookahead_inv_qscale(const xgh_lookahead* la, int32_t frame);
+/* VBV lookahead results: counts of valid entries come back through n */
+const int64_t* xgh_lookahead_planned_satd(const xgh_lookahead* la, int32_t frame, const int32_t** types, int32_t* indB);
+const int32_t* xgh_lookahead_recalc_row_satds(const xgh_lookahead* la, int32_t frame);
+int xgh_lookahead_decide_calls(const xgh_lookahead* la);
 }
 
 #endif

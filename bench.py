@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
-"""Lookahead throughput on MI355X: frames/sec of the lowres lookahead hot path.
+"""Lookahead throughput on MI355X: frames/sec of x265's lowres lookahead, preset medium.
 
-One step = the whole lookahead workload of one synthetic clip segment, issued
-the way x265's batch mode issues it (slicetype.cpp:2925-2988): Lowres::init and
-the intra estimate for every frame, then batch 1 (every motion search, both
-lists, distances 1..bframes+1) and batch 2 (every (p0, p1, b) frame-cost
-combination).  Source frames are resident in HBM before the timed region; the
-per-request scalars come back to the host inside it.  With --gpus N every rank
-runs its own segment (weak scaling) and the cost scalars of all ranks are
-gathered over RCCL inside the timed step.
+Two workloads per run, both through the C++ host layer (x265_amd/host) over the C-ABI:
 
-Prints ONE JSON line (rank 0).
+  segment  (the headline `value`): one step = the whole lookahead work of one 60-frame segment handed to the
+           device in x265's batch order (slicetype.cpp:2925-2988 on a fresh window): per frame Lowres::init,
+           calcAdaptiveQuantFrame (AQ mode 2) and the intra estimate; batch 1 = every motion search (both lists,
+           distances 1..bframes+1) with weightsAnalyse in front of each L0 search; batch 2 = every (p0, p1, b)
+           frame cost; then one cuTree pass over the segment (B-pyramid mini-GOPs).  This is the throughput with
+           many frames in flight, e.g. GOP segments of one or several encodes.
+  steady   (`steady_state`): the real decision loop, Lookahead::slicetypeDecide with rc-lookahead 20 and a pool
+           (batches per decision), fed picture by picture and drained as Encoder::encode does; frames/s and
+           milliseconds per slicetypeDecide call are what ONE encoder instance sees.
+
+Source pictures (Y, U, V) are resident in HBM before the timed region.  With --gpus N the parent starts N rank
+processes (one per GPU, torch.distributed over RCCL); every rank runs its own segment (weak scaling) and the
+per-request cost scalars of all ranks are gathered inside the timed step.  Under torchrun (WORLD_SIZE set) the
+process is a rank itself.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+SIMDS = 1024            # 256 compute units x 4
+ISSUE_BENCH = os.path.join(ROOT, "benchmarks", "micro", "issue_bench")
 
 
 def batch_requests(nframes, bframes):
@@ -63,49 +73,150 @@ def batch_requests(nframes, bframes):
     return b1, b2
 
 
-def plan_step(ctx, nframes, bframes):
-    """Device requests of one step with their doSearch flags (identical for every fresh window)."""
-    from x265_amd.lookahead import CostEstimateGroup, LowresState
-    frames = [LowresState(i, i, ctx.D) for i in range(nframes)]
-    est = CostEstimateGroup(ctx, frames)
-    b1, b2 = batch_requests(nframes, bframes)
-    r1 = [est._request(*r) for r in b1]
-    for fr in frames:
-        fr.pending.clear()
-    r2 = [est._request(*r) for r in b2]
-    assert None not in r1 and None not in r2
-    assert not any(r[6] or r[7] for r in r2), "batch 2 must not search"
-    return r1, r2
+def segment_slice_types(nframes, bframes):
+    """The fixed mini-GOP pattern the segment workload's cuTree pass walks: I, then bframes B frames (the
+    middle one a B-ref) before every P."""
+    I, P, BREF, B = 2, 3, 4, 5
+    types = [I]
+    for k in range(1, nframes):
+        pos = (k - 1) % (bframes + 1)
+        types.append(P if pos == bframes else (BREF if bframes > 1 and pos == (bframes + 1) // 2 - 1 else B))
+    types[-1] = P
+    return types
 
 
-def cpu_baseline(width, height, depth, bframes, sample_frames, seed, hme=False):
-    """The oracle (a scalar C port of the reference path) on one host core, same request pattern."""
-    from oracle import orc
+def make_clip(width, height, frames, depth, seed):
+    """(luma clip, [(u, v), ...]): the synthetic segment; chroma is only read by AQ."""
     from x265_amd import synth
-    clip = synth.luma_clip(width, height, sample_frames, depth, seed=seed)
-    param = orc.make_param(width, height, bframes=bframes, hme=hme)
+    clip = synth.luma_clip(width, height, frames, depth, seed=seed)
+    rng = np.random.default_rng(seed + 99)
+    top = (1 << depth) - 1
+    base = rng.integers(top // 3, 2 * top // 3, (height // 2, width // 2))
+    chroma = []
+    for i in range(frames):
+        u = np.clip(np.roll(base, 2 * i, axis=1) + rng.integers(-3, 4, base.shape), 0, top).astype(clip.dtype)
+        v = np.clip(np.roll(base[::-1], i, axis=0) + rng.integers(-3, 4, base.shape), 0, top).astype(clip.dtype)
+        chroma.append((u, v))
+    return clip, chroma
+
+
+MEDIUM = dict(bframes=4, lookaheadDepth=20, bFrameAdaptive=2, bBPyramid=1, scenecutThreshold=40, scenecutBias=0.05,
+              keyframeMin=25, keyframeMax=250, bOpenGOP=1, bIntraRefresh=0, radl=0, gopLookahead=0, cuTree=1, bFrameBias=0,
+              vbvBufferSize=0, vbvMaxBitrate=0, bCqp=0, bEnableTemporalSubLayers=0, maxNumReferences=3,
+              bEnableWeightedPred=1, bEnableWeightedBiPred=0, fpsNum=30, fpsDenom=1, qCompress=0.6, bitDepth=8,
+              poolWorkers=16, bAdaptiveQuant=1, aqMode=2, aqStrength=1.0)
+
+
+# ---------------------------------------------------------------- CPU baseline: the oracle on host cores
+
+def _oracle_frames(width, height, depth, bframes, clip, chroma, hme):
+    from oracle import orc
+    param = orc.make_param(width, height, bframes=bframes, weightp=True, hme=hme)
+    look = orc.Lookahead(depth, param, with_aq=True)
+    for i, y in enumerate(clip):
+        qa, qc, inv, wsum, wssd = orc.calc_adaptive_quant_frame(depth, y, chroma[i][0], chroma[i][1], 2, 1.0, weightp=True)[:5]
+        lr = look.add_frame(y, inv)
+        lr.qp_aq_offset()[:] = qa
+        lr.qp_cutree_offset()[:] = qc
+        s, d = lr.wp()
+        s[:], d[:] = wsum, wssd
+    return look
+
+
+def cpu_segment_seconds(width, height, depth, bframes, frames, seed, hme=False):
+    """The segment workload on the oracle, one core: seconds for `frames` frames."""
+    from oracle import orc
+    clip, chroma = make_clip(width, height, frames, depth, seed)
     t0 = time.perf_counter()
-    ref = orc.Lookahead(depth, param)
-    for f in clip:
-        ref.add_frame(f)
-    b1, b2 = batch_requests(sample_frames, bframes)
+    look = _oracle_frames(width, height, depth, bframes, clip, chroma, hme)
+    b1, b2 = batch_requests(frames, bframes)
     for r in b1 + b2:
-        ref.frame_cost(*r)
+        look.frame_cost(*r)
+    for k, t in enumerate(segment_slice_types(frames, bframes)):
+        look.frames[k].set_slice_type(t)
+    look.cu_tree(orc.CuTreeParam(30, 1, 1, 0, 20, 0, 0.6), frames - 1, False)
     dt = time.perf_counter() - t0
-    ref.close()
-    return {"value": sample_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d-frame %dx%d %d-bit window, same batch-1 + batch-2 request pattern, %.1f s"
-                      % (sample_frames, width, height, depth, dt)}
+    look.close()
+    return dt
 
 
-PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "latest_pmc_summary.json")
+def _cpu_segment_worker(a):
+    return cpu_segment_seconds(*a)
 
 
-def _pmc_kernel(kernel_name):
-    """Counters of one kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/run_pmc.sh + summarize_pmc.py), or None."""
+def cpu_steady_seconds(width, height, depth, frames, seed, hme=False):
+    """The steady workload (slicetypeDecide loop, rc-lookahead 20, batches) on the oracle, one core."""
+    from oracle import orc
+    p = dict(MEDIUM, bitDepth=depth)
+    clip, chroma = make_clip(width, height, frames, depth, seed)
+    t0 = time.perf_counter()
+    look = _oracle_frames(width, height, depth, p["bframes"], clip, chroma, hme)
+    dec = orc.SliceDecider(look, p)
+    for i in range(frames):
+        dec.add_picture(i)
+        dec.get_decided()
+    dec.flush()
+    while dec.get_decided() is not None:
+        pass
+    dt = time.perf_counter() - t0
+    dec.close()
+    look.close()
+    return dt
+
+
+def cpu_baselines(args):
+    W, H, D = args.width, args.height, args.depth
+    n = args.cpu_frames
+    out = {}
+    dt = cpu_segment_seconds(W, H, D, args.bframes, n, 1234, args.hme)
+    out["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                           "sample": "segment workload, %d frames of %dx%d %d-bit, %.1f s on one core" % (n, W, H, D, dt)}
+    dt = cpu_steady_seconds(W, H, D, n, 1234, args.hme)
+    out["cpu_baseline_steady"] = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                                  "sample": "steady workload (slicetypeDecide loop, rc-lookahead 20), %d frames, %.1f s" % (n, dt)}
+    cores = max(1, min(args.cpu_cores, os.cpu_count() or 1))
+    if cores > 1:
+        import multiprocessing as mp
+        ctx = mp.get_context("spawn")
+        t0 = time.perf_counter()
+        with ctx.Pool(cores) as pool:
+            pool.map(_cpu_segment_worker, [(W, H, D, args.bframes, n, 2000 + k, args.hme) for k in range(cores)])
+        dt = time.perf_counter() - t0
+        out["cpu_baseline_all_cores"] = {"value": cores * n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+                                         "sample": "segment workload, one independent %d-frame segment per core, %d cores, %.1f s"
+                                                   % (n, cores, dt)}
+    return out
+
+
+# ---------------------------------------------------------------- measured machine constants and counters
+
+def issue_rates():
+    """Cycles per wave64 instruction and the clock held, measured on this GPU by benchmarks/micro/issue_bench."""
+    if not os.path.exists(ISSUE_BENCH):
+        return None
     try:
-        with open(PMC_SUMMARY) as f:
+        txt = subprocess.run([ISSUE_BENCH], capture_output=True, timeout=120, check=True).stdout.decode()
+        d = json.loads(txt)
+    except (OSError, ValueError, subprocess.SubprocessError):
+        return None
+    k = d["kinds"]
+    valu = [k[n]["waves_per_simd_8"]["cycles_per_instruction_per_simd"] for n in ("v_sad_u8", "v_pk_add_i16", "v_min_i32", "v_alignbyte_b32")]
+    return {"valu_cycles_per_inst_per_simd_8_waves": sum(valu) / len(valu),
+            "valu_cycles_per_inst_per_simd_1_wave": k["v_sad_u8"]["waves_per_simd_1"]["cycles_per_instruction_per_simd"],
+            "salu_cycles_per_inst_per_simd_8_waves": k["s_add_u32"]["waves_per_simd_8"]["cycles_per_instruction_per_simd"],
+            "clock_GHz": d["clock_GHz_at_8_waves"], "source": "benchmarks/micro/issue_bench (s_memtime / s_memrealtime)"}
+
+
+def config_key(args):
+    return "%dx%d_%dbit%s" % (args.width, args.height, args.depth, "_hme" if args.hme else "")
+
+
+def pmc_kernel(args, kernel_name):
+    """Counters of one kernel from the committed rocprofv3 --pmc passes of THIS configuration
+    (profiles/pmc_<config>.json, made by profiles/run_pmc.sh + summarize_pmc.py), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_%s.json" % config_key(args))
+    try:
+        with open(path) as f:
             summary = json.load(f)
     except (OSError, ValueError):
         return None
@@ -115,54 +226,94 @@ def _pmc_kernel(kernel_name):
     return None
 
 
-def pmc_traffic_per_launch(kernel_name):
+def pmc_traffic_per_launch(c):
     """Bytes per launch between L2 and memory: (2 x FETCH_SIZE + WRITE_SIZE) KiB per dispatch.  FETCH_SIZE counts
     128-byte requests as 64 bytes on gfx950, hence the factor 2 on the read side."""
-    c = _pmc_kernel(kernel_name)
     if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or not c.get("dispatches"):
         return None
     return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / c["dispatches"]
 
 
-def valu_utilisation(kernel_name, units, ms_per_step):
-    """Share of the chip's VALU issue slots the dominant kernel fills: wave-level VALU instructions per step
-    (counter pass: SQ_INSTS_VALU per wave x waves) x 4 cycles each / (1024 SIMDs x clock x time)."""
-    c = _pmc_kernel(kernel_name)
-    if not c or not units or not c.get("SQ_WAVES") or "SQ_INSTS_VALU" not in c:
-        return None
-    per_wave = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
-    clock_hz = 2.4e9
-    cycles = per_wave * units * 4.0 / 1024.0
-    return {"valu_insts_per_block_search": per_wave, "salu_insts_per_block_search": c.get("SQ_INSTS_SALU", 0) / c["SQ_WAVES"],
-            "frac_of_valu_issue_at_2.4GHz": cycles / (clock_hz * ms_per_step * 1e-3),
-            "note": "one wave = one 8x8 block search; instruction counts from profiles/latest_pmc_summary.json"}
+# ---------------------------------------------------------------- launcher
+
+def launch_ranks(args, argv):
+    """--gpus N outside torchrun: N fresh rank processes; nothing in this process touches the GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = rc or p.wait()
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--frames", type=int, default=60, help="frames per step (one device batch)")
-    ap.add_argument("--bframes", type=int, default=4)
-    ap.add_argument("--cpu-frames", type=int, default=60, help="frames in the bounded CPU baseline sample (0 = skip)")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise the process group and run the gather even at world size 1 (rehearsal of the N>1 path)")
-    ap.add_argument("--hme", action="store_true", help="--hme: quarter-res hex then half-res umh (x265's defaults, ranges 16 / 32)")
-    args = ap.parse_args()
+# ---------------------------------------------------------------- rank body
 
+def standin_rank(args, rank, world):
+    """Test rehearsal of the N > 1 path on CPU: gloo, and the oracle in the device's place.  Not a measurement."""
+    import torch
+    import torch.distributed as dist
+    from x265_amd import sharding
+    dist.init_process_group(args.backend, rank=rank, world_size=world)
+    from oracle import orc
+    clip, _ = make_clip(args.width, args.height, args.frames, args.depth, 1234 + rank)
+    look = orc.Lookahead(args.depth, orc.make_param(args.width, args.height, bframes=args.bframes))
+    for f in clip:
+        look.add_frame(f)
+    b1, b2 = batch_requests(args.frames, args.bframes)
+    t0 = time.perf_counter()
+    rows = []
+    for (p0, p1, b) in b1 + b2:
+        look.frame_cost(p0, p1, b)
+        fr = look.frames[b]
+        rows.append((fr.i64("costEst", b - p0, p1 - b), fr.i64("costEstAq", b - p0, p1 - b), fr.i64("intraMbs", b - p0)))
+    parts = sharding.gather_costs(np.array(rows, np.int64).reshape(-1, 3))
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    look.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    return {"metric": "lookahead frames/sec", "value": args.frames * world / float(t.item()), "unit": "frames/s",
+            "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": 1000.0 * float(t.item()),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "CPU stand-in rehearsal of the multi-rank path (oracle + gloo); NOT a measurement",
+                       "gathered_requests": [int(p.shape[0]) for p in parts]}}
+
+
+def rank_main(args):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     # Libraries under the process group print banners on stdout; keep fd 1 for the one JSON line.
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.cpu_standin:
+        rec = standin_rank(args, rank, world)
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        os.close(json_fd)
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+        return
 
+    # Everything that starts another process (the issue-rate microbenchmark, the worker pool of the all-cores CPU
+    # baseline) runs before this process initialises the GPU.
+    rates = issue_rates() if rank == 0 and not args.no_micro else None
+    cpu = cpu_baselines(args) if rank == 0 and args.cpu_frames > 0 else {}
+
+    import ctypes as C
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1 or args.force_dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the lookahead path has no CPU fallback")
@@ -171,51 +322,78 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from oracle import orc
-    from x265_amd import api, synth
+    from x265_amd import api
 
     W, H, D, F = args.width, args.height, args.depth, args.frames
     bpp = 1 if D == 8 else 2
-    clip = synth.luma_clip(W, H, F, D, seed=1234 + rank)
-    if D == 8:
-        dev_clip = torch.from_numpy(clip).cuda()
-    else:
-        dev_clip = torch.from_numpy(clip.view(np.int16)).cuda()
+    clip, chroma = make_clip(W, H, F, D, 1234 + rank)
+
+    def to_dev(a):
+        return torch.from_numpy(a if D == 8 else a.view(np.int16)).cuda()
+    dev_y = to_dev(clip)
+    dev_u = to_dev(np.stack([c[0] for c in chroma]))
+    dev_v = to_dev(np.stack([c[1] for c in chroma]))
     torch.cuda.synchronize()
-    frame_bytes = W * H * bpp
-    ptrs = [dev_clip.data_ptr() + i * frame_bytes for i in range(F)]
-    slots = list(range(F))
+    yb, cb = W * H * bpp, (W // 2) * (H // 2) * bpp
+    y_ptrs = [dev_y.data_ptr() + i * yb for i in range(F)]
+    u_ptrs = [dev_u.data_ptr() + i * cb for i in range(F)]
+    v_ptrs = [dev_v.data_ptr() + i * cb for i in range(F)]
 
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = api.Context(W, H, depth=D, bframes=args.bframes, num_slots=F, device=local_rank, stream=stream, hme=args.hme)
-    table, centre = orc.bitcost_table(D)          # host-built input table (float math stays on the host)
+    hme_kw = dict(hme=True) if args.hme else {}
+    ctx = api.Context(W, H, depth=D, bframes=args.bframes, num_slots=F, device=local_rank, stream=stream, **hme_kw)
+    table, centre = api.bitcost_table(D)
     ctx.set_mvcost(table, centre)
-    r1, r2 = plan_step(ctx, F, args.bframes)
-    a1, a2 = ctx._pack(r1), ctx._pack(r2)
-    o1, o2 = (api.FrameCost * len(a1))(), (api.FrameCost * len(a2))()
-    n_search = sum(int(r[6]) + int(r[7]) for r in r1 + r2)
-    n_cost = len(r1) + len(r2)
-    gather_buf = None
-    if distributed:
-        local = torch.zeros((n_cost, 3), dtype=torch.int64, device="cuda")
-        cost_dtype = np.dtype([("costEst", "<i8"), ("costEstAq", "<i8"), ("intraMbs", "<i4"), ("reserved", "<i4")])
-        host = np.zeros((n_cost, 3), np.int64)
-        offs = [0, len(a1), len(a1) + len(a2)]
-        gather_buf = [torch.zeros_like(local) for _ in range(world)]
+    n = ctx.geom.cuCount
 
-    def step():
-        ctx.lowres_init_device(slots, ptrs, [W] * F)
-        ctx.intra_estimate(slots)
-        ctx._chk(ctx.L.x265gpu_estimate_costs(ctx.h, len(a1), a1, o1))
-        ctx._chk(ctx.L.x265gpu_estimate_costs(ctx.h, len(a2), a2, o2))
-        if distributed:
-            for k, o in enumerate((o1, o2)):        # x265gpu_frame_cost records viewed in place, no per-record Python work
-                rec = np.frombuffer(o, dtype=cost_dtype)
-                host[offs[k]:offs[k + 1], 0] = rec["costEst"]
-                host[offs[k]:offs[k + 1], 1] = rec["costEstAq"]
-                host[offs[k]:offs[k + 1], 2] = rec["intraMbs"]
-            local.copy_(torch.from_numpy(host))
-            dist.all_gather(gather_buf, local)
+    # ---- segment workload through xgh_window ----
+    Hlib = api.load_host_library()
+    win = api.HostWindow(ctx, F, weightp=True)
+    offs = [(np.zeros(n), np.zeros(n)) for _ in range(F)]
+    invs = [np.zeros(n, np.int32) for _ in range(F)]
+    for i in range(F):
+        win.set_qp_offsets(i, *offs[i])
+    for k, t in enumerate(segment_slice_types(F, args.bframes)):
+        win.set_slice_type(k, t)
+    b1, b2 = batch_requests(F, args.bframes)
+    a1 = np.ascontiguousarray(np.array(b1, np.int32).reshape(-1, 3))
+    a2 = np.ascontiguousarray(np.array(b2, np.int32).reshape(-1, 3))
+    n_search = sum(1 + (1 if p1 > b else 0) for (_, p1, b) in b1)
+    n_cost = len(b1) + len(b2)
+    vpn = C.c_void_p * F
+    frames_arr = (C.c_int32 * F)(*range(F))
+    ys, us, vs = vpn(*y_ptrs), vpn(*u_ptrs), vpn(*v_ptrs)
+    sy, sc = (C.c_ssize_t * F)(*[W] * F), (C.c_ssize_t * F)(*[W // 2] * F)
+    aqp = api.AqParams(2, 1, 0, 0, 1.0, 32, 0, None, None, None, 0, 0, 0.0, None)
+    iq = vpn(*[a.ctypes.data for a in invs])
+
+    gather = None
+    if distributed:
+        pinned = torch.zeros((n_cost, 3), dtype=torch.int64).pin_memory()
+        local = torch.zeros((n_cost, 3), dtype=torch.int64, device="cuda")
+        gathered = torch.zeros((world * n_cost, 3), dtype=torch.int64, device="cuda")
+        gathered_host = torch.zeros((world * n_cost, 3), dtype=torch.int64).pin_memory()
+        req_all = np.ascontiguousarray(np.concatenate([a1, a2]))
+        pin_np = pinned.numpy()
+
+        def gather():
+            # this rank's per-request scalars (already on its host, where its own decisions read them) go to the
+            # other ranks in one collective; rank 0 also brings the whole set back to its host
+            Hlib.xgh_collect_costs(win.h, len(req_all), req_all.ctypes.data_as(C.c_void_p), pin_np.ctypes.data_as(C.c_void_p))
+            local.copy_(pinned, non_blocking=True)
+            dist.all_gather_into_tensor(gathered, local)
+            if rank == 0:
+                gathered_host.copy_(gathered, non_blocking=True)
+
+    def segment_step():
+        win._chk(Hlib.xgh_pre_lookahead_aq(win.h, F, frames_arr, ys, us, vs, sy, sc, C.byref(aqp), iq, api.MEM_DEVICE))
+        Hlib.xgh_add_many(win.h, len(a1), a1.ctypes.data_as(C.c_void_p))
+        win.finish_batch()
+        Hlib.xgh_add_many(win.h, len(a2), a2.ctypes.data_as(C.c_void_p))
+        win.finish_batch()
+        win.cu_tree(F - 1, False, b_pyramid=True)
+        if gather is not None:
+            gather()
 
     def fence():
         if distributed:
@@ -223,11 +401,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        segment_step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        segment_step()
     fence()
     dt = time.perf_counter() - t0
     if distributed:
@@ -237,26 +415,58 @@ def main():
     ms_per_step = 1000.0 * dt / args.steps
     fps = F * world * args.steps / dt
 
-    # per-phase kernel time with HIP events on the library's stream (separate, untimed pass)
+    # ---- per-phase kernel time with HIP events on the library's stream (separate, untimed pass) ----
     ctx.profile_enable(True)
     ctx.profile_read(reset=True)
     prof_steps = 2
+    tp = time.perf_counter()
     for _ in range(prof_steps):
-        step()
+        segment_step()
     torch.cuda.synchronize()
+    prof_wall_ms = 1000.0 * (time.perf_counter() - tp) / prof_steps
     prof = ctx.profile_read(reset=True)
     ctx.profile_enable(False)
 
+    # ---- steady workload: the real decision loop, one encoder instance ----
+    steady = None
+    if rank == 0 and args.steady_steps > 0:
+        p = api.LookaheadParam(**dict(MEDIUM, bitDepth=D, bframes=args.bframes))
+
+        def steady_step():
+            la = api.HostLookahead(ctx, p)
+            out = 0
+            for i in range(F):
+                la.add_device_picture(y_ptrs[i], u_ptrs[i], v_ptrs[i], W, W // 2)
+                out += la.get_decided() is not None
+            la.flush()
+            while la.get_decided() is not None:
+                out += 1
+            calls = la.decide_calls()
+            la.close()
+            assert out == F
+            return calls
+        steady_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        calls = 0
+        for _ in range(args.steady_steps):
+            calls += steady_step()
+        torch.cuda.synchronize()
+        sdt = time.perf_counter() - t0
+        steady = {"frames_per_s": F * args.steady_steps / sdt, "ms_per_slicetypeDecide": 1000.0 * sdt / calls,
+                  "slicetypeDecide_calls_per_segment": calls / args.steady_steps, "ms_per_segment": 1000.0 * sdt / args.steady_steps,
+                  "workload": "Lookahead::slicetypeDecide loop, preset medium (rc-lookahead 20, b-adapt 2, B-pyramid, weightp, AQ 2, "
+                              "cuTree), pool of 16 (batched requests per decision), %d-frame clip fed picture by picture" % F}
+
     g = ctx.geom
     P = W * H
-    n = g.cuCount
     alg = {   # algorithmic bytes per step, per phase
         "lowres": F * 2 * P * bpp,
         "intra": F * ((P // 4) * bpp + 7 * n),
         "search": n_search * (5 * (P // 4) * bpp + 12 * n),
-        "cost": n_cost * (9 * (P // 4) * bpp + 2 * n + 4 * g.heightInCU + 20),
+        # lower bound: the encode plane and one reference block per list actually read (co-located candidates hit the same lines)
+        "cost": n_cost * (3 * (P // 4) * bpp + 2 * n + 4 * g.heightInCU + 20),
     }
-    dominant = max(prof, key=lambda k: prof[k][0])
     kernels = {}
     for k, (ms, launches) in prof.items():
         ms_step, l_step = ms / prof_steps, launches / prof_steps
@@ -264,7 +474,8 @@ def main():
             continue
         kernels[k] = {"ms_per_step": ms_step, "launches_per_step": l_step,
                       "avg_launch_us": 1000.0 * ms_step / max(1.0, l_step),
-                      "achieved_GBs": alg[k] / (ms_step * 1e-3) / 1e9}
+                      "algorithmic_GBs": alg[k] / (ms_step * 1e-3) / 1e9}
+    dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     dom = kernels[dominant]
     kernel_name = {"lowres": "lowres_init_kernel", "intra": "intra_kernel", "search": "search_diag_kernel",
                    "cost": "cost_rows_kernel"}[dominant]
@@ -276,28 +487,48 @@ def main():
         streams = max(1, min(4, int(os.environ.get("X265GPU_SEARCH_STREAMS", "2"))))
     bytes_per_launch = alg[dominant] / max(1.0, dom["launches_per_step"])
     avg_launch_us = streams * dom["avg_launch_us"]
-    roofline = {"bound": "hbm", "kernel": kernel_name,
-                "achieved": streams * bytes_per_launch / (avg_launch_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["achieved_GBs"] / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(kernel_name),
-                "avg_launch_us": avg_launch_us, "concurrent_launches": streams,
-                "launches_per_step": dom["launches_per_step"], "algorithmic_bytes_per_launch": bytes_per_launch,
-                "note": "the integer SAD/SATD search is VALU-issue bound, not HBM bound (see 'valu'); "
-                        "per-phase figures in 'kernels'"}
-    valu = valu_utilisation(kernel_name, n_search * n if dominant == "search" else None, dom["ms_per_step"])
+    pmc = pmc_kernel(args, kernel_name)
+    hbm = {"achieved": dom["algorithmic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["algorithmic_GBs"] / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": pmc_traffic_per_launch(pmc)}
+    roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": hbm["frac"], "traffic": hbm["traffic"], "avg_launch_us": avg_launch_us, "concurrent_launches": streams,
+                "launches_per_step": dom["launches_per_step"], "algorithmic_bytes_per_launch": bytes_per_launch}
+    if dominant == "search" and pmc and pmc.get("SQ_WAVES") and "SQ_INSTS_VALU" in pmc and rates:
+        # The block search is integer SAD / SATD work out of LDS: its ceiling is the SIMDs' vector issue rate, not
+        # HBM.  Instructions per block search come from the counter passes of this configuration, cycles per
+        # instruction and the clock from the microbenchmark run at the top of this process.
+        per_wave = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"]
+        units = n_search * n                                            # block searches per step
+        peak = SIMDS * rates["clock_GHz"] / rates["valu_cycles_per_inst_per_simd_8_waves"]      # G wave-instructions / s
+        achieved = per_wave * units / (dom["ms_per_step"] * 1e-3) / 1e9
+        roofline.update({"bound": "valu", "achieved": achieved, "peak": peak, "unit": "G wave64-instructions/s",
+                         "frac": achieved / peak, "valu_insts_per_block_search": per_wave,
+                         "salu_insts_per_block_search": pmc.get("SQ_INSTS_SALU", 0) / pmc["SQ_WAVES"],
+                         "block_searches_per_step": units, "hbm": hbm,
+                         "note": "vector-issue roofline: measured instructions per 8x8 block search x block searches / phase time, "
+                                 "against 1024 SIMDs x measured clock / measured cycles per wave64 instruction"})
+    elif dominant == "search":
+        roofline["note"] = ("no counter pass committed for this configuration (profiles/pmc_%s.json): the vector-issue "
+                            "fraction is not reported; the HBM fraction is small by construction (integer search out of LDS)"
+                            % config_key(args))
 
     out = {
         "metric": "lookahead frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8" if D == 8 else "u16", "data": "synthetic",
-        "config": {"workload": "%dx%d %d-bit lookahead%s, bframes %d, b-adapt 2 batch order, %d-frame segment per step"
-                               % (W, H, D, " with --hme (hex / umh)" if args.hme else "", args.bframes, F),
+        "config": {"workload": "%dx%d %d-bit lookahead%s, preset medium per segment: Lowres::init + AQ mode 2 + intra per frame, "
+                               "batch 1 (all searches, weightp analysis) + batch 2 (all frame costs) in b-adapt 2 batch order, one cuTree "
+                               "pass; %d-frame segment per step" % (W, H, D, " with --hme (hex / umh)" if args.hme else "", F),
                    "frames_per_step": F, "search_requests_per_step": n_search, "cost_requests_per_step": n_cost,
-                   "blocks_per_frame": n, "sharding": "frame segments per rank, RCCL all_gather of cost scalars"
-                   if distributed else "single GPU"},
-        "roofline": roofline, "valu": valu, "kernels": kernels,
+                   "blocks_per_frame": n, "bframes": args.bframes,
+                   "sharding": "one frame segment per rank, RCCL all_gather of the per-request cost scalars" if distributed else "single GPU"},
+        "roofline": roofline, "kernels": kernels, "machine": rates,
+        "step_wall_ms_with_event_timers": prof_wall_ms,
     }
-    if rank == 0 and args.cpu_frames > 0:
-        out["cpu_baseline"] = cpu_baseline(W, H, D, args.bframes, args.cpu_frames, 1234, args.hme)
+    if steady:
+        out["steady_state"] = steady
+    out.update(cpu)
+    win.close()
     ctx.close()
     if distributed:
         dist.barrier()
@@ -307,6 +538,32 @@ def main():
     os.close(json_fd)
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=60, help="frames per step (one segment)")
+    ap.add_argument("--bframes", type=int, default=4)
+    ap.add_argument("--steady-steps", type=int, default=3, help="repetitions of the steady (slicetypeDecide loop) workload, 0 = skip")
+    ap.add_argument("--cpu-frames", type=int, default=60, help="frames in the bounded CPU baseline samples (0 = skip)")
+    ap.add_argument("--cpu-cores", type=int, default=16, help="host cores for the all-cores CPU baseline")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the gather even at world size 1 (rehearsal of the N>1 path)")
+    ap.add_argument("--hme", action="store_true", help="--hme: quarter-res hex then half-res umh (x265's defaults, ranges 16 / 32)")
+    ap.add_argument("--no-micro", action="store_true", help="skip the issue-rate microbenchmark (it runs as a child process)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend of --cpu-standin (tests use gloo)")
+    ap.add_argument("--cpu-standin", action="store_true",
+                    help="TEST ONLY: rehearse the multi-rank path on CPU with the oracle in the device's place")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    rank_main(args)
 
 
 if __name__ == "__main__":

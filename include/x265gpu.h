@@ -181,6 +181,13 @@ int x265gpu_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs);
  * 2987: only costEst/intraMbs are read before the next decision). */
 int x265gpu_estimate_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, x265gpu_frame_cost* out);
 
+/* Same work, results left on the device and no wait: request i's frame totals go to deviceSums[3i .. 3i+2] =
+ * { costEst BEFORE the B-frame scaling of slicetype.cpp:4372-4373, costEstAq, intraMbs } (device memory of this
+ * context's GPU, 24 bytes per request), ordered on the context's stream.  For callers that pass the totals on
+ * without reading them on this host first: a multi-GPU lookahead gathers them over RCCL (each rank owns a
+ * frame segment) and only the rank that runs slicetypeAnalyse applies the scaling and reads them. */
+int x265gpu_estimate_sums_device(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, int64_t* deviceSums);
+
 /* ---- weighted prediction analysis: LookaheadTLD::weightsAnalyse
  *      (slicetype.cpp:870-971); the float guessing stays with the caller ---- */
 
@@ -220,6 +227,11 @@ int x265gpu_get_hme_mvs(x265gpu_ctx* ctx, int32_t slot, int32_t list, int32_t di
                         int32_t* mvsXY, int32_t* mvCosts);
 int x265gpu_get_costs(x265gpu_ctx* ctx, int32_t slot, int32_t d0, int32_t d1,
                       uint16_t* lowresCosts, int32_t* rowSatds, x265gpu_frame_cost* frameCost);
+
+/* The frame totals of n (slot, d0, d1) results with one wait: x265gpu_get_costs' frameCost for each.  d0 / d1 may be
+ * NULL for the intra estimate's totals (costEst[0][0], costEstAq[0][0] of Lowres, slicetype.cpp:795-812). */
+int x265gpu_get_frame_costs(x265gpu_ctx* ctx, int32_t n, const int32_t* slots, const int32_t* d0, const int32_t* d1,
+                            x265gpu_frame_cost* out);
 
 /* ---- instrumentation --------------------------------------------------- */
 
@@ -360,6 +372,23 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
                      intptr_t strideC, int32_t memKind, const x265gpu_aq_params* params,
                      const float* quantOffsets /* Frame::m_quantOffsets or NULL */, double* qpAqOffset,
                      double* qpCuTreeOffset, int32_t* invQscaleFactor, uint64_t wpSum[3], uint64_t wpSsd[3]);
+
+/* x265gpu_aq_frame for the n pictures of a pre-lookahead batch (PreLookaheadGroup::processTasks hands one frame to
+ * each pool worker, slicetype.cpp:1836-1861): every picture's device pass is queued first, their results come back
+ * in one transfer, and the double-precision mapping of the pictures runs on host threads side by side (as many as
+ * X265GPU_HOST_THREADS says, by default the host's cores up to 16).  Fields are x265gpu_aq_frame's arguments; results
+ * are identical to n calls of it.  Pictures in host memory, qgSize 8, rc.hevcAq and bBlockVariance are simply
+ * handled by those n calls. */
+typedef struct x265gpu_aq_picture
+{
+    int32_t slot;                          /* slot that receives the scale factors, or -1 */
+    const void* y; const void* u; const void* v;
+    intptr_t strideY, strideC;
+    const float* quantOffsets;             /* or NULL */
+    double* qpAqOffset; double* qpCuTreeOffset; int32_t* invQscaleFactor;    /* out */
+    uint64_t wpSum[3], wpSsd[3];           /* out */
+} x265gpu_aq_picture;
+int x265gpu_aq_frames(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int32_t memKind, const x265gpu_aq_params* params);
 
 /* ---- cuTree: propagation of block costs along the lookahead's motion vectors ----
  *

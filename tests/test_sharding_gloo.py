@@ -149,3 +149,23 @@ def test_two_rank_gather_matches_single_process(oracle_built):
     for r in range(2):
         s, e = sharding.segment_bounds(TOTAL, 2, r)
         np.testing.assert_array_equal(np.array(parts[r], np.int64).reshape(-1, 3), _segment_costs(s, e))
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_2_launches_two_ranks(oracle_built):
+    """`bench.py --gpus 2` outside torchrun starts two rank processes itself and rank 0 prints one JSON line with
+    n_gpus 2: the same launcher the GPU run uses, here with gloo and the oracle standing in for the device."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-standin", "--backend", "gloo",
+                          "--width", str(W), "--height", str(H), "--frames", "8", "--bframes", str(BFRAMES), "--steps", "1",
+                          "--warmup", "0", "--cpu-frames", "0"], capture_output=True, timeout=240,
+                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    import bench
+    b1, b2 = bench.batch_requests(8, BFRAMES)
+    assert rec["config"]["gathered_requests"] == [len(b1) + len(b2)] * 2

@@ -21,8 +21,8 @@ PHASES = ("lowres", "intra", "search", "cost")
 EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
-    "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_weight_cost", "x265gpu_weight_cost_static", "x265gpu_weight_planes",
-    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
+    "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_estimate_sums_device", "x265gpu_weight_cost", "x265gpu_weight_cost_static", "x265gpu_weight_planes",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_aq_frames", "x265gpu_get_frame_costs", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
     "x265gpu_cutree_clear", "x265gpu_cutree_swap", "x265gpu_cutree_propagate", "x265gpu_cutree_get_propagate_cost",
     "x265gpu_cutree_finish", "x265gpu_hist_stats", "x265gpu_mcstf_motion_search",
     "x265gpu_profile_enable", "x265gpu_profile_read",
@@ -140,6 +140,7 @@ def load_library(path=None):
     L.x265gpu_intra_estimate.argtypes = [vp, i32, vp]
     L.x265gpu_estimate.argtypes = [vp, i32, vp]
     L.x265gpu_estimate_costs.argtypes = [vp, i32, vp, vp]
+    L.x265gpu_estimate_sums_device.argtypes = [vp, i32, vp, vp]
     L.x265gpu_weight_cost.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint32)]
     L.x265gpu_weight_cost_static.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint32)]
     L.x265gpu_weight_planes.argtypes = [vp, i32, i32, i32, i32, i32, i32]
@@ -164,6 +165,8 @@ def load_library(path=None):
     L.x265gpu_cutree_finish_hevc.argtypes = [vp, i32, i32, C.c_double, C.c_double, i32, i32, vp, vp]
     L.x265gpu_hist_stats.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp]
     L.x265gpu_aq_frame.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.x265gpu_aq_frames.argtypes = [vp, i32, vp, i32, vp]
+    L.x265gpu_get_frame_costs.argtypes = [vp, i32, vp, vp, vp, vp]
     L.x265gpu_mcstf_motion_search.argtypes = [vp, i32, i32, vp, vp, vp, vp]
     L.x265gpu_interp_luma.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.x265gpu_profile_enable.argtypes = [vp, i32]
@@ -544,8 +547,8 @@ class Context:
 HOST_LIB_PATH = os.path.join(_HERE, "libx265gpu_host.so")
 HOST_EXPORTS = (
     "xgh_window_create", "xgh_window_destroy", "xgh_pre_lookahead", "xgh_pre_lookahead_aq", "xgh_get_wp", "xgh_set_wp", "xgh_set_slice_type",
-    "xgh_set_qp_offsets", "xgh_single_cost", "xgh_add", "xgh_finish_batch", "xgh_cost_est", "xgh_intra_mbs",
-    "xgh_is_weighted", "xgh_cu_tree", "xgh_status",
+    "xgh_set_qp_offsets", "xgh_single_cost", "xgh_add", "xgh_add_many", "xgh_finish_batch", "xgh_cost_est", "xgh_collect_costs", "xgh_intra_mbs",
+    "xgh_is_weighted", "xgh_cu_tree", "xgh_status", "xgh_bitcost_table",
     "xgh_lookahead_create", "xgh_lookahead_destroy", "xgh_lookahead_add_picture", "xgh_lookahead_flush",
     "xgh_lookahead_get_decided", "xgh_lookahead_trace", "xgh_lookahead_cost_est", "xgh_lookahead_cost_est_aq",
     "xgh_lookahead_intra_mbs", "xgh_lookahead_slot", "xgh_lookahead_qp_offsets", "xgh_lookahead_inv_qscale",
@@ -596,7 +599,7 @@ def load_host_library():
     H.xgh_window_destroy.argtypes = [vp]
     H.xgh_window_destroy.restype = None
     H.xgh_pre_lookahead.argtypes = [vp, i32, vp, vp, vp, vp]
-    H.xgh_pre_lookahead_aq.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    H.xgh_pre_lookahead_aq.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32]
     H.xgh_get_wp.argtypes = [vp, i32, vp, vp]
     H.xgh_get_wp.restype = None
     H.xgh_set_wp.argtypes = [vp, i32, C.c_uint64, C.c_uint64]
@@ -609,13 +612,19 @@ def load_host_library():
     H.xgh_single_cost.restype = i64
     H.xgh_add.argtypes = [vp, i32, i32, i32]
     H.xgh_add.restype = None
+    H.xgh_add_many.argtypes = [vp, i32, vp]
+    H.xgh_add_many.restype = None
     H.xgh_finish_batch.argtypes = [vp]
     H.xgh_cost_est.argtypes = [vp, i32, i32, i32]
     H.xgh_cost_est.restype = i64
+    H.xgh_collect_costs.argtypes = [vp, i32, vp, vp]
+    H.xgh_collect_costs.restype = None
     H.xgh_intra_mbs.argtypes = [vp, i32, i32]
     H.xgh_is_weighted.argtypes = [vp, i32, i32]
     H.xgh_cu_tree.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.c_double, i32, i32]
     H.xgh_status.argtypes = [vp]
+    H.xgh_bitcost_table.argtypes = [C.c_double, vp]
+    H.xgh_bitcost_table.restype = None
     H.xgh_lookahead_create.argtypes = [vp, C.POINTER(LookaheadParam)]
     H.xgh_lookahead_create.restype = vp
     H.xgh_lookahead_destroy.argtypes = [vp]
@@ -641,6 +650,19 @@ def load_host_library():
     H.xgh_lookahead_decide_calls.argtypes = [vp]
     _libs[HOST_LIB_PATH] = H
     return H
+
+
+# x265_lambda_tab[X265_LOOKAHEAD_QP] (source/common/constants.cpp:34-130, common.h:217-221)
+LOOKAHEAD_LAMBDA = {8: 1.0, 10: 16.0, 12: 256.0}
+
+
+def bitcost_table(depth=8, lam=None):
+    """(table, centre index) of the MV-cost table for the lookahead's lambda at `depth` (or `lam`), built by the
+    host layer's restatement of BitCost::setQP; what x265gpu_set_mvcost / x265gpu_me_set_mvcost take."""
+    H = load_host_library()
+    t = np.zeros(4 * 32768 + 1, np.uint16)
+    H.xgh_bitcost_table(float(LOOKAHEAD_LAMBDA[depth] if lam is None else lam), _ptr(t))
+    return t, 2 * 32768
 
 
 class HostWindow:
@@ -690,7 +712,7 @@ class HostWindow:
         sc = (C.c_ssize_t * n)(*[pic[1].shape[1] for pic in pics])
         prm = AqParams(int(aq_mode), int(weightp), 0, 0, float(strength), int(qg_size), 0, None, None, None, 0, 0, 0.0, None)
         iq = vpn(*[a.ctypes.data for a in invs])
-        self._chk(self.H.xgh_pre_lookahead_aq(self.h, n, frames, ys, us, vs, sy, sc, C.byref(prm), iq))
+        self._chk(self.H.xgh_pre_lookahead_aq(self.h, n, frames, ys, us, vs, sy, sc, C.byref(prm), iq, MEM_HOST))
         return invs
 
     def get_wp(self, frame):

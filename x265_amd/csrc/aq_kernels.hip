@@ -92,21 +92,30 @@ __global__ void __launch_bounds__(256) aq_energy_kernel(AqJob job)
         if (job.lumaSum)
             job.lumaSum[(long long)by * blocksX + bx] = sumY;
     }
-    // frame sums: lane 0 of a block carries Y and U, the first lane of the upper half carries V
-    if (live && (k == 0 || k == HALF))
+    // Frame sums: lane 0 of a block carries Y and U, the first lane of the upper half carries V.  They are added up
+    // over the wave and the workgroup first, and the workgroup adds its six totals to one of AQ_WP_SHARDS sets of
+    // accumulators, each on a 128-byte line of its own: thousands of atomics on one line serialise (they took
+    // four fifths of this kernel's time), a few per line do not.  The host adds the shards (integer sums, so the
+    // order does not matter).
+    const bool first = live && k == 0, upper = live && k == HALF;
+    unsigned long long part[6] = { first ? sumY : 0u, first ? sC : 0u, upper ? sC : 0u,
+                                   first ? sqrY : 0u, first ? qC : 0u, upper ? qC : 0u };
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+            part[i] += __shfl_xor(part[i], m, 64);
+    __shared__ unsigned long long red[4][6];
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+            red[threadIdx.x >> 6][i] = part[i];
+    __syncthreads();
+    if (threadIdx.x < 6)
     {
-        if (k == 0)
-        {
-            atomicAdd(job.wp + 0, (unsigned long long)sumY);
-            atomicAdd(job.wp + 3, (unsigned long long)sqrY);
-            atomicAdd(job.wp + 1, (unsigned long long)sC);
-            atomicAdd(job.wp + 4, (unsigned long long)qC);
-        }
-        else
-        {
-            atomicAdd(job.wp + 2, (unsigned long long)sC);
-            atomicAdd(job.wp + 5, (unsigned long long)qC);
-        }
+        const unsigned long long total = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const unsigned shard = (blockIdx.x + blockIdx.y * gridDim.x) % AQ_WP_SHARDS;
+        atomicAdd(job.wp + shard * AQ_WP_SHARD_STRIDE + threadIdx.x, total);
     }
 }
 

@@ -162,8 +162,11 @@ struct AqJob
     int blockSize;                           // 16 (qgSize >= 16) or 8 (qgSize 8)
     uint32_t* energy;                        // [ceil(visitHeight/blockSize)][ceil(visitWidth/blockSize)]
     uint32_t* lumaSum;                       // same shape: sum of the block's luma samples (lumaSumCu), or null
-    unsigned long long* wp;                  // [0..2] wp_sum Y,U,V; [3..5] wp_ssd Y,U,V (zeroed by the caller)
+    unsigned long long* wp;                  // AQ_WP_SHARDS sets of { wp_sum Y,U,V, wp_ssd Y,U,V }, AQ_WP_SHARD_STRIDE words
+                                             // apart, zeroed by the caller; the frame sums are the totals over the shards
 };
+constexpr int AQ_WP_SHARDS = 64, AQ_WP_SHARD_STRIDE = 16;    // one 128-byte line per shard
+constexpr size_t AQ_WP_BYTES = (size_t)AQ_WP_SHARDS * AQ_WP_SHARD_STRIDE * sizeof(unsigned long long);
 hipError_t launch_aq_energy(hipStream_t s, int bpp, const AqJob& job);
 // xPreanalyze's quadrant sums: out holds 8 values per part (4 sums, 4 sums of squares), parts in raster order
 hipError_t launch_aq_quadrants(hipStream_t s, int bpp, const void* luma, long long stride, int width, int height, int partW,

@@ -10,6 +10,8 @@
 #include <string>
 #include <utility>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 using namespace xg;
@@ -814,7 +816,8 @@ int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots)
     return X265GPU_OK;
 }
 
-static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, bool wantBatchOut)
+static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, bool wantBatchOut,
+                        long long* deviceOut = nullptr)
 {
     if (!ctx || n < 0 || (n && !reqs))
         return X265GPU_ERR_ARG;
@@ -941,7 +944,7 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
         c.rowSatds = sb.rowSatds + q * g.H;
         c.rowPartials = sb.rowPartials + q * g.H * 3;
         c.sums = sb.sums + q * 3;
-        c.batchOut = wantBatchOut ? ctx->batchSums + (size_t)i * 3 : nullptr;
+        c.batchOut = deviceOut ? deviceOut + (size_t)i * 3 : wantBatchOut ? ctx->batchSums + (size_t)i * 3 : nullptr;
         c.bBidir = bBidir;
     }
 
@@ -1008,6 +1011,15 @@ int x265gpu_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs)
 {
     DeviceScope deviceScope(ctx, false);
     return run_estimate(ctx, n, reqs, false);
+}
+
+int x265gpu_estimate_sums_device(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, int64_t* deviceSums)
+{
+    DeviceScope deviceScope(ctx, false);
+    if (!deviceSums && n)
+        return X265GPU_ERR_ARG;
+    static_assert(sizeof(long long) == sizeof(int64_t), "frame totals are 64-bit");
+    return run_estimate(ctx, n, reqs, false, (long long*)deviceSums);
 }
 
 int x265gpu_estimate_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, x265gpu_frame_cost* out)
@@ -1712,6 +1724,16 @@ int stage_yuv(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const void* u, 
     return X265GPU_OK;
 }
 
+// the six frame sums out of the energy kernel's sharded accumulators
+void sum_wp_shards(const unsigned long long* shards, unsigned long long wp[6])
+{
+    for (int i = 0; i < 6; i++)
+        wp[i] = 0;
+    for (int s = 0; s < AQ_WP_SHARDS; s++)
+        for (int i = 0; i < 6; i++)
+            wp[i] += shards[s * AQ_WP_SHARD_STRIDE + i];
+}
+
 // One device pass over a staged 4:2:0 picture: block energies (blockSize 16 or 8), optional block luma
 // sums and the six frame accumulators, copied to the host.  The block loop runs while blockX < visitW and
 // blockY < visitH; arrays hold ceil(visitW / blockSize) * ceil(visitH / blockSize) entries in loop order.
@@ -1724,7 +1746,7 @@ int aq_energy_pass(x265gpu_ctx* ctx, const YuvOnDevice& pic, int blockSize, int 
     if (blocks < 1)
         return X265GPU_OK;
     const size_t arrayBytes = align256(sizeof(uint32_t) * (size_t)blocks);
-    int rc = ensure_pu_buf(ctx, 2 * arrayBytes + 256);
+    int rc = ensure_pu_buf(ctx, 2 * arrayBytes + AQ_WP_BYTES);
     if (rc)
         return rc;
     AqJob job;
@@ -1742,13 +1764,15 @@ int aq_energy_pass(x265gpu_ctx* ctx, const YuvOnDevice& pic, int blockSize, int 
     job.energy = (uint32_t*)ctx->puBuf;
     job.lumaSum = lumaSum ? (uint32_t*)(ctx->puBuf + arrayBytes) : nullptr;
     job.wp = (unsigned long long*)(ctx->puBuf + 2 * arrayBytes);
-    HIPCHK(hipMemsetAsync(job.wp, 0, 256, ctx->stream));
+    HIPCHK(hipMemsetAsync(job.wp, 0, AQ_WP_BYTES, ctx->stream));
     HIPCHK(launch_aq_energy(ctx->stream, ctx->bpp, job));
     HIPCHK(hipMemcpyAsync(energy, job.energy, sizeof(uint32_t) * (size_t)blocks, hipMemcpyDeviceToHost, ctx->stream));
     if (lumaSum)
         HIPCHK(hipMemcpyAsync(lumaSum, job.lumaSum, sizeof(uint32_t) * (size_t)blocks, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(wp, job.wp, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long shards[AQ_WP_SHARDS * AQ_WP_SHARD_STRIDE];
+    HIPCHK(hipMemcpyAsync(shards, job.wp, AQ_WP_BYTES, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    sum_wp_shards(shards, wp);
     return X265GPU_OK;
 }
 
@@ -1955,6 +1979,172 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
     }
     if (slot >= 0 && offsets)
         return x265gpu_lowres_set_aq(ctx, slot, qg8 ? params->invQscaleFactor8x8 : invQscaleFactor);
+    return X265GPU_OK;
+}
+
+int x265gpu_aq_frames(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int32_t memKind, const x265gpu_aq_params* params)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || !params || n < 0 || (n && !pics))
+        return X265GPU_ERR_ARG;
+    if (!n)
+        return X265GPU_OK;
+    const int w = ctx->cfg.sourceWidth, h = ctx->cfg.sourceHeight;
+    const bool offsets = !params->bSkipOffsets && params->aqMode != 0;
+    const bool mapped = offsets && params->aqStrength != 0;
+    // The batched form covers what a lookahead window normally is: device-resident 4:2:0 pictures, 16x16 AQ blocks,
+    // one of the variance modes.  Everything else goes picture by picture through x265gpu_aq_frame.
+    const bool fast = memKind == X265GPU_MEM_DEVICE && params->qgSize != 8 && !params->bHevcAq && !params->bBlockVariance &&
+                      params->aqMode >= 0 && params->aqMode <= 3 && (mapped || params->bWeightedPred) && (mapped || !offsets);
+    if (!fast)
+    {
+        for (int i = 0; i < n; i++)
+        {
+            x265gpu_aq_picture& p = pics[i];
+            int rc = x265gpu_aq_frame(ctx, p.slot, p.y, p.strideY, p.u, p.v, p.strideC, memKind, params, p.quantOffsets,
+                                      p.qpAqOffset, p.qpCuTreeOffset, p.invQscaleFactor, p.wpSum, p.wpSsd);
+            if (rc)
+                return rc;
+        }
+        return X265GPU_OK;
+    }
+    const int cw = w >> 1, ch = h >> 1;
+    const int cols = (w + 15) / 16, rows = (h + 15) / 16, blocks = cols * rows;
+    for (int i = 0; i < n; i++)
+    {
+        const x265gpu_aq_picture& p = pics[i];
+        if (!p.y || !p.u || !p.v || p.strideY < w || p.strideC < cw || cw < 1 || ch < 1 || (p.slot >= 0 && !slot_ok(ctx, p.slot)) ||
+            (mapped && (!p.qpAqOffset || !p.qpCuTreeOffset || !p.invQscaleFactor)))
+            return fail(ctx, X265GPU_ERR_ARG, "aq_frames: bad picture");
+        if (p.slot >= 0 && blocks != ctx->g.cuCount)
+            return fail(ctx, X265GPU_ERR_ARG, "aq_frames: 16x16 block grid differs from the slot's 8x8 lowres grid");
+    }
+    const bool hdr = params->bHDR10Opt && mapped;
+    const size_t arrayBytes = align256(sizeof(uint32_t) * (size_t)blocks);
+    const size_t perPic = (hdr ? 2 : 1) * arrayBytes + AQ_WP_BYTES;
+    int rc = ensure_pu_buf(ctx, perPic * n);
+    if (rc)
+        return rc;
+    // every picture's energy pass, then one transfer and one wait
+    HIPCHK(hipMemsetAsync(ctx->puBuf, 0, perPic * n, ctx->stream));
+    for (int i = 0; i < n; i++)
+    {
+        const x265gpu_aq_picture& p = pics[i];
+        char* base = ctx->puBuf + perPic * i;
+        AqJob job;
+        memset(&job, 0, sizeof(job));
+        job.width = job.visitWidth = w;
+        job.height = job.visitHeight = h;
+        job.blockSize = 16;
+        job.luma = p.y;
+        job.u = p.u;
+        job.v = p.v;
+        job.lumaStride = p.strideY;
+        job.chromaStride = p.strideC;
+        job.energy = (uint32_t*)base;
+        job.lumaSum = hdr ? (uint32_t*)(base + arrayBytes) : nullptr;
+        job.wp = (unsigned long long*)(base + (hdr ? 2 : 1) * arrayBytes);
+        HIPCHK(launch_aq_energy(ctx->stream, ctx->bpp, job));
+    }
+    std::vector<char> host(perPic * n);
+    HIPCHK(hipMemcpyAsync(host.data(), ctx->puBuf, perPic * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+
+    // The double-precision mapping of each picture is independent of the others: host threads share the pictures
+    // the way x265's pool workers share the frames of PreLookaheadGroup (slicetype.cpp:1843-1859).
+    AqFrameParams ap;
+    ap.aqMode = params->aqMode;
+    ap.depth = ctx->cfg.internalBitDepth;
+    ap.hdr10 = hdr;
+    ap.strength = params->aqStrength;
+    ap.blockSize = 16;
+    ap.blockCount = blocks;
+    const bool wantWp = params->bWeightedPred != 0;
+    auto work = [&](int i) {
+        x265gpu_aq_picture& p = pics[i];
+        const char* base = host.data() + perPic * i;
+        const uint32_t* energy = (const uint32_t*)base;
+        const uint32_t* lumaSum = hdr ? (const uint32_t*)(base + arrayBytes) : nullptr;
+        unsigned long long wp[6];
+        sum_wp_shards((const unsigned long long*)(base + (hdr ? 2 : 1) * arrayBytes), wp);
+        if (mapped)
+            aq_frame_offsets(ap, blocks, energy, lumaSum, p.quantOffsets, p.qpAqOffset, p.qpCuTreeOffset, p.invQscaleFactor);
+        if (wantWp)
+            aq_finish_wp(w, h, wp, wp + 3);
+        for (int k = 0; k < 3; k++)
+        {
+            p.wpSum[k] = wp[k];
+            p.wpSsd[k] = wp[3 + k];
+        }
+    };
+    int threads = 1;
+    if (mapped && n > 1)
+    {
+        const char* e = getenv("X265GPU_HOST_THREADS");
+        const unsigned hw = std::thread::hardware_concurrency();
+        threads = e ? atoi(e) : (int)(hw ? (hw < 16 ? hw : 16) : 4);
+        threads = threads < 1 ? 1 : (threads > n ? n : threads);
+    }
+    if (threads == 1)
+        for (int i = 0; i < n; i++)
+            work(i);
+    else
+    {
+        std::atomic<int> next(0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++)
+            pool.emplace_back([&]() {
+                for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1))
+                    work(i);
+            });
+        for (auto& th : pool)
+            th.join();
+    }
+    if (mapped)
+    {
+        for (int i = 0; i < n; i++)
+            if (pics[i].slot >= 0)
+            {
+                Slot& sl = ctx->slots[pics[i].slot];
+                HIPCHK(hipMemcpyAsync(sl.invQscale, pics[i].invQscaleFactor, sizeof(int32_t) * ctx->g.cuCount,
+                                      hipMemcpyHostToDevice, ctx->stream));
+                sl.hasAq = true;
+            }
+        // the callers' arrays are theirs again when this returns
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return X265GPU_OK;
+}
+
+int x265gpu_get_frame_costs(x265gpu_ctx* ctx, int32_t n, const int32_t* slots, const int32_t* d0, const int32_t* d1,
+                            x265gpu_frame_cost* out)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || n < 0 || (n && (!slots || !out)))
+        return X265GPU_ERR_ARG;
+    if (!n)
+        return X265GPU_OK;
+    std::vector<long long> sums((size_t)3 * n);
+    for (int i = 0; i < n; i++)
+    {
+        const int a = d0 ? d0[i] : 0, b = d1 ? d1[i] : 0;
+        if (!slot_ok(ctx, slots[i]) || a < 0 || a >= ctx->D || b < 0 || b >= ctx->D)
+            return X265GPU_ERR_ARG;
+        HIPCHK(hipMemcpyAsync(&sums[3 * (size_t)i], ctx->slots[slots[i]].sums + ((size_t)a * ctx->D + b) * 3, 3 * sizeof(long long),
+                              hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; i++)
+    {
+        const int a = d0 ? d0[i] : 0, b = d1 ? d1[i] : 0;
+        long long score = sums[3 * (size_t)i];
+        if (b != 0)
+            score = score * 100 / (130 + ctx->cfg.bFrameBias);
+        out[i].costEst = score;
+        out[i].costEstAq = sums[3 * (size_t)i + 1];
+        out[i].intraMbs = (a == 0 && b == 0) ? 0 : (int32_t)sums[3 * (size_t)i + 2];
+        out[i].reserved = 0;
+    }
     return X265GPU_OK;
 }
 

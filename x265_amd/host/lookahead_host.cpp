@@ -145,7 +145,14 @@ int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const void* co
 int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const Picture* pics, const x265gpu_aq_params& aq,
                                     const float* const* quantOffsets)
 {
+    if (n < 1)
+        return X265GPU_OK;
     std::vector<int32_t> slots(n);
+    std::vector<x265gpu_aq_picture> ap(n);
+    // Lowres::init of every frame, then calcAdaptiveQuantFrame of every frame (when the lookahead has AQ or weighted
+    // prediction, slicetype.cpp:1849-1850; the call installs the scale factors for the slots as well), then
+    // lowresIntraEstimate of every frame: the per-frame task of x265 regrouped by stage, which changes no result
+    // because a frame's task reads nothing of another frame's
     for (int i = 0; i < n; i++)
     {
         Lowres& fr = *frames[i];
@@ -154,29 +161,40 @@ int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const Picture*
         if (rc != X265GPU_OK)
             return rc;
         fr.reset();
-        // tld.calcAdaptiveQuantFrame(preFrame, param) when the lookahead has AQ or weighted prediction
-        // (slicetype.cpp:1849-1850); the call installs the scale factors for the slot as well
-        uint64_t wpSum[3], wpSsd[3];
-        rc = x265gpu_aq_frame(m_ctx, fr.slot, p.y, p.strideY, p.u, p.v, p.strideC, p.memKind, &aq,
-                              quantOffsets ? quantOffsets[i] : nullptr, fr.qpAqOffset, fr.qpCuTreeOffset, fr.invQscaleFactor,
-                              wpSum, wpSsd);
-        if (rc != X265GPU_OK)
-            return rc;
-        fr.wp_sum = wpSum[0];
-        fr.wp_ssd = wpSsd[0];
         slots[i] = fr.slot;
+        x265gpu_aq_picture& a = ap[i];
+        memset(&a, 0, sizeof(a));
+        a.slot = fr.slot;
+        a.y = p.y;
+        a.u = p.u;
+        a.v = p.v;
+        a.strideY = p.strideY;
+        a.strideC = p.strideC;
+        a.quantOffsets = quantOffsets ? quantOffsets[i] : nullptr;
+        a.qpAqOffset = fr.qpAqOffset;
+        a.qpCuTreeOffset = fr.qpCuTreeOffset;
+        a.invQscaleFactor = fr.invQscaleFactor;
     }
-    int rc = x265gpu_intra_estimate(m_ctx, n, slots.data());
+    // pictures of one batch live in one kind of memory
+    int rc = x265gpu_aq_frames(m_ctx, n, ap.data(), pics[0].memKind, &aq);
     if (rc != X265GPU_OK)
         return rc;
     for (int i = 0; i < n; i++)
     {
-        x265gpu_frame_cost fc;
-        rc = x265gpu_get_costs(m_ctx, frames[i]->slot, 0, 0, nullptr, nullptr, &fc);
-        if (rc != X265GPU_OK)
-            return rc;
-        frames[i]->costEst[0][0] = fc.costEst;
-        frames[i]->costEstAq[0][0] = fc.costEstAq;
+        frames[i]->wp_sum = ap[i].wpSum[0];
+        frames[i]->wp_ssd = ap[i].wpSsd[0];
+    }
+    rc = x265gpu_intra_estimate(m_ctx, n, slots.data());
+    if (rc != X265GPU_OK)
+        return rc;
+    std::vector<x265gpu_frame_cost> fc(n);
+    rc = x265gpu_get_frame_costs(m_ctx, n, slots.data(), nullptr, nullptr, fc.data());
+    if (rc != X265GPU_OK)
+        return rc;
+    for (int i = 0; i < n; i++)
+    {
+        frames[i]->costEst[0][0] = fc[i].costEst;
+        frames[i]->costEstAq[0][0] = fc[i].costEstAq;
     }
     return X265GPU_OK;
 }
@@ -494,6 +512,11 @@ int Lookahead::unsupported() const
 
 int64_t Lookahead::cost(Lowres** frames, int p0, int p1, int b, bool bIntraPenalty)
 {
+    // the trellis asks for the same costs thousands of times per decision: answer those from the cache
+    // without setting a group up (estimateFrameCost's own first test, slicetype.cpp:4290)
+    const int64_t cached = frames[b]->costEst[b - p0][p1 - b];
+    if (cached >= 0 && !frames[b]->pending[b - p0][p1 - b])
+        return bIntraPenalty ? cached + cached * frames[b]->intraMbs[b - p0] / (m_8x8Blocks * 8) : cached;
     CostEstimateGroup est(m_ctx, frames, m_param.bEnableWeightedPred, m_param.bitDepth, &m_trace);
     const int64_t c = est.singleCost(p0, p1, b, bIntraPenalty);
     note(est.status());
@@ -1294,7 +1317,7 @@ int xgh_pre_lookahead(xgh_window* w, int32_t n, const int32_t* frames, const voi
 
 int xgh_pre_lookahead_aq(xgh_window* w, int32_t n, const int32_t* frames, const void* const* y, const void* const* u,
                          const void* const* v, const intptr_t* strideY, const intptr_t* strideC,
-                         const x265gpu_aq_params* aq, int32_t* const* invQscale)
+                         const x265gpu_aq_params* aq, int32_t* const* invQscale, int32_t memKind)
 {
     std::vector<Lowres*> fr(n);
     std::vector<PreLookaheadGroup::Picture> pics(n);
@@ -1302,7 +1325,7 @@ int xgh_pre_lookahead_aq(xgh_window* w, int32_t n, const int32_t* frames, const 
     {
         fr[i] = w->frames[frames[i]];
         fr[i]->invQscaleFactor = invQscale ? invQscale[i] : nullptr;
-        pics[i] = { y[i], u[i], v[i], strideY[i], strideC[i] };
+        pics[i] = { y[i], u[i], v[i], strideY[i], strideC[i], memKind };
     }
     return PreLookaheadGroup(w->ctx).processTasks(n, fr.data(), pics.data(), *aq, nullptr);
 }
@@ -1334,6 +1357,12 @@ int64_t xgh_single_cost(xgh_window* w, int32_t p0, int32_t p1, int32_t b, int32_
 
 void xgh_add(xgh_window* w, int32_t p0, int32_t p1, int32_t b) { w->est->add(p0, p1, b); }
 
+void xgh_add_many(xgh_window* w, int32_t n, const int32_t* p0p1b)
+{
+    for (int i = 0; i < n; i++)
+        w->est->add(p0p1b[3 * i], p0p1b[3 * i + 1], p0p1b[3 * i + 2]);
+}
+
 int xgh_finish_batch(xgh_window* w)
 {
     w->est->finishBatch();
@@ -1341,6 +1370,18 @@ int xgh_finish_batch(xgh_window* w)
 }
 
 int64_t xgh_cost_est(const xgh_window* w, int32_t b, int32_t d0, int32_t d1) { return w->frames[b]->costEst[d0][d1]; }
+
+void xgh_collect_costs(const xgh_window* w, int32_t n, const int32_t* p0p1b, int64_t* out)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const int p0 = p0p1b[3 * i], p1 = p0p1b[3 * i + 1], b = p0p1b[3 * i + 2];
+        const Lowres& f = *w->frames[b];
+        out[3 * i] = f.costEst[b - p0][p1 - b];
+        out[3 * i + 1] = f.costEstAq[b - p0][p1 - b];
+        out[3 * i + 2] = f.intraMbs[b - p0];
+    }
+}
 int32_t xgh_intra_mbs(const xgh_window* w, int32_t b, int32_t d0) { return w->frames[b]->intraMbs[d0]; }
 int32_t xgh_is_weighted(const xgh_window* w, int32_t b, int32_t d0) { return w->frames[b]->weighted[d0]; }
 
@@ -1359,6 +1400,23 @@ int xgh_cu_tree(xgh_window* w, int32_t fpsNum, int32_t fpsDenom, int32_t bBPyram
 }
 
 int xgh_status(const xgh_window* w) { return w->est->status(); }
+
+// BitCost::setQP's table for one lambda (source/encoder/bitcost.cpp:31-56, 87-102): bits(|mvd|) in single
+// precision as CalculateLogs forms them, scaled by lambda, rounded and capped at 2^15 - 1; symmetric around
+// entry 2 * 32768.  Inside x265 the table is BitCost's own (m_cost); this builder serves callers without one.
+void xgh_bitcost_table(double lambda, uint16_t* out)
+{
+    const int maxMv = 1 << 15;                       // BC_MAX_MV (bitcost.h:92)
+    uint16_t* centre = out + 2 * maxMv;
+    const float twoOverLn2 = 2.0f / logf(2.0f);
+    for (int mvd = 0; mvd <= 2 * maxMv; mvd++)
+    {
+        const float bits = mvd ? logf((float)(mvd + 1)) * twoOverLn2 + 1.718f : 0.718f;
+        const double scaled = bits * lambda + 0.5f;
+        const uint16_t c = (uint16_t)(scaled < 32767.0 ? scaled : 32767.0);
+        centre[mvd] = centre[-mvd] = c;
+    }
+}
 
 struct LaFrame
 {

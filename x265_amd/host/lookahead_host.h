@@ -276,20 +276,26 @@ int xgh_pre_lookahead(xgh_window* w, int32_t n, const int32_t* frames, const voi
  * arrays given with xgh_set_qp_offsets, wp_sum / wp_ssd of the luma plane are kept for weightsAnalyse */
 int xgh_pre_lookahead_aq(xgh_window* w, int32_t n, const int32_t* frames, const void* const* y, const void* const* u,
                          const void* const* v, const intptr_t* strideY, const intptr_t* strideC,
-                         const x265gpu_aq_params* aq, int32_t* const* invQscale);
+                         const x265gpu_aq_params* aq, int32_t* const* invQscale, int32_t memKind);
 void xgh_get_wp(const xgh_window* w, int32_t frame, uint64_t* sum, uint64_t* ssd);
 void xgh_set_wp(xgh_window* w, int32_t frame, uint64_t sum, uint64_t ssd);
 void xgh_set_slice_type(xgh_window* w, int32_t frame, int32_t sliceType);
 void xgh_set_qp_offsets(xgh_window* w, int32_t frame, double* qpAqOffset, double* qpCuTreeOffset);
 int64_t xgh_single_cost(xgh_window* w, int32_t p0, int32_t p1, int32_t b, int32_t bIntraPenalty);
 void xgh_add(xgh_window* w, int32_t p0, int32_t p1, int32_t b);
+void xgh_add_many(xgh_window* w, int32_t n, const int32_t* p0p1b);   /* n x { p0, p1, b } */
 int xgh_finish_batch(xgh_window* w);
 int64_t xgh_cost_est(const xgh_window* w, int32_t b, int32_t d0, int32_t d1);
+/* { costEst, costEstAq, intraMbs } of n requests { p0, p1, b } into out[3n]: what a multi-GPU lookahead gathers */
+void xgh_collect_costs(const xgh_window* w, int32_t n, const int32_t* p0p1b, int64_t* out);
 int32_t xgh_intra_mbs(const xgh_window* w, int32_t b, int32_t d0);
 int32_t xgh_is_weighted(const xgh_window* w, int32_t b, int32_t d0);
 int xgh_cu_tree(xgh_window* w, int32_t fpsNum, int32_t fpsDenom, int32_t bBPyramid, int32_t bEnableWeightedBiPred,
                 int32_t lookaheadDepth, int32_t vbvBufferSize, double qCompress, int32_t numframes, int32_t bIntra);
 int xgh_status(const xgh_window* w);
+/* BitCost::setQP's table for `lambda` (source/encoder/bitcost.cpp:31-56): out holds 4 * 32768 + 1 entries, entry
+ * 2 * 32768 is MVD 0.  For callers that have no BitCost of their own; x265 passes BitCost::m_cost instead. */
+void xgh_bitcost_table(double lambda, uint16_t* out);
 
 /* the whole lookahead: queue in, decided frames out.  Every frame gets a device slot of its own (the context
  * needs as many slots as frames are alive at once: here, as frames are added in total). */

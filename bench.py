@@ -104,7 +104,7 @@ MEDIUM = dict(bframes=4, lookaheadDepth=20, bFrameAdaptive=2, bBPyramid=1, scene
               keyframeMin=25, keyframeMax=250, bOpenGOP=1, bIntraRefresh=0, radl=0, gopLookahead=0, cuTree=1, bFrameBias=0,
               vbvBufferSize=0, vbvMaxBitrate=0, bCqp=0, bEnableTemporalSubLayers=0, maxNumReferences=3,
               bEnableWeightedPred=1, bEnableWeightedBiPred=0, fpsNum=30, fpsDenom=1, qCompress=0.6, bitDepth=8,
-              poolWorkers=16, bAdaptiveQuant=1, aqMode=2, aqStrength=1.0)
+              poolWorkers=16, bAdaptiveQuant=1, aqMode=2, aqStrength=1.0, bPresearch=1, lookaheadSlices=0)
 
 
 # ---------------------------------------------------------------- CPU baseline: the oracle on host cores

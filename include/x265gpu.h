@@ -113,6 +113,12 @@ typedef struct x265gpu_request
                                          starts without the predictors of the row below it (:4248-4276).  Ignored when
                                          the context has one slice.  Only the searches differ; sums and per-block costs
                                          are the totals over all slices, as x265 adds them up (:4336-4342). */
+    int32_t bSearchOnly;              /* run the motion searches of doSearch[] and nothing else: no per-block costs, no
+                                         sums (the request's x265gpu_frame_cost comes back as -1).  For a caller that
+                                         issues, inside a batch, the searches of requests it will make one by one later
+                                         (then with doSearch cleared): the vectors are those the later request would
+                                         have found, since a search depends only on the two frames, the list, the
+                                         distance, p1 > b and bCoopSlices. */
 } x265gpu_request;
 
 /* per-request scalars, as stored by x265 in Lowres::costEst/costEstAq/intraMbs */

@@ -354,7 +354,7 @@ class SliceDecider:
         cp = CuTreeParam(p["fpsNum"], p["fpsDenom"], p["bBPyramid"], p["bEnableWeightedBiPred"], p["lookaheadDepth"],
                          p["vbvBufferSize"], p["qCompress"])
         assert look.param.bframes == p["bframes"] and look.param.bEnableWeightedPred == p["bEnableWeightedPred"]
-        assert look.param.bFrameBias == p["bFrameBias"]
+        assert look.param.bFrameBias == p["bFrameBias"] and look.param.lookaheadSlices == p.get("lookaheadSlices", 0)
         self.h = L.orc_la_create(C.byref(look.param), C.byref(lp), C.byref(cp), look.tld)
         self.by_handle = {}
 

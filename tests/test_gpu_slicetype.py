@@ -20,8 +20,10 @@ pytestmark = pytest.mark.gpu
 def _compare(clip, chroma, depth, p, forced=None, ctx_kw=None, param_kw=None):
     N, H, W = clip.shape
     forced = forced or {}
-    look, dec = du.oracle_lookahead(clip, chroma, depth, p, **(param_kw or {}))
-    ctx = api.Context(W, H, depth=depth, bframes=p["bframes"], num_slots=N, bframe_bias=p["bFrameBias"], **(ctx_kw or {}))
+    slices = p.get("lookaheadSlices", 0)
+    look, dec = du.oracle_lookahead(clip, chroma, depth, p, lookahead_slices=slices, **(param_kw or {}))
+    ctx = api.Context(W, H, depth=depth, bframes=p["bframes"], num_slots=N, bframe_bias=p["bFrameBias"], lookahead_slices=slices,
+                      **(ctx_kw or {}))
     la = api.HostLookahead(ctx, api.LookaheadParam(**dict(p, bitDepth=depth)))
     try:
         ctx.set_mvcost(look.table, look.centre)
@@ -86,6 +88,10 @@ def _compare(clip, chroma, depth, p, forced=None, ctx_kw=None, param_kw=None):
                 if rr is not None:
                     np.testing.assert_array_equal(rr, wr, err_msg="frameCostRecalculate rows of frame %d" % i)
             assert planned > 0
+        if p["poolWorkers"] and p["bFrameAdaptive"] == 2 and p.get("bPresearch", 1) and N > 8:
+            assert la.presearch_hits() > 0           # single requests did find searches that ran ahead with a batch
+        if not p.get("bPresearch", 1):
+            assert la.presearch_hits() == 0
         return [d.sliceType for d in sorted(got, key=lambda d: d.frame)], [d.bScenecut for d in sorted(got, key=lambda d: d.frame)], t_want
     finally:
         la.close()
@@ -97,6 +103,7 @@ def _compare(clip, chroma, depth, p, forced=None, ctx_kw=None, param_kw=None):
 CASES = [
     {},                                                       # preset medium, no pool: lazy request order
     {"poolWorkers": 16},                                      # pool > 12 workers: both batches, every time
+    {"poolWorkers": 16, "bPresearch": 0},                     # the same without the searches queued ahead of single requests
     {"poolWorkers": 8},                                       # 4..12 workers: frame-cost batch only the first time
     {"poolWorkers": 2},                                       # < 4 workers: batches only the first time
     {"bFrameAdaptive": 1},
@@ -143,6 +150,15 @@ def test_forced_types_and_ten_bit():
     clip = du.two_scene_clip(W, H, N, depth, seed=31)
     types, _, _ = _compare(clip, du.chroma_for(clip, depth, 32), depth, p, forced={5: 2, 8: 3, 13: 1})
     assert types[5] == 2 and types[8] == 3 and types[13] == 1
+
+
+def test_720p_pool_with_cooperative_slices():
+    """x265's default with a pool: --lookahead-slices 8 (preset medium), so single requests run in cooperative slices
+    while batched ones do not (slicetype.cpp:4312); searches queued ahead of single requests must follow suit."""
+    p = dict(api.LookaheadParam.MEDIUM, poolWorkers=16, lookaheadSlices=8)
+    N, W, H, depth = 30, 1280, 720, 8
+    clip = du.two_scene_clip(W, H, N, depth, seed=51)
+    _compare(clip, du.chroma_for(clip, depth, 52), depth, p)
 
 
 @pytest.mark.parametrize("pool", [0, 16], ids=["lazy-no-pool", "batched-pool16"])

@@ -68,7 +68,7 @@ class Request(C.Structure):
     _fields_ = [
         ("slotP0", C.c_int32), ("slotB", C.c_int32), ("slotP1", C.c_int32),
         ("p0", C.c_int32), ("b", C.c_int32), ("p1", C.c_int32),
-        ("doSearch", C.c_int32 * 2), ("weightedL0", C.c_int32), ("bCoopSlices", C.c_int32),
+        ("doSearch", C.c_int32 * 2), ("weightedL0", C.c_int32), ("bCoopSlices", C.c_int32), ("bSearchOnly", C.c_int32),
     ]
 
 
@@ -270,6 +270,7 @@ class Context:
             arr[k].doSearch[0], arr[k].doSearch[1] = int(r[6]), int(r[7])
             arr[k].weightedL0 = int(r[8]) if len(r) > 8 else 0
             arr[k].bCoopSlices = int(r[9]) if len(r) > 9 else 0
+            arr[k].bSearchOnly = int(r[10]) if len(r) > 10 else 0
         return arr
 
     def estimate(self, requests):
@@ -552,7 +553,7 @@ HOST_EXPORTS = (
     "xgh_lookahead_create", "xgh_lookahead_destroy", "xgh_lookahead_add_picture", "xgh_lookahead_flush",
     "xgh_lookahead_get_decided", "xgh_lookahead_trace", "xgh_lookahead_cost_est", "xgh_lookahead_cost_est_aq",
     "xgh_lookahead_intra_mbs", "xgh_lookahead_slot", "xgh_lookahead_qp_offsets", "xgh_lookahead_inv_qscale",
-    "xgh_lookahead_planned_satd", "xgh_lookahead_recalc_row_satds", "xgh_lookahead_decide_calls",
+    "xgh_lookahead_planned_satd", "xgh_lookahead_recalc_row_satds", "xgh_lookahead_decide_calls", "xgh_lookahead_presearch_hits", "xgh_lookahead_seconds",
 )
 
 
@@ -565,13 +566,14 @@ class LookaheadParam(C.Structure):
                 ("vbvMaxBitrate", C.c_int32), ("bCqp", C.c_int32), ("bEnableTemporalSubLayers", C.c_int32),
                 ("maxNumReferences", C.c_int32), ("bEnableWeightedPred", C.c_int32), ("bEnableWeightedBiPred", C.c_int32),
                 ("fpsNum", C.c_int32), ("fpsDenom", C.c_int32), ("qCompress", C.c_double), ("bitDepth", C.c_int32),
-                ("poolWorkers", C.c_int32), ("bAdaptiveQuant", C.c_int32), ("aqMode", C.c_int32), ("aqStrength", C.c_double)]
+                ("poolWorkers", C.c_int32), ("bAdaptiveQuant", C.c_int32), ("aqMode", C.c_int32), ("aqStrength", C.c_double),
+                ("bPresearch", C.c_int32), ("lookaheadSlices", C.c_int32)]
 
     MEDIUM = dict(bframes=4, lookaheadDepth=20, bFrameAdaptive=2, bBPyramid=1, scenecutThreshold=40, scenecutBias=0.05,
                   keyframeMin=25, keyframeMax=250, bOpenGOP=1, bIntraRefresh=0, radl=0, gopLookahead=0, cuTree=1,
                   bFrameBias=0, vbvBufferSize=0, vbvMaxBitrate=0, bCqp=0, bEnableTemporalSubLayers=0, maxNumReferences=3,
                   bEnableWeightedPred=1, bEnableWeightedBiPred=0, fpsNum=30, fpsDenom=1, qCompress=0.6, bitDepth=8,
-                  poolWorkers=0, bAdaptiveQuant=1, aqMode=2, aqStrength=1.0)
+                  poolWorkers=0, bAdaptiveQuant=1, aqMode=2, aqStrength=1.0, bPresearch=1, lookaheadSlices=0)
 
     def __init__(self, **kw):
         super().__init__()
@@ -648,6 +650,9 @@ def load_host_library():
     H.xgh_lookahead_recalc_row_satds.argtypes = [vp, i32]
     H.xgh_lookahead_recalc_row_satds.restype = C.POINTER(i32)
     H.xgh_lookahead_decide_calls.argtypes = [vp]
+    H.xgh_lookahead_presearch_hits.argtypes = [vp]
+    H.xgh_lookahead_seconds.argtypes = [vp, C.POINTER(C.c_double * 6)]
+    H.xgh_lookahead_seconds.restype = None
     _libs[HOST_LIB_PATH] = H
     return H
 
@@ -859,3 +864,13 @@ class HostLookahead:
 
     def decide_calls(self):
         return self.H.xgh_lookahead_decide_calls(self.h)
+
+    def seconds(self):
+        """Wall-clock seconds inside slicetypeDecide: pre-analysis, batch 1, batch 2, single requests, cuTree, total."""
+        out = (C.c_double * 6)()
+        self.H.xgh_lookahead_seconds(self.h, C.byref(out))
+        return dict(zip(("pre", "batch1", "batch2", "single", "cutree", "decide"), out))
+
+    def presearch_hits(self):
+        """Searches that single requests found already done (queued ahead with a batch)."""
+        return self.H.xgh_lookahead_presearch_hits(self.h)

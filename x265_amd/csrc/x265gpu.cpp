@@ -841,7 +841,8 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
     const bool hme = ctx->cfg.bEnableHME != 0;
     std::vector<SearchJob> sj;      // half-res searches
     std::vector<SearchJob> sj4;     // quarter-res searches (HME level 0), run first
-    std::vector<CostJob> cj(n);
+    std::vector<CostJob> cj;
+    cj.reserve(n);
     int slicesMax = 1, sliceHeightMax = 0;
     for (int i = 0; i < n; i++)
     {
@@ -928,7 +929,10 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
             j.sliceRows = coop ? ctx->numRowsPerSlice : g.H;
             sj.push_back(j);
         }
-        CostJob& c = cj[i];
+        if (r.bSearchOnly)
+            continue;
+        cj.emplace_back();
+        CostJob& c = cj.back();
         memset(&c, 0, sizeof(c));
         const size_t q = (size_t)d0 * D + d1;
         c.fencPlane0 = plane_origin(ctx, sb.planes);
@@ -969,9 +973,12 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
             return rc;
         first = false;
     }
-    rc = upload_jobs(ctx, s4Bytes + sBytes, cj.data(), cBytes, first);
-    if (rc)
-        return rc;
+    if (!cj.empty())
+    {
+        rc = upload_jobs(ctx, s4Bytes + sBytes, cj.data(), cBytes, first);
+        if (rc)
+            return rc;
+    }
 
     if (!sj.empty() && ctx->searchRows)
     {
@@ -999,9 +1006,10 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
         pt.stop(launches);
     }
     join_intra(ctx);          // the cost pass reads intraCost; the searches above did not have to wait for it
+    if (!cj.empty())
     {
         PhaseTimer pt(ctx, X265GPU_PHASE_COST);
-        HIPCHK(launch_cost(ctx->stream, g, ctx->bpp, (const CostJob*)(ctx->jobBuf + s4Bytes + sBytes), n));
+        HIPCHK(launch_cost(ctx->stream, g, ctx->bpp, (const CostJob*)(ctx->jobBuf + s4Bytes + sBytes), (int)cj.size()));
         pt.stop(2);
     }
     return X265GPU_OK;
@@ -1041,6 +1049,12 @@ int x265gpu_estimate_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* r
         return rc;
     for (int i = 0; i < n; i++)
     {
+        if (reqs[i].bSearchOnly)
+        {
+            out[i].costEst = out[i].costEstAq = -1;
+            out[i].intraMbs = out[i].reserved = 0;
+            continue;
+        }
         long long score = ctx->batchSumsHost[3 * i];
         if (reqs[i].p1 != reqs[i].b)
             score = score * 100 / (130 + ctx->cfg.bFrameBias);   // slicetype.cpp:4372-4373

@@ -2,9 +2,12 @@
 #include "lookahead_host.h"
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 
 namespace x265gpu_host {
 
@@ -12,7 +15,12 @@ void Lowres::reset()
 {
     for (int l = 0; l < 2; l++)
         for (int d = 0; d < MAX_D; d++)
+        {
             searched[l][d] = false;
+            presearched[l][d] = PRE_NONE;
+        }
+    for (int d = 0; d < MAX_D; d++)
+        presearchWeighted[d] = false;
     for (int i = 0; i < MAX_D; i++)
     {
         for (int j = 0; j < MAX_D; j++)
@@ -153,15 +161,24 @@ int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const Picture*
     // prediction, slicetype.cpp:1849-1850; the call installs the scale factors for the slots as well), then
     // lowresIntraEstimate of every frame: the per-frame task of x265 regrouped by stage, which changes no result
     // because a frame's task reads nothing of another frame's
+    std::vector<const void*> lumas(n);
+    std::vector<intptr_t> strides(n);
+    std::vector<int32_t> pocs(n);
+    for (int i = 0; i < n; i++)
+    {
+        slots[i] = frames[i]->slot;
+        lumas[i] = pics[i].y;
+        strides[i] = pics[i].strideY;
+        pocs[i] = frames[i]->frameNum;
+    }
+    int rc = x265gpu_lowres_init_batch(m_ctx, n, slots.data(), lumas.data(), strides.data(), pics[0].memKind, pocs.data());
+    if (rc != X265GPU_OK)
+        return rc;
     for (int i = 0; i < n; i++)
     {
         Lowres& fr = *frames[i];
         const Picture& p = pics[i];
-        int rc = x265gpu_lowres_init(m_ctx, fr.slot, p.y, p.strideY, p.memKind, fr.frameNum);
-        if (rc != X265GPU_OK)
-            return rc;
         fr.reset();
-        slots[i] = fr.slot;
         x265gpu_aq_picture& a = ap[i];
         memset(&a, 0, sizeof(a));
         a.slot = fr.slot;
@@ -176,7 +193,7 @@ int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const Picture*
         a.invQscaleFactor = fr.invQscaleFactor;
     }
     // pictures of one batch live in one kind of memory
-    int rc = x265gpu_aq_frames(m_ctx, n, ap.data(), pics[0].memKind, &aq);
+    rc = x265gpu_aq_frames(m_ctx, n, ap.data(), pics[0].memKind, &aq);
     if (rc != X265GPU_OK)
         return rc;
     for (int i = 0; i < n; i++)
@@ -208,6 +225,17 @@ CostEstimateGroup::CostEstimateGroup(x265gpu_ctx* ctx, Lowres* const* frames, bo
     x265gpu_get_geometry(ctx, &g);
     const int W = g.widthInCU, H = g.heightInCU;
     m_ncu = (W > 2 && H > 2) ? W * H + 4 - 2 * (W + H) : W * H;
+    m_numCoopSlices = g.numCoopSlices;
+}
+
+// weightsAnalyse for the list-0 search of (fenc, ref); returns isWeighted
+bool CostEstimateGroup::analyseWeights(Lowres& fenc, Lowres& ref)
+{
+    const int d0 = fenc.frameNum - ref.frameNum;
+    int rc = m_tld.weightsAnalyse(fenc, ref, m_bitDepth);
+    if (rc != X265GPU_OK && m_status == X265GPU_OK)
+        m_status = rc;
+    return fenc.weighted[d0];
 }
 
 // The first lines of estimateFrameCost (slicetype.cpp:4290-4310): cache check, bDoSearch, weights
@@ -217,26 +245,40 @@ bool CostEstimateGroup::makeRequest(int p0, int p1, int b, Pending& out)
     const int d0 = b - p0, d1 = p1 - b;
     if (fenc.costEst[d0][d1] >= 0 || fenc.pending[d0][d1])
         return false;
-    const bool do0 = !fenc.searched[0][d0];
-    const bool do1 = p1 > b && !fenc.searched[1][d1];
-    if (do0)
+    // what x265 would search now ...
+    const bool need0 = !fenc.searched[0][d0];
+    const bool need1 = p1 > b && !fenc.searched[1][d1];
+    // ... and what is left of it after the searches that ran ahead (only outside batch mode: they were made for
+    // single requests, with their cooperative slices)
+    const bool usable = !m_batchMode || m_numCoopSlices <= 1;     // without slices a batch request searches the same way
+    const bool pre0 = need0 && usable && fenc.presearched[0][d0] == (p1 > b ? PRE_B : PRE_P);
+    const bool pre1 = need1 && usable && fenc.presearched[1][d1] == PRE_B;
+    const bool do0 = need0 && !pre0, do1 = need1 && !pre1;
+    m_presearchHits += (int)pre0 + (int)pre1;
+    if (need0)
+    {
         fenc.searched[0][d0] = true;
-    if (do1)
+        fenc.presearched[0][d0] = PRE_NONE;       // a regular search overwrites whatever ran ahead
+    }
+    if (need1)
+    {
         fenc.searched[1][d1] = true;
+        fenc.presearched[1][d1] = PRE_NONE;
+    }
+    if (getenv("XGH_DEBUG_SINGLES") && !m_batchMode && (do0 || do1))
+        fprintf(stderr, "single with search: p0 %d p1 %d b %d (frames %d %d %d) do %d %d pre-state %d %d\n", p0, p1, b,
+                m_frames[p0]->frameNum, m_frames[p1]->frameNum, fenc.frameNum, do0, do1, fenc.presearched[0][d0], fenc.presearched[1][d1]);
     fenc.pending[d0][d1] = true;
     if (m_trace)
-        m_trace->push_back({ m_frames[p0]->frameNum, m_frames[p1]->frameNum, fenc.frameNum, { do0, do1 }, m_batchMode });
+        m_trace->push_back({ m_frames[p0]->frameNum, m_frames[p1]->frameNum, fenc.frameNum, { need0, need1 }, m_batchMode });
     bool weighted = false;
     if (m_weightp)
     {
         fenc.weighted[d0] = false;
-        if (do0)
-        {
-            int rc = m_tld.weightsAnalyse(fenc, *m_frames[p0], m_bitDepth);
-            if (rc != X265GPU_OK && m_status == X265GPU_OK)
-                m_status = rc;
-            weighted = fenc.weighted[d0];
-        }
+        if (pre0)
+            weighted = fenc.weighted[d0] = fenc.presearchWeighted[d0];    // the analysis ran with the search
+        else if (do0)
+            weighted = analyseWeights(fenc, *m_frames[p0]);
     }
     memset(&out.req, 0, sizeof(out.req));
     out.req.slotP0 = m_frames[p0]->slot;
@@ -247,7 +289,7 @@ bool CostEstimateGroup::makeRequest(int p0, int p1, int b, Pending& out)
     out.req.p1 = p1;
     out.req.doSearch[0] = do0;
     out.req.doSearch[1] = do1;
-    out.req.weightedL0 = weighted;
+    out.req.weightedL0 = weighted && do0;
     out.req.bCoopSlices = !m_batchMode;        // slicetype.cpp:4312
     out.b = b;
     out.d0 = d0;
@@ -255,8 +297,57 @@ bool CostEstimateGroup::makeRequest(int p0, int p1, int b, Pending& out)
     return true;
 }
 
+void CostEstimateGroup::addPresearch(int p0, int p1, int b, int lists)
+{
+    Lowres& fenc = *m_frames[b];
+    const int d0 = b - p0, d1 = p1 - b;
+    const uint8_t kind = p1 > b ? PRE_B : PRE_P;
+    const bool do0 = (lists & 1) && !fenc.searched[0][d0] && fenc.presearched[0][d0] != kind;
+    const bool do1 = (lists & 2) && p1 > b && !fenc.searched[1][d1] && fenc.presearched[1][d1] != PRE_B;
+    if (!do0 && !do1)
+        return;
+    m_batchMode = true;
+    Pending p;
+    memset(&p.req, 0, sizeof(p.req));
+    bool weighted = false;
+    if (do0)
+    {
+        if (m_weightp)
+        {
+            // weightsAnalyse leaves its verdict in fenc.weighted[d0], which belongs to the request that is current
+            // in x265's order: keep that one intact and file the verdict with the presearch
+            const bool keep = fenc.weighted[d0];
+            const double keepDelta = fenc.weightedCostDelta[d0];
+            weighted = analyseWeights(fenc, *m_frames[p0]);
+            fenc.weighted[d0] = keep;
+            fenc.weightedCostDelta[d0] = keepDelta;
+        }
+        fenc.presearched[0][d0] = kind;
+        fenc.presearchWeighted[d0] = weighted;
+    }
+    if (do1)
+        fenc.presearched[1][d1] = PRE_B;
+    p.req.slotP0 = m_frames[p0]->slot;
+    p.req.slotB = fenc.slot;
+    p.req.slotP1 = m_frames[p1]->slot;
+    p.req.p0 = p0;
+    p.req.b = b;
+    p.req.p1 = p1;
+    p.req.doSearch[0] = do0;
+    p.req.doSearch[1] = do1;
+    p.req.weightedL0 = weighted;
+    p.req.bCoopSlices = 1;                     // the request this stands in for is a single one
+    p.req.bSearchOnly = 1;
+    p.b = b;
+    p.d0 = d0;
+    p.d1 = d1;
+    m_batch.push_back(p);
+}
+
 void CostEstimateGroup::collect(const Pending& p, const x265gpu_frame_cost& fc)
 {
+    if (p.req.bSearchOnly)
+        return;
     Lowres& fenc = *m_frames[p.b];
     fenc.costEst[p.d0][p.d1] = fc.costEst;
     fenc.costEstAq[p.d0][p.d1] = fc.costEstAq;
@@ -311,7 +402,8 @@ void CostEstimateGroup::finishBatch()
         if (m_status == X265GPU_OK)
             m_status = rc;
         for (const Pending& p : m_batch)
-            m_frames[p.b]->pending[p.d0][p.d1] = false;
+            if (!p.req.bSearchOnly)
+                m_frames[p.b]->pending[p.d0][p.d1] = false;
     }
     else
         for (size_t i = 0; i < m_batch.size(); i++)
@@ -477,6 +569,16 @@ static int exp2fix8(double x)
     return (lut[i & 63] + 256) << (i >> 6) >> 8;
 }
 
+namespace {
+struct ScopeTimer
+{
+    double& acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit ScopeTimer(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~ScopeTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}
+
 static inline bool isTypeI(int t) { return t == TYPE_I || t == TYPE_IDR; }
 static inline bool isTypeB(int t) { return t == TYPE_B || t == TYPE_BREF; }
 
@@ -517,14 +619,17 @@ int64_t Lookahead::cost(Lowres** frames, int p0, int p1, int b, bool bIntraPenal
     const int64_t cached = frames[b]->costEst[b - p0][p1 - b];
     if (cached >= 0 && !frames[b]->pending[b - p0][p1 - b])
         return bIntraPenalty ? cached + cached * frames[b]->intraMbs[b - p0] / (m_8x8Blocks * 8) : cached;
+    ScopeTimer timer(m_seconds[T_SINGLE]);
     CostEstimateGroup est(m_ctx, frames, m_param.bEnableWeightedPred, m_param.bitDepth, &m_trace);
     const int64_t c = est.singleCost(p0, p1, b, bIntraPenalty);
     note(est.status());
+    m_presearchHits += est.presearchHits();
     return c;
 }
 
 void Lookahead::cuTree(Lowres** frames, int numframes, bool bIntra)
 {
+    ScopeTimer timer(m_seconds[T_CUTREE]);
     CuTreeParam cp;
     cp.fpsNum = m_param.fpsNum;
     cp.fpsDenom = m_param.fpsDenom;
@@ -883,8 +988,13 @@ void Lookahead::slicetypeAnalyse(Lowres** frames, bool bKeyframe)
                 const bool both = b + d < numFrames && !frames[b]->searched[1][d];
                 est.add(b - d, both ? b + d : b, b);
             }
+        if (P.bPresearch)
+            presearchEdges(est, frames, numFrames);
         m_bBatchMotionSearch = m_bBatchMotionSearch && P.poolWorkers >= 4;
-        est.finishBatch();
+        {
+            ScopeTimer timer(m_seconds[T_BATCH1]);
+            est.finishBatch();
+        }
         if (m_bBatchFrameCosts)
         {
             // ... then every frame cost those searches allow (:2949-2988)
@@ -903,6 +1013,7 @@ void Lookahead::slicetypeAnalyse(Lowres** frames, bool bKeyframe)
                     }
                 }
             m_bBatchFrameCosts = m_bBatchFrameCosts && P.poolWorkers > 12;
+            ScopeTimer timer(m_seconds[T_BATCH2]);
             est.finishBatch();
         }
         note(est.status());
@@ -1053,6 +1164,33 @@ void Lookahead::slicetypeAnalyse(Lowres** frames, bool bKeyframe)
     }
 }
 
+// Not in x265: the searches its two batch loops leave out, queued with batch 1.  The loops start at frame 2 and stop
+// before frame numFrames, take a list-1 search only towards a frame before numFrames, and only together with the
+// list-0 search of the same distance; what is left x265 runs one request at a time when the scene-cut test and
+// the trellis ask, each a whole wavefront over the frame by itself.
+// On the device such a lone search is latency (one launch per anti-diagonal), while inside the batch it costs
+// almost nothing.  Each is queued exactly as the single request would run it (list, distance, P or bidirectional,
+// cooperative slices), kept aside, and handed to that request when it comes, so decisions, vectors and costs are
+// the ones x265 gets; a search nobody asks for stays invisible (the host's `searched` flags say what x265's
+// sentinel would).
+void Lookahead::presearchEdges(CostEstimateGroup& est, Lowres** /*frames*/, int numFrames)
+{
+    const int bf = m_param.bframes;
+    // the first frame: scenecut() always asks for (0, 1, 1) first, a P request
+    est.addPresearch(0, 1, 1, 1);
+    // the last frame of the window as the P frame that closes a path of the trellis
+    for (int d = 1; d <= bf + 1 && numFrames - d >= 0; d++)
+        est.addPresearch(numFrames - d, numFrames, numFrames, 1);
+    // Every list-1 search inside the window that batch 1 did not queue: those of frame 1, those towards the last
+    // frame, and those the batch loop passes over because the list-0 search of the same distance exists already
+    // (:2934-2935; typically frames that were the window's last frames a decision ago) or would reach before the
+    // window.  A list-1 search always belongs to a bidirectional request, whatever that request's p0.
+    // (addPresearch drops what is searched or queued already.)
+    for (int b = 1; b < numFrames; b++)
+        for (int d = 1; d <= bf && b + d <= numFrames; d++)
+            est.addPresearch(b - 1, b + d, b, 2);
+}
+
 void Lookahead::placeBref(Lowres** list, int start, int end, int num, int& brefs)      // :1864-1886
 {
     const int avg = (start + end) / 2;
@@ -1085,6 +1223,7 @@ void Lookahead::compCostBref(Lowres** frames, int start, int end, int num)      
 void Lookahead::slicetypeDecide()
 {
     const LookaheadParam& P = m_param;
+    ScopeTimer decideTimer(m_seconds[T_DECIDE]);
     m_decideCalls++;
     std::vector<Lowres*> framesV(LOOKAHEAD_MAX + X265GPU_BFRAME_MAX + 4, nullptr);
     std::vector<Lowres*> listV(X265GPU_BFRAME_MAX + 4, nullptr);
@@ -1108,6 +1247,7 @@ void Lookahead::slicetypeDecide()
     // pre-analysis of the frames that entered the window: PreLookaheadGroup::processTasks (:2033-2040)
     if (!pre.empty())
     {
+        ScopeTimer timer(m_seconds[T_PRE]);
         PreLookaheadGroup group(m_ctx);
         std::vector<Picture> pics(pre.size());
         for (size_t i = 0; i < pre.size(); i++)
@@ -1468,6 +1608,8 @@ xgh_lookahead* xgh_lookahead_create(x265gpu_ctx* ctx, const xgh_lookahead_param*
     q.aq.aqMode = p->aqMode;
     q.aq.aqStrength = p->aqStrength;
     q.aq.bWeightedPred = q.bEnableWeightedPred || q.bEnableWeightedBiPred;
+    q.bPresearch = p->bPresearch != 0;
+    q.lookaheadSlices = p->lookaheadSlices;
     xgh_lookahead* h = new xgh_lookahead;
     h->ctx = ctx;
     h->la = new Lookahead(ctx, q);
@@ -1571,5 +1713,11 @@ const int32_t* xgh_lookahead_recalc_row_satds(const xgh_lookahead* h, int32_t fr
     return f.recalcRowSatds.empty() ? nullptr : f.recalcRowSatds.data();
 }
 int xgh_lookahead_decide_calls(const xgh_lookahead* h) { return h->la->decideCalls(); }
+int xgh_lookahead_presearch_hits(const xgh_lookahead* h) { return h->la->presearchHits(); }
+void xgh_lookahead_seconds(const xgh_lookahead* h, double out[6])
+{
+    for (int i = 0; i < Lookahead::T_COUNT; i++)
+        out[i] = h->la->seconds()[i];
+}
 
 } // extern "C"

@@ -35,6 +35,7 @@ enum { TYPE_AUTO = 0, TYPE_IDR = 1, TYPE_I = 2, TYPE_P = 3, TYPE_BREF = 4, TYPE_
 
 constexpr int MAX_D = X265GPU_BFRAME_MAX + 2;
 constexpr int LOOKAHEAD_MAX = 250;    // X265_LOOKAHEAD_MAX (source/x265.h:103)
+enum { PRE_NONE = 0, PRE_P = 1, PRE_B = 2 };
 
 // a 4:2:0 source picture; planes point at pixel (0,0), strides in pixels.  memKind says where the planes
 // live (X265GPU_MEM_HOST / X265GPU_MEM_DEVICE); u and v may be null when no AQ pass reads them
@@ -62,6 +63,11 @@ struct Lowres
     int frameNum = 0;
     int sliceType = TYPE_AUTO;
     bool searched[2][MAX_D];          // lowresMvs[l][d][0].x != 0x7FFF
+    // A search run ahead of the request that will ask for it (CostEstimateGroup::addPresearch): the device arrays
+    // of (list, distance) already hold that request's vectors, while `searched` still says what x265's sentinel
+    // would.  0: none; PRE_P: searched as a P request's list 0; PRE_B: as part of a bidirectional request.
+    uint8_t presearched[2][MAX_D];
+    bool presearchWeighted[MAX_D];    // weightsAnalyse's outcome for the presearched list-0 search
     int64_t costEst[MAX_D][MAX_D];    // -1: not measured (lowres.cpp:354-371)
     int64_t costEstAq[MAX_D][MAX_D];
     bool pending[MAX_D][MAX_D];       // queued in a batch that has not finished
@@ -128,12 +134,20 @@ public:
 
     int64_t singleCost(int p0, int p1, int b, bool bIntraPenalty = false);
     void add(int p0, int p1, int b);
+    // Queues, into the current batch, the motion search(es) that a later singleCost(p0, p1, b) outside batch mode
+    // would run for the lists in `lists` (bit 0: list 0, bit 1: list 1), and nothing else.  When that request
+    // comes, it finds its vectors on the device and only measures costs.  A search's outcome depends on the frame
+    // pair, the list, the distance, whether the request is bidirectional and whether it runs in cooperative slices;
+    // a presearched list 0 is therefore only used by a later request of the same kind (p1 > b or not).
+    void addPresearch(int p0, int p1, int b, int lists);
     void finishBatch();
     int status() const { return m_status; }      // first failure of any call, or X265GPU_OK
+    int presearchHits() const { return m_presearchHits; }
 
 private:
     struct Pending { x265gpu_request req; int b, d0, d1; };
     bool makeRequest(int p0, int p1, int b, Pending& out);
+    bool analyseWeights(Lowres& fenc, Lowres& ref);
     void collect(const Pending& p, const x265gpu_frame_cost& fc);
 
     x265gpu_ctx* m_ctx;
@@ -143,9 +157,11 @@ private:
     int m_bitDepth;
     bool m_batchMode = false;
     int m_ncu;                                    // LookaheadTLD::ncu (slicetype.cpp:1065-1066)
+    int m_numCoopSlices = 1;
     int m_status = X265GPU_OK;
     std::vector<Pending> m_batch;
     std::vector<RequestTrace>* m_trace;
+    int m_presearchHits = 0;
 };
 
 // The subset of x265_param that cuTree reads
@@ -206,6 +222,10 @@ struct LookaheadParam
     int fpsNum = 30, fpsDenom = 1;
     double qCompress = 0.6;
     int bitDepth = 8;
+    bool bPresearch = true;                       // with batches: also queue, in batch 1, the searches of the window's first
+                                                  // and last frames that x265 leaves to single requests (results unchanged)
+    int lookaheadSlices = 0;                      // as the context was opened with; only read to know whether single requests
+                                                  // run in cooperative slices
     int poolWorkers = 0;                          // ThreadPool::m_numWorkers of the lookahead's pool; 0: no pool, so
                                                   // requests are issued one by one in the order the decision needs them;
                                                   // > 0 with trellis B-adapt: the two batches of slicetypeAnalyse
@@ -230,8 +250,13 @@ public:
     int status() const { return m_status; }
     const std::vector<RequestTrace>& trace() const { return m_trace; }
     int decideCalls() const { return m_decideCalls; }
+    int presearchHits() const { return m_presearchHits; }
+    // wall-clock seconds spent inside slicetypeDecide, split by what was running (profiling aid)
+    enum { T_PRE, T_BATCH1, T_BATCH2, T_SINGLE, T_CUTREE, T_DECIDE, T_COUNT };
+    const double* seconds() const { return m_seconds; }
 
 private:
+    double m_seconds[T_COUNT] = { 0, 0, 0, 0, 0, 0 };
     void slicetypeDecide();
     void slicetypeAnalyse(Lowres** frames, bool bKeyframe);
     bool scenecut(Lowres** frames, int p0, int p1, bool bRealScenecut, int numFrames);
@@ -261,6 +286,8 @@ private:
     std::vector<RequestTrace> m_trace;
     int m_status = X265GPU_OK;
     int m_decideCalls = 0;
+    int m_presearchHits = 0;
+    void presearchEdges(CostEstimateGroup& est, Lowres** frames, int numFrames);
 };
 
 } // namespace x265gpu_host
@@ -310,6 +337,7 @@ typedef struct xgh_lookahead_param
     double  qCompress;
     int32_t bitDepth, poolWorkers, bAdaptiveQuant, aqMode;
     double  aqStrength;
+    int32_t bPresearch, lookaheadSlices;
 } xgh_lookahead_param;
 typedef struct xgh_decided
 {
@@ -335,6 +363,9 @@ const int32_t* xgh_lookahead_inv_qscale(const xgh_lookahead* la, int32_t frame);
 const int64_t* xgh_lookahead_planned_satd(const xgh_lookahead* la, int32_t frame, const int32_t** types, int32_t* indB);
 const int32_t* xgh_lookahead_recalc_row_satds(const xgh_lookahead* la, int32_t frame);
 int xgh_lookahead_decide_calls(const xgh_lookahead* la);
+int xgh_lookahead_presearch_hits(const xgh_lookahead* la);
+/* seconds inside slicetypeDecide: { pre-analysis, batch 1, batch 2, single requests, cuTree, whole decide calls } */
+void xgh_lookahead_seconds(const xgh_lookahead* la, double out[6]);
 }
 
 #endif

@@ -202,6 +202,14 @@ int x265gpu_estimate_sums_device(x265gpu_ctx* ctx, int32_t n, const x265gpu_requ
  * unweighted reference.  The result is written to *cost after a sync. */
 int x265gpu_weight_cost(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t wtPresent,
                         int32_t scale, int32_t log2Denom, int32_t offset, uint32_t* cost);
+/* n x265gpu_weight_cost measurements with one wait at the end (the weight analyses of a batch of requests are
+ * independent of each other).  costs[i] receives job i's sum. */
+typedef struct x265gpu_weight_job
+{
+    int32_t slotFenc, slotRef;
+    int32_t wtPresent, scale, log2Denom, offset;
+} x265gpu_weight_job;
+int x265gpu_weight_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_weight_job* jobs, uint32_t* costs);
 /* x265gpu_weight_cost for callers that cannot allocate device memory (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
  * arguments and result as x265gpu_weight_cost; the accumulator and the weighted copy of plane 0 live in a

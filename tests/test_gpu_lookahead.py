@@ -400,6 +400,7 @@ def test_extreme_content_hme_umh_12bit(kind):
     (3840, 2160, 10, False),
     (3840, 2160, 10, True),      # 4K Main10 with --hme: hexagon on the quarter-res, multi-hexagon on the half-res planes
     (7680, 4320, 10, False),
+    (7680, 4320, 10, True),      # 8K Main10 with --hme
 ])
 def test_full_size_against_oracle(width, height, depth, hme):
     """The benchmark sizes, three frames, against the oracle directly (a request takes it under a second)."""

@@ -21,7 +21,7 @@ PHASES = ("lowres", "intra", "search", "cost")
 EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
-    "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_estimate_sums_device", "x265gpu_weight_cost", "x265gpu_weight_cost_static", "x265gpu_weight_planes",
+    "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_estimate_sums_device", "x265gpu_weight_cost", "x265gpu_weight_costs", "x265gpu_weight_cost_static", "x265gpu_weight_planes",
     "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_aq_frames", "x265gpu_get_frame_costs", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
     "x265gpu_cutree_clear", "x265gpu_cutree_swap", "x265gpu_cutree_propagate", "x265gpu_cutree_get_propagate_cost",
     "x265gpu_cutree_finish", "x265gpu_hist_stats", "x265gpu_mcstf_motion_search",
@@ -142,6 +142,7 @@ def load_library(path=None):
     L.x265gpu_estimate_costs.argtypes = [vp, i32, vp, vp]
     L.x265gpu_estimate_sums_device.argtypes = [vp, i32, vp, vp]
     L.x265gpu_weight_cost.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint32)]
+    L.x265gpu_weight_costs.argtypes = [vp, i32, vp, vp]
     L.x265gpu_weight_cost_static.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint32)]
     L.x265gpu_weight_planes.argtypes = [vp, i32, i32, i32, i32, i32, i32]
     L.x265gpu_get_plane.argtypes = [vp, i32, i32, vp]

@@ -1100,6 +1100,62 @@ int x265gpu_weight_cost(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int
     return X265GPU_OK;
 }
 
+namespace {
+int ensure_pu_buf(x265gpu_ctx* ctx, size_t bytes);
+}
+
+int x265gpu_weight_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_weight_job* jobs, uint32_t* costs)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || n < 0 || (n && (!jobs || !costs)))
+        return X265GPU_ERR_ARG;
+    if (!n)
+        return X265GPU_OK;
+    const Geometry& g = ctx->g;
+    const int depth = ctx->cfg.internalBitDepth;
+    const size_t planeBytes = align256((size_t)g.planeSize * ctx->bpp);
+    int weightedJobs = 0;
+    for (int i = 0; i < n; i++)
+    {
+        if (!slot_ok(ctx, jobs[i].slotFenc) || !slot_ok(ctx, jobs[i].slotRef))
+            return fail(ctx, X265GPU_ERR_ARG, "weight_costs: bad slot");
+        weightedJobs += jobs[i].wtPresent != 0;
+    }
+    int rc = ensure_src_stage(ctx, planeBytes * (weightedJobs > 0 ? weightedJobs : 1));
+    if (rc)
+        return rc;
+    rc = ensure_pu_buf(ctx, align256(sizeof(unsigned int) * (size_t)n));
+    if (rc)
+        return rc;
+    unsigned int* acc = (unsigned int*)ctx->puBuf;
+    HIPCHK(hipMemsetAsync(acc, 0, sizeof(unsigned int) * (size_t)n, ctx->stream));
+    int w = 0;
+    for (int i = 0; i < n; i++)
+    {
+        const x265gpu_weight_job& j = jobs[i];
+        Slot& sf = ctx->slots[j.slotFenc];
+        Slot& sr = ctx->slots[j.slotRef];
+        WeightCostJob job;
+        job.fencPlane0 = plane_origin(ctx, sf.planes);
+        job.refPlane0 = plane_origin(ctx, sr.planes);
+        job.intraCost = sf.intraCost;
+        job.out = acc + i;
+        if (j.wtPresent)
+        {
+            char* stage = ctx->srcStage + planeBytes * w++;
+            const int corr = 14 - depth;
+            const int round = j.log2Denom ? 1 << (j.log2Denom - 1) : 0;
+            HIPCHK(launch_weight_planes(ctx->stream, g, ctx->bpp, depth, 1, sr.planes, stage, j.scale, round << corr,
+                                        j.log2Denom + corr, j.offset * (1 << (depth - 8))));
+            job.refPlane0 = plane_origin(ctx, stage);
+        }
+        HIPCHK(launch_weight_cost(ctx->stream, g, ctx->bpp, &job));
+    }
+    HIPCHK(hipMemcpyAsync(costs, acc, sizeof(unsigned int) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
 int x265gpu_weight_cost_static(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t wtPresent, int32_t scale,
                                int32_t log2Denom, int32_t offset, uint32_t* cost)
 {

@@ -45,77 +45,127 @@ void Lowres::reset()
 //      single precision, so that the same pictures give the same scale / offset / denominator. ----
 int LookaheadTLD::weightsAnalyse(Lowres& fenc, Lowres& ref, int bitDepth)
 {
+    Lowres* f = &fenc;
+    Lowres* r = &ref;
+    return weightsAnalyse(1, &f, &r, bitDepth);
+}
+
+int LookaheadTLD::weightsAnalyse(int n, Lowres* const* fencs, Lowres* const* refs, int bitDepth)
+{
     static const float epsilon = 1.f / 128.f;
-    const int deltaIndex = fenc.frameNum - ref.frameNum;
-    fenc.weighted[deltaIndex] = false;
+    struct Guess { int idx; int mindenom, minscale; float fencMean, refMean; int curScale, curOffset; uint32_t orig, s; };
+    std::vector<Guess> live;
+    for (int i = 0; i < n; i++)
+    {
+        Lowres& fenc = *fencs[i];
+        Lowres& ref = *refs[i];
+        const int deltaIndex = fenc.frameNum - ref.frameNum;
+        fenc.weighted[deltaIndex] = false;
 
-    float guessScale, fencMean, refMean;
-    if (fenc.wp_ssd && ref.wp_ssd)
-        guessScale = sqrtf((float)fenc.wp_ssd / ref.wp_ssd);
-    else
-        guessScale = 1.0f;
-    fencMean = (float)fenc.wp_sum / (m_geom.lines * m_geom.width) / (1 << (bitDepth - 8));
-    refMean = (float)ref.wp_sum / (m_geom.lines * m_geom.width) / (1 << (bitDepth - 8));
+        float guessScale, fencMean, refMean;
+        if (fenc.wp_ssd && ref.wp_ssd)
+            guessScale = sqrtf((float)fenc.wp_ssd / ref.wp_ssd);
+        else
+            guessScale = 1.0f;
+        fencMean = (float)fenc.wp_sum / (m_geom.lines * m_geom.width) / (1 << (bitDepth - 8));
+        refMean = (float)ref.wp_sum / (m_geom.lines * m_geom.width) / (1 << (bitDepth - 8));
 
-    // nothing to gain when means and spread already agree (:906)
-    if (fabsf(refMean - fencMean) < 0.5f && fabsf(1.f - guessScale) < epsilon)
+        // nothing to gain when means and spread already agree (:906)
+        if (fabsf(refMean - fencMean) < 0.5f && fabsf(1.f - guessScale) < epsilon)
+            continue;
+
+        // WeightParam::setFromWeightAndOffset(w, 0, 7, true) (source/common/slice.h)
+        int w = (int)(guessScale * 128 + 0.5f), mindenom = 7;
+        while (mindenom > 0 && w > 127)
+        {
+            mindenom--;
+            w >>= 1;
+        }
+        Guess g;
+        g.idx = i;
+        g.mindenom = mindenom;
+        g.minscale = w < 127 ? w : 127;
+        g.fencMean = fencMean;
+        g.refMean = refMean;
+        g.orig = g.s = 0;
+        g.curScale = g.curOffset = 0;
+        live.push_back(g);
+    }
+    if (live.empty())
         return X265GPU_OK;
 
-    // WeightParam::setFromWeightAndOffset(w, 0, 7, true) (source/common/slice.h)
-    int w = (int)(guessScale * 128 + 0.5f), mindenom = 7;
-    while (mindenom > 0 && w > 127)
-    {
-        mindenom--;
-        w >>= 1;
-    }
-    int minscale = w < 127 ? w : 127, minoff = 0;
-
-    uint32_t origscore = 0, minscore = 0, s = 0;
-    int rc = x265gpu_weight_cost(m_ctx, fenc.slot, ref.slot, 0, 0, 0, 0, &origscore);
+    // first device pass: the unweighted cost of every pair left
+    std::vector<x265gpu_weight_job> jobs(live.size());
+    std::vector<uint32_t> costs(live.size());
+    for (size_t k = 0; k < live.size(); k++)
+        jobs[k] = { fencs[live[k].idx]->slot, refs[live[k].idx]->slot, 0, 0, 0, 0 };
+    int rc = x265gpu_weight_costs(m_ctx, (int32_t)jobs.size(), jobs.data(), costs.data());
     if (rc != X265GPU_OK)
         return rc;
-    minscore = origscore;
-    if (!minscore)
+    std::vector<Guess> second;
+    for (size_t k = 0; k < live.size(); k++)
+    {
+        Guess g = live[k];
+        g.orig = costs[k];
+        if (!g.orig)
+            continue;
+        g.curScale = g.minscale;
+        g.curOffset = (int)(g.fencMean - g.refMean * g.curScale / (1 << g.mindenom) + 0.5f);
+        if (g.curOffset < -128 || g.curOffset > 127)
+        {
+            /* Rescale considering the constraints on curOffset (slicetype.cpp:926-931) */
+            g.curOffset = g.curOffset < -128 ? -128 : 127;
+            g.curScale = (int)((1 << g.mindenom) * (g.fencMean - g.curOffset) / g.refMean + 0.5f);
+            g.curScale = g.curScale < 0 ? 0 : (g.curScale > 127 ? 127 : g.curScale);
+        }
+        second.push_back(g);
+    }
+    if (second.empty())
         return X265GPU_OK;
 
-    int curScale = minscale;
-    int curOffset = (int)(fencMean - refMean * curScale / (1 << mindenom) + 0.5f);
-    if (curOffset < -128 || curOffset > 127)
-    {
-        /* Rescale considering the constraints on curOffset (slicetype.cpp:926-931) */
-        curOffset = curOffset < -128 ? -128 : 127;
-        curScale = (int)((1 << mindenom) * (fencMean - curOffset) / refMean + 0.5f);
-        curScale = curScale < 0 ? 0 : (curScale > 127 ? 127 : curScale);
-    }
-    rc = x265gpu_weight_cost(m_ctx, fenc.slot, ref.slot, 1, curScale, mindenom, curOffset, &s);
+    // second device pass: the cost with the guessed weight
+    jobs.resize(second.size());
+    costs.resize(second.size());
+    for (size_t k = 0; k < second.size(); k++)
+        jobs[k] = { fencs[second[k].idx]->slot, refs[second[k].idx]->slot, 1, second[k].curScale, second[k].mindenom, second[k].curOffset };
+    rc = x265gpu_weight_costs(m_ctx, (int32_t)jobs.size(), jobs.data(), costs.data());
     if (rc != X265GPU_OK)
         return rc;
-    bool found = false;
-    if (s < minscore)
+    for (size_t k = 0; k < second.size(); k++)
     {
-        minscore = s;
-        minscale = curScale;
-        minoff = curOffset;
-        found = true;
+        const Guess& g = second[k];
+        Lowres& fenc = *fencs[g.idx];
+        Lowres& ref = *refs[g.idx];
+        const int deltaIndex = fenc.frameNum - ref.frameNum;
+        uint32_t minscore = g.orig;
+        int minscale = g.minscale, minoff = 0, mindenom = g.mindenom;
+        bool found = false;
+        if (costs[k] < minscore)
+        {
+            minscore = costs[k];
+            minscale = g.curScale;
+            minoff = g.curOffset;
+            found = true;
+        }
+
+        // drop common factors of two from scale and denominator (:943-950)
+        if (mindenom > 0 && minscale && !(minscale & 1))
+        {
+            int idx = __builtin_ctz((unsigned)minscale);
+            int shift = idx < mindenom ? idx : mindenom;
+            mindenom -= shift;
+            minscale >>= shift;
+        }
+
+        if (!found || (minscale == (1 << mindenom) && minoff == 0) || (float)minscore / g.orig > 0.998f)
+            continue;
+
+        fenc.weightedCostDelta[deltaIndex] = minscore / g.orig;    // integer division, slicetype.cpp:955
+        rc = x265gpu_weight_planes(m_ctx, fenc.slot, deltaIndex, ref.slot, minscale, mindenom, minoff);
+        if (rc != X265GPU_OK)
+            return rc;
+        fenc.weighted[deltaIndex] = true;
     }
-
-    // drop common factors of two from scale and denominator (:943-950)
-    if (mindenom > 0 && minscale && !(minscale & 1))
-    {
-        int idx = __builtin_ctz((unsigned)minscale);
-        int shift = idx < mindenom ? idx : mindenom;
-        mindenom -= shift;
-        minscale >>= shift;
-    }
-
-    if (!found || (minscale == (1 << mindenom) && minoff == 0) || (float)minscore / origscore > 0.998f)
-        return X265GPU_OK;
-
-    fenc.weightedCostDelta[deltaIndex] = minscore / origscore;    // integer division, slicetype.cpp:955
-    rc = x265gpu_weight_planes(m_ctx, fenc.slot, deltaIndex, ref.slot, minscale, mindenom, minoff);
-    if (rc != X265GPU_OK)
-        return rc;
-    fenc.weighted[deltaIndex] = true;
     return X265GPU_OK;
 }
 
@@ -272,11 +322,16 @@ bool CostEstimateGroup::makeRequest(int p0, int p1, int b, Pending& out)
     if (m_trace)
         m_trace->push_back({ m_frames[p0]->frameNum, m_frames[p1]->frameNum, fenc.frameNum, { need0, need1 }, m_batchMode });
     bool weighted = false;
+    out.deferWeights = false;
+    out.presearch = false;
+    out.p0 = p0;
     if (m_weightp)
     {
         fenc.weighted[d0] = false;
         if (pre0)
             weighted = fenc.weighted[d0] = fenc.presearchWeighted[d0];    // the analysis ran with the search
+        else if (do0 && m_batchMode)
+            out.deferWeights = true;           // finishBatch analyses the batch's pairs together
         else if (do0)
             weighted = analyseWeights(fenc, *m_frames[p0]);
     }
@@ -309,21 +364,14 @@ void CostEstimateGroup::addPresearch(int p0, int p1, int b, int lists)
     m_batchMode = true;
     Pending p;
     memset(&p.req, 0, sizeof(p.req));
-    bool weighted = false;
+    const bool weighted = false;
+    p.deferWeights = do0 && m_weightp;         // analysed with the batch's other pairs in finishBatch
+    p.presearch = true;
+    p.p0 = p0;
     if (do0)
     {
-        if (m_weightp)
-        {
-            // weightsAnalyse leaves its verdict in fenc.weighted[d0], which belongs to the request that is current
-            // in x265's order: keep that one intact and file the verdict with the presearch
-            const bool keep = fenc.weighted[d0];
-            const double keepDelta = fenc.weightedCostDelta[d0];
-            weighted = analyseWeights(fenc, *m_frames[p0]);
-            fenc.weighted[d0] = keep;
-            fenc.weightedCostDelta[d0] = keepDelta;
-        }
         fenc.presearched[0][d0] = kind;
-        fenc.presearchWeighted[d0] = weighted;
+        fenc.presearchWeighted[d0] = false;
     }
     if (do1)
         fenc.presearched[1][d1] = PRE_B;
@@ -388,10 +436,52 @@ void CostEstimateGroup::add(int p0, int p1, int b)
         m_batch.push_back(p);
 }
 
+// weightsAnalyse of every list-0 search in the batch, two device passes for all of them together.  A regular
+// request's verdict goes to fenc.weighted[d0] as in x265; a presearch's verdict is filed with the presearch, and
+// fenc.weighted[d0] / weightedCostDelta[d0], which belong to the request current in x265's order, are put back.
+void CostEstimateGroup::analyseDeferredWeights()
+{
+    std::vector<Lowres*> fencs, refs;
+    std::vector<size_t> which;
+    for (size_t i = 0; i < m_batch.size(); i++)
+        if (m_batch[i].deferWeights)
+        {
+            fencs.push_back(m_frames[m_batch[i].b]);
+            refs.push_back(m_frames[m_batch[i].p0]);
+            which.push_back(i);
+        }
+    if (which.empty())
+        return;
+    std::vector<bool> keep(which.size());
+    std::vector<double> keepDelta(which.size());
+    for (size_t k = 0; k < which.size(); k++)
+    {
+        keep[k] = fencs[k]->weighted[m_batch[which[k]].d0];
+        keepDelta[k] = fencs[k]->weightedCostDelta[m_batch[which[k]].d0];
+    }
+    int rc = m_tld.weightsAnalyse((int)which.size(), fencs.data(), refs.data(), m_bitDepth);
+    if (rc != X265GPU_OK && m_status == X265GPU_OK)
+        m_status = rc;
+    for (size_t k = 0; k < which.size(); k++)
+    {
+        Pending& p = m_batch[which[k]];
+        Lowres& fenc = *fencs[k];
+        const bool weighted = fenc.weighted[p.d0];
+        p.req.weightedL0 = weighted;
+        if (p.presearch)
+        {
+            fenc.presearchWeighted[p.d0] = weighted;
+            fenc.weighted[p.d0] = keep[k];
+            fenc.weightedCostDelta[p.d0] = keepDelta[k];
+        }
+    }
+}
+
 void CostEstimateGroup::finishBatch()
 {
     if (m_batch.empty())
         return;
+    analyseDeferredWeights();
     std::vector<x265gpu_request> reqs(m_batch.size());
     std::vector<x265gpu_frame_cost> out(m_batch.size());
     for (size_t i = 0; i < m_batch.size(); i++)

@@ -99,6 +99,8 @@ class LookaheadTLD
 public:
     explicit LookaheadTLD(x265gpu_ctx* ctx) : m_ctx(ctx) { x265gpu_get_geometry(ctx, &m_geom); }
     int weightsAnalyse(Lowres& fenc, Lowres& ref, int bitDepth);
+    // the same for n independent (fenc, ref) pairs: their two device passes each run as one batch
+    int weightsAnalyse(int n, Lowres* const* fencs, Lowres* const* refs, int bitDepth);
 
 private:
     x265gpu_ctx* m_ctx;
@@ -145,7 +147,8 @@ public:
     int presearchHits() const { return m_presearchHits; }
 
 private:
-    struct Pending { x265gpu_request req; int b, d0, d1; };
+    struct Pending { x265gpu_request req; int b, d0, d1; int p0; bool deferWeights, presearch; };
+    void analyseDeferredWeights();
     bool makeRequest(int p0, int p1, int b, Pending& out);
     bool analyseWeights(Lowres& fenc, Lowres& ref);
     void collect(const Pending& p, const x265gpu_frame_cost& fc);

@@ -277,8 +277,14 @@ typedef struct x265gpu_pu_job
     int32_t mvminX, mvminY, mvmaxX, mvmaxY;   /* full-pel bounds (mvmin / mvmax) */
     int32_t numCandidates;                /* extra quarter-pel candidates mvc[], at most 12 */
     int32_t mvc[24];                      /* x, y pairs */
-    int32_t reserved;
+    int32_t flags;                        /* X265GPU_PU_VERT_RESTRICTION or 0 */
 } x265gpu_pu_job;
+
+/* motionEstimate's m_vertRestriction argument (the reference picture is the current picture, search.cpp:367): the
+ * clipped predictor's y is also held to mvmax.y << 2 (motion.cpp:957-963).  With mvmin <= mvmax, which this entry
+ * point requires, clipping has already done that; the restriction that matters is the one Search::setSearchRange
+ * applies to mvmax (search.cpp:4975-4982), which is the caller's. */
+#define X265GPU_PU_VERT_RESTRICTION 1
 
 typedef struct x265gpu_pu_result
 {

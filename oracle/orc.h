@@ -93,6 +93,7 @@ void orc_luma_hvpp(int w, int h, const pixel* src, intptr_t ss, pixel* dst, intp
 /* ---- MV cost table (orc_bitcost.c) ---- */
 /* out has 4*ORC_BC_MAX_MV+1 entries; element [2*ORC_BC_MAX_MV] is MVD 0 */
 void   orc_bitcost_table(double lambda, uint16_t* out);
+void   orc_bitsizes(float* out);     /* BitCost::s_bitsizes, centred at out[2 * ORC_BC_MAX_MV] */
 double orc_lookahead_lambda(void);   /* x265_lambda_tab[X265_LOOKAHEAD_QP] for this depth */
 
 /* ---- reference planes + motion search (orc_motion.c) ---- */
@@ -113,6 +114,7 @@ typedef struct orc_me {
     int       searchMethod, searchMethodL0, searchMethodL1, subpelRefine;
     /* executed-compare counters (for the algorithmic-op denominators) */
     uint64_t  nSad, nSatd;
+    int       vertRestriction;   /* motionEstimate's m_vertRestriction argument (orc_me_set_vert_restriction) */
 } orc_me;
 
 void orc_me_init(orc_me* me, const uint16_t* centredCost);
@@ -121,6 +123,10 @@ void orc_me_destroy(orc_me* me);
 void orc_me_set_source(orc_me* me, const pixel* fencY, intptr_t stride, intptr_t offset, int w, int h,
                        int method, int searchL0, int searchL1, int refine);
 int  orc_me_buf_satd(orc_me* me, const pixel* ref, intptr_t stride);
+void orc_me_set_vert_restriction(orc_me* me, int on);
+/* SAD of the source PU against the prediction at a quarter-pel vector: predInterLumaPixel + bufSAD as
+ * Search::selectMVP measures a candidate (source/encoder/search.cpp:2372-2379) */
+int  orc_me_pred_sad(orc_me* me, const orc_refplanes* ref, orc_mv qmv);
 /* hmePlane: 0 = search the half-res plane set, 1 = search the quarter-res (HME level-0) plane set */
 int  orc_motion_estimate(orc_me* me, const orc_refplanes* ref, orc_mv mvmin, orc_mv mvmax, orc_mv qmvp,
                          int numCandidates, const orc_mv* mvc, int merange, orc_mv* outQMv,

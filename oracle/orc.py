@@ -153,6 +153,10 @@ def lib(depth=8):
     L.orc_motion_estimate.restype = i
     L.orc_diamond_search.argtypes = [vp, C.POINTER(RefPlanes), MV, MV, MV, C.POINTER(MV)]
     L.orc_diamond_search.restype = i
+    L.orc_me_pred_sad.argtypes = [vp, C.POINTER(RefPlanes), MV]
+    L.orc_me_pred_sad.restype = i
+    L.orc_me_set_vert_restriction.argtypes = [vp, i]
+    L.orc_bitsizes.argtypes = [vp]
     L.orc_mcstf_motion_error.argtypes = [vp, i, vp, i, i, i, i, i, i]
     L.orc_mcstf_level.argtypes = [i, C.POINTER(McstfPlanes), C.POINTER(McstfPlanes), C.POINTER(McstfMvs)]
     L.orc_la_create.argtypes = [C.POINTER(Param), C.POINTER(LaParam), C.POINTER(CuTreeParam), vp]
@@ -203,6 +207,13 @@ def bitcost_table(depth, lam=None):
     L = lib(depth)
     t = np.zeros(4 * BC_MAX_MV + 1, np.uint16)
     L.orc_bitcost_table(L.orc_lookahead_lambda() if lam is None else lam, ptr(t))
+    return t, 2 * BC_MAX_MV
+
+
+def bitsizes(depth=8):
+    """(float32 array, centre index): BitCost::s_bitsizes."""
+    t = np.zeros(4 * BC_MAX_MV + 1, np.float32)
+    lib(depth).orc_bitsizes(ptr(t))
     return t, 2 * BC_MAX_MV
 
 
@@ -410,9 +421,17 @@ class FullResME:
             self.L.orc_me_destroy(self.me)
             self.me = None
 
-    def estimate(self, x, y, w, h, mvp, mvmin, mvmax, method, merange, subpel, mvc=(), max_slices=1):
+    def pred_sad(self, x, y, w, h, qmv):
+        """SAD of the PU against the prediction at quarter-pel vector qmv (one candidate of Search::selectMVP)"""
+        L = self.L
+        L.orc_me_set_source(self.me, C.c_void_p(self.fenc_org), self.stride, y * self.stride + x, w, h, 3, 3, 3, 3)
+        return L.orc_me_pred_sad(self.me, C.byref(self.rp), MV(*qmv))
+
+    def estimate(self, x, y, w, h, mvp, mvmin, mvmax, method, merange, subpel, mvc=(), max_slices=1,
+                 vert_restriction=False):
         """-> ((mvx, mvy), cost)"""
         L = self.L
+        L.orc_me_set_vert_restriction(self.me, int(vert_restriction))
         L.orc_me_set_source(self.me, C.c_void_p(self.fenc_org), self.stride, y * self.stride + x, w, h,
                             method, method, method, subpel)
         arr = (MV * max(1, len(mvc)))(*[MV(int(a), int(b)) for a, b in mvc])

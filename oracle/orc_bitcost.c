@@ -33,3 +33,13 @@ void orc_bitcost_table(double lambda, uint16_t* out)
         c[i] = c[-i] = (uint16_t)v;
     }
 }
+
+/* The float bit sizes behind BitCost::bitcost(mv, mvp): source/encoder/bitcost.cpp:86-101 */
+void orc_bitsizes(float* out)
+{
+    float* c = out + 2 * ORC_BC_MAX_MV;
+    const float log2_2 = 2.0f / logf(2.0f);
+    c[0] = 0.718f;
+    for (int i = 1; i <= 2 * ORC_BC_MAX_MV; i++)
+        c[i] = c[-i] = logf((float)(i + 1)) * log2_2 + 1.718f;
+}

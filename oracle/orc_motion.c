@@ -85,6 +85,8 @@ static int cmp_satd(orc_me* me, const pixel* ref, intptr_t stride)
 
 int orc_me_buf_satd(orc_me* me, const pixel* ref, intptr_t stride) { return cmp_satd(me, ref, stride); }
 
+void orc_me_set_vert_restriction(orc_me* me, int on) { me->vertRestriction = on; }
+
 /* quarter-pel sample fetch by averaging the two nearest half-pel planes:
  * source/common/lowres.h:72-93 */
 const pixel* orc_lowres_mc(const orc_refplanes* ref, intptr_t blockOffset, orc_mv qmv, pixel* buf,
@@ -690,6 +692,18 @@ static int subpel_compare(srch* s, orc_mv qmv, int useSatd)
     return useSatd ? cmp_satd(me, buf, me->bw) : cmp_sad(me, buf, me->bw);
 }
 
+/* One AMVP candidate's cost in Search::selectMVP (source/encoder/search.cpp:2372-2379): the PU is predicted
+ * with Predict::predInterLumaPixel (source/common/predict.cpp:279-300: a copy, luma_hpp, luma_vpp or luma_hvpp
+ * by the vector's fractions) and compared by SAD, which is subpelCompare's arithmetic without the MV cost. */
+int orc_me_pred_sad(orc_me* me, const orc_refplanes* ref, orc_mv qmv)
+{
+    srch S;
+    memset(&S, 0, sizeof(S));
+    S.me = me;
+    S.ref = ref;
+    return subpel_compare(&S, qmv, 0);
+}
+
 /* MotionEstimate::diamondSearch, source/encoder/motion.cpp:631-788: the coarse
  * search Search::puMotionEstimation runs for an area's starting vector
  * (isMVP, source/encoder/search.cpp:360-364).  Full-pel in, full-pel out.
@@ -836,6 +850,8 @@ int orc_motion_estimate(orc_me* me, const orc_refplanes* ref, orc_mv mvmin, orc_
 
     /* clipped quarter-pel predictor, measured by SAD (no MV cost on this term) */
     orc_mv pmv = { imax(imin(qmvp.x, qmax.x), qmin.x), imax(imin(qmvp.y, qmax.y), qmin.y) };
+    if (me->vertRestriction && pmv.y > mvmax.y * 4)       /* motion.cpp:957-963 */
+        pmv.y = mvmax.y * 4;
     orc_mv bestpre = pmv;
     int bprecost = ref->isLowres ? orc_lowres_qpel_cost(me, ref, me->blockOffset, pmv, 0, hme)
                                  : subpel_compare(s, pmv, 0);

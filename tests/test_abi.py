@@ -79,13 +79,14 @@ def test_null_context_is_an_error(lib):
 
 
 def test_host_layer_exports():
-    """The C++ host layer's plain-C face (x265_amd/host/lookahead_host.h) loads beside the library."""
+    """The C++ host layer's plain-C face (x265_amd/host/*.h) loads beside the library."""
     from x265_amd import api
     if not os.path.exists(api.HOST_LIB_PATH):
         import __graft_entry__
         __graft_entry__.build()
     H = api.load_host_library()
-    text = open(os.path.join(ROOT, "x265_amd", "host", "lookahead_host.h")).read()
+    text = "".join(open(os.path.join(ROOT, "x265_amd", "host", f)).read()
+                   for f in ("lookahead_host.h", "threaded_me_host.h"))
     declared = sorted(set(re.findall(r"\b(xgh_[a-z_]+)\s*\(", text)))
     assert declared == sorted(api.HOST_EXPORTS)
     for n in declared:

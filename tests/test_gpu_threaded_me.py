@@ -1,0 +1,138 @@
+"""--threaded-me: the host layer's CTU job generator over the GPU searches against the serial restatement of
+Analysis::deriveMVsForCTU over the CPU oracle's searches, table entry for table entry."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests.tme_serial import SerialTME
+from x265_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _padded(clip, W, H, ctu):
+    mx, my = ctu + 32, ctu + 16
+    fw, fh = -(-W // ctu) * ctu, -(-H // ctu) * ctu
+    return [np.pad(f, ((my, my + fh - H), (mx, mx + fw - W)), mode="edge") for f in clip], mx, my
+
+
+def _run(W, H, depth, rows, method=api.STAR_SEARCH, merange=57, subpel=3, amp=False, rect=True, min_cu=8, ctu=64,
+         num_refs=1, lam=4.0, lookahead=True, seed=3, median=False, second_picture=False):
+    nframes = num_refs + 1 + int(second_picture)
+    clip = synth.luma_clip(W, H, nframes, depth, seed=seed, scene_cut=False)
+    pads, mx, my = _padded(clip, W, H, ctu)
+    cur = num_refs                                            # the P picture; references are the frames before it
+    ref_frames = [cur - 1 - r for r in range(num_refs)]       # list 0, nearest first
+    bitsizes = orc.bitsizes(depth)
+    table, centre = orc.bitcost_table(depth, lam)
+    la_table, la_centre = orc.bitcost_table(depth)
+    with api.Context(W, H, depth=depth, num_slots=nframes, ctu=ctu, keep_full_res=True, bframes=4) as ctx:
+        for k in range(nframes):
+            ctx.lowres_init(k, clip[k], poc=k)
+        lowres = [None] * num_refs
+        if lookahead:
+            # the lookahead's own vectors for the P picture: what Search::getLowresMV reads
+            ctx.set_mvcost(la_table, la_centre)
+            ctx.intra_estimate(list(range(nframes)))
+            for r, f in enumerate(ref_frames):
+                if cur - f <= 5:
+                    ctx.estimate([(f, cur, cur, f, cur, cur, 1, 0)])
+                    lowres[r] = ctx.get_mvs(cur, 0, cur - f)[0]
+        cols, nrows = -(-W // ctu), -(-H // ctu)
+        med = None
+        if median:
+            rng = np.random.default_rng(seed)
+            med = np.zeros((cols * nrows, num_refs, 3), np.int32)
+            med[:, :, 0] = rng.integers(0, 2, (cols * nrows, num_refs))
+            med[:, :, 1:] = rng.integers(-24, 25, (cols * nrows, num_refs, 2))
+        tme = api.ThreadedME(ctx, search=method, merange=merange, subpel=subpel, amp=amp, rect=rect, min_cu=min_cu, lam=lam)
+        try:
+            got = tme.new_table()
+            refs = [(f, f, True, None, lowres[r]) for r, f in enumerate(ref_frames)]
+            tme.estimate_rows(cur, cur, refs, rows[0], rows[1], got, median_mv=med)
+            counts = tme.counts()
+            got2 = None
+            if second_picture:
+                # the next P picture predicted from this one: its reference is a P slice with a table of its own
+                got2 = tme.new_table()
+                tme.estimate_rows(cur + 1, cur + 1, [(cur, cur, False, got, None)], rows[0], rows[1], got2)
+        finally:
+            tme.close()
+    mes = [orc.FullResME(depth, table, centre, pads[cur], pads[f], mx, my) for f in ref_frames]
+    ser = SerialTME(mes, ref_frames, cur, W, H, bitsizes, (table, centre), lam, method=method, merange=merange,
+                    subpel=subpel, amp=amp, rect=rect, ctu=ctu, min_cu=min_cu, lowres_mvs=lowres, median_mv=med)
+    want = ser.run_rows(rows[0], rows[1])
+    for m in mes:
+        m.close()
+    lo, hi = rows[0] * cols, rows[1] * cols
+    for name in ME_FIELDS:
+        np.testing.assert_array_equal(got[name][lo:hi], want[name][lo:hi], err_msg=name)
+    assert (got["ref"][:lo] == -1).all() and (got["ref"][hi:] == -1).all()
+    assert counts["searches"] == ser.searches
+    if second_picture:
+        mes = [orc.FullResME(depth, table, centre, pads[cur + 1], pads[cur], mx, my)]
+        ser2 = SerialTME(mes, [cur], cur + 1, W, H, bitsizes, (table, centre), lam, method=method, merange=merange,
+                         subpel=subpel, amp=amp, rect=rect, ctu=ctu, min_cu=min_cu, ref_is_intra=[False], ref_tables=[want])
+        want2 = ser2.run_rows(rows[0], rows[1])
+        mes[0].close()
+        for name in ME_FIELDS:
+            np.testing.assert_array_equal(got2[name][lo:hi], want2[name][lo:hi], err_msg="second picture " + name)
+    return got, counts
+
+
+ME_FIELDS = ("ref", "mv", "mvp", "mvCost", "bits", "cost")
+
+
+def test_ctu_rows_4k_star_57():
+    """3840x2160, --me star --merange 57 --subme 3, rectangular PUs: the first two CTU rows and the last one,
+    which hangs over the bottom edge of the picture."""
+    got, counts = _run(3840, 2160, 8, (0, 2))
+    assert counts["cols"] == 60 and counts["rows"] == 34
+    used = got[:120]
+    moved = (used["ref"][:, :, 0] >= 0) & ((used["mv"][:, :, 0, 0] != 0) | (used["mv"][:, :, 0, 1] != 0))
+    assert moved.mean() > 0.2                                  # a clip that moves, not a still
+    _run(3840, 2160, 8, (33, 34), seed=4)
+
+
+def test_ctu_rows_4k_10bit():
+    _run(3840, 2160, 10, (16, 17), lam=16.0, seed=5)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(amp=True),                                            # all 24 shapes of the lookup
+    dict(rect=False),                                          # square PUs only (preset medium)
+    dict(amp=True, num_refs=3, lam=9.5),                       # --ref 3: scaled neighbour vectors, best reference per PU
+    dict(method=api.HEX_SEARCH, merange=24, subpel=2, num_refs=2),
+    dict(method=api.UMH_SEARCH, merange=32, subpel=5, amp=True),
+    dict(lookahead=False),                                     # no lookahead vectors: a single search per PU
+    dict(median=True, amp=True),                               # CUData::getMedianColMV overriding the area vectors
+    dict(second_picture=True),                                 # predictors from the reference picture's own table
+    dict(ctu=32, min_cu=16, amp=True),
+    dict(ctu=16, min_cu=8),
+    dict(min_cu=64, size=(448, 256)),                          # one CU per CTU
+], ids=lambda kw: "-".join("%s=%s" % kv for kv in kw.items()))
+def test_ctu_rows_shapes_and_settings(kw):
+    kw = dict(kw)
+    W, H = kw.pop("size", (416, 240))
+    ctu = kw.get("ctu", 64)
+    _run(W, H, 8, (0, -(-H // ctu)), **kw)
+
+
+def test_generator_rejects_what_it_does_not_cover():
+    with api.Context(416, 240, num_slots=2, keep_full_res=True) as ctx:
+        with pytest.raises(api.X265GpuError):
+            api.ThreadedME(ctx, min_cu=4)
+        with pytest.raises(api.X265GpuError):
+            api.ThreadedME(ctx, subpel=9)
+        clip = synth.luma_clip(416, 240, 2, 8, seed=1)
+        ctx.lowres_init(0, clip[0])
+        ctx.lowres_init(1, clip[1])
+        tme = api.ThreadedME(ctx)
+        try:
+            out = tme.new_table()
+            with pytest.raises(api.X265GpuError):               # the picture as its own reference
+                tme.estimate_rows(1, 1, [(1, 1, True, None, None)], 0, 1, out)
+            with pytest.raises(api.X265GpuError):               # rows outside the picture
+                tme.estimate_rows(1, 1, [(0, 0, True, None, None)], 3, 5, out)
+        finally:
+            tme.close()

@@ -384,3 +384,26 @@ def test_picture_statistics_oracle_pin(oracle_built):
     rows = (var.sum(1) // W) & 0xFFFF
     assert st.picAvgVariance == (int(rows.sum()) // H) & 0xFFFF
     lr.close()
+
+
+def test_serial_threaded_me_fills_every_entry_once():
+    """The serial restatement of Analysis::deriveMVsForCTU on one small picture: with AMP and rectangular PUs
+    every one of the 593 entries of a 64x64 CTU's table is written, and a P slice leaves list 1 empty."""
+    from tests.tme_serial import SerialTME
+    from x265_amd import synth
+    W, H, ctu = 128, 64, 64
+    clip = synth.luma_clip(W, H, 2, 8, seed=2, scene_cut=False)
+    mx, my = ctu + 32, ctu + 16
+    pads = [np.pad(f, ((my, my), (mx, mx)), mode="edge") for f in clip]
+    table, centre = orc.bitcost_table(8, 4.0)
+    me = orc.FullResME(8, table, centre, pads[1], pads[0], mx, my)
+    ser = SerialTME([me], [0], 1, W, H, orc.bitsizes(8), (table, centre), 4.0, method=orc.HEX, merange=16, subpel=2,
+                    amp=True, rect=True)
+    out = ser.run_rows(0, 1)
+    me.close()
+    assert (out["ref"][:, :, 0] == 0).all() and (out["ref"][:, :, 1] == -1).all()
+    assert ser.searches >= 2 * (5 + 593)
+    # a vector's bits never cost less than the shortest code: mode bits + MVP index + two zero differences
+    assert (out["bits"] >= 1 + 1 + 1).all() and (out["cost"] > 0).all()
+    # the 64x64 entry is the last of the table (g_puStartIdx), and its predictor is one of its two AMVP candidates
+    assert tuple(out["mvp"][0, 592, 1]) == (0, 0)

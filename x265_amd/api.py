@@ -76,7 +76,7 @@ class PuJob(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32),
                 ("mvpX", C.c_int32), ("mvpY", C.c_int32), ("mvminX", C.c_int32), ("mvminY", C.c_int32),
                 ("mvmaxX", C.c_int32), ("mvmaxY", C.c_int32), ("numCandidates", C.c_int32), ("mvc", C.c_int32 * 24),
-                ("reserved", C.c_int32)]
+                ("flags", C.c_int32)]
 
 
 class PuResult(C.Structure):
@@ -368,13 +368,14 @@ class Context:
         max_mvd = min(centre, len(t) - 1 - centre)
         self._chk(self.L.x265gpu_me_set_mvcost(self.h, C.c_void_p(t.ctypes.data + 2 * centre), max_mvd))
 
-    def pu_motion_estimate(self, slot_fenc, slot_ref, method, merange, subpel, jobs):
+    def pu_motion_estimate(self, slot_fenc, slot_ref, method, merange, subpel, jobs, vert_restriction=False):
         """jobs: iterable of (x, y, w, h, (mvpx, mvpy), (minx, miny), (maxx, maxy), [(cx, cy), ...]);
         returns [((mvx, mvy), cost), ...] in job order."""
         jobs = list(jobs)
         arr = (PuJob * len(jobs))()
         for k, (x, y, w, h, mvp, mvmin, mvmax, mvc) in enumerate(jobs):
             j = arr[k]
+            j.flags = 1 if vert_restriction else 0
             j.x, j.y, j.w, j.h = x, y, w, h
             j.mvpX, j.mvpY = mvp
             j.mvminX, j.mvminY = mvmin
@@ -555,6 +556,7 @@ HOST_EXPORTS = (
     "xgh_lookahead_get_decided", "xgh_lookahead_trace", "xgh_lookahead_cost_est", "xgh_lookahead_cost_est_aq",
     "xgh_lookahead_intra_mbs", "xgh_lookahead_slot", "xgh_lookahead_qp_offsets", "xgh_lookahead_inv_qscale",
     "xgh_lookahead_planned_satd", "xgh_lookahead_recalc_row_satds", "xgh_lookahead_decide_calls", "xgh_lookahead_presearch_hits", "xgh_lookahead_seconds",
+    "xgh_tme_create", "xgh_tme_destroy", "xgh_tme_unsupported", "xgh_tme_estimate_rows", "xgh_tme_counts",
 )
 
 
@@ -654,6 +656,15 @@ def load_host_library():
     H.xgh_lookahead_presearch_hits.argtypes = [vp]
     H.xgh_lookahead_seconds.argtypes = [vp, C.POINTER(C.c_double * 6)]
     H.xgh_lookahead_seconds.restype = None
+    H.xgh_tme_create.argtypes = [vp, vp]
+    H.xgh_tme_create.restype = vp
+    H.xgh_tme_destroy.argtypes = [vp]
+    H.xgh_tme_destroy.restype = None
+    H.xgh_tme_unsupported.argtypes = [vp]
+    H.xgh_tme_unsupported.restype = C.c_char_p
+    H.xgh_tme_estimate_rows.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp]
+    H.xgh_tme_counts.argtypes = [vp, C.POINTER(i64 * 6)]
+    H.xgh_tme_counts.restype = None
     _libs[HOST_LIB_PATH] = H
     return H
 
@@ -875,3 +886,87 @@ class HostLookahead:
     def presearch_hits(self):
         """Searches that single requests found already done (queued ahead with a batch)."""
         return self.H.xgh_lookahead_presearch_hits(self.h)
+
+
+# ---- --threaded-me: motion vectors of every PU shape of a CTU, ahead of analysis ----
+
+MAX_NUM_PUS_PER_CTU = 593
+# MEData (source/encoder/threadedme.h:122-130)
+ME_DATA = np.dtype([("mv", np.int32, (2, 2)), ("mvp", np.int32, (2, 2)), ("mvCost", np.uint32, 2),
+                    ("ref", np.int32, 2), ("bits", np.int32), ("cost", np.uint32)])
+
+
+class TmeParam(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "searchMethod", "searchRange", "subpelRefine", "bEnableAMP", "bEnableRectInter", "maxCUSize", "minCUSize",
+        "bframes", "picWidth", "picHeight", "refLagPixels")] + [("pad", C.c_int32), ("lambda_", C.c_double)]
+
+
+class TmeRef(C.Structure):
+    _fields_ = [("slot", C.c_int32), ("poc", C.c_int32), ("isIntraSlice", C.c_int32), ("pad", C.c_int32),
+                ("ctuMV", C.c_void_p), ("lowresMvs", C.c_void_p)]
+
+
+class ThreadedME:
+    """The host layer's CTU job generator (x265_amd/host/threaded_me_host.h) over a context opened with
+    keep_full_res: Analysis::deriveMVsForCTU for whole CTU rows of a P picture."""
+
+    def __init__(self, ctx, search=STAR_SEARCH, merange=57, subpel=3, amp=False, rect=True, min_cu=8, bframes=4,
+                 lam=1.0, ref_lag_pixels=None):
+        self.H = load_host_library()
+        self.ctx = ctx
+        p = TmeParam()
+        p.searchMethod, p.searchRange, p.subpelRefine = search, merange, subpel
+        p.bEnableAMP, p.bEnableRectInter = int(amp), int(rect)
+        p.maxCUSize, p.minCUSize, p.bframes = ctx.cfg.maxCUSize, min_cu, bframes
+        p.picWidth, p.picHeight = ctx.cfg.sourceWidth, ctx.cfg.sourceHeight
+        p.refLagPixels = ctx.cfg.sourceHeight if ref_lag_pixels is None else ref_lag_pixels
+        p.lambda_ = lam
+        self.param = p
+        self.h = self.H.xgh_tme_create(ctx.h, C.byref(p))
+        if not self.h:
+            raise X265GpuError("xgh_tme_create failed")
+        why = self.H.xgh_tme_unsupported(self.h)
+        if why:
+            self.close()
+            raise X265GpuError("threaded ME: " + why.decode())
+
+    def close(self):
+        if self.h:
+            self.H.xgh_tme_destroy(self.h)
+            self.h = None
+
+    def counts(self):
+        c = (C.c_int64 * 6)()
+        self.H.xgh_tme_counts(self.h, C.byref(c))
+        return dict(zip(("tasks", "levels", "cols", "rows", "searches", "device_calls"), list(c)))
+
+    def new_table(self):
+        c = self.counts()
+        t = np.zeros((c["cols"] * c["rows"], MAX_NUM_PUS_PER_CTU), ME_DATA)
+        t["ref"] = -1
+        return t
+
+    def estimate_rows(self, slot_fenc, poc, refs, row_begin, row_end, out, median_mv=None):
+        """refs: [(slot, poc, is_intra_slice, ctuMV table or None, lowres (cuCount, 2) int32 vectors or None)];
+        fills `out` (new_table()) for the CTU rows [row_begin, row_end)."""
+        arr = (TmeRef * len(refs))()
+        keep = []
+        for k, (slot, rpoc, intra, table, lowres) in enumerate(refs):
+            arr[k].slot, arr[k].poc, arr[k].isIntraSlice = slot, rpoc, int(intra)
+            if table is not None:
+                assert table.dtype == ME_DATA and table.flags.c_contiguous
+                arr[k].ctuMV = table.ctypes.data
+            if lowres is not None:
+                lowres = np.ascontiguousarray(lowres, np.int32)
+                keep.append(lowres)
+                arr[k].lowresMvs = lowres.ctypes.data
+        med = None
+        if median_mv is not None:
+            med = np.ascontiguousarray(median_mv, np.int32)
+        assert out.dtype == ME_DATA and out.flags.c_contiguous
+        rc = self.H.xgh_tme_estimate_rows(self.h, slot_fenc, poc, len(refs), arr, row_begin, row_end,
+                                          None if med is None else med.ctypes.data, out.ctypes.data)
+        if rc:
+            raise X265GpuError("xgh_tme_estimate_rows failed with status %d" % rc)
+        return out

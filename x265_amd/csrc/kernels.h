@@ -118,7 +118,7 @@ struct PuJob
     int minx, miny, maxx, maxy;        // full-pel search bounds
     int numCandidates;                 // extra quarter-pel candidates (at most 12)
     int mvc[24];
-    int reserved;
+    int flags;                         // bit 0: m_vertRestriction
 };
 struct PuResult { int mvx, mvy, cost, reserved; };
 struct PuFrame

@@ -1134,7 +1134,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XG_PU_
 
     // ---- MotionEstimate::motionEstimate, full-resolution reference ----
     const int qminx = job.minx * 4, qminy = job.miny * 4, qmaxx = job.maxx * 4, qmaxy = job.maxy * 4;
-    const int pmvx = clampi(job.mvpx, qminx, qmaxx), pmvy = clampi(job.mvpy, qminy, qmaxy);
+    const int pmvx = clampi(job.mvpx, qminx, qmaxx);
+    int pmvy = clampi(job.mvpy, qminy, qmaxy);
+    if ((job.flags & 1) && pmvy > qmaxy)                      // m_vertRestriction, motion.cpp:957-963
+        pmvy = qmaxy;
     int bestprex = pmvx, bestprey = pmvy;
     int bprecost = block_cost<P, false>(c, pmvx, pmvy);       // SAD, no MV cost on this term
     c.bmx = (pmvx + 2) >> 2;

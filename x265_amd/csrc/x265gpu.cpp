@@ -1416,7 +1416,7 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
         // the PU inside the picture, shapes the tiling handles, vectors that stay inside the padded plane
         if (j.w < 4 || j.h < 4 || j.w > 64 || j.h > 64 || (j.w & 3) || (j.h & 3) || j.x < 0 || j.y < 0 ||
             j.x + j.w > ctx->fullW || j.y + j.h > ctx->fullH || j.numCandidates < 0 || j.numCandidates > 12 ||
-            j.mvminX > j.mvmaxX || j.mvminY > j.mvmaxY ||
+            j.mvminX > j.mvmaxX || j.mvminY > j.mvmaxY || (j.flags & ~X265GPU_PU_VERT_RESTRICTION) ||
             j.x + j.mvminX < -ctx->fullMarginX + 8 || j.x + j.w + j.mvmaxX > ctx->fullW + ctx->fullMarginX - 16 ||
             j.y + j.mvminY < -ctx->fullMarginY + 8 || j.y + j.h + j.mvmaxY > ctx->fullH + ctx->fullMarginY - 8)
         {

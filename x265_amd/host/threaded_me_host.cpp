@@ -1,0 +1,721 @@
+// --threaded-me CTU job generator above the x265gpu C-ABI (see threaded_me_host.h)
+#include "threaded_me_host.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+namespace x265gpu_host {
+
+namespace {
+
+constexpr int BC_MAX_MV = 1 << 15;          // source/encoder/bitcost.h:92
+constexpr int MVP_IDX_BITS = 1;             // source/encoder/search.h
+constexpr int AREA_SEARCH_RANGE = 32;       // search.cpp:234
+
+struct PUBlock { int w, h, part; bool amp; };
+
+// g_puLookup (source/encoder/threadedme.h:67-92): every luma PU shape of a 64x64 CTU, smallest CU first
+const PUBlock kPuLookup[MAX_NUM_PU_SIZES] = {
+    { 8, 4, SIZE_2NxN, false },   { 4, 8, SIZE_Nx2N, false },   { 8, 8, SIZE_2Nx2N, false },
+    { 16, 4, SIZE_2NxnU, true },  { 16, 12, SIZE_2NxnD, true }, { 4, 16, SIZE_nLx2N, true },  { 12, 16, SIZE_nRx2N, true },
+    { 16, 8, SIZE_2NxN, false },  { 8, 16, SIZE_Nx2N, false },  { 16, 16, SIZE_2Nx2N, false },
+    { 32, 8, SIZE_2NxnU, true },  { 32, 24, SIZE_2NxnD, true }, { 8, 32, SIZE_nLx2N, true },  { 24, 32, SIZE_nRx2N, true },
+    { 32, 16, SIZE_2NxN, false }, { 16, 32, SIZE_Nx2N, false }, { 32, 32, SIZE_2Nx2N, false },
+    { 64, 16, SIZE_2NxnU, true }, { 64, 48, SIZE_2NxnD, true }, { 16, 64, SIZE_nLx2N, true }, { 48, 64, SIZE_nRx2N, true },
+    { 64, 32, SIZE_2NxN, false }, { 32, 64, SIZE_Nx2N, false }, { 64, 64, SIZE_2Nx2N, false },
+};
+
+inline bool operator==(MV a, MV b) { return a.x == b.x && a.y == b.y; }
+inline bool operator!=(MV a, MV b) { return !(a == b); }
+inline bool notZero(MV a) { return (a.x | a.y) != 0; }
+inline int clip3(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
+
+// scaleMv + CUData::scaleMvByPOCDist (source/common/cudata.cpp:104-110, 2229-2244)
+MV scaleMvByPOCDist(MV in, int curPOC, int curRefPOC, int colPOC, int colRefPOC)
+{
+    const int diffPocD = colPOC - colRefPOC, diffPocB = curPOC - curRefPOC;
+    if (diffPocD == diffPocB)
+        return in;
+    const int tdb = clip3(-128, 127, diffPocB), tdd = clip3(-128, 127, diffPocD);
+    const int x = (0x4000 + abs(tdd / 2)) / tdd;
+    const int scale = clip3(-4096, 4095, (tdb * x + 32) >> 6);
+    MV out;
+    out.x = clip3(-32768, 32767, (scale * in.x + 127 + (scale * in.x < 0)) >> 8);
+    out.y = clip3(-32768, 32767, (scale * in.y + 127 + (scale * in.y < 0)) >> 8);
+    return out;
+}
+
+// InterNeighbourMV (source/common/cudata.h:106-125), the fields this path reads
+struct Neighbour { MV mv[2]; int refIdx[2]; };
+
+struct SliceRefs
+{
+    int poc;
+    int numRefIdx[2];
+    int refPOC[2][16];
+};
+
+// CUData::getDirectPMV / getIndirectPMV (source/common/cudata.cpp:2110-2156)
+bool getDirectPMV(const SliceRefs& s, MV& pmv, const Neighbour& nb, int picList, int refIdx)
+{
+    const int curRefPOC = s.refPOC[picList][refIdx];
+    for (int i = 0; i < 2; i++, picList = !picList)
+    {
+        const int partRefIdx = nb.refIdx[picList];
+        if (partRefIdx >= 0 && curRefPOC == s.refPOC[picList][partRefIdx])
+        {
+            pmv = nb.mv[picList];
+            return true;
+        }
+    }
+    return false;
+}
+
+bool getIndirectPMV(const SliceRefs& s, MV& out, const Neighbour& nb, int picList, int refIdx)
+{
+    const int curRefPOC = s.refPOC[picList][refIdx];
+    for (int i = 0; i < 2; i++, picList = !picList)
+    {
+        const int partRefIdx = nb.refIdx[picList];
+        if (partRefIdx >= 0)
+        {
+            out = scaleMvByPOCDist(nb.mv[picList], s.poc, curRefPOC, s.poc, s.refPOC[picList][partRefIdx]);
+            return true;
+        }
+    }
+    return false;
+}
+
+// CUData::getPMV without a temporal candidate (source/common/cudata.cpp:1845-1905, 1980-1983): the two AMVP
+// candidates and the wider list of motion candidates; returns the size of that list
+int getPMV(const SliceRefs& s, const Neighbour* nb, int picList, int refIdx, MV amvpCand[2], MV* pmv)
+{
+    MV direct[MD_ABOVE_LEFT + 1], indirect[MD_ABOVE_LEFT + 1];
+    bool validDirect[MD_ABOVE_LEFT + 1], validIndirect[MD_ABOVE_LEFT + 1];
+    for (int dir = MD_LEFT; dir <= MD_ABOVE_LEFT; dir++)
+    {
+        validDirect[dir] = getDirectPMV(s, direct[dir], nb[dir], picList, refIdx);
+        validIndirect[dir] = getIndirectPMV(s, indirect[dir], nb[dir], picList, refIdx);
+    }
+    int num = 0;
+    if (validDirect[MD_BELOW_LEFT])
+        amvpCand[num++] = direct[MD_BELOW_LEFT];
+    else if (validDirect[MD_LEFT])
+        amvpCand[num++] = direct[MD_LEFT];
+    else if (validIndirect[MD_BELOW_LEFT])
+        amvpCand[num++] = indirect[MD_BELOW_LEFT];
+    else if (validIndirect[MD_LEFT])
+        amvpCand[num++] = indirect[MD_LEFT];
+    const bool addedLeft = num > 0;
+    if (validDirect[MD_ABOVE_RIGHT])
+        amvpCand[num++] = direct[MD_ABOVE_RIGHT];
+    else if (validDirect[MD_ABOVE])
+        amvpCand[num++] = direct[MD_ABOVE];
+    else if (validDirect[MD_ABOVE_LEFT])
+        amvpCand[num++] = direct[MD_ABOVE_LEFT];
+    if (!addedLeft)
+    {
+        if (validIndirect[MD_ABOVE_RIGHT])
+            amvpCand[num++] = indirect[MD_ABOVE_RIGHT];
+        else if (validIndirect[MD_ABOVE])
+            amvpCand[num++] = indirect[MD_ABOVE];
+        else if (validIndirect[MD_ABOVE_LEFT])
+            amvpCand[num++] = indirect[MD_ABOVE_LEFT];
+    }
+    int numMvc = 0;
+    for (int dir = MD_LEFT; dir <= MD_ABOVE_LEFT; dir++)
+    {
+        if (validDirect[dir] && notZero(direct[dir]))
+            pmv[numMvc++] = direct[dir];
+        if (validIndirect[dir] && notZero(indirect[dir]))
+            pmv[numMvc++] = indirect[dir];
+    }
+    if (num == 2)
+        num -= amvpCand[0] == amvpCand[1];
+    while (num < 2)
+        amvpCand[num].x = amvpCand[num].y = 0, num++;
+    return numMvc;
+}
+
+// Search::getBlkBits for a P slice (search.cpp:4894-4940): list-selection bits of list 0
+int listSelBitsP(int partSize) { return partSize == SIZE_2Nx2N || partSize == SIZE_NxN ? 1 : 3; }
+
+inline int getTUBits(int idx, int numIdx) { return idx + (idx < numIdx - 1); }   // search.h:252-255
+
+}  // namespace
+
+ThreadedME::ThreadedME(x265gpu_ctx* ctx, const TmeParam& p)
+    : m_ctx(ctx), m_p(p), m_unsupported(NULL), m_numCuInWidth(0), m_numCuInHeight(0), m_numLevels(0), m_lambdaFix8(0),
+      m_searches(0), m_deviceCalls(0)
+{
+    const int ctu = p.maxCUSize, mn = p.minCUSize;
+    if ((ctu != 16 && ctu != 32 && ctu != 64) || (mn != 8 && mn != 16 && mn != 32 && mn != 64) || mn > ctu)
+        m_unsupported = "maxCUSize must be 16, 32 or 64 and minCUSize 8..maxCUSize";
+    else if (p.picWidth < ctu || p.picHeight < ctu || p.picWidth % mn || p.picHeight % mn)
+        m_unsupported = "picture size must be a multiple of minCUSize";
+    else if (p.searchRange < 1 || p.searchRange > 32767 || p.subpelRefine < 0 || p.subpelRefine > 7 || !(p.lambda > 0))
+        m_unsupported = "searchRange, subpelRefine or lambda out of range";
+    if (m_unsupported)
+        return;
+    m_numCuInWidth = (p.picWidth + ctu - 1) / ctu;
+    m_numCuInHeight = (p.picHeight + ctu - 1) / ctu;
+    // BitCost::s_bitsizes and the lambda-scaled table of BitCost::setQP (source/encoder/bitcost.cpp:31-101)
+    m_bitsizes.resize(4 * BC_MAX_MV + 1);
+    m_costTable.resize(4 * BC_MAX_MV + 1);
+    float* bs = m_bitsizes.data() + 2 * BC_MAX_MV;
+    uint16_t* ct = m_costTable.data() + 2 * BC_MAX_MV;
+    const float twoOverLn2 = 2.0f / logf(2.0f);
+    bs[0] = 0.718f;
+    for (int i = 1; i <= 2 * BC_MAX_MV; i++)
+        bs[i] = bs[-i] = logf((float)(i + 1)) * twoOverLn2 + 1.718f;
+    for (int i = 0; i <= 2 * BC_MAX_MV; i++)
+    {
+        const double scaled = bs[i] * p.lambda + 0.5f;
+        ct[i] = ct[-i] = (uint16_t)(scaled < 32767.0 ? scaled : 32767.0);
+    }
+    m_lambdaFix8 = (uint64_t)floor(256.0 * p.lambda);       // RDCost::setLambda (source/encoder/rdcost.h:88-92)
+    buildTasks();
+}
+
+// ThreadedME::initPuStartIdx (source/encoder/threadedme.cpp:84-106), then the call order of
+// Analysis::computeMVForPUs for one CTU
+void ThreadedME::buildTasks()
+{
+    const int ctu = m_p.maxCUSize;
+    for (auto& row : m_puStartIdx)
+        for (int& v : row)
+            v = -1;
+    int startIdx = 0;
+    for (const PUBlock& pu : kPuLookup)
+    {
+        if (pu.w > ctu || pu.h > ctu)
+            continue;
+        const int indexW = pu.amp ? std::max(pu.w, pu.h) : pu.w, indexH = pu.amp ? indexW : pu.h;
+        const int numPUs = (ctu / indexW) * (ctu / indexH);
+        m_puStartIdx[pu.w + pu.h][pu.part] = startIdx;
+        startIdx += pu.amp ? 2 * numPUs : numPUs;
+    }
+    std::vector<int> writer(MAX_NUM_PUS_PER_CTU, -1);
+    m_tasks.clear();
+    visit(0, 0, ctu, writer);
+    m_numLevels = 0;
+    for (const PuTask& t : m_tasks)
+        m_numLevels = std::max(m_numLevels, t.level + 1);
+}
+
+// Analysis::computeMVForPUs (analysis.cpp:161-246): children first, then every shape of this CU size.
+// writer[entry] = the task that fills that entry of the CTU's table, -1 while nobody has.
+void ThreadedME::visit(int cuX, int cuY, int cuSize, std::vector<int>& writer)
+{
+    const int ctu = m_p.maxCUSize;
+    if (cuSize > m_p.minCUSize)
+        for (int sub = 0; sub < 4; sub++)
+            visit(cuX + (sub & 1) * (cuSize >> 1), cuY + (sub >> 1) * (cuSize >> 1), cuSize >> 1, writer);
+    const int areaId = cuSize != ctu ? (cuX >= ctu / 2) + 2 * (cuY >= ctu / 2) + 1 : 0;
+    for (const PUBlock& pu : kPuLookup)
+    {
+        if (pu.w > cuSize || pu.h > cuSize || (pu.w != cuSize && pu.h != cuSize))
+            continue;
+        if (!m_p.bEnableAMP && pu.amp)
+            continue;
+        if (!m_p.bEnableRectInter && pu.w != pu.h && !pu.amp)
+            continue;
+        const int startIdx = m_puStartIdx[pu.w + pu.h][pu.part];
+        const int blockW = pu.amp ? std::max(pu.w, pu.h) : pu.w, blockH = pu.amp ? blockW : pu.h;
+        const int numCols = ctu / blockW, numRows = ctu / blockH;
+        PuTask t;
+        memset(&t, 0, sizeof(t));
+        t.cuX = cuX;
+        t.cuY = cuY;
+        t.cuSize = cuSize;
+        t.partSize = pu.part;
+        t.numPart = pu.part == SIZE_2Nx2N ? 1 : 2;
+        t.areaId = areaId;
+        t.puOffset = pu.amp ? numRows * numCols : pu.part == SIZE_2NxN ? numCols : pu.part == SIZE_Nx2N ? 1 : 0;
+        const int puCol = cuX / blockW, puRow = cuY / blockH;
+        t.finalIdx = startIdx + puRow * numCols + puCol;
+        const int left = puCol > 0 ? startIdx + puRow * numCols + puCol - 1 : -1;
+        const int above = puRow > 0 ? startIdx + (puRow - 1) * numCols + puCol : -1;
+        const int aboveLeft = puRow > 0 && puCol > 0 ? startIdx + (puRow - 1) * numCols + puCol - 1 : -1;
+        const int aboveRight = puRow > 0 && puCol < numCols - 1 ? startIdx + (puRow - 1) * numCols + puCol + 1 : -1;
+        const int nb[5] = { left, above, aboveRight, -1, aboveLeft };
+        t.level = 0;
+        for (int dir = 0; dir < 5; dir++)
+        {
+            // an entry nobody has filled yet still holds REF_NOT_VALID when x265 reads it (framedata.cpp:93-102)
+            const bool written = nb[dir] >= 0 && writer[nb[dir]] >= 0;
+            t.nb[dir] = written ? nb[dir] : -1;
+            if (written)
+                t.level = std::max(t.level, m_tasks[writer[nb[dir]]].level + 1);
+        }
+        // CUData::getPartIndexAndSize for both parts (source/common/cudata.cpp:1313-1322)
+        const int s = cuSize, q = s >> 2, hlf = s >> 1;
+        switch (pu.part)
+        {
+        case SIZE_2Nx2N: t.pu[0] = { 0, 0, s, s }; break;
+        case SIZE_2NxN:  t.pu[0] = { 0, 0, s, hlf };   t.pu[1] = { 0, hlf, s, hlf }; break;
+        case SIZE_Nx2N:  t.pu[0] = { 0, 0, hlf, s };   t.pu[1] = { hlf, 0, hlf, s }; break;
+        case SIZE_2NxnU: t.pu[0] = { 0, 0, s, q };     t.pu[1] = { 0, q, s, s - q }; break;
+        case SIZE_2NxnD: t.pu[0] = { 0, 0, s, s - q }; t.pu[1] = { 0, s - q, s, q }; break;
+        case SIZE_nLx2N: t.pu[0] = { 0, 0, q, s };     t.pu[1] = { q, 0, s - q, s }; break;
+        default:         t.pu[0] = { 0, 0, s - q, s }; t.pu[1] = { s - q, 0, q, s }; break;
+        }
+        for (int k = 0; k < t.numPart; k++)
+        {
+            t.pu[k].x += cuX;
+            t.pu[k].y += cuY;
+            writer[t.finalIdx + k * t.puOffset] = (int)m_tasks.size();
+        }
+        m_tasks.push_back(t);
+    }
+}
+
+// BitCost::bitcost(mv, mvp) and BitCost::mvcost (source/encoder/bitcost.h:56-69)
+uint32_t ThreadedME::bitcost(MV mv, MV mvp) const
+{
+    const float* bs = m_bitsizes.data() + 2 * BC_MAX_MV;
+    return (uint32_t)(bs[mv.x - mvp.x] + bs[mv.y - mvp.y] + 0.5f);
+}
+
+uint32_t ThreadedME::mvcost(MV mv, MV mvp) const
+{
+    const uint16_t* ct = m_costTable.data() + 2 * BC_MAX_MV;
+    return (uint16_t)(ct[mv.x - mvp.x] + ct[mv.y - mvp.y]);
+}
+
+// CUData::clipMv (source/common/cudata.cpp:2094-2107)
+void ThreadedME::clipMv(int cuPelX, int cuPelY, MV& mv) const
+{
+    const int offset = 8;
+    const int xmax = (m_p.picWidth + offset - cuPelX - 1) * 4, xmin = -((m_p.maxCUSize + offset + cuPelX - 1) * 4);
+    const int ymax = (m_p.picHeight + offset - cuPelY - 1) * 4, ymin = -((m_p.maxCUSize + offset + cuPelY - 1) * 4);
+    mv.x = std::min(xmax, std::max(xmin, mv.x));
+    mv.y = std::min(ymax, std::max(ymin, mv.y));
+}
+
+// Search::setSearchRange (search.cpp:4969-5022) for one slice, no intra refresh, and a reference that is not
+// the current picture
+void ThreadedME::setSearchRange(int cuPelX, int cuPelY, MV mvp, int merange, MV& mvmin, MV& mvmax) const
+{
+    mvmin = { mvp.x - merange * 4, mvp.y - merange * 4 };
+    mvmax = { mvp.x + merange * 4, mvp.y + merange * 4 };
+    clipMv(cuPelX, cuPelY, mvmin);
+    clipMv(cuPelX, cuPelY, mvmax);
+    const int maxMvLen = (1 << 15) - 1;
+    mvmin.x = std::max(mvmin.x, -maxMvLen);
+    mvmin.y = std::max(mvmin.y, -maxMvLen);
+    mvmax.x = std::min(mvmax.x, maxMvLen);
+    mvmax.y = std::min(mvmax.y, maxMvLen);
+    mvmin.x >>= 2;
+    mvmin.y >>= 2;
+    mvmax.x >>= 2;
+    mvmax.y >>= 2;
+    mvmin.y = std::min(mvmin.y, m_p.refLagPixels);
+    mvmax.y = std::min(mvmax.y, m_p.refLagPixels);
+    mvmax.y = std::max(mvmax.y, mvmin.y);
+}
+
+namespace {
+
+// one puIdx of one puMotionEstimation call of one CTU
+struct Item
+{
+    int ctuAddr, ctuLocal, task, puIdx;
+    int x, y, w, h;              // PU in the picture
+    int cuPelX, cuPelY;
+};
+
+// what one reference's pass leaves for the closing bookkeeping
+struct RefPass
+{
+    MV amvp[2];
+    MV mvp, mvpLowres;
+    int mvpIdx, numMvc;
+    MV mvc[14];
+    bool bLowresMVP;
+    int cmpJob, job0, job1;
+};
+
+struct RefOut { MV mv, mvp; uint32_t bits, cost, mvCost; };
+
+inline x265gpu_pu_job makeJob(const Item& it, MV mvp, MV mvmin, MV mvmax, int numMvc, const MV* mvc)
+{
+    x265gpu_pu_job j;
+    memset(&j, 0, sizeof(j));
+    j.x = it.x;
+    j.y = it.y;
+    j.w = it.w;
+    j.h = it.h;
+    j.mvpX = mvp.x;
+    j.mvpY = mvp.y;
+    j.mvminX = mvmin.x;
+    j.mvminY = mvmin.y;
+    j.mvmaxX = mvmax.x;
+    j.mvmaxY = mvmax.y;
+    j.numCandidates = numMvc;
+    for (int i = 0; i < numMvc; i++)
+    {
+        j.mvc[2 * i] = mvc[i].x;
+        j.mvc[2 * i + 1] = mvc[i].y;
+    }
+    return j;
+}
+
+}  // namespace
+
+int ThreadedME::estimateRows(int slotFenc, int poc, int numRefs, const TmeRef* refs, int rowBegin, int rowEnd,
+                             const int32_t* medianMv, MEData* out)
+{
+    if (m_unsupported || !m_ctx || !refs || !out || numRefs < 1 || numRefs > 16 || rowBegin < 0 || rowEnd > m_numCuInHeight ||
+        rowBegin >= rowEnd)
+        return X265GPU_ERR_ARG;
+    SliceRefs slice;
+    memset(&slice, 0, sizeof(slice));
+    slice.poc = poc;
+    slice.numRefIdx[0] = numRefs;
+    for (int r = 0; r < numRefs; r++)
+    {
+        if (refs[r].poc == poc)
+            return X265GPU_ERR_UNSUPPORTED;          // the current picture as its own reference (screen content)
+        slice.refPOC[0][r] = refs[r].poc;
+    }
+    const int ctu = m_p.maxCUSize;
+    const int numCtus = (rowEnd - rowBegin) * m_numCuInWidth, firstCtu = rowBegin * m_numCuInWidth;
+    const int lowresBlocksInRow = ((m_p.picWidth / 2) + 7) >> 3;       // Lowres::maxBlocksInRow
+    int rc = x265gpu_me_set_mvcost(m_ctx, m_costTable.data() + 2 * BC_MAX_MV, 2 * BC_MAX_MV);
+    if (rc)
+        return rc;
+    m_deviceCalls++;
+
+    for (int c = 0; c < numCtus; c++)
+        for (int k = 0; k < MAX_NUM_PUS_PER_CTU; k++)
+        {
+            MEData& e = out[(size_t)(firstCtu + c) * MAX_NUM_PUS_PER_CTU + k];
+            memset(&e, 0, sizeof(e));
+            e.ref[0] = e.ref[1] = REF_NOT_VALID;
+        }
+
+    // ---- the area searches of deriveMVsForCTU (analysis.cpp:258-302): a diamond search over the CTU and over
+    //      its four quadrants from the zero vector, per reference; their full-pel results become predictors ----
+    const int numAreas = ctu != m_p.minCUSize ? 5 : 1;
+    std::vector<MV> areaBest((size_t)numCtus * 5 * numRefs, MV{ 0, 0 });
+    std::vector<x265gpu_pu_job> jobs;
+    std::vector<x265gpu_pu_result> results;
+    for (int r = 0; r < numRefs; r++)
+    {
+        jobs.clear();
+        for (int c = 0; c < numCtus; c++)
+        {
+            const int addr = firstCtu + c, ctuX = (addr % m_numCuInWidth) * ctu, ctuY = (addr / m_numCuInWidth) * ctu;
+            for (int a = 0; a < numAreas; a++)
+            {
+                Item it;
+                it.w = it.h = a ? ctu / 2 : ctu;
+                it.x = ctuX + (a ? ((a - 1) & 1) * (ctu / 2) : 0);
+                it.y = ctuY + (a ? ((a - 1) >> 1) * (ctu / 2) : 0);
+                MV mvmin, mvmax;
+                setSearchRange(it.x, it.y, MV{ 0, 0 }, AREA_SEARCH_RANGE, mvmin, mvmax);
+                jobs.push_back(makeJob(it, MV{ 0, 0 }, mvmin, mvmax, 0, NULL));
+            }
+        }
+        results.resize(jobs.size());
+        rc = x265gpu_pu_motion_estimate(m_ctx, slotFenc, refs[r].slot, X265GPU_AREA_DIAMOND_SEARCH, AREA_SEARCH_RANGE, 0,
+                                        (int)jobs.size(), jobs.data(), results.data());
+        if (rc)
+            return rc;
+        m_deviceCalls++;
+        m_searches += (int64_t)jobs.size();
+        for (int c = 0; c < numCtus; c++)
+            for (int a = 0; a < numAreas; a++)
+            {
+                const x265gpu_pu_result& res = results[(size_t)c * numAreas + a];
+                areaBest[((size_t)c * 5 + a) * numRefs + r] = MV{ res.mvX, res.mvY };
+            }
+        if (medianMv)
+            for (int c = 0; c < numCtus; c++)
+            {
+                const int32_t* m = medianMv + ((size_t)(firstCtu + c) * numRefs + r) * 3;
+                if (m[0])
+                    for (int a = 0; a < 5; a++)
+                        areaBest[((size_t)c * 5 + a) * numRefs + r] = MV{ m[1], m[2] };
+            }
+    }
+
+    // ---- computeMVForPUs, one dependency level at a time over all CTUs ----
+    std::vector<Item> items;
+    std::vector<RefPass> pass;
+    std::vector<RefOut> refOut;
+    std::vector<x265gpu_block_job> cmpJobs;
+    std::vector<int32_t> cmpCosts;
+    for (int level = 0; level < m_numLevels; level++)
+    {
+        items.clear();
+        for (int c = 0; c < numCtus; c++)
+        {
+            const int addr = firstCtu + c, ctuX = (addr % m_numCuInWidth) * ctu, ctuY = (addr / m_numCuInWidth) * ctu;
+            for (size_t ti = 0; ti < m_tasks.size(); ti++)
+            {
+                const PuTask& t = m_tasks[ti];
+                if (t.level != level)
+                    continue;
+                for (int k = 0; k < t.numPart; k++)
+                    items.push_back(Item{ addr, c, (int)ti, k, ctuX + t.pu[k].x, ctuY + t.pu[k].y, t.pu[k].w, t.pu[k].h,
+                                          ctuX + t.cuX, ctuY + t.cuY });
+            }
+        }
+        refOut.assign(items.size() * numRefs, RefOut());
+        for (int r = 0; r < numRefs; r++)
+        {
+            pass.assign(items.size(), RefPass());
+            cmpJobs.clear();
+            // predictors (search.cpp:269-330)
+            for (size_t i = 0; i < items.size(); i++)
+            {
+                const Item& it = items[i];
+                const PuTask& t = m_tasks[it.task];
+                RefPass& ps = pass[i];
+                ps.mvp = areaBest[((size_t)it.ctuLocal * 5 + t.areaId) * numRefs + r];
+                ps.amvp[0] = ps.amvp[1] = MV{ 0, 0 };
+                ps.mvpIdx = 0;
+                ps.cmpJob = ps.job0 = ps.job1 = -1;
+                Neighbour nb[MD_ABOVE_LEFT + 1];
+                for (int dir = MD_LEFT; dir <= MD_ABOVE_LEFT; dir++)
+                {
+                    if (t.nb[dir] >= 0)
+                    {
+                        const MEData& nd = out[(size_t)it.ctuAddr * MAX_NUM_PUS_PER_CTU + t.nb[dir]];
+                        for (int l = 0; l < 2; l++)
+                        {
+                            nb[dir].mv[l] = nd.mv[l];
+                            nb[dir].refIdx[l] = nd.ref[l];
+                        }
+                    }
+                    else
+                    {
+                        nb[dir].mv[0] = nb[dir].mv[1] = MV{ 0, 0 };
+                        nb[dir].refIdx[0] = nb[dir].refIdx[1] = -1;
+                    }
+                }
+                MV cand[2];
+                ps.numMvc = getPMV(slice, nb, 0, r, cand, ps.mvc);
+                if (ps.numMvc > 0)
+                {
+                    ps.amvp[0] = cand[0];
+                    ps.amvp[1] = cand[1];
+                    if (cand[0] != cand[1])
+                    {
+                        // Search::selectMVP (search.cpp:2347-2383): SAD of the prediction at each clipped candidate
+                        ps.cmpJob = (int)cmpJobs.size();
+                        for (int k = 0; k < 2; k++)
+                        {
+                            MV mvCand = cand[k];
+                            clipMv(it.cuPelX, it.cuPelY, mvCand);
+                            x265gpu_block_job bj = { it.x, it.y, it.w, it.h, mvCand.x, mvCand.y, X265GPU_OP_SAD, 0 };
+                            cmpJobs.push_back(bj);
+                        }
+                    }
+                    else
+                        ps.mvp = cand[0];
+                }
+                else if (!refs[r].isIntraSlice && refs[r].ctuMV)
+                {
+                    const int pos = t.finalIdx + it.puIdx * t.puOffset;
+                    const MEData& md = refs[r].ctuMV[(size_t)it.ctuAddr * MAX_NUM_PUS_PER_CTU + pos];
+                    const bool bi = md.ref[0] >= 0 && md.ref[1] >= 0;
+                    const bool uniL0 = md.ref[0] >= 0 && md.ref[1] == REF_NOT_VALID;
+                    const bool uniL1 = md.ref[1] >= 0 && md.ref[0] == REF_NOT_VALID;
+                    if (uniL0)
+                        ps.mvp = md.mv[0];
+                    else if (uniL1)
+                        ps.mvp = md.mv[1];
+                    else if (bi)
+                        ps.mvp = md.mv[0];
+                }
+            }
+            if (!cmpJobs.empty())
+            {
+                cmpCosts.resize(cmpJobs.size());
+                rc = x265gpu_block_compare(m_ctx, slotFenc, refs[r].slot, (int)cmpJobs.size(), cmpJobs.data(), cmpCosts.data());
+                if (rc)
+                    return rc;
+                m_deviceCalls++;
+            }
+            // lookahead candidate, search windows, search jobs (search.cpp:332-386)
+            jobs.clear();
+            const int diffPoc = abs(poc - refs[r].poc);
+            const int32_t* lowresMvs = diffPoc > m_p.bframes + 1 ? NULL : refs[r].lowresMvs;
+            for (size_t i = 0; i < items.size(); i++)
+            {
+                const Item& it = items[i];
+                RefPass& ps = pass[i];
+                if (ps.cmpJob >= 0)
+                {
+                    ps.mvpIdx = (uint32_t)cmpCosts[ps.cmpJob] <= (uint32_t)cmpCosts[ps.cmpJob + 1] ? 0 : 1;
+                    ps.mvp = ps.amvp[ps.mvpIdx];
+                }
+                ps.bLowresMVP = false;
+                ps.mvpLowres = MV{ 0, 0 };
+                const int blockX = it.x + (it.w >> 1), blockY = it.y + (it.h >> 1);
+                if (blockX < m_p.picWidth && blockY < m_p.picHeight)
+                {
+                    MV lmv = { 0, 0 };
+                    if (lowresMvs)       // Search::getLowresMV (search.cpp:2323-2343)
+                    {
+                        const size_t idx = (size_t)(blockY >> 4) * lowresBlocksInRow + (blockX >> 4);
+                        lmv = MV{ lowresMvs[2 * idx] * 2, lowresMvs[2 * idx + 1] * 2 };
+                    }
+                    if (notZero(lmv))
+                    {
+                        ps.mvc[ps.numMvc++] = lmv;
+                        ps.bLowresMVP = true;
+                    }
+                    ps.mvpLowres = lmv;
+                }
+                MV mvmin, mvmax;
+                setSearchRange(it.cuPelX, it.cuPelY, ps.mvp, m_p.searchRange, mvmin, mvmax);
+                ps.job0 = (int)jobs.size();
+                jobs.push_back(makeJob(it, ps.mvp, mvmin, mvmax, ps.numMvc, ps.mvc));
+                if (ps.bLowresMVP && notZero(ps.mvpLowres) && ps.mvpLowres != ps.mvp)
+                {
+                    setSearchRange(it.cuPelX, it.cuPelY, ps.mvpLowres, m_p.searchRange, mvmin, mvmax);
+                    ps.job1 = (int)jobs.size();
+                    jobs.push_back(makeJob(it, ps.mvpLowres, mvmin, mvmax, ps.numMvc, ps.mvc));
+                }
+            }
+            results.resize(jobs.size());
+            rc = x265gpu_pu_motion_estimate(m_ctx, slotFenc, refs[r].slot, m_p.searchMethod, m_p.searchRange, m_p.subpelRefine,
+                                            (int)jobs.size(), jobs.data(), results.data());
+            if (rc)
+                return rc;
+            m_deviceCalls++;
+            m_searches += (int64_t)jobs.size();
+            // bits and cost of this reference's vector (search.cpp:366-398)
+            for (size_t i = 0; i < items.size(); i++)
+            {
+                const Item& it = items[i];
+                const PuTask& t = m_tasks[it.task];
+                RefPass& ps = pass[i];
+                uint32_t bits = (uint32_t)(listSelBitsP(t.partSize) + MVP_IDX_BITS + getTUBits(r, numRefs));
+                MV outmv = { results[ps.job0].mvX, results[ps.job0].mvY };
+                int satdCost = results[ps.job0].cost;
+                MV meMvp = ps.mvp;                    // the predictor MotionEstimate holds after its last search
+                bool bLowresMVP = ps.bLowresMVP;
+                if (ps.job1 >= 0)
+                {
+                    bLowresMVP = false;
+                    meMvp = ps.mvpLowres;
+                    if (results[ps.job1].cost < satdCost)
+                    {
+                        outmv = MV{ results[ps.job1].mvX, results[ps.job1].mvY };
+                        satdCost = results[ps.job1].cost;
+                        bLowresMVP = true;
+                    }
+                }
+                bits += bitcost(outmv, meMvp);
+                const uint32_t mvCost = mvcost(outmv, meMvp);
+                uint32_t cost = ((uint32_t)satdCost - mvCost) + getCost(bits);
+                if (bLowresMVP)
+                {
+                    // Search::updateMVP (search.cpp:4961-4967)
+                    const int diffBits = (int)bitcost(outmv, ps.mvp) - (int)bitcost(outmv, ps.mvpLowres);
+                    const uint32_t origBits = bits;
+                    bits = origBits + diffBits;
+                    cost = (cost - getCost(origBits)) + getCost(bits);
+                }
+                // Search::checkBestMVP (search.cpp:4947-4958)
+                int mvpIdx = ps.mvpIdx;
+                const int diffBits = (int)bitcost(outmv, ps.amvp[!mvpIdx]) - (int)bitcost(outmv, ps.amvp[mvpIdx]);
+                if (diffBits < 0)
+                {
+                    mvpIdx = !mvpIdx;
+                    const uint32_t origBits = bits;
+                    bits = origBits + diffBits;
+                    cost = (cost - getCost(origBits)) + getCost(bits);
+                }
+                RefOut& ro = refOut[i * numRefs + r];
+                ro.mv = outmv;
+                ro.mvp = ps.amvp[mvpIdx];
+                ro.bits = bits;
+                ro.cost = cost;
+                ro.mvCost = mvCost;
+            }
+        }
+        // best reference per PU (search.cpp:399-408, 512-545).  bestME is declared outside the loop over the parts
+        // of the partition, so the second part starts from the first part's winner.
+        uint32_t bestCost = 0xFFFFFFFFu;
+        RefOut best = RefOut();
+        int bestRef = 0;
+        for (size_t i = 0; i < items.size(); i++)
+        {
+            const Item& it = items[i];
+            const PuTask& t = m_tasks[it.task];
+            if (it.puIdx == 0)
+            {
+                bestCost = 0xFFFFFFFFu;
+                best = RefOut();
+                bestRef = 0;
+            }
+            for (int r = 0; r < numRefs; r++)
+            {
+                const RefOut& ro = refOut[i * numRefs + r];
+                if (ro.cost < bestCost)
+                {
+                    bestCost = ro.cost;
+                    best = ro;
+                    bestRef = r;
+                }
+            }
+            MEData& o = out[(size_t)it.ctuAddr * MAX_NUM_PUS_PER_CTU + t.finalIdx + it.puIdx * t.puOffset];
+            o.mv[0] = best.mv;
+            o.mvp[0] = best.mvp;
+            o.mvCost[0] = best.mvCost;
+            o.cost = bestCost;
+            o.bits = (int32_t)best.bits;
+            o.ref[0] = bestRef;
+            o.ref[1] = REF_NOT_VALID;
+        }
+    }
+    return X265GPU_OK;
+}
+
+}  // namespace x265gpu_host
+
+using namespace x265gpu_host;
+
+struct xgh_tme { ThreadedME me; xgh_tme(x265gpu_ctx* c, const TmeParam& p) : me(c, p) {} };
+
+extern "C" {
+
+xgh_tme* xgh_tme_create(x265gpu_ctx* ctx, const xgh_tme_param* p)
+{
+    if (!ctx || !p)
+        return NULL;
+    return new (std::nothrow) xgh_tme(ctx, *p);
+}
+
+void xgh_tme_destroy(xgh_tme* t) { delete t; }
+
+const char* xgh_tme_unsupported(const xgh_tme* t) { return t ? t->me.unsupported() : "no generator"; }
+
+int xgh_tme_estimate_rows(xgh_tme* t, int32_t slotFenc, int32_t poc, int32_t numRefs, const xgh_tme_ref* refs,
+                          int32_t rowBegin, int32_t rowEnd, const int32_t* medianMv, xgh_me_data* out)
+{
+    if (!t)
+        return X265GPU_ERR_ARG;
+    return t->me.estimateRows(slotFenc, poc, numRefs, refs, rowBegin, rowEnd, medianMv, out);
+}
+
+void xgh_tme_counts(const xgh_tme* t, int64_t counts[6])
+{
+    counts[0] = (int64_t)t->me.tasks().size();
+    counts[1] = t->me.numLevels();
+    counts[2] = t->me.numCuInWidth();
+    counts[3] = t->me.numCuInHeight();
+    counts[4] = t->me.searches();
+    counts[5] = t->me.deviceCalls();
+}
+}

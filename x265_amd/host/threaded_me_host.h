@@ -1,0 +1,153 @@
+// Host side of --threaded-me above the x265gpu C-ABI: the CTU job generator.
+//
+// x265 derives the motion vectors of every enabled prediction-unit shape of a CTU ahead of analysis
+// (ThreadedME::findJob -> Analysis::deriveMVsForCTU, source/encoder/threadedme.cpp:207-261,
+// source/encoder/analysis.cpp:161-306), one Search::puMotionEstimation call per shape and CU
+// (source/encoder/search.cpp:226-560).  A CTU reads nothing of its neighbour CTUs on that path: the AMVP
+// neighbours are entries of the same CTU's result table (search.cpp:287-306), so every CTU of a picture may
+// run at once, and inside a CTU the calls fall into dependency levels by the table entries they read.
+// ThreadedME below walks those levels for a batch of CTU rows: per level one x265gpu_block_compare call
+// (Search::selectMVP's candidate SADs) and one x265gpu_pu_motion_estimate call per reference picture, with
+// the predictor logic (CUData::getPMV, Search::setSearchRange, getLowresMV, updateMVP, checkBestMVP and the
+// bit accounting) kept here, as x265 keeps it on the host.  Pixels never come here.
+//
+// Covered: P slices (list 0, any number of references), every shape of g_puLookup
+// (source/encoder/threadedme.h:67-92) under bEnableAMP / bEnableRectInter, one slice QP for the picture
+// (no per-CU delta QP), one slice, no frame-parallel lag window beyond refLagPixels.  B slices need the
+// bidirectional average of search.cpp:415-511 and are reported as unsupported.  The temporal candidate
+// (neighbours[MD_COLLOCATED]) and CUData::getMedianColMV read the reference picture's coded CUs, which
+// only the encoder has: the median vector is an optional input, the temporal candidate is taken as
+// unavailable (--no-temporal-mvp).
+#ifndef X265GPU_THREADED_ME_HOST_H
+#define X265GPU_THREADED_ME_HOST_H
+
+#include "../../include/x265gpu.h"
+
+#include <stdint.h>
+#include <vector>
+
+namespace x265gpu_host {
+
+constexpr int MAX_NUM_PUS_PER_CTU = 593;   // source/common/common.h:355
+constexpr int MAX_NUM_PU_SIZES = 24;       // source/common/common.h:356
+constexpr int REF_NOT_VALID = -1;
+
+// PartSize (source/common/common.h:266-279)
+enum { SIZE_2Nx2N = 0, SIZE_2NxN, SIZE_Nx2N, SIZE_NxN, SIZE_2NxnU, SIZE_2NxnD, SIZE_nLx2N, SIZE_nRx2N };
+// MVP_DIR (source/common/cudata.h:67-75)
+enum { MD_LEFT = 0, MD_ABOVE, MD_ABOVE_RIGHT, MD_BELOW_LEFT, MD_ABOVE_LEFT, MD_COLLOCATED };
+
+struct MV { int32_t x, y; };
+
+// MEData (source/encoder/threadedme.h:122-130)
+struct MEData
+{
+    MV       mv[2];
+    MV       mvp[2];
+    uint32_t mvCost[2];
+    int32_t  ref[2];
+    int32_t  bits;
+    uint32_t cost;
+};
+
+struct TmeParam
+{
+    int32_t searchMethod;        // param->searchMethod (X265GPU_*_SEARCH)
+    int32_t searchRange;         // param->searchRange
+    int32_t subpelRefine;        // param->subpelRefine
+    int32_t bEnableAMP;          // param->bEnableAMP
+    int32_t bEnableRectInter;    // param->bEnableRectInter
+    int32_t maxCUSize;           // param->maxCUSize, equal to the context's CTU size
+    int32_t minCUSize;           // param->minCUSize
+    int32_t bframes;             // param->bframes: reach of the lookahead vectors (Search::getLowresMV)
+    int32_t picWidth;            // sps->picWidthInLumaSamples / picHeightInLumaSamples: the source size
+    int32_t picHeight;           //   padded to a multiple of minCUSize
+    int32_t refLagPixels;        // Search::m_refLagPixels (search.cpp:96): sourceHeight without frame threads
+    double  lambda;              // x265_lambda_tab[slice QP]: MV cost table and RDCost::getCost
+};
+
+// one entry of slice->m_refPOCList[0] / m_mref[0]
+struct TmeRef
+{
+    int32_t slot;                // device slot holding the reference picture (its full-resolution plane)
+    int32_t poc;
+    int32_t isIntraSlice;        // the reference picture was coded as an I slice (search.cpp:315)
+    const MEData* ctuMV;         // that picture's own result table (all CTUs), or NULL
+    const int32_t* lowresMvs;    // m_frame->m_lowres.lowresMvs[0][|poc - ref poc|] as x,y pairs, or NULL when that
+                                 //   distance was never searched (the 0x7FFF sentinel of search.cpp:2331)
+};
+
+// One prediction-unit search call of Analysis::computeMVForPUs: a CU and one g_puLookup entry.
+struct PuTask
+{
+    int cuX, cuY, cuSize;        // CU inside the CTU
+    int partSize, numPart;
+    int finalIdx, puOffset, areaId;
+    int nb[5];                   // neighborIdx[], already -1 where the entry is written later in call order
+    int level;                   // dependency level: every entry it reads belongs to a lower level
+    struct { int x, y, w, h; } pu[2];   // relative to the CTU
+};
+
+class ThreadedME
+{
+public:
+    ThreadedME(x265gpu_ctx* ctx, const TmeParam& p);
+
+    // Why this configuration cannot be run, or NULL
+    const char* unsupported() const { return m_unsupported; }
+
+    // deriveMVsForCTU for every CTU of rows [rowBegin, rowEnd) of the P picture in slotFenc.
+    // medianMv: NULL, or per CTU of the picture and reference {valid, x, y} (CUData::getMedianColMV's result).
+    // out: the picture's table, numCtuInPicture x MAX_NUM_PUS_PER_CTU entries; the rows' entries are reset
+    // (FrameData::reinit, source/common/framedata.cpp:93-102) and filled.
+    int estimateRows(int slotFenc, int poc, int numRefs, const TmeRef* refs, int rowBegin, int rowEnd,
+                     const int32_t* medianMv, MEData* out);
+
+    const std::vector<PuTask>& tasks() const { return m_tasks; }
+    int numLevels() const { return m_numLevels; }
+    int numCuInWidth() const { return m_numCuInWidth; }
+    int numCuInHeight() const { return m_numCuInHeight; }
+    int64_t searches() const { return m_searches; }        // PU searches issued so far (area searches included)
+    int64_t deviceCalls() const { return m_deviceCalls; }
+
+private:
+    void buildTasks();
+    void visit(int cuX, int cuY, int cuSize, std::vector<int>& writer);
+    uint32_t bitcost(MV mv, MV mvp) const;
+    uint32_t mvcost(MV mv, MV mvp) const;
+    uint32_t getCost(uint32_t bits) const { return (uint32_t)(((uint64_t)bits * m_lambdaFix8 + 128) >> 8); }
+    void clipMv(int cuPelX, int cuPelY, MV& mv) const;
+    void setSearchRange(int cuPelX, int cuPelY, MV mvp, int merange, MV& mvmin, MV& mvmax) const;
+
+    x265gpu_ctx* m_ctx;
+    TmeParam m_p;
+    const char* m_unsupported;
+    int m_numCuInWidth, m_numCuInHeight;
+    int m_puStartIdx[2 * 64 + 1][8];                // g_puStartIdx
+    std::vector<PuTask> m_tasks;                    // call order of computeMVForPUs
+    int m_numLevels;
+    std::vector<float> m_bitsizes;                  // BitCost::s_bitsizes, centred
+    std::vector<uint16_t> m_costTable;              // BitCost::m_cost, centred
+    uint64_t m_lambdaFix8;                          // RDCost::m_lambda
+    int64_t m_searches, m_deviceCalls;
+};
+
+}  // namespace x265gpu_host
+
+extern "C" {
+
+typedef x265gpu_host::MEData xgh_me_data;
+typedef x265gpu_host::TmeParam xgh_tme_param;
+typedef x265gpu_host::TmeRef xgh_tme_ref;
+typedef struct xgh_tme xgh_tme;
+
+xgh_tme* xgh_tme_create(x265gpu_ctx* ctx, const xgh_tme_param* p);
+void xgh_tme_destroy(xgh_tme* t);
+const char* xgh_tme_unsupported(const xgh_tme* t);
+int xgh_tme_estimate_rows(xgh_tme* t, int32_t slotFenc, int32_t poc, int32_t numRefs, const xgh_tme_ref* refs,
+                          int32_t rowBegin, int32_t rowEnd, const int32_t* medianMv, xgh_me_data* out);
+// counts: {tasks per CTU, dependency levels, CTUs per row, CTU rows, searches so far, device calls so far}
+void xgh_tme_counts(const xgh_tme* t, int64_t counts[6]);
+}
+
+#endif

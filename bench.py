@@ -199,12 +199,26 @@ def issue_rates():
         d = json.loads(txt)
     except (OSError, ValueError, subprocess.SubprocessError):
         return None
+    return rates_from(d, "benchmarks/micro/issue_bench, run by this process (s_memtime / s_memrealtime)")
+
+
+def recorded_issue_rates():
+    """The microbenchmark's output as recorded on an MI355X (profiles/issue_bench_mi355x.json): used when this run may
+    not start a child process (--no-micro, e.g. under rocprofv3)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "issue_bench_mi355x.json")) as f:
+            return rates_from(json.load(f), "profiles/issue_bench_mi355x.json (recorded run of benchmarks/micro/issue_bench)")
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def rates_from(d, source):
     k = d["kinds"]
     valu = [k[n]["waves_per_simd_8"]["cycles_per_instruction_per_simd"] for n in ("v_sad_u8", "v_pk_add_i16", "v_min_i32", "v_alignbyte_b32")]
     return {"valu_cycles_per_inst_per_simd_8_waves": sum(valu) / len(valu),
             "valu_cycles_per_inst_per_simd_1_wave": k["v_sad_u8"]["waves_per_simd_1"]["cycles_per_instruction_per_simd"],
             "salu_cycles_per_inst_per_simd_8_waves": k["s_add_u32"]["waves_per_simd_8"]["cycles_per_instruction_per_simd"],
-            "clock_GHz": d["clock_GHz_at_8_waves"], "source": "benchmarks/micro/issue_bench (s_memtime / s_memrealtime)"}
+            "clock_GHz": d["clock_GHz_at_8_waves"], "source": source}
 
 
 def config_key(args):
@@ -309,7 +323,7 @@ def rank_main(args):
 
     # Everything that starts another process (the issue-rate microbenchmark, the worker pool of the all-cores CPU
     # baseline) runs before this process initialises the GPU.
-    rates = issue_rates() if rank == 0 and not args.no_micro else None
+    rates = (issue_rates() if not args.no_micro else None) or recorded_issue_rates() if rank == 0 else None
     cpu = cpu_baselines(args) if rank == 0 and args.cpu_frames > 0 else {}
 
     import ctypes as C
@@ -460,12 +474,33 @@ def rank_main(args):
 
     g = ctx.geom
     P = W * H
+
+    # Bytes the cost evaluation touches, counted from the vectors this step produced (frame k sits in slot k): a P
+    # request reads no pixels (vector costs, intra costs and AQ factors of each block); a B request reads the encode
+    # block, the two co-located blocks and, per list, the one half-pel plane block its vector points into, or the two
+    # blocks a quarter-pel vector averages (lowresMC, source/common/lowres.h:72-93).
+    def counted_cost_bytes():
+        cache = {}
+
+        def planes(slot, lst, dist):
+            if (slot, lst, dist) not in cache:
+                mv = ctx.get_mvs(slot, lst, dist)[0]
+                cache[(slot, lst, dist)] = int(n + np.count_nonzero((mv[:, 0] | mv[:, 1]) & 1))
+            return cache[(slot, lst, dist)]
+        total = 0
+        for p0, p1, b in list(b1) + list(b2):
+            total += 4 * g.heightInCU + 24                     # row sums and the request's totals
+            if p1 > b:
+                blocks = 3 * n + planes(b, 0, b - p0) + planes(b, 1, p1 - b)
+                total += 64 * bpp * blocks + n * (8 + 8 + 4 + 4 + 4 + 2)
+            else:
+                total += n * (4 + 4 + 4 + 2)
+        return total
     alg = {   # algorithmic bytes per step, per phase
         "lowres": F * 2 * P * bpp,
         "intra": F * ((P // 4) * bpp + 7 * n),
         "search": n_search * (5 * (P // 4) * bpp + 12 * n),
-        # lower bound: the encode plane and one reference block per list actually read (co-located candidates hit the same lines)
-        "cost": n_cost * (3 * (P // 4) * bpp + 2 * n + 4 * g.heightInCU + 20),
+        "cost": counted_cost_bytes(),
     }
     kernels = {}
     for k, (ms, launches) in prof.items():

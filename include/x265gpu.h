@@ -58,8 +58,10 @@ typedef struct x265gpu_ctx x265gpu_ctx;
  * source/common/param.cpp:197-260,310-315). */
 typedef struct x265gpu_config
 {
-    int32_t sourceWidth;
-    int32_t sourceHeight;
+    int32_t sourceWidth;          /* param->sourceWidth / sourceHeight, at least 16.  Sizes of the form 16k+1 are */
+    int32_t sourceHeight;         /* X265GPU_ERR_UNSUPPORTED: padded to the minimum CU size they gain a row or column  */
+                                  /* of 8x8 lowres blocks (Lowres::create sizes its arrays from the padded picture,   */
+                                  /* lowres.cpp:84-103) that this library, which sizes from the source, does not hold */
     int32_t internalBitDepth;     /* 8, 10 or 12 */
     int32_t maxCUSize;            /* CTU size; margins are maxCUSize+32 / maxCUSize+16 */
     int32_t bframes;              /* sizes the [bframes+2] result arrays */
@@ -166,7 +168,8 @@ int x265gpu_lowres_init_batch(x265gpu_ctx* ctx, int32_t n, const int32_t* slots,
                               const intptr_t* strides, int32_t memKind, const int32_t* pocs);
 
 /* invQscaleFactor from the host's calcAdaptiveQuantFrame (slicetype.cpp:454-704),
- * one int per 8x8 lowres block; NULL clears it (costEstAq == costEst). */
+ * one int per 8x8 lowres block; NULL clears it (costEstAq == costEst).  The
+ * array is copied before the call returns (the upload itself stays asynchronous). */
 int x265gpu_lowres_set_aq(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQscaleFactor);
 
 /* LookaheadTLD::lowresIntraEstimate (slicetype.cpp:706-815) for n slots. */
@@ -179,7 +182,7 @@ int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots);
  * a bottom-right to top-left wavefront over the 8x8 blocks), then all
  * per-block cost evaluations; a request may therefore use vectors searched by
  * any request of the same batch, and requests of one batch must not search
- * the same (frame, list, distance) twice. */
+ * the same (frame, list, distance) twice: such a batch is X265GPU_ERR_ARG. */
 int x265gpu_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs);
 /* Same, then waits and returns the n per-request scalars in one transfer; the
  * per-block arrays stay on the device until a getter asks for them.  This is

@@ -5,7 +5,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/test_$TAG.log 2>&1
 rc=$?; tail -4 gpurun_out/test_$TAG.log
 [ $rc -ne 0 ] && { grep -E "Error|assert|FAILED" gpurun_out/test_$TAG.log | head -20; exit $rc; }
-timeout -k 10 300 python -u bench.py --steps 5 --warmup 2 --cpu-frames 0 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err || { tail -5 gpurun_out/bench_$TAG.err; exit 1; }
+timeout -k 10 300 python -u bench.py --steps 5 --warmup 2 --cpu-frames 0 --steady-steps 0 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err || { tail -5 gpurun_out/bench_$TAG.err; exit 1; }
 python3 - <<PY
 import json
 d=json.load(open("gpurun_out/bench_$TAG.json"))

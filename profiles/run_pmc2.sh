@@ -5,7 +5,7 @@ set -u
 OUT=${1:-pmc2}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-frames 0"
+BENCH="python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-micro --steady-steps 0"
 pass() {
   name=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $ROOT/gpurun_out/$OUT/$name -- $BENCH > $ROOT/gpurun_out/$OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $ROOT/gpurun_out/$OUT/$name.log; return 1; }

@@ -1,4 +1,6 @@
 """GPU parity: the HIP path through the C-ABI against the CPU oracle, bit-exact."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -428,6 +430,47 @@ def test_hme_odd_block_grid_wild_predictor():
                                  hme_methods=(orc.UMH, orc.HEX, orc.UMH), hme_range=(24, 16, 48))
     try:
         _run_sequence(ref, ctx, frames, [(0, 1, 1), (0, 2, 2), (0, 3, 1), (1, 3, 2), (0, 3, 2)])
+    finally:
+        ctx.close()
+        ref.close()
+
+
+def test_duplicate_search_in_one_batch_is_refused():
+    """Two requests of one call that both search (frame 2, list 0, distance 2) would race on one vector array."""
+    clip, ref, ctx, frames = _setup(320, 192, 4, 8, seed=5)
+    try:
+        with pytest.raises(api.X265GpuError):
+            ctx.estimate([(0, 2, 2, 0, 2, 2, 1, 0), (0, 2, 3, 0, 2, 3, 1, 1)])
+        # the same pair is fine once only one of them searches list 0
+        ctx.estimate([(0, 2, 2, 0, 2, 2, 1, 0), (0, 2, 3, 0, 2, 3, 0, 1)])
+        ref.frame_cost(0, 2, 2)
+        ref.frame_cost(0, 3, 2)
+        np.testing.assert_array_equal(ctx.get_mvs(2, 0, 2)[0], ref.frames[2].mvs(0, 2))
+        np.testing.assert_array_equal(ctx.get_mvs(2, 1, 1)[0], ref.frames[2].mvs(1, 1))
+    finally:
+        ctx.close()
+        ref.close()
+
+
+def test_set_aq_copies_the_callers_array():
+    """x265gpu_lowres_set_aq must have taken its copy when it returns, also from page-locked memory where the
+    upload is truly asynchronous: the caller overwrites the array right after the call."""
+    clip, ref, ctx, frames = _setup(320, 192, 2, 8, seed=6, with_aq=True)
+    try:
+        n = ctx.geom.cuCount
+        pinned = ctx.host_alloc(C.c_int32, n)
+        want = np.asarray(ref.frames[1].inv_qscale()).copy()
+        view = np.frombuffer(pinned, np.int32, n)
+        for _ in range(4):                       # keep the stream busy so that the upload is queued behind work
+            ctx.intra_estimate([0, 1])
+        view[:] = want
+        ctx.set_aq(1, view)
+        view[:] = 1                              # the caller reuses its array for the next frame
+        ctx.estimate([(0, 1, 1, 0, 1, 1, 1, 0)])
+        ref.frame_cost(0, 1, 1)
+        _, _, (ce, ceaq, _) = ctx.get_costs(1, 1, 0)
+        assert ceaq == ref.frames[1].i64("costEstAq", 1, 0) and ce == ref.frames[1].i64("costEst", 1, 0)
+        ctx.host_free(pinned)
     finally:
         ctx.close()
         ref.close()

@@ -109,6 +109,12 @@ constexpr int SEARCH_SYNC_ERROR = 64;
 size_t search_rows_sync_bytes(const Geometry& g, int n);
 hipError_t launch_search_rows(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0,
                               int method, const uint16_t* costTab, int maxMvd, int* dSync, int* launches);
+// single-launch search in diagonal order with the vectors as ready flags (search_kernels.hip); the chunk table
+// lists (diagonal, first block) of every group of four blocks: search_flow_chunks returns its length and fills it
+int search_flow_chunks(int W, int H, uint32_t* out);
+hipError_t launch_search_flow(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0, int method,
+                              const uint32_t* dChunkTab, int numChunks, const uint16_t* costTab, int maxMvd, int* dSync,
+                              int gridPad, int* launches);
 // ---- full-resolution PU motion estimation ----
 // same layout as x265gpu_pu_job / x265gpu_pu_result
 struct PuJob

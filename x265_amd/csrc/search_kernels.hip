@@ -821,12 +821,19 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     return bcost;
 }
 
-// ROWS: the caller walks a block row right to left inside one launch while other
+// MODE_ROWS: the caller walks a block row right to left inside one launch while other
 // waves walk the rows below it.  The right neighbour's vector then comes in
 // (rightX,rightY) from the previous step, the vectors of the row below are read
 // with L1-bypassing (sc1) loads, and this block's vector is stored write-through
 // and handed back in (rightX,rightY).
-template <typename P, int METHOD, bool ROWS>
+// MODE_FLOW: one launch for all anti-diagonals with the blocks in diagonal order.  Every
+// vector array starts out filled with FLOW_PENDING in x; a block reads its neighbours'
+// vectors with sc1 loads until none of them is pending (the vector is its own ready flag)
+// and stores its own write-through.  `rowCount` then points at the launch's error word.
+constexpr int MODE_DIAG = 0, MODE_ROWS = 1, MODE_FLOW = 2;
+constexpr int FLOW_PENDING = 0x7FFF;          // no search produces this x: vectors stay within the padded picture
+constexpr int FLOW_POLL_LIMIT = 1 << 18;
+template <typename P, int METHOD, int MODE>
 __device__ __forceinline__ void search_block(const SearchJob& job, const Geometry& g, int level0, int cuX, int cuY,
                                              bool lastRow, int lane, const uint16_t* costTab, int maxMvd,
                                              XG_LDS uint32_t* lds, int& rightX, int& rightY,
@@ -906,7 +913,36 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         const int off = (c.g == 0) ? 1 : (c.g == 1) ? W : (c.g == 2) ? W - 1 : W + 1;
         const bool mine = (c.g == 0) ? v0 : (c.g == 1) ? v1 : (c.g == 2) ? v2 : (c.g == 3) ? v3 : false;
         int cx = 0, cy = 0;
-        if (ROWS)
+        if (MODE == MODE_FLOW)
+        {
+            long long v = 0;
+            int polls = 0;
+            for (;;)
+            {
+                if (mine)
+                    v = __hip_atomic_load((const XG_GLOBAL long long*)(mvs + 2 * (cuXY + off)), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+                if (!__builtin_amdgcn_ballot_w64(mine && (int)v == FLOW_PENDING))
+                    break;
+                // never expected to run out (a block only waits for blocks handed out before it); rather than hang
+                // the device, stop waiting here and, through the error word, everywhere, and let the host call fail
+                if ((++polls & 255) == 0)
+                {
+                    int err = __hip_atomic_load(rowCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    err = __builtin_amdgcn_readfirstlane(err);
+                    if (err || polls > FLOW_POLL_LIMIT)
+                    {
+                        if (lane == 0)
+                            __hip_atomic_store(rowCount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            cx = (int)v;
+            cy = (int)(v >> 32);
+        }
+        else if (MODE == MODE_ROWS)
         {
             if (mine && c.g != 0)
             {
@@ -999,7 +1035,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         fencCost = skipCost;
         mx = my = 0;
     }
-    if (ROWS)
+    if (MODE == MODE_ROWS)
     {
         // Announce the `done` blocks before this one: the previous block's vector was stored a
         // whole search ago, and this drain makes sure of it without waiting on anything new.
@@ -1009,7 +1045,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     }
     if (lane == 0)
     {
-        if (ROWS)
+        if (MODE != MODE_DIAG)
             __hip_atomic_store((XG_GLOBAL long long*)(as_global<int32_t>(job.mvs) + 2 * cuXY),
                                (long long)(((unsigned long long)(unsigned)my << 32) | (unsigned)mx), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -1064,7 +1100,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) s
         return;                       // whole wave leaves together
     const int xq = t - 2 * yq;
     int rx = 0, ry = 0;
-    search_block<P, METHOD, false>(job, g, level0, W - 1 - xq, last - yq, yq == 0, threadIdx.x & 63, costTab, maxMvd,
+    search_block<P, METHOD, MODE_DIAG>(job, g, level0, W - 1 - xq, last - yq, yq == 0, threadIdx.x & 63, costTab, maxMvd,
                                    (XG_LDS uint32_t*)ldsBuf + wave * WaveLds<P>::TOTAL, rx, ry);
 }
 
@@ -1138,7 +1174,7 @@ __device__ __forceinline__ void search_rows_body(const SearchJob* jobs, int nJob
                 if (seen < W)
                     ahead = __hip_atomic_load(prog - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            search_block<P, METHOD, true>(job, g, level0, W - 1 - xq, H - 1 - yq, bottom, lane, costTab, maxMvd, lds, rx, ry,
+            search_block<P, METHOD, MODE_ROWS>(job, g, level0, W - 1 - xq, H - 1 - yq, bottom, lane, costTab, maxMvd, lds, rx, ry,
                                           prog, xq);
         }
         // the last vector's store must have left before the count that announces it
@@ -1168,6 +1204,92 @@ search_rows_kernel_wide(const SearchJob* jobs, int nJobs, Geometry g, int level0
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     search_rows_body<P, METHOD>(jobs, nJobs, g, level0, costTab, maxMvd, sync,
                                 (XG_LDS uint32_t*)ldsBuf + wave * WaveLds<P>::TOTAL);
+}
+
+// ---- one launch for all anti-diagonals, vectors as ready flags -------------------
+// grid: (jobs, chunks); chunk c = up to four consecutive blocks of one anti-diagonal, chunks sorted by diagonal
+// (chunkTab[c] = t | first block << 16).  Workgroups are handed out in the order of their linear index, x (the
+// job) fastest: a block only ever waits for blocks of lower chunks, i.e. of workgroups handed out before its own,
+// so the lowest unfinished workgroup can always run.  Should the hardware not hold to that, the bounded poll in
+// search_block ends the wait and the call fails.
+template <typename P, int METHOD>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8)))
+search_flow_kernel(const SearchJob* jobs, int nJobs, Geometry g, int level0, const uint32_t* chunkTab, const uint16_t* costTab,
+                   int maxMvd, int* sync)
+{
+    __shared__ uint32_t ldsBuf[4 * WaveLds<P>::TOTAL];
+    if ((int)blockIdx.x >= nJobs)
+        return;
+    const int W = level0 ? g.W4 : g.W, H = level0 ? g.H4 : g.H;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t chunk = chunkTab[blockIdx.y];
+    const int t = (int)(chunk & 0xffffu), k = (int)(chunk >> 16) + wave;
+    const SearchJob job = jobs[blockIdx.x];
+    const int ylo = max(0, (t - (W - 1) + 1) >> 1), yhi = min(H - 1, t >> 1);
+    const int yq = ylo + k;
+    if (yq > yhi)
+        return;
+    const int xq = t - 2 * yq;
+    int rx = 0, ry = 0;
+    search_block<P, METHOD, MODE_FLOW>(job, g, level0, W - 1 - xq, H - 1 - yq, yq == 0, threadIdx.x & 63, costTab, maxMvd,
+                                       (XG_LDS uint32_t*)ldsBuf + wave * WaveLds<P>::TOTAL, rx, ry,
+                                       (XG_GLOBAL int*)sync + SYNC_ERROR, 0);
+}
+
+// every vector of the jobs' arrays pending
+__global__ void __launch_bounds__(256) search_flow_fill_kernel(const SearchJob* jobs, int blocks)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < blocks)
+        jobs[blockIdx.y].mvs[2 * i] = FLOW_PENDING;
+}
+
+int search_flow_chunks(int W, int H, uint32_t* out)
+{
+    int n = 0;
+    for (int t = 0; t <= (W - 1) + 2 * (H - 1); t++)
+    {
+        const int ylo = (t - (W - 1) + 1) >> 1 > 0 ? (t - (W - 1) + 1) >> 1 : 0;
+        const int yhi = (t >> 1) < H - 1 ? (t >> 1) : H - 1;
+        for (int k = 0; k <= yhi - ylo; k += 4, n++)
+            if (out)
+                out[n] = (uint32_t)t | ((uint32_t)k << 16);
+    }
+    return n;
+}
+
+template <typename P>
+static void launch_flow_method(int method, hipStream_t s, dim3 grid, const SearchJob* dJobs, int n, const Geometry& g,
+                               int level0, const uint32_t* chunkTab, const uint16_t* costTab, int maxMvd, int* sync)
+{
+    if (method == X265GPU_DIA)
+        hipLaunchKernelGGL((search_flow_kernel<P, X265GPU_DIA>), grid, dim3(256), 0, s, dJobs, n, g, level0, chunkTab, costTab,
+                           maxMvd, sync);
+    else if (method == X265GPU_UMH)
+        hipLaunchKernelGGL((search_flow_kernel<P, X265GPU_UMH>), grid, dim3(256), 0, s, dJobs, n, g, level0, chunkTab, costTab,
+                           maxMvd, sync);
+    else
+        hipLaunchKernelGGL((search_flow_kernel<P, X265GPU_HEX>), grid, dim3(256), 0, s, dJobs, n, g, level0, chunkTab, costTab,
+                           maxMvd, sync);
+}
+
+hipError_t launch_search_flow(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0, int method,
+                              const uint32_t* dChunkTab, int numChunks, const uint16_t* costTab, int maxMvd, int* dSync,
+                              int gridPad, int* launches)
+{
+    if (n <= 0)
+        return hipSuccess;
+    const int blocks = level0 ? g.W4 * g.H4 : g.cuCount;
+    hipLaunchKernelGGL(search_flow_fill_kernel, dim3((blocks + 255) / 256, n), dim3(256), 0, s, dJobs, blocks);
+    const int gx = gridPad > 1 ? (n + gridPad - 1) / gridPad * gridPad : n;
+    const dim3 grid(gx, numChunks);
+    if (bpp == 1)
+        launch_flow_method<uint8_t>(method, s, grid, dJobs, n, g, level0, dChunkTab, costTab, maxMvd, dSync);
+    else
+        launch_flow_method<uint16_t>(method, s, grid, dJobs, n, g, level0, dChunkTab, costTab, maxMvd, dSync);
+    if (launches)
+        (*launches) += 2;
+    return hipGetLastError();
 }
 
 template <typename P, int METHOD>

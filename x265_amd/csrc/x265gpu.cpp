@@ -27,6 +27,8 @@ struct Slot
     uint8_t* intraMode = nullptr;
     int32_t* invQscale = nullptr;
     bool hasAq = false;
+    int32_t* aqStage = nullptr;    // page-locked staging copy of the caller's invQscaleFactor, allocated on first use
+    hipEvent_t aqStaged = nullptr; // the last upload from aqStage
     unsigned long long* propagate = nullptr; // cuTree: unsaturated propagateCost totals, [n]
     int32_t* mvs = nullptr;        // [2][D][n][2]
     int32_t* mvCosts = nullptr;    // [2][D][n]
@@ -108,6 +110,10 @@ struct x265gpu_ctx
     size_t intraJobBufSize = 0;
     // single-launch search: row-progress words on the device, and its sticky error word mirrored here
     bool searchRows = false;
+    bool searchFlow = false;           // X265GPU_SEARCH_MODE=flow: one launch, vectors as ready flags
+    int flowGridPad = 1;
+    uint32_t* flowChunks[2] = { nullptr, nullptr };   // chunk tables of the half-res and the quarter-res block grid
+    int flowChunkCount[2] = { 0, 0 };
     int* searchSync = nullptr;
     size_t searchSyncBytes = 0;
     int* searchErrHost = nullptr;     // pinned
@@ -399,6 +405,17 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
         (cfg->internalBitDepth != 8 && cfg->internalBitDepth != 10 && cfg->internalBitDepth != 12) ||
         (cfg->maxCUSize != 16 && cfg->maxCUSize != 32 && cfg->maxCUSize != 64))
         return X265GPU_ERR_ARG;
+    {
+        // x265 sizes the per-block arrays of Lowres from the picture padded to the minimum CU size (lowres.cpp:84-103)
+        // and runs its loops over the source size (slicetype.cpp:1061-1064); this library sizes both from the source
+        // size.  The few sizes where padding to a multiple of 8 adds a row or column of 8x8 lowres blocks (17, 33, ...)
+        // would make the 16x16-unit loops of the cuTree and AQ host code step past those arrays.
+        auto blocks = [](int v) { return ((v / 2) + 7) >> 3; };
+        auto pad8 = [](int v) { return (v + 7) & ~7; };
+        if (blocks(pad8(cfg->sourceWidth)) != blocks(cfg->sourceWidth) ||
+            blocks(pad8(cfg->sourceHeight)) != blocks(cfg->sourceHeight))
+            return X265GPU_ERR_UNSUPPORTED;
+    }
     auto methodOk = [](int m) { return m == X265GPU_DIA_SEARCH || m == X265GPU_HEX_SEARCH || m == X265GPU_UMH_SEARCH; };
     if (!methodOk(cfg->searchMethod))
         return X265GPU_ERR_UNSUPPORTED;
@@ -499,6 +516,26 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
             // default: one launch per anti-diagonal (the faster of the two as measured)
             const char* e = getenv("X265GPU_SEARCH_MODE");
             ctx->searchRows = e && !strcmp(e, "rows");
+            ctx->searchFlow = e && !strcmp(e, "flow");
+            const char* pad = getenv("X265GPU_FLOW_PAD");
+            ctx->flowGridPad = pad ? atoi(pad) : 1;
+            if (ctx->searchFlow)
+            {
+                for (int lv = 0; lv < 2 && rc == X265GPU_OK; lv++)
+                {
+                    const int W = lv ? ctx->g.W4 : ctx->g.W, H = lv ? ctx->g.H4 : ctx->g.H;
+                    if (W <= 0 || H <= 0)
+                        continue;
+                    std::vector<uint32_t> tab((size_t)search_flow_chunks(W, H, nullptr));
+                    search_flow_chunks(W, H, tab.data());
+                    ctx->flowChunkCount[lv] = (int)tab.size();
+                    if (hipMalloc((void**)&ctx->flowChunks[lv], tab.size() * sizeof(uint32_t)) != hipSuccess ||
+                        hipMemcpy(ctx->flowChunks[lv], tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+                        rc = X265GPU_ERR_NOMEM;
+                }
+                if (rc)
+                    break;
+            }
             if (hipHostMalloc((void**)&ctx->searchErrHost, 64) != hipSuccess)
             {
                 rc = X265GPU_ERR_NOMEM;
@@ -562,6 +599,10 @@ void x265gpu_close(x265gpu_ctx* ctx)
             (void)hipFree(s.base);
         if (s.full)
             (void)hipFree(s.full);
+        if (s.aqStage)
+            (void)hipHostFree(s.aqStage);
+        if (s.aqStaged)
+            (void)hipEventDestroy(s.aqStaged);
         for (char* w : s.weighted)
             if (w)
                 (void)hipFree(w);
@@ -591,6 +632,8 @@ void x265gpu_close(x265gpu_ctx* ctx)
     if (ctx->intraDone) (void)hipEventDestroy(ctx->intraDone);
     if (ctx->intraStream) (void)hipStreamDestroy(ctx->intraStream);
     if (ctx->searchSync) (void)hipFree(ctx->searchSync);
+    for (uint32_t* t : ctx->flowChunks)
+        if (t) (void)hipFree(t);
     if (ctx->searchErrHost) (void)hipHostFree(ctx->searchErrHost);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -748,8 +791,19 @@ int x265gpu_lowres_set_aq(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQsca
         s.hasAq = false;
         return X265GPU_OK;
     }
-    HIPCHK(hipMemcpyAsync(s.invQscale, invQscaleFactor, sizeof(int32_t) * ctx->g.cuCount, hipMemcpyHostToDevice,
-                          ctx->stream));
+    // The upload reads a staging copy the slot owns, so the caller's array is theirs again on return whatever
+    // kind of memory it is, and the copy still overlaps the stream's earlier work.
+    const size_t bytes = sizeof(int32_t) * ctx->g.cuCount;
+    if (!s.aqStage)
+    {
+        HIPCHK(hipHostMalloc((void**)&s.aqStage, bytes, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&s.aqStaged, hipEventDisableTiming));
+    }
+    else
+        HIPCHK(hipEventSynchronize(s.aqStaged));      // the previous upload of this slot has left the staging copy
+    memcpy(s.aqStage, invQscaleFactor, bytes);
+    HIPCHK(hipMemcpyAsync(s.invQscale, s.aqStage, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipEventRecord(s.aqStaged, ctx->stream));
     s.hasAq = true;
     return X265GPU_OK;
 }
@@ -903,6 +957,11 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
                 j.sliceRows = g.H4;
                 sj4.push_back(j);
             }
+            // Searches of one call run side by side on several streams and read their own earlier vectors, so two of them
+            // must never share a (frame, list, distance) vector array: the second would read what the first is writing.
+            for (const SearchJob& other : sj)
+                if (other.mvs == mvs[l])
+                    return fail(ctx, X265GPU_ERR_ARG, "estimate: two searches of the same frame, list and distance in one call");
             SearchJob j;
             memset(&j, 0, sizeof(j));
             j.fencPlane0 = plane_origin(ctx, sb.planes);
@@ -992,6 +1051,23 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
                                       sj4[0].method, ctx->costCentre, ctx->maxMvd, ctx->searchSync, &launches));
         HIPCHK(launch_search_rows(ctx->stream, g, ctx->bpp, (const SearchJob*)(ctx->jobBuf + s4Bytes), (int)sj.size(), 0,
                                   sj[0].method, ctx->costCentre, ctx->maxMvd, ctx->searchSync, &launches));
+        pt.stop(launches);
+    }
+    else if (!sj.empty() && ctx->searchFlow && slicesMax == 1 && ctx->flowChunkCount[0] <= 65535 &&
+             (sj4.empty() || ctx->flowChunkCount[1] <= 65535))
+    {
+        rc = ensure_search_sync(ctx, 1);
+        if (rc)
+            return rc;
+        PhaseTimer pt(ctx, X265GPU_PHASE_SEARCH);
+        int launches = 0;
+        if (!sj4.empty())
+            HIPCHK(launch_search_flow(ctx->stream, g, ctx->bpp, (const SearchJob*)ctx->jobBuf, (int)sj4.size(), 1, sj4[0].method,
+                                      ctx->flowChunks[1], ctx->flowChunkCount[1], ctx->costCentre, ctx->maxMvd, ctx->searchSync,
+                                      ctx->flowGridPad, &launches));
+        HIPCHK(launch_search_flow(ctx->stream, g, ctx->bpp, (const SearchJob*)(ctx->jobBuf + s4Bytes), (int)sj.size(), 0,
+                                  sj[0].method, ctx->flowChunks[0], ctx->flowChunkCount[0], ctx->costCentre, ctx->maxMvd,
+                                  ctx->searchSync, ctx->flowGridPad, &launches));
         pt.stop(launches);
     }
     else if (!sj.empty())

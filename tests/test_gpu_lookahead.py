@@ -244,9 +244,12 @@ def test_weighted_prediction():
         ref.close()
 
 
-def test_single_launch_search_mode(monkeypatch):
-    """X265GPU_SEARCH_MODE=rows: the whole search in one launch, rows handing their progress to the row above."""
-    monkeypatch.setenv("X265GPU_SEARCH_MODE", "rows")
+@pytest.mark.parametrize("mode", ["rows", "diag", "flow"])
+def test_search_launch_modes(monkeypatch, mode):
+    """X265GPU_SEARCH_MODE: "flow" (the default: one launch, blocks in diagonal order, every vector its own ready
+    flag), "diag" (one launch per anti-diagonal) and "rows" (one launch, rows handing their progress to the row
+    above) give the same results."""
+    monkeypatch.setenv("X265GPU_SEARCH_MODE", mode)
     clip, ref, ctx, frames = _setup(448, 256, 6, 8, seed=21)
     try:
         _run_sequence(ref, ctx, frames)

@@ -512,11 +512,12 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
             }
         }
         {
-            // "rows": one launch for the whole search with in-launch hand-off between block rows;
-            // default: one launch per anti-diagonal (the faster of the two as measured)
+            // X265GPU_SEARCH_MODE: "flow" (default) = one launch for all anti-diagonals, blocks in diagonal order, every
+            // vector its own ready flag; "diag" = one launch per anti-diagonal; "rows" = one launch with a hand-off
+            // between block rows.  Requests with cooperative slices always take the diagonal launches.
             const char* e = getenv("X265GPU_SEARCH_MODE");
             ctx->searchRows = e && !strcmp(e, "rows");
-            ctx->searchFlow = e && !strcmp(e, "flow");
+            ctx->searchFlow = !e || !strcmp(e, "flow");
             const char* pad = getenv("X265GPU_FLOW_PAD");
             ctx->flowGridPad = pad ? atoi(pad) : 1;
             if (ctx->searchFlow)

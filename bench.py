@@ -512,36 +512,60 @@ def rank_main(args):
                       "algorithmic_GBs": alg[k] / (ms_step * 1e-3) / 1e9}
     dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     dom = kernels[dominant]
-    kernel_name = {"lowres": "lowres_init_kernel", "intra": "intra_kernel", "search": "search_diag_kernel",
-                   "cost": "cost_rows_kernel"}[dominant]
-    # The search spreads its job groups over concurrent streams (X265GPU_SEARCH_STREAMS, default 2): that many
-    # launches are in flight at a time, so one launch lasts (streams x phase time / launches) while the phase's
-    # aggregate rate is bytes / phase time.  rocprofv3's per-kernel average duration is the former.
+    mode = os.environ.get("X265GPU_SEARCH_MODE", "flow")
+    search_kernel = {"flow": "search_flow_kernel", "rows": "search_rows_kernel"}.get(mode, "search_diag_kernel")
+    names = {"lowres": "lowres_init_kernel", "intra": "intra_kernel", "search": search_kernel, "cost": "cost_rows_kernel"}
+    kernel_name = names[dominant]
+    # Launches of the dominant kernel in flight at a time: the diagonal mode spreads its job groups over concurrent
+    # streams (X265GPU_SEARCH_STREAMS, default 2), so one launch lasts (streams x phase time / launches) while the
+    # phase's aggregate rate is bytes / phase time; rocprofv3's per-kernel average duration is the former.  The flow
+    # mode is one launch of the search kernel behind a small fill kernel, which the launch count leaves out.
     streams = 1
-    if dominant == "search" and os.environ.get("X265GPU_SEARCH_MODE", "diag") != "rows":
+    dom_launches = dom["launches_per_step"]
+    if dominant == "search" and mode == "diag":
         streams = max(1, min(4, int(os.environ.get("X265GPU_SEARCH_STREAMS", "2"))))
-    bytes_per_launch = alg[dominant] / max(1.0, dom["launches_per_step"])
-    avg_launch_us = streams * dom["avg_launch_us"]
+    elif dominant == "search" and mode == "flow":
+        dom_launches = max(1.0, dom_launches / 2)
+    bytes_per_launch = alg[dominant] / max(1.0, dom_launches)
+    avg_launch_us = streams * 1000.0 * dom["ms_per_step"] / max(1.0, dom_launches)
+
+    # Vector-issue fraction of every phase whose kernel has a counter pass for this configuration: wave64 VALU
+    # instructions per step (counted per dispatch by rocprofv3, times the launches of a step) over the phase time,
+    # against 1024 SIMDs x measured clock / measured cycles per instruction.
+    valu_peak = SIMDS * rates["clock_GHz"] / rates["valu_cycles_per_inst_per_simd_8_waves"] if rates else None
+    for k, v in kernels.items():
+        c = pmc_kernel(args, names[k])
+        if not c or not valu_peak or not c.get("dispatches") or "SQ_INSTS_VALU" not in c:
+            continue
+        launches = v["launches_per_step"] / 2 if (k == "search" and mode == "flow") else v["launches_per_step"]
+        insts = c["SQ_INSTS_VALU"] / c["dispatches"] * launches
+        v["valu_G_insts_per_s"] = insts / (v["ms_per_step"] * 1e-3) / 1e9
+        v["valu_frac"] = v["valu_G_insts_per_s"] / valu_peak
+        t = pmc_traffic_per_launch(c)
+        if t is not None:
+            v["pmc_traffic_bytes_per_step"] = t * launches
+            v["pmc_traffic_over_algorithmic"] = t * launches / alg[k]
+
     pmc = pmc_kernel(args, kernel_name)
     hbm = {"achieved": dom["algorithmic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["algorithmic_GBs"] / HBM_PEAK_GBS,
            "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": pmc_traffic_per_launch(pmc)}
     roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": hbm["frac"], "traffic": hbm["traffic"], "avg_launch_us": avg_launch_us, "concurrent_launches": streams,
-                "launches_per_step": dom["launches_per_step"], "algorithmic_bytes_per_launch": bytes_per_launch}
+                "launches_per_step": dom_launches, "algorithmic_bytes_per_launch": bytes_per_launch}
     if dominant == "search" and pmc and pmc.get("SQ_WAVES") and "SQ_INSTS_VALU" in pmc and rates:
-        # The block search is integer SAD / SATD work out of LDS: its ceiling is the SIMDs' vector issue rate, not
-        # HBM.  Instructions per block search come from the counter passes of this configuration, cycles per
-        # instruction and the clock from the microbenchmark run at the top of this process.
+        # The block search is integer SAD / SATD work out of LDS: the resource it uses most is the SIMDs' vector issue,
+        # not HBM.  Instructions per block search come from the counter passes of this configuration, cycles per
+        # instruction and the clock from the microbenchmark.
         per_wave = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"]
         units = n_search * n                                            # block searches per step
-        peak = SIMDS * rates["clock_GHz"] / rates["valu_cycles_per_inst_per_simd_8_waves"]      # G wave-instructions / s
         achieved = per_wave * units / (dom["ms_per_step"] * 1e-3) / 1e9
-        roofline.update({"bound": "valu", "achieved": achieved, "peak": peak, "unit": "G wave64-instructions/s",
-                         "frac": achieved / peak, "valu_insts_per_block_search": per_wave,
+        roofline.update({"bound": "valu", "achieved": achieved, "peak": valu_peak, "unit": "G wave64-instructions/s",
+                         "frac": achieved / valu_peak, "valu_insts_per_block_search": per_wave,
                          "salu_insts_per_block_search": pmc.get("SQ_INSTS_SALU", 0) / pmc["SQ_WAVES"],
                          "block_searches_per_step": units, "hbm": hbm,
                          "note": "vector-issue roofline: measured instructions per 8x8 block search x block searches / phase time, "
-                                 "against 1024 SIMDs x measured clock / measured cycles per wave64 instruction"})
+                                 "against 1024 SIMDs x measured clock / measured cycles per wave64 instruction; the rest of a "
+                                 "wave's life is latency (memory round trips, LDS, scalar chain) that eight waves per SIMD do not cover"})
     elif dominant == "search":
         roofline["note"] = ("no counter pass committed for this configuration (profiles/pmc_%s.json): the vector-issue "
                             "fraction is not reported; the HBM fraction is small by construction (integer search out of LDS)"

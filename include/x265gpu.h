@@ -413,6 +413,18 @@ typedef struct x265gpu_aq_picture
 } x265gpu_aq_picture;
 int x265gpu_aq_frames(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int32_t memKind, const x265gpu_aq_params* params);
 
+/* The same in two halves, so that the host's double-precision mapping of the offsets (the part of
+ * calcAdaptiveQuantFrame that x265 also runs on CPU threads, slicetype.cpp:1843-1859) overlaps the motion searches.
+ * x265gpu_aq_frames_begin runs the energy pass, waits for it and fills wpSum / wpSsd (what LookaheadTLD::weightsAnalyse
+ * reads); qpAqOffset, qpCuTreeOffset and invQscaleFactor are being written by library threads when it returns and
+ * the arrays (and `quantOffsets`) must stay where they are.  x265gpu_aq_frames_finish joins those threads and installs
+ * the scale factors; after it the arrays are the caller's again.  Until then x265gpu_intra_estimate calls are held
+ * back (their AQ-weighted sums need the factors), and every call that reads scale factors or intra results - the cost
+ * pass of an estimate call (after its searches have been queued), the cuTree calls, the getters, x265gpu_sync -
+ * finishes the pending batches first, so only the caller's own reads of the three arrays need the explicit call. */
+int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int32_t memKind, const x265gpu_aq_params* params);
+int x265gpu_aq_frames_finish(x265gpu_ctx* ctx);
+
 /* ---- cuTree: propagation of block costs along the lookahead's motion vectors ----
  *
  * The data passes of Lookahead::cuTree (source/encoder/slicetype.cpp:3665-3766) on the arrays the

@@ -22,7 +22,7 @@ EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_estimate_sums_device", "x265gpu_weight_cost", "x265gpu_weight_costs", "x265gpu_weight_cost_static", "x265gpu_weight_planes",
-    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_aq_frames", "x265gpu_get_frame_costs", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_aq_frames", "x265gpu_aq_frames_begin", "x265gpu_aq_frames_finish", "x265gpu_get_frame_costs", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
     "x265gpu_cutree_clear", "x265gpu_cutree_swap", "x265gpu_cutree_propagate", "x265gpu_cutree_get_propagate_cost",
     "x265gpu_cutree_finish", "x265gpu_hist_stats", "x265gpu_mcstf_motion_search",
     "x265gpu_profile_enable", "x265gpu_profile_read",
@@ -550,7 +550,7 @@ class Context:
 HOST_LIB_PATH = os.path.join(_HERE, "libx265gpu_host.so")
 HOST_EXPORTS = (
     "xgh_window_create", "xgh_window_destroy", "xgh_pre_lookahead", "xgh_pre_lookahead_aq", "xgh_get_wp", "xgh_set_wp", "xgh_set_slice_type",
-    "xgh_set_qp_offsets", "xgh_single_cost", "xgh_add", "xgh_add_many", "xgh_finish_batch", "xgh_cost_est", "xgh_collect_costs", "xgh_intra_mbs",
+    "xgh_set_qp_offsets", "xgh_single_cost", "xgh_add", "xgh_add_many", "xgh_finish_batch", "xgh_resolve", "xgh_cost_est", "xgh_collect_costs", "xgh_intra_mbs",
     "xgh_is_weighted", "xgh_cu_tree", "xgh_status", "xgh_bitcost_table",
     "xgh_lookahead_create", "xgh_lookahead_destroy", "xgh_lookahead_add_picture", "xgh_lookahead_flush",
     "xgh_lookahead_get_decided", "xgh_lookahead_trace", "xgh_lookahead_cost_est", "xgh_lookahead_cost_est_aq",
@@ -620,6 +620,7 @@ def load_host_library():
     H.xgh_add_many.argtypes = [vp, i32, vp]
     H.xgh_add_many.restype = None
     H.xgh_finish_batch.argtypes = [vp]
+    H.xgh_resolve.argtypes = [vp]
     H.xgh_cost_est.argtypes = [vp, i32, i32, i32]
     H.xgh_cost_est.restype = i64
     H.xgh_collect_costs.argtypes = [vp, i32, vp, vp]
@@ -730,6 +731,7 @@ class HostWindow:
         prm = AqParams(int(aq_mode), int(weightp), 0, 0, float(strength), int(qg_size), 0, None, None, None, 0, 0, 0.0, None)
         iq = vpn(*[a.ctypes.data for a in invs])
         self._chk(self.H.xgh_pre_lookahead_aq(self.h, n, frames, ys, us, vs, sy, sc, C.byref(prm), iq, MEM_HOST))
+        self._chk(self.H.xgh_resolve(self.h))       # the arrays returned here are complete
         return invs
 
     def get_wp(self, frame):

@@ -105,12 +105,25 @@ struct x265gpu_ctx
     hipStream_t intraStream = nullptr;
     hipEvent_t intraFork = nullptr, intraDone = nullptr;
     bool intraPending = false;        // intraDone not yet awaited by the main stream
+    bool intraNoFork = false;         // the next side-stream intra launch depends on nothing queued on the main stream
     char* intraJobBuf = nullptr;      // job descriptors of the intra launch in flight (device, pinned mirror)
     char* intraJobHost = nullptr;
     size_t intraJobBufSize = 0;
     // single-launch search: row-progress words on the device, and its sticky error word mirrored here
     bool searchRows = false;
     bool searchFlow = false;           // X265GPU_SEARCH_MODE=flow: one launch, vectors as ready flags
+    // x265gpu_aq_frames_begin batches whose double-precision mapping is still running on host threads
+    struct AqPending
+    {
+        std::vector<x265gpu_aq_picture> pics;
+        x265gpu_aq_params params;
+        char* host = nullptr;          // page-locked copy of the energy arrays
+        char* dev = nullptr;
+        std::vector<std::thread> workers;
+        std::atomic<int>* next = nullptr;
+    };
+    std::vector<AqPending*> aqPending;
+    std::vector<int32_t> intraDeferred;    // slots whose intra estimate waits for those batches' scale factors
     int flowGridPad = 1;
     uint32_t* flowChunks[2] = { nullptr, nullptr };   // chunk tables of the half-res and the quarter-res block grid
     int flowChunkCount[2] = { 0, 0 };
@@ -118,6 +131,11 @@ struct x265gpu_ctx
     size_t searchSyncBytes = 0;
     int* searchErrHost = nullptr;     // pinned
 };
+
+// x265gpu_aq_frames_begin batches still on host threads: joined, uploaded, and the intra estimates that waited for
+// them launched, before anything reads scale factors or intra results
+static int aq_finish_pending(x265gpu_ctx* ctx);
+#define FINISH_AQ(ctx) do { if (ctx) { const int rcAq_ = aq_finish_pending(ctx); if (rcAq_) return rcAq_; } } while (0)
 
 namespace {
 
@@ -592,6 +610,7 @@ void x265gpu_close(x265gpu_ctx* ctx)
     DeviceScope deviceScope(ctx);
     if (!ctx)
         return;
+    (void)aq_finish_pending(ctx);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     for (auto& s : ctx->slots)
@@ -689,6 +708,7 @@ int x265gpu_host_free(x265gpu_ctx* ctx, void* p)
 int x265gpu_sync(x265gpu_ctx* ctx)
 {
     DeviceScope deviceScope(ctx);
+    FINISH_AQ(ctx);
     if (!ctx)
         return X265GPU_ERR_ARG;
     int rc = fetch_search_error(ctx);
@@ -781,11 +801,10 @@ int x265gpu_lowres_init(x265gpu_ctx* ctx, int32_t slot, const void* luma, intptr
     return x265gpu_lowres_init_batch(ctx, 1, &slot, &luma, &stride, memKind, &poc);
 }
 
-int x265gpu_lowres_set_aq(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQscaleFactor)
+static int set_aq_staged(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQscaleFactor, hipStream_t stream = nullptr)
 {
-    DeviceScope deviceScope(ctx);
-    if (!ctx || !slot_ok(ctx, slot))
-        return X265GPU_ERR_ARG;
+    if (!stream)
+        stream = ctx->stream;
     Slot& s = ctx->slots[slot];
     if (!invQscaleFactor)
     {
@@ -803,10 +822,21 @@ int x265gpu_lowres_set_aq(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQsca
     else
         HIPCHK(hipEventSynchronize(s.aqStaged));      // the previous upload of this slot has left the staging copy
     memcpy(s.aqStage, invQscaleFactor, bytes);
-    HIPCHK(hipMemcpyAsync(s.invQscale, s.aqStage, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipEventRecord(s.aqStaged, ctx->stream));
+    HIPCHK(hipMemcpyAsync(s.invQscale, s.aqStage, bytes, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipEventRecord(s.aqStaged, stream));
     s.hasAq = true;
     return X265GPU_OK;
+}
+
+int x265gpu_lowres_set_aq(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQscaleFactor)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || !slot_ok(ctx, slot))
+        return X265GPU_ERR_ARG;
+    int rc = aq_finish_pending(ctx);
+    if (rc)
+        return rc;
+    return set_aq_staged(ctx, slot, invQscaleFactor);
 }
 
 int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots)
@@ -819,6 +849,13 @@ int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots)
     for (int i = 0; i < n; i++)
         if (!slot_ok(ctx, slots[i]))
             return fail(ctx, X265GPU_ERR_ARG, "intra_estimate: bad slot");
+    if (!ctx->aqPending.empty())
+    {
+        // the AQ-weighted sums of the intra estimate need scale factors that host threads are still computing:
+        // the launch is made when they are done (aq_finish_pending), ahead of whatever reads its results
+        ctx->intraDeferred.insert(ctx->intraDeferred.end(), slots, slots + n);
+        return X265GPU_OK;
+    }
     std::vector<IntraJob> jobs(n);
     for (int i = 0; i < n; i++)
     {
@@ -849,8 +886,11 @@ int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots)
             ctx->intraJobBufSize = sz;
         }
         memcpy(ctx->intraJobHost, jobs.data(), bytes);
-        HIPCHK(hipEventRecord(ctx->intraFork, ctx->stream));
-        HIPCHK(hipStreamWaitEvent(ctx->intraStream, ctx->intraFork, 0));
+        if (!ctx->intraNoFork)
+        {
+            HIPCHK(hipEventRecord(ctx->intraFork, ctx->stream));
+            HIPCHK(hipStreamWaitEvent(ctx->intraStream, ctx->intraFork, 0));
+        }
         HIPCHK(hipMemcpyAsync(ctx->intraJobBuf, ctx->intraJobHost, bytes, hipMemcpyHostToDevice, ctx->intraStream));
         HIPCHK(launch_intra(ctx->intraStream, ctx->g, ctx->bpp, ctx->cfg.internalBitDepth, ctx->cfg.lookaheadLambda,
                             (const IntraJob*)ctx->intraJobBuf, n));
@@ -1081,6 +1121,14 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
         HIPCHK(launch_search(ctx->stream, ctx->searchAux, g, ctx->bpp, (const SearchJob*)(ctx->jobBuf + s4Bytes), (int)sj.size(), 0,
                              sj[0].method, ctx->costCentre, ctx->maxMvd, slicesMax, sliceHeightMax, &launches));
         pt.stop(launches);
+    }
+    if (!cj.empty())
+    {
+        // scale factors (and the intra estimates that wait for them) of x265gpu_aq_frames_begin batches: the host's
+        // double-precision mapping ran beside the searches queued above
+        rc = aq_finish_pending(ctx);
+        if (rc)
+            return rc;
     }
     join_intra(ctx);          // the cost pass reads intraCost; the searches above did not have to wait for it
     if (!cj.empty())
@@ -1320,6 +1368,7 @@ int x265gpu_get_plane(x265gpu_ctx* ctx, int32_t slot, int32_t planeIdx, void* pa
 int x265gpu_get_intra(x265gpu_ctx* ctx, int32_t slot, int32_t* intraCost, uint8_t* intraMode)
 {
     DeviceScope deviceScope(ctx);
+    FINISH_AQ(ctx);
     if (!ctx || !slot_ok(ctx, slot))
         return X265GPU_ERR_ARG;
     Slot& s = ctx->slots[slot];
@@ -1365,6 +1414,7 @@ int x265gpu_get_costs(x265gpu_ctx* ctx, int32_t slot, int32_t d0, int32_t d1, ui
                       int32_t* rowSatds, x265gpu_frame_cost* fc)
 {
     DeviceScope deviceScope(ctx);
+    FINISH_AQ(ctx);
     if (!ctx || !slot_ok(ctx, slot) || d0 < 0 || d0 >= ctx->D || d1 < 0 || d1 >= ctx->D)
         return X265GPU_ERR_ARG;
     Slot& s = ctx->slots[slot];
@@ -1692,6 +1742,7 @@ int x265gpu_cutree_propagate(x265gpu_ctx* ctx, int32_t slotP0, int32_t slotP1, i
                              int32_t referenced, double fpsFactor, int32_t bipredWeight)
 {
     DeviceScope deviceScope(ctx);
+    FINISH_AQ(ctx);
     if (!ctx || !slot_ok(ctx, slotP0) || !slot_ok(ctx, slotP1) || !slot_ok(ctx, slotB) || d0 < 1 || d0 >= ctx->D ||
         d1 < 0 || d1 >= ctx->D || bipredWeight < 0 || bipredWeight > 64)
         return X265GPU_ERR_ARG;
@@ -1780,6 +1831,7 @@ int x265gpu_cutree_finish(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor, dou
                           const double* qpAqOffset, double* qpCuTreeOffset)
 {
     DeviceScope deviceScope(ctx);
+    FINISH_AQ(ctx);
     return cutree_finish(ctx, slot, false, fpsFactor, weightDelta, cuTreeStrength, qpAqOffset, qpCuTreeOffset);
 }
 
@@ -1787,6 +1839,7 @@ int x265gpu_cutree_finish_qg8(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor,
                               const double* qpAqOffset, double* qpCuTreeOffset)
 {
     DeviceScope deviceScope(ctx);
+    FINISH_AQ(ctx);
     return cutree_finish(ctx, slot, true, fpsFactor, weightDelta, cuTreeStrength, qpAqOffset, qpCuTreeOffset);
 }
 
@@ -1794,6 +1847,7 @@ int x265gpu_cutree_finish_hevc(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor
                                int32_t qgSize, int32_t numLayers, x265gpu_hevc_aq_layer* layers, double* dCuTreeOffset8x8)
 {
     DeviceScope deviceScope(ctx);
+    FINISH_AQ(ctx);
     if (!ctx || !slot_ok(ctx, slot) || numLayers < 1 || numLayers > 4 || !layers)
         return X265GPU_ERR_ARG;
     const bool qg8 = qgSize == 8;
@@ -1962,6 +2016,7 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
                      uint64_t wpSsd[3])
 {
     DeviceScope deviceScope(ctx);
+    FINISH_AQ(ctx);
     if (!ctx || !params || !y || !u || !v || !wpSum || !wpSsd)
         return X265GPU_ERR_ARG;
     if (params->aqMode < 0 || params->aqMode > 3)
@@ -2129,7 +2184,9 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
     return X265GPU_OK;
 }
 
-int x265gpu_aq_frames(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int32_t memKind, const x265gpu_aq_params* params)
+// Launches the energy pass of every picture, waits for the sums, fills wpSum / wpSsd and hands the double-precision
+// mapping of the offsets to host threads.  Returns with those threads running when there is a mapping to do.
+int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int32_t memKind, const x265gpu_aq_params* params)
 {
     DeviceScope deviceScope(ctx);
     if (!ctx || !params || n < 0 || (n && !pics))
@@ -2169,15 +2226,22 @@ int x265gpu_aq_frames(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int
     const bool hdr = params->bHDR10Opt && mapped;
     const size_t arrayBytes = align256(sizeof(uint32_t) * (size_t)blocks);
     const size_t perPic = (hdr ? 2 : 1) * arrayBytes + AQ_WP_BYTES;
-    int rc = ensure_pu_buf(ctx, perPic * n);
-    if (rc)
-        return rc;
+    x265gpu_ctx::AqPending* b = new (std::nothrow) x265gpu_ctx::AqPending;
+    if (!b)
+        return X265GPU_ERR_NOMEM;
+    if (hipMalloc((void**)&b->dev, perPic * n) != hipSuccess || hipHostMalloc((void**)&b->host, perPic * n, hipHostMallocDefault) != hipSuccess)
+    {
+        if (b->dev) (void)hipFree(b->dev);
+        delete b;
+        return fail(ctx, X265GPU_ERR_NOMEM, "aq_frames: out of memory");
+    }
+    auto drop = [&]() { (void)hipFree(b->dev); (void)hipHostFree(b->host); delete b; };
     // every picture's energy pass, then one transfer and one wait
-    HIPCHK(hipMemsetAsync(ctx->puBuf, 0, perPic * n, ctx->stream));
-    for (int i = 0; i < n; i++)
+    hipError_t e = hipMemsetAsync(b->dev, 0, perPic * n, ctx->stream);
+    for (int i = 0; i < n && e == hipSuccess; i++)
     {
         const x265gpu_aq_picture& p = pics[i];
-        char* base = ctx->puBuf + perPic * i;
+        char* base = b->dev + perPic * i;
         AqJob job;
         memset(&job, 0, sizeof(job));
         job.width = job.visitWidth = w;
@@ -2191,14 +2255,39 @@ int x265gpu_aq_frames(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int
         job.energy = (uint32_t*)base;
         job.lumaSum = hdr ? (uint32_t*)(base + arrayBytes) : nullptr;
         job.wp = (unsigned long long*)(base + (hdr ? 2 : 1) * arrayBytes);
-        HIPCHK(launch_aq_energy(ctx->stream, ctx->bpp, job));
+        e = launch_aq_energy(ctx->stream, ctx->bpp, job);
     }
-    std::vector<char> host(perPic * n);
-    HIPCHK(hipMemcpyAsync(host.data(), ctx->puBuf, perPic * n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(b->host, b->dev, perPic * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess)
+    {
+        drop();
+        return fail(ctx, X265GPU_ERR_DEVICE, hipGetErrorString(e));
+    }
+    const bool wantWp = params->bWeightedPred != 0;
+    for (int i = 0; i < n; i++)
+    {
+        unsigned long long wp[6];
+        sum_wp_shards((const unsigned long long*)(b->host + perPic * i + (hdr ? 2 : 1) * arrayBytes), wp);
+        if (wantWp)
+            aq_finish_wp(w, h, wp, wp + 3);
+        for (int k = 0; k < 3; k++)
+        {
+            pics[i].wpSum[k] = wp[k];
+            pics[i].wpSsd[k] = wp[3 + k];
+        }
+    }
+    if (!mapped)
+    {
+        drop();
+        return X265GPU_OK;
+    }
     // The double-precision mapping of each picture is independent of the others: host threads share the pictures
     // the way x265's pool workers share the frames of PreLookaheadGroup (slicetype.cpp:1843-1859).
+    b->pics.assign(pics, pics + n);
+    b->params = *params;
     AqFrameParams ap;
     ap.aqMode = params->aqMode;
     ap.depth = ctx->cfg.internalBitDepth;
@@ -2206,67 +2295,92 @@ int x265gpu_aq_frames(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int
     ap.strength = params->aqStrength;
     ap.blockSize = 16;
     ap.blockCount = blocks;
-    const bool wantWp = params->bWeightedPred != 0;
-    auto work = [&](int i) {
-        x265gpu_aq_picture& p = pics[i];
-        const char* base = host.data() + perPic * i;
-        const uint32_t* energy = (const uint32_t*)base;
-        const uint32_t* lumaSum = hdr ? (const uint32_t*)(base + arrayBytes) : nullptr;
-        unsigned long long wp[6];
-        sum_wp_shards((const unsigned long long*)(base + (hdr ? 2 : 1) * arrayBytes), wp);
-        if (mapped)
-            aq_frame_offsets(ap, blocks, energy, lumaSum, p.quantOffsets, p.qpAqOffset, p.qpCuTreeOffset, p.invQscaleFactor);
-        if (wantWp)
-            aq_finish_wp(w, h, wp, wp + 3);
-        for (int k = 0; k < 3; k++)
-        {
-            p.wpSum[k] = wp[k];
-            p.wpSsd[k] = wp[3 + k];
-        }
-    };
-    int threads = 1;
-    if (mapped && n > 1)
-    {
-        const char* e = getenv("X265GPU_HOST_THREADS");
-        const unsigned hw = std::thread::hardware_concurrency();
-        threads = e ? atoi(e) : (int)(hw ? (hw < 16 ? hw : 16) : 4);
-        threads = threads < 1 ? 1 : (threads > n ? n : threads);
-    }
-    if (threads == 1)
-        for (int i = 0; i < n; i++)
-            work(i);
-    else
-    {
-        std::atomic<int> next(0);
-        std::vector<std::thread> pool;
-        for (int t = 0; t < threads; t++)
-            pool.emplace_back([&]() {
-                for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1))
-                    work(i);
-            });
-        for (auto& th : pool)
-            th.join();
-    }
-    if (mapped)
-    {
-        for (int i = 0; i < n; i++)
-            if (pics[i].slot >= 0)
+    const char* env = getenv("X265GPU_HOST_THREADS");
+    const unsigned hw = std::thread::hardware_concurrency();
+    int threads = env ? atoi(env) : (int)(hw ? (hw < 16 ? hw : 16) : 4);
+    threads = threads < 1 ? 1 : (threads > n ? n : threads);
+    b->next = new std::atomic<int>(0);
+    x265gpu_ctx::AqPending* batch = b;
+    for (int t = 0; t < threads; t++)
+        b->workers.emplace_back([batch, ap, n, perPic, arrayBytes, hdr, blocks]() {
+            for (int i = batch->next->fetch_add(1); i < n; i = batch->next->fetch_add(1))
             {
-                Slot& sl = ctx->slots[pics[i].slot];
-                HIPCHK(hipMemcpyAsync(sl.invQscale, pics[i].invQscaleFactor, sizeof(int32_t) * ctx->g.cuCount,
-                                      hipMemcpyHostToDevice, ctx->stream));
-                sl.hasAq = true;
+                const x265gpu_aq_picture& p = batch->pics[i];
+                const char* base = batch->host + perPic * i;
+                aq_frame_offsets(ap, blocks, (const uint32_t*)base, hdr ? (const uint32_t*)(base + arrayBytes) : nullptr,
+                                 p.quantOffsets, p.qpAqOffset, p.qpCuTreeOffset, p.invQscaleFactor);
             }
-        // the callers' arrays are theirs again when this returns
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
+        });
+    ctx->aqPending.push_back(b);
     return X265GPU_OK;
+}
+
+// Joins the host threads of every batch begun, installs the scale factors for the slots and launches the intra
+// estimates that waited for them.
+static int aq_finish_pending(x265gpu_ctx* ctx)
+{
+    if (ctx->aqPending.empty() && ctx->intraDeferred.empty())
+        return X265GPU_OK;
+    int rc = X265GPU_OK;
+    // x265gpu_aq_frames_begin waited for the stream, so the planes these frames' intra estimates read are in place:
+    // the uploads and the held-back intra launches depend on nothing queued since and go to the side stream, beside
+    // the searches; the main stream joins before its next pass that reads them.
+    const bool side = ctx->intraStream && !ctx->prof;
+    hipStream_t up = side ? ctx->intraStream : ctx->stream;
+    std::vector<x265gpu_ctx::AqPending*> batches;
+    batches.swap(ctx->aqPending);
+    for (x265gpu_ctx::AqPending* b : batches)
+    {
+        for (std::thread& th : b->workers)
+            th.join();
+        for (const x265gpu_aq_picture& p : b->pics)
+            if (p.slot >= 0 && rc == X265GPU_OK)
+                rc = set_aq_staged(ctx, p.slot, p.invQscaleFactor, up);
+        (void)hipFree(b->dev);
+        (void)hipHostFree(b->host);
+        delete b->next;
+        delete b;
+    }
+    if (rc == X265GPU_OK && !ctx->intraDeferred.empty())
+    {
+        std::vector<int32_t> slots;
+        slots.swap(ctx->intraDeferred);
+        ctx->intraNoFork = side;
+        rc = x265gpu_intra_estimate(ctx, (int)slots.size(), slots.data());
+        ctx->intraNoFork = false;
+    }
+    else if (rc == X265GPU_OK && side && !batches.empty())
+    {
+        if (hipEventRecord(ctx->intraDone, up) != hipSuccess)
+            rc = X265GPU_ERR_DEVICE;
+        ctx->intraPending = true;
+    }
+    ctx->intraDeferred.clear();
+    join_intra(ctx);
+    return rc;
+}
+
+int x265gpu_aq_frames_finish(x265gpu_ctx* ctx)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx)
+        return X265GPU_ERR_ARG;
+    return aq_finish_pending(ctx);
+}
+
+int x265gpu_aq_frames(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int32_t memKind, const x265gpu_aq_params* params)
+{
+    int rc = x265gpu_aq_frames_begin(ctx, n, pics, memKind, params);
+    if (rc == X265GPU_OK && ctx)
+        rc = x265gpu_aq_frames_finish(ctx);
+    return rc;
 }
 
 int x265gpu_get_frame_costs(x265gpu_ctx* ctx, int32_t n, const int32_t* slots, const int32_t* d0, const int32_t* d1,
                             x265gpu_frame_cost* out)
 {
     DeviceScope deviceScope(ctx);
+    FINISH_AQ(ctx);
     if (!ctx || n < 0 || (n && (!slots || !out)))
         return X265GPU_ERR_ARG;
     if (!n)

@@ -21,6 +21,7 @@ void Lowres::reset()
         }
     for (int d = 0; d < MAX_D; d++)
         presearchWeighted[d] = false;
+    intraTotalsPending = false;
     for (int i = 0; i < MAX_D; i++)
     {
         for (int j = 0; j < MAX_D; j++)
@@ -242,8 +243,11 @@ int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const Picture*
         a.qpCuTreeOffset = fr.qpCuTreeOffset;
         a.invQscaleFactor = fr.invQscaleFactor;
     }
-    // pictures of one batch live in one kind of memory
-    rc = x265gpu_aq_frames(m_ctx, n, ap.data(), pics[0].memKind, &aq);
+    // pictures of one batch live in one kind of memory.  The sums that weightsAnalyse reads are back when this
+    // returns; the offsets are still being mapped on the library's host threads, the intra estimate (whose AQ-weighted
+    // sums need them) is held back with them, and both are finished from inside the next estimate call, after its
+    // searches have been queued: resolveIntraTotals() then reads the frames' intra totals.
+    rc = x265gpu_aq_frames_begin(m_ctx, n, ap.data(), pics[0].memKind, &aq);
     if (rc != X265GPU_OK)
         return rc;
     for (int i = 0; i < n; i++)
@@ -254,14 +258,32 @@ int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const Picture*
     rc = x265gpu_intra_estimate(m_ctx, n, slots.data());
     if (rc != X265GPU_OK)
         return rc;
-    std::vector<x265gpu_frame_cost> fc(n);
-    rc = x265gpu_get_frame_costs(m_ctx, n, slots.data(), nullptr, nullptr, fc.data());
+    for (int i = 0; i < n; i++)
+        frames[i]->intraTotalsPending = true;
+    return X265GPU_OK;
+}
+
+int resolveIntraTotals(x265gpu_ctx* ctx, Lowres* const* frames, int n)
+{
+    std::vector<int32_t> slots;
+    std::vector<Lowres*> which;
+    for (int i = 0; i < n; i++)
+        if (frames[i] && frames[i]->intraTotalsPending)
+        {
+            slots.push_back(frames[i]->slot);
+            which.push_back(frames[i]);
+        }
+    if (which.empty())
+        return X265GPU_OK;
+    std::vector<x265gpu_frame_cost> fc(which.size());
+    const int rc = x265gpu_get_frame_costs(ctx, (int32_t)which.size(), slots.data(), nullptr, nullptr, fc.data());
     if (rc != X265GPU_OK)
         return rc;
-    for (int i = 0; i < n; i++)
+    for (size_t i = 0; i < which.size(); i++)
     {
-        frames[i]->costEst[0][0] = fc[i].costEst;
-        frames[i]->costEstAq[0][0] = fc[i].costEstAq;
+        which[i]->costEst[0][0] = fc[i].costEst;
+        which[i]->costEstAq[0][0] = fc[i].costEstAq;
+        which[i]->intraTotalsPending = false;
     }
     return X265GPU_OK;
 }
@@ -704,6 +726,8 @@ int Lookahead::unsupported() const
 
 int64_t Lookahead::cost(Lowres** frames, int p0, int p1, int b, bool bIntraPenalty)
 {
+    if (frames[b]->intraTotalsPending)
+        note(resolveIntraTotals(m_ctx, &frames[b], 1));
     // the trellis asks for the same costs thousands of times per decision: answer those from the cache
     // without setting a group up (estimateFrameCost's own first test, slicetype.cpp:4290)
     const int64_t cached = frames[b]->costEst[b - p0][p1 - b];
@@ -720,6 +744,8 @@ int64_t Lookahead::cost(Lowres** frames, int p0, int p1, int b, bool bIntraPenal
 void Lookahead::cuTree(Lowres** frames, int numframes, bool bIntra)
 {
     ScopeTimer timer(m_seconds[T_CUTREE]);
+    note(resolveIntraTotals(m_ctx, frames, numframes + 1));
+    note(x265gpu_aq_frames_finish(m_ctx));
     CuTreeParam cp;
     cp.fpsNum = m_param.fpsNum;
     cp.fpsDenom = m_param.fpsDenom;
@@ -1108,6 +1134,7 @@ void Lookahead::slicetypeAnalyse(Lowres** frames, bool bKeyframe)
         }
         note(est.status());
     }
+    note(resolveIntraTotals(m_ctx, frames, numFrames + 1));
 
     int numBFrames = 0, numAnalyzed = numFrames, resetStart;
     const bool isScenecut = scenecut(frames, 0, 1, true, origNumFrames);
@@ -1532,6 +1559,7 @@ void xgh_window_destroy(xgh_window* w)
 {
     if (!w)
         return;
+    x265gpu_aq_frames_finish(w->ctx);     // library threads may still be writing the frames' AQ arrays
     delete w->est;
     delete w;
 }
@@ -1593,16 +1621,33 @@ void xgh_add_many(xgh_window* w, int32_t n, const int32_t* p0p1b)
         w->est->add(p0p1b[3 * i], p0p1b[3 * i + 1], p0p1b[3 * i + 2]);
 }
 
+// what the AQ form of the pre-lookahead left running or on the device
+static int window_resolve(const xgh_window* w)
+{
+    int rc = resolveIntraTotals(w->ctx, w->frames.data(), (int)w->frames.size());
+    if (rc == X265GPU_OK)
+        rc = x265gpu_aq_frames_finish(w->ctx);
+    return rc;
+}
+
+int xgh_resolve(xgh_window* w) { return window_resolve(w); }
+
 int xgh_finish_batch(xgh_window* w)
 {
     w->est->finishBatch();
-    return w->est->status();
+    const int rc = window_resolve(w);
+    return w->est->status() != X265GPU_OK ? w->est->status() : rc;
 }
 
-int64_t xgh_cost_est(const xgh_window* w, int32_t b, int32_t d0, int32_t d1) { return w->frames[b]->costEst[d0][d1]; }
+int64_t xgh_cost_est(const xgh_window* w, int32_t b, int32_t d0, int32_t d1)
+{
+    window_resolve(w);
+    return w->frames[b]->costEst[d0][d1];
+}
 
 void xgh_collect_costs(const xgh_window* w, int32_t n, const int32_t* p0p1b, int64_t* out)
 {
+    window_resolve(w);
     for (int i = 0; i < n; i++)
     {
         const int p0 = p0p1b[3 * i], p1 = p0p1b[3 * i + 1], b = p0p1b[3 * i + 2];
@@ -1626,6 +1671,9 @@ int xgh_cu_tree(xgh_window* w, int32_t fpsNum, int32_t fpsDenom, int32_t bBPyram
     p.lookaheadDepth = lookaheadDepth;
     p.vbvBufferSize = vbvBufferSize;
     p.qCompress = qCompress;
+    const int rc = window_resolve(w);
+    if (rc != X265GPU_OK)
+        return rc;
     return CuTree(w->ctx, p).cuTree(w->frames.data(), numframes, bIntra != 0);
 }
 
@@ -1718,6 +1766,7 @@ void xgh_lookahead_destroy(xgh_lookahead* h)
 {
     if (!h)
         return;
+    x265gpu_aq_frames_finish(h->ctx);     // library threads may still be writing the frames' AQ arrays
     delete h->la;
     delete h;
 }
@@ -1775,21 +1824,40 @@ int xgh_lookahead_trace(const xgh_lookahead* h, const int32_t** out)
     return (int)t.size();
 }
 
+// the getters may be called while frames added after the last decision still have their AQ mapping running
+static void lookahead_resolve(const xgh_lookahead* h)
+{
+    std::vector<Lowres*> fr;
+    for (const LaFrame& f : h->frames)
+        if (f.lowres.intraTotalsPending)
+            fr.push_back(const_cast<Lowres*>(&f.lowres));
+    if (!fr.empty())
+        resolveIntraTotals(h->ctx, fr.data(), (int)fr.size());
+    x265gpu_aq_frames_finish(h->ctx);
+}
+
 int64_t xgh_lookahead_cost_est(const xgh_lookahead* h, int32_t frame, int32_t d0, int32_t d1)
 {
+    lookahead_resolve(h);
     return h->frames[frame].lowres.costEst[d0][d1];
 }
 int64_t xgh_lookahead_cost_est_aq(const xgh_lookahead* h, int32_t frame, int32_t d0, int32_t d1)
 {
+    lookahead_resolve(h);
     return h->frames[frame].lowres.costEstAq[d0][d1];
 }
 int32_t xgh_lookahead_intra_mbs(const xgh_lookahead* h, int32_t frame, int32_t d0) { return h->frames[frame].lowres.intraMbs[d0]; }
 int32_t xgh_lookahead_slot(const xgh_lookahead* h, int32_t frame) { return h->frames[frame].lowres.slot; }
 const double* xgh_lookahead_qp_offsets(const xgh_lookahead* h, int32_t frame, int32_t which)
 {
+    lookahead_resolve(h);
     return which ? h->frames[frame].qpCuTree.data() : h->frames[frame].qpAq.data();
 }
-const int32_t* xgh_lookahead_inv_qscale(const xgh_lookahead* h, int32_t frame) { return h->frames[frame].invQ.data(); }
+const int32_t* xgh_lookahead_inv_qscale(const xgh_lookahead* h, int32_t frame)
+{
+    lookahead_resolve(h);
+    return h->frames[frame].invQ.data();
+}
 const int64_t* xgh_lookahead_planned_satd(const xgh_lookahead* h, int32_t frame, const int32_t** types, int32_t* indB)
 {
     const Lowres& f = h->frames[frame].lowres;

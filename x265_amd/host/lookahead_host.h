@@ -71,6 +71,7 @@ struct Lowres
     int64_t costEst[MAX_D][MAX_D];    // -1: not measured (lowres.cpp:354-371)
     int64_t costEstAq[MAX_D][MAX_D];
     bool pending[MAX_D][MAX_D];       // queued in a batch that has not finished
+    bool intraTotalsPending = false;  // costEst[0][0] / costEstAq[0][0] not read back yet (resolveIntraTotals)
     int intraMbs[MAX_D];
     uint64_t wp_sum = 0, wp_ssd = 0;  // plane 0, as calcAdaptiveQuantFrame leaves them (slicetype.cpp:663-686)
     bool weighted[MAX_D];             // weightedRef[d].isWeighted
@@ -106,6 +107,12 @@ private:
     x265gpu_ctx* m_ctx;
     x265gpu_geometry m_geom;
 };
+
+// costEst[0][0] / costEstAq[0][0] of the frames whose pre-lookahead left them on the device (the AQ form of
+// PreLookaheadGroup::processTasks returns while the host threads that map the AQ offsets are still running, so
+// that the mapping overlaps the first batch of searches); one transfer for all of them.  Also ends that overlap:
+// after it qpAqOffset / qpCuTreeOffset / invQscaleFactor of every frame are complete.
+int resolveIntraTotals(x265gpu_ctx* ctx, Lowres* const* frames, int n);
 
 class PreLookaheadGroup
 {
@@ -314,6 +321,8 @@ void xgh_set_qp_offsets(xgh_window* w, int32_t frame, double* qpAqOffset, double
 int64_t xgh_single_cost(xgh_window* w, int32_t p0, int32_t p1, int32_t b, int32_t bIntraPenalty);
 void xgh_add(xgh_window* w, int32_t p0, int32_t p1, int32_t b);
 void xgh_add_many(xgh_window* w, int32_t n, const int32_t* p0p1b);   /* n x { p0, p1, b } */
+// finishes what xgh_pre_lookahead_aq left running: after it the frames' AQ arrays and intra totals are complete
+int xgh_resolve(xgh_window* w);
 int xgh_finish_batch(xgh_window* w);
 int64_t xgh_cost_est(const xgh_window* w, int32_t b, int32_t d0, int32_t d1);
 /* { costEst, costEstAq, intraMbs } of n requests { p0, p1, b } into out[3n]: what a multi-GPU lookahead gathers */

@@ -537,7 +537,11 @@ def rank_main(args):
         c = pmc_kernel(args, names[k])
         if not c or not valu_peak or not c.get("dispatches") or "SQ_INSTS_VALU" not in c:
             continue
-        launches = v["launches_per_step"] / 2 if (k == "search" and mode == "flow") else v["launches_per_step"]
+        # launches of the phase's main kernel: the intra and cost phases count their small finalize kernel as well,
+        # the flow search its fill kernel
+        launches = v["launches_per_step"]
+        if k in ("intra", "cost") or (k == "search" and mode == "flow"):
+            launches /= 2
         insts = c["SQ_INSTS_VALU"] / c["dispatches"] * launches
         v["valu_G_insts_per_s"] = insts / (v["ms_per_step"] * 1e-3) / 1e9
         v["valu_frac"] = v["valu_G_insts_per_s"] / valu_peak

@@ -881,13 +881,11 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     c.maxy = (H - cuY - 1) * 8 + 8;
     c.xr = c.maxx - c.minx;
     c.yr = c.maxy - c.miny;
-    // group 0 reads the encode block; the other groups take their row from it across lanes
+    // group 0 reads the encode block; the other groups take their row from it across lanes, but only once the
+    // neighbour vectors and everything they lead to have been put in flight behind this load: the first use of the
+    // rows is the predictor SATD, and one memory round trip carries both
     if (c.g == 0)
         c.fr = load_row_g<P>(as_global<P>(job.fencPlane0) - padOffset, padOffset + (c.by + c.r) * stride + c.bx);
-#pragma unroll
-    for (int i = 0; i < PixT<P>::NW; i++)
-        c.fr.w[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c.r, (int)c.fr.w[i]);
-    c.f = pair_cols<P>(c.fr);
 
     // ---- predictor: lowest-SATD neighbour vector (slicetype.cpp:4438-4476) ----
     const XG_GLOBAL int32_t* mvs = as_global<int32_t>(job.mvs);
@@ -980,22 +978,61 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         sy = (clampi(sy, c.miny * 4, c.maxy * 4) + 2) >> 2;
 
         const bool cand = mine || (c.g == 4 && v4);
-        Row<P> ref = cand_row<P>(c, cx, cy, cand || c.g == 6);
+        // The kernel pays for every line a load touches (the vector L1 serves about one line per two cycles per
+        // compute unit whether it hits or not), so nothing is fetched twice.  Neighbouring blocks mostly carry the
+        // same vector: a candidate equal to one of a lower group takes that group's SATD instead of reading the
+        // same eight rows again (it can never be picked, the first strictly smaller cost wins).  The zero block of
+        // the searched plane is the zero block of the closing check whenever both are plane 0 of the same picture.
+        // The table entry of mvcost(0,0) comes out of the table window staged below when it lies inside it.
+        int origin = c.g;
+#define SAME_AS(G, VALID)                                                                    \
+        if ((VALID) && cand && c.g > G && origin == c.g && cx == group_value<G>(cx) && cy == group_value<G>(cy)) \
+            origin = G;
+        SAME_AS(0, v0)
+        SAME_AS(1, v1)
+        SAME_AS(2, v2)
+        SAME_AS(3, v3)
+#undef SAME_AS
+        const bool dup = origin != c.g;
+        const bool zeroShared = job.zeroRef == job.refOrigin && job.zeroStride == stride;     // wave-uniform
+        Row<P> ref = cand_row<P>(c, cx, cy, (cand && !dup) || (c.g == 6 && !zeroShared));
         if (c.g == 5)
             ref = load_row_g<P>(as_global<P>(job.zeroRef), c.by * stride + c.bx + c.r * job.zeroStride);
         // table entries of mvcost(0,0) should this group's vector become the predictor
         // (group 6 stands in for the zero predictor of a block without neighbours)
         int t0 = 0;
-        if ((cand || c.g == 6) && c.r < 2)
-            t0 = (int)c.costBase[(unsigned)(clampi(c.r == 0 ? -cx : -cy, -maxMvd, maxMvd) + maxMvd)];
+        const int t0d = c.r == 0 ? -cx : -cy;                    // the MVD of the zero vector under this predictor
+        const bool t0need = (cand || c.g == 6) && c.r < 2 && !dup;
+        const bool t0staged = (unsigned)(t0d + 4 * (TAB_N / 8)) < (unsigned)TAB_N && maxMvd >= TAB_N;
+        if (t0need && !t0staged)
+            t0 = (int)c.costBase[(unsigned)(clampi(t0d, -maxMvd, maxMvd) + maxMvd)];
         const WinStage<P> ws = win_load<P>(c, sx, sy);
         const TabStage ts = tab_load<P>(c, 0, 0);
         lds_handover();
         win_store<P>(c, ws);
         tab_store<P>(c, ts);
         lds_handover();
+        if (t0need && t0staged)
+            t0 = (int)((const XG_LDS uint16_t*)c.tab)[(c.r & 1) * TAB_N + t0d - (c.r ? c.tabLoY : c.tabLoX)];
+#pragma unroll
+        for (int i = 0; i < PixT<P>::NW; i++)
+            c.fr.w[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c.r, (int)c.fr.w[i]);
+        c.f = pair_cols<P>(c.fr);
+        if (zeroShared)
+        {
+#pragma unroll
+            for (int i = 0; i < PixT<P>::NW; i++)
+            {
+                const uint32_t fromG5 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (40 + c.r), (int)ref.w[i]);
+                ref.w[i] = c.g == 6 ? fromG5 : ref.w[i];
+            }
+        }
 
-        const int cost = reduce_cost<P, EV_SATD>(c, ref, 0);
+        int cost = reduce_cost<P, EV_SATD>(c, ref, 0);
+        {
+            const int fromOrigin = __builtin_amdgcn_ds_bpermute(32 * origin, cost);
+            cost = dup ? fromOrigin : cost;
+        }
         const int sad = sad8x8<P>(c.fr, ref);
         t0 += dpp<DPP_XOR1>(t0);
         zeroSatd = group_value<5>(cost);

@@ -549,7 +549,7 @@ class Context:
 # ---- the C++ host layer (x265_amd/host/lookahead_host.h) through its plain-C face ----
 HOST_LIB_PATH = os.path.join(_HERE, "libx265gpu_host.so")
 HOST_EXPORTS = (
-    "xgh_window_create", "xgh_window_destroy", "xgh_pre_lookahead", "xgh_pre_lookahead_aq", "xgh_get_wp", "xgh_set_wp", "xgh_set_slice_type",
+    "xgh_window_create", "xgh_new_group", "xgh_window_destroy", "xgh_pre_lookahead", "xgh_pre_lookahead_aq", "xgh_get_wp", "xgh_set_wp", "xgh_set_slice_type",
     "xgh_set_qp_offsets", "xgh_single_cost", "xgh_add", "xgh_add_many", "xgh_finish_batch", "xgh_resolve", "xgh_cost_est", "xgh_collect_costs", "xgh_intra_mbs",
     "xgh_is_weighted", "xgh_cu_tree", "xgh_status", "xgh_bitcost_table",
     "xgh_lookahead_create", "xgh_lookahead_destroy", "xgh_lookahead_add_picture", "xgh_lookahead_flush",
@@ -602,6 +602,8 @@ def load_host_library():
     H.xgh_window_create.argtypes = [vp, i32, i32, i32]
     H.xgh_window_create.restype = vp
     H.xgh_window_destroy.argtypes = [vp]
+    H.xgh_new_group.argtypes = [vp, i32, i32]
+    H.xgh_new_group.restype = None
     H.xgh_window_destroy.restype = None
     H.xgh_pre_lookahead.argtypes = [vp, i32, vp, vp, vp, vp]
     H.xgh_pre_lookahead_aq.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32]
@@ -733,6 +735,10 @@ class HostWindow:
         self._chk(self.H.xgh_pre_lookahead_aq(self.h, n, frames, ys, us, vs, sy, sc, C.byref(prm), iq, MEM_HOST))
         self._chk(self.H.xgh_resolve(self.h))       # the arrays returned here are complete
         return invs
+
+    def new_group(self, weightp=False):
+        """A fresh CostEstimateGroup over the window (batch mode off again), as x265 sets one up per call site."""
+        self.H.xgh_new_group(self.h, int(weightp), self.ctx.depth)
 
     def get_wp(self, frame):
         a, b = C.c_uint64(), C.c_uint64()

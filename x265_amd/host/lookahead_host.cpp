@@ -1555,6 +1555,14 @@ xgh_window* xgh_window_create(x265gpu_ctx* ctx, int32_t nframes, int32_t bEnable
     return w;
 }
 
+// A fresh CostEstimateGroup over the window's frames, as x265 sets one up per call site (slicetype.cpp:2920, 3030,
+// 3691): m_batchMode starts out false again
+void xgh_new_group(xgh_window* w, int32_t bEnableWeightedPred, int32_t bitDepth)
+{
+    delete w->est;
+    w->est = new CostEstimateGroup(w->ctx, w->frames.data(), bEnableWeightedPred != 0, bitDepth);
+}
+
 void xgh_window_destroy(xgh_window* w)
 {
     if (!w)

@@ -306,6 +306,7 @@ private:
 extern "C" {
 typedef struct xgh_window xgh_window;
 xgh_window* xgh_window_create(x265gpu_ctx* ctx, int32_t nframes, int32_t bEnableWeightedPred, int32_t bitDepth);
+void xgh_new_group(xgh_window* w, int32_t bEnableWeightedPred, int32_t bitDepth);
 void xgh_window_destroy(xgh_window* w);
 int xgh_pre_lookahead(xgh_window* w, int32_t n, const int32_t* frames, const void* const* lumas, const intptr_t* strides,
                       const int32_t* const* invQscale);

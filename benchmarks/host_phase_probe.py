@@ -89,7 +89,7 @@ def main():
     srch = (tr[:, 3] + tr[:, 4]) > 0
     print("steady: %.1f ms, %d decide calls, %d requests: %d batched (%d with searches), %d single (%d with searches)"
           % (1000 * dt, la.decide_calls(), len(tr), batch.sum(), (batch & srch).sum(), (~batch).sum(), (~batch & srch).sum()))
-    print("steady phases, ms:", {k: round(1000 * v, 2) for k, v in la.seconds().items()}, "presearch hits", la.presearch_hits())
+    print("steady phases, ms:", {k: round(1000 * v, 2) for k, v in la.seconds().items()}, "presearch hits", la.presearch_hits(), "precost hits", la.precost_hits())
     la.close()
     win.close()
     ctx.close()

@@ -1,6 +1,5 @@
 """CPU: the oracle's lookahead (Lowres::init, intra estimate, motion search, frame
-costs) against the committed golden vectors, domain properties, and the host-side
-mirror of CostEstimateGroup driven with the oracle standing in for the device."""
+costs) against the committed golden vectors and domain properties."""
 import importlib.util
 import os
 import zlib
@@ -10,7 +9,6 @@ import pytest
 
 from oracle import orc
 from x265_amd import synth
-from x265_amd.lookahead import CostEstimateGroup, LowresState
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -106,67 +104,5 @@ def test_cost_cache_and_bias(oracle_built):
     raw = [r for r in range(lo, lo + 3) if r * 100 // 130 == a]
     assert any(r * 100 // 150 == b for r in raw)
     assert la.frame_cost(0, 1, 1) == la.frames[1].i64("costEst", 1, 0)   # P requests are not scaled
-    la.close()
-    lb.close()
-
-
-class OracleBackedCtx:
-    """Stands in for the device context: executes requests with the oracle and checks the
-    doSearch flags the host mirror decided against the oracle's own 0x7FFF sentinels."""
-
-    class _G:
-        pass
-
-    def __init__(self, la):
-        self.la = la
-        g = la.frames[0].geometry
-        self.geom = self._G()
-        self.geom.widthInCU, self.geom.heightInCU = g["widthInCU"], g["heightInCU"]
-        self.D = la.param.bframes + 2
-        self.searches = 0
-
-    def estimate_costs(self, requests):
-        out = []
-        for (s0, sb, s1, p0, b, p1, do0, do1, _w, _coop) in requests:
-            fr = self.la.frames[b]
-            assert bool(do0) == (int(fr.mvs(0, b - p0)[0, 0]) == 0x7FFF)
-            assert bool(do1) == (p1 > b and int(fr.mvs(1, p1 - b)[0, 0]) == 0x7FFF)
-            self.searches += int(do0) + int(do1)
-            before = fr.i64("intraMbs", b - p0)
-            self.la.frame_cost(p0, p1, b)
-            out.append((fr.i64("costEst", b - p0, p1 - b), fr.i64("costEstAq", b - p0, p1 - b),
-                        fr.i64("intraMbs", b - p0) - before))
-        return out
-
-
-def test_host_mirror_decisions_match_oracle(oracle_built):
-    import bench
-    W, H, N = 192, 128, 9
-    clip = synth.luma_clip(W, H, N, 8, seed=21)
-    param = orc.make_param(W, H)
-    la = orc.Lookahead(8, param)      # executes the mirror's requests
-    lb = orc.Lookahead(8, param)      # straight sequential reference
-    for f in clip:
-        la.add_frame(f)
-        lb.add_frame(f)
-    ctx = OracleBackedCtx(la)
-    frames = [LowresState(i, i, ctx.D) for i in range(N)]
-    est = CostEstimateGroup(ctx, frames)
-    # lazy order with penalties and repeats
-    for (p0, p1, b) in [(0, 2, 2), (0, 2, 1), (0, 1, 1), (1, 2, 2), (0, 2, 2), (3, 6, 6), (3, 6, 4), (3, 6, 5)]:
-        for pen in (True, False):
-            assert est.single_cost(p0, p1, b, pen) == lb.frame_cost(p0, p1, b, pen)
-    # the two batch loops: batch 2 must not need any search
-    b1, b2 = bench.batch_requests(N, 4)
-    for r in b1:
-        est.add(*r)
-    est.finish_batch()
-    n_after_b1 = ctx.searches
-    for r in b2:
-        est.add(*r)
-    est.finish_batch()
-    assert ctx.searches == n_after_b1
-    for (p0, p1, b) in b1 + b2:
-        assert frames[b].cost_est[(b - p0, p1 - b)] == lb.frame_cost(p0, p1, b)
     la.close()
     lb.close()

@@ -555,7 +555,7 @@ HOST_EXPORTS = (
     "xgh_lookahead_create", "xgh_lookahead_destroy", "xgh_lookahead_add_picture", "xgh_lookahead_flush",
     "xgh_lookahead_get_decided", "xgh_lookahead_trace", "xgh_lookahead_cost_est", "xgh_lookahead_cost_est_aq",
     "xgh_lookahead_intra_mbs", "xgh_lookahead_slot", "xgh_lookahead_qp_offsets", "xgh_lookahead_inv_qscale",
-    "xgh_lookahead_planned_satd", "xgh_lookahead_recalc_row_satds", "xgh_lookahead_decide_calls", "xgh_lookahead_presearch_hits", "xgh_lookahead_seconds",
+    "xgh_lookahead_planned_satd", "xgh_lookahead_recalc_row_satds", "xgh_lookahead_decide_calls", "xgh_lookahead_presearch_hits", "xgh_lookahead_precost_hits", "xgh_lookahead_seconds",
     "xgh_tme_create", "xgh_tme_destroy", "xgh_tme_unsupported", "xgh_tme_estimate_rows", "xgh_tme_counts",
 )
 
@@ -657,6 +657,7 @@ def load_host_library():
     H.xgh_lookahead_recalc_row_satds.restype = C.POINTER(i32)
     H.xgh_lookahead_decide_calls.argtypes = [vp]
     H.xgh_lookahead_presearch_hits.argtypes = [vp]
+    H.xgh_lookahead_precost_hits.argtypes = [vp]
     H.xgh_lookahead_seconds.argtypes = [vp, C.POINTER(C.c_double * 6)]
     H.xgh_lookahead_seconds.restype = None
     H.xgh_tme_create.argtypes = [vp, vp]
@@ -894,6 +895,10 @@ class HostLookahead:
     def presearch_hits(self):
         """Searches that single requests found already done (queued ahead with a batch)."""
         return self.H.xgh_lookahead_presearch_hits(self.h)
+
+    def precost_hits(self):
+        """Single requests answered from a cost pass that ran ahead with a batch."""
+        return self.H.xgh_lookahead_precost_hits(self.h)
 
 
 # ---- --threaded-me: motion vectors of every PU shape of a CTU, ahead of analysis ----

@@ -19,6 +19,7 @@ void Lowres::reset()
             searched[l][d] = false;
             presearched[l][d] = PRE_NONE;
         }
+    memset(preCost, 0, sizeof(preCost));
     for (int d = 0; d < MAX_D; d++)
         presearchWeighted[d] = false;
     intraTotalsPending = false;
@@ -337,15 +338,20 @@ bool CostEstimateGroup::makeRequest(int p0, int p1, int b, Pending& out)
         fenc.searched[1][d1] = true;
         fenc.presearched[1][d1] = PRE_NONE;
     }
-    if (getenv("XGH_DEBUG_SINGLES") && !m_batchMode && (do0 || do1))
-        fprintf(stderr, "single with search: p0 %d p1 %d b %d (frames %d %d %d) do %d %d pre-state %d %d\n", p0, p1, b,
-                m_frames[p0]->frameNum, m_frames[p1]->frameNum, fenc.frameNum, do0, do1, fenc.presearched[0][d0], fenc.presearched[1][d1]);
+    // a search that runs now rewrites vectors: costs measured ahead over the old ones are void
+    if (do0)
+        for (int j = 0; j < MAX_D; j++)
+            fenc.preCost[d0][j].valid = false;
+    if (do1)
+        for (int i = 0; i < MAX_D; i++)
+            fenc.preCost[i][d1].valid = false;
     fenc.pending[d0][d1] = true;
     if (m_trace)
         m_trace->push_back({ m_frames[p0]->frameNum, m_frames[p1]->frameNum, fenc.frameNum, { need0, need1 }, m_batchMode });
     bool weighted = false;
     out.deferWeights = false;
     out.presearch = false;
+    out.precost = false;
     out.p0 = p0;
     if (m_weightp)
     {
@@ -356,6 +362,19 @@ bool CostEstimateGroup::makeRequest(int p0, int p1, int b, Pending& out)
             out.deferWeights = true;           // finishBatch analyses the batch's pairs together
         else if (do0)
             weighted = analyseWeights(fenc, *m_frames[p0]);
+    }
+    if (!do0 && !do1 && fenc.preCost[d0][d1].valid)
+    {
+        // nothing to search, and the cost pass over these vectors ran ahead (addPrecost): its result is this request's
+        const Lowres::PreCost& pc = fenc.preCost[d0][d1];
+        fenc.costEst[d0][d1] = pc.costEst;
+        fenc.costEstAq[d0][d1] = pc.costEstAq;
+        if (d1 == 0)
+            fenc.intraMbs[d0] += pc.intraMbs;
+        fenc.preCost[d0][d1].valid = false;
+        fenc.pending[d0][d1] = false;
+        m_precostHits++;
+        return false;
     }
     memset(&out.req, 0, sizeof(out.req));
     out.req.slotP0 = m_frames[p0]->slot;
@@ -389,14 +408,21 @@ void CostEstimateGroup::addPresearch(int p0, int p1, int b, int lists)
     const bool weighted = false;
     p.deferWeights = do0 && m_weightp;         // analysed with the batch's other pairs in finishBatch
     p.presearch = true;
+    p.precost = false;
     p.p0 = p0;
     if (do0)
     {
         fenc.presearched[0][d0] = kind;
         fenc.presearchWeighted[d0] = false;
+        for (int j = 0; j < MAX_D; j++)
+            fenc.preCost[d0][j].valid = false;
     }
     if (do1)
+    {
         fenc.presearched[1][d1] = PRE_B;
+        for (int i = 0; i < MAX_D; i++)
+            fenc.preCost[i][d1].valid = false;
+    }
     p.req.slotP0 = m_frames[p0]->slot;
     p.req.slotB = fenc.slot;
     p.req.slotP1 = m_frames[p1]->slot;
@@ -414,11 +440,54 @@ void CostEstimateGroup::addPresearch(int p0, int p1, int b, int lists)
     m_batch.push_back(p);
 }
 
+// Not in x265: the cost pass of a request x265 has not made yet, over vectors that are on the device already - found
+// by a regular search or by one that ran ahead (addPresearch), of the kind (P or bidirectional) the request would
+// search with.  The result is kept aside (Lowres::preCost) and becomes the request's when x265's order makes it and
+// finds nothing left to search (makeRequest); the per-block costs and row sums it leaves on the device are the ones
+// the request would write.  Nothing x265 can observe changes before that moment.
+void CostEstimateGroup::addPrecost(int p0, int p1, int b)
+{
+    Lowres& fenc = *m_frames[b];
+    const int d0 = b - p0, d1 = p1 - b;
+    if (fenc.costEst[d0][d1] >= 0 || fenc.pending[d0][d1] || fenc.preCost[d0][d1].valid)
+        return;
+    const uint8_t kind = p1 > b ? PRE_B : PRE_P;
+    const bool have0 = fenc.searched[0][d0] || fenc.presearched[0][d0] == kind;
+    const bool have1 = p1 == b || fenc.searched[1][d1] || fenc.presearched[1][d1] == PRE_B;
+    if (!have0 || !have1)
+        return;
+    for (const Pending& q : m_batch)
+        if (q.precost && q.b == b && q.d0 == d0 && q.d1 == d1)
+            return;
+    m_batchMode = true;
+    Pending p;
+    memset(&p.req, 0, sizeof(p.req));
+    p.deferWeights = false;
+    p.presearch = false;
+    p.precost = true;
+    p.p0 = p0;
+    p.req.slotP0 = m_frames[p0]->slot;
+    p.req.slotB = fenc.slot;
+    p.req.slotP1 = m_frames[p1]->slot;
+    p.req.p0 = p0;
+    p.req.b = b;
+    p.req.p1 = p1;
+    p.b = b;
+    p.d0 = d0;
+    p.d1 = d1;
+    m_batch.push_back(p);
+}
+
 void CostEstimateGroup::collect(const Pending& p, const x265gpu_frame_cost& fc)
 {
     if (p.req.bSearchOnly)
         return;
     Lowres& fenc = *m_frames[p.b];
+    if (p.precost)
+    {
+        fenc.preCost[p.d0][p.d1] = { fc.costEst, fc.costEstAq, fc.intraMbs, true };
+        return;
+    }
     fenc.costEst[p.d0][p.d1] = fc.costEst;
     fenc.costEstAq[p.d0][p.d1] = fc.costEstAq;
     if (p.d1 == 0)
@@ -514,7 +583,7 @@ void CostEstimateGroup::finishBatch()
         if (m_status == X265GPU_OK)
             m_status = rc;
         for (const Pending& p : m_batch)
-            if (!p.req.bSearchOnly)
+            if (!p.req.bSearchOnly && !p.precost)
                 m_frames[p.b]->pending[p.d0][p.d1] = false;
     }
     else
@@ -738,6 +807,7 @@ int64_t Lookahead::cost(Lowres** frames, int p0, int p1, int b, bool bIntraPenal
     const int64_t c = est.singleCost(p0, p1, b, bIntraPenalty);
     note(est.status());
     m_presearchHits += est.presearchHits();
+    m_precostHits += est.precostHits();
     return c;
 }
 
@@ -1129,6 +1199,8 @@ void Lookahead::slicetypeAnalyse(Lowres** frames, bool bKeyframe)
                     }
                 }
             m_bBatchFrameCosts = m_bBatchFrameCosts && P.poolWorkers > 12;
+            if (P.bPresearch)
+                precostEdges(est, numFrames);
             ScopeTimer timer(m_seconds[T_BATCH2]);
             est.finishBatch();
         }
@@ -1306,6 +1378,18 @@ void Lookahead::presearchEdges(CostEstimateGroup& est, Lowres** /*frames*/, int 
     for (int b = 1; b < numFrames; b++)
         for (int d = 1; d <= bf && b + d <= numFrames; d++)
             est.addPresearch(b - 1, b + d, b, 2);
+}
+
+// Not in x265: with the frame costs of batch 2, the cost of every other request of the window whose vectors are on
+// the device by now (the window's first and last frames, and whatever the searches that ran ahead made possible).
+// x265 asks for these one at a time, each a round trip to the device here; addPrecost keeps the answers aside.
+void Lookahead::precostEdges(CostEstimateGroup& est, int numFrames)
+{
+    const int bf = m_param.bframes;
+    for (int b = 1; b <= numFrames; b++)
+        for (int d0 = 1; d0 <= bf + 1 && b - d0 >= 0; d0++)
+            for (int d1 = 0; d1 <= bf && b + d1 <= numFrames; d1++)
+                est.addPrecost(b - d0, b + d1, b);
 }
 
 void Lookahead::placeBref(Lowres** list, int start, int end, int num, int& brefs)      // :1864-1886
@@ -1880,6 +1964,7 @@ const int32_t* xgh_lookahead_recalc_row_satds(const xgh_lookahead* h, int32_t fr
 }
 int xgh_lookahead_decide_calls(const xgh_lookahead* h) { return h->la->decideCalls(); }
 int xgh_lookahead_presearch_hits(const xgh_lookahead* h) { return h->la->presearchHits(); }
+int xgh_lookahead_precost_hits(const xgh_lookahead* h) { return h->la->precostHits(); }
 void xgh_lookahead_seconds(const xgh_lookahead* h, double out[6])
 {
     for (int i = 0; i < Lookahead::T_COUNT; i++)

@@ -68,6 +68,11 @@ struct Lowres
     // would.  0: none; PRE_P: searched as a P request's list 0; PRE_B: as part of a bidirectional request.
     uint8_t presearched[2][MAX_D];
     bool presearchWeighted[MAX_D];    // weightsAnalyse's outcome for the presearched list-0 search
+    // Costs measured ahead of x265's order over vectors that are already on the device (searched or presearched),
+    // kept out of costEst until x265's order asks for them.  A search that rewrites one of the two vector sets drops
+    // the entry.
+    struct PreCost { int64_t costEst, costEstAq; int32_t intraMbs; bool valid; };
+    PreCost preCost[MAX_D][MAX_D];
     int64_t costEst[MAX_D][MAX_D];    // -1: not measured (lowres.cpp:354-371)
     int64_t costEstAq[MAX_D][MAX_D];
     bool pending[MAX_D][MAX_D];       // queued in a batch that has not finished
@@ -149,12 +154,14 @@ public:
     // pair, the list, the distance, whether the request is bidirectional and whether it runs in cooperative slices;
     // a presearched list 0 is therefore only used by a later request of the same kind (p1 > b or not).
     void addPresearch(int p0, int p1, int b, int lists);
+    void addPrecost(int p0, int p1, int b);
     void finishBatch();
     int status() const { return m_status; }      // first failure of any call, or X265GPU_OK
     int presearchHits() const { return m_presearchHits; }
+    int precostHits() const { return m_precostHits; }
 
 private:
-    struct Pending { x265gpu_request req; int b, d0, d1; int p0; bool deferWeights, presearch; };
+    struct Pending { x265gpu_request req; int b, d0, d1; int p0; bool deferWeights, presearch, precost; };
     void analyseDeferredWeights();
     bool makeRequest(int p0, int p1, int b, Pending& out);
     bool analyseWeights(Lowres& fenc, Lowres& ref);
@@ -172,6 +179,7 @@ private:
     std::vector<Pending> m_batch;
     std::vector<RequestTrace>* m_trace;
     int m_presearchHits = 0;
+    int m_precostHits = 0;
 };
 
 // The subset of x265_param that cuTree reads
@@ -261,6 +269,7 @@ public:
     const std::vector<RequestTrace>& trace() const { return m_trace; }
     int decideCalls() const { return m_decideCalls; }
     int presearchHits() const { return m_presearchHits; }
+    int precostHits() const { return m_precostHits; }
     // wall-clock seconds spent inside slicetypeDecide, split by what was running (profiling aid)
     enum { T_PRE, T_BATCH1, T_BATCH2, T_SINGLE, T_CUTREE, T_DECIDE, T_COUNT };
     const double* seconds() const { return m_seconds; }
@@ -297,7 +306,9 @@ private:
     int m_status = X265GPU_OK;
     int m_decideCalls = 0;
     int m_presearchHits = 0;
+    int m_precostHits = 0;
     void presearchEdges(CostEstimateGroup& est, Lowres** frames, int numFrames);
+    void precostEdges(CostEstimateGroup& est, int numFrames);
 };
 
 } // namespace x265gpu_host
@@ -377,6 +388,7 @@ const int64_t* xgh_lookahead_planned_satd(const xgh_lookahead* la, int32_t frame
 const int32_t* xgh_lookahead_recalc_row_satds(const xgh_lookahead* la, int32_t frame);
 int xgh_lookahead_decide_calls(const xgh_lookahead* la);
 int xgh_lookahead_presearch_hits(const xgh_lookahead* la);
+int xgh_lookahead_precost_hits(const xgh_lookahead* la);
 /* seconds inside slicetypeDecide: { pre-analysis, batch 1, batch 2, single requests, cuTree, whole decide calls } */
 void xgh_lookahead_seconds(const xgh_lookahead* la, double out[6]);
 }

@@ -42,6 +42,7 @@ extern "C" {
 #define X265GPU_HEX_SEARCH  1
 #define X265GPU_UMH_SEARCH  2
 #define X265GPU_STAR_SEARCH 3
+#define X265GPU_SEA_SEARCH  4
 #define X265GPU_FULL_SEARCH 5
 /* not an x265 method value: MotionEstimate::diamondSearch (source/encoder/motion.cpp:631-788), the coarse
  * search behind an area's starting vector (Search::puMotionEstimation with isMVP, source/encoder/search.cpp:360-364).
@@ -300,10 +301,16 @@ typedef struct x265gpu_pu_result
  * unlike the lookahead's): same meaning as x265gpu_set_mvcost. */
 int x265gpu_me_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd);
 
-/* searchMethod: X265GPU_DIA_SEARCH, _HEX_, _UMH_, _STAR_ or _FULL_SEARCH (param->searchMethod; SEA, which needs
- * integral planes of the reference, is X265GPU_ERR_UNSUPPORTED);
+/* searchMethod: X265GPU_DIA_SEARCH, _HEX_, _UMH_, _STAR_, _SEA_ or _FULL_SEARCH (param->searchMethod);
  * merange: param->searchRange; subpelRefine: param->subpelRefine (0..7, workload table
  * motion.cpp:48-58).  Results come back in job order; the call returns when they are in `out`. */
+/* X265GPU_SEA_SEARCH (motion.cpp:1438-1591): the block sums FrameFilter::computeMEIntegral keeps per reference
+ * (source/encoder/framefilter.cpp:731-831) are made on the device from the reference slot's padded picture when
+ * first needed and kept until that slot is uploaded again or another reference is searched.  merange up to 126.
+ * The reference's elimination test for 8x4, 4x8, 32x8 and 8x32 PUs compares sums taken over encode-buffer bytes
+ * outside the PU (what an earlier PU left there), so no result is defined for them: X265GPU_ERR_UNSUPPORTED, as for
+ * sizes HEVC has no partition for.  A window whose block sums would leave the padded picture (the reference reads
+ * past its planes there) is X265GPU_ERR_ARG: keep mvmax 32 pixels inside the padding. */
 int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t searchMethod,
                                int32_t merange, int32_t subpelRefine, int32_t n, const x265gpu_pu_job* jobs,
                                x265gpu_pu_result* out);

@@ -115,7 +115,16 @@ typedef struct orc_me {
     /* executed-compare counters (for the algorithmic-op denominators) */
     uint64_t  nSad, nSatd;
     int       vertRestriction;   /* motionEstimate's m_vertRestriction argument (orc_me_set_vert_restriction) */
+    const uint32_t* integral[12];/* MotionEstimate::integral before the PU offset is added: element (0,0) of the
+                                  * reference's twelve block-sum planes (orc_me_set_integral), for ORC_SEA */
 } orc_me;
+
+/* FrameFilter::computeMEIntegral for a whole padded picture (source/encoder/framefilter.cpp:731-831): planes[k]
+ * points at element (0,0) of a zeroed buffer shaped like the picture's (same stride, padX columns and padY rows
+ * before the origin, `height` + padY rows from it).  Plane order as FrameData::m_meIntegral:
+ * 32x32 32x24 32x8 24x32 16x16 16x12 16x4 12x16 8x32 8x8 4x16 4x4. */
+void orc_sea_integral(const pixel* picOrg, intptr_t stride, int padX, int padY, int height, uint32_t* const planes[12]);
+void orc_me_set_integral(orc_me* me, uint32_t* const planes[12]);
 
 void orc_me_init(orc_me* me, const uint16_t* centredCost);
 orc_me* orc_me_create(const uint16_t* centredCost);
@@ -127,6 +136,9 @@ void orc_me_set_vert_restriction(orc_me* me, int on);
 /* SAD of the source PU against the prediction at a quarter-pel vector: predInterLumaPixel + bufSAD as
  * Search::selectMVP measures a candidate (source/encoder/search.cpp:2372-2379) */
 int  orc_me_pred_sad(orc_me* me, const orc_refplanes* ref, orc_mv qmv);
+/* the X265_SEA stage of motionEstimate alone, from the start (*bmv, bcost); returns the cost, *bmv the vector */
+int  orc_sea_search_only(orc_me* me, const orc_refplanes* ref, orc_mv mvmin, orc_mv mvmax, orc_mv qmvp, int merange,
+                         orc_mv* bmv, int bcost);
 /* hmePlane: 0 = search the half-res plane set, 1 = search the quarter-res (HME level-0) plane set */
 int  orc_motion_estimate(orc_me* me, const orc_refplanes* ref, orc_mv mvmin, orc_mv mvmax, orc_mv qmvp,
                          int numCandidates, const orc_mv* mvc, int merange, orc_mv* outQMv,

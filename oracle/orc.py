@@ -156,6 +156,10 @@ def lib(depth=8):
     L.orc_me_pred_sad.argtypes = [vp, C.POINTER(RefPlanes), MV]
     L.orc_me_pred_sad.restype = i
     L.orc_me_set_vert_restriction.argtypes = [vp, i]
+    L.orc_sea_integral.argtypes = [vp, ip, i, i, i, vp]
+    L.orc_me_set_integral.argtypes = [vp, vp]
+    L.orc_sea_search_only.argtypes = [vp, C.POINTER(RefPlanes), MV, MV, MV, i, C.POINTER(MV), i]
+    L.orc_sea_search_only.restype = i
     L.orc_bitsizes.argtypes = [vp]
     L.orc_mcstf_motion_error.argtypes = [vp, i, vp, i, i, i, i, i, i]
     L.orc_mcstf_level.argtypes = [i, C.POINTER(McstfPlanes), C.POINTER(McstfPlanes), C.POINTER(McstfMvs)]
@@ -420,6 +424,30 @@ class FullResME:
         if self.me:
             self.L.orc_me_destroy(self.me)
             self.me = None
+
+    def build_integral(self):
+        """The reference picture's twelve block-sum planes (FrameFilter::computeMEIntegral), needed by method 4 (SEA).
+        The padded plane is taken to have the same margin on both sides."""
+        rows, stride = self.ref.shape
+        pad_x, pad_y = self.org % stride, self.org // stride
+        self.integral = [np.zeros((rows + 1) * stride, np.uint32) for _ in range(12)]
+        arr = (C.c_void_p * 12)(*[a.ctypes.data + 4 * self.org for a in self.integral])
+        self.L.orc_sea_integral(C.c_void_p(self.rp.plane[0]), stride, pad_x, pad_y, rows - 2 * pad_y, arr)
+        self.L.orc_me_set_integral(self.me, arr)
+
+    def integral_plane(self, k):
+        """plane k as a 2-D array shaped like the padded reference"""
+        rows, stride = self.ref.shape
+        return self.integral[k][:rows * stride].reshape(rows, stride)
+
+    def sea_search_only(self, x, y, w, h, mvp, mvmin, mvmax, merange, start_mv, start_cost):
+        """the SEA stage of motionEstimate alone, from (start_mv, start_cost) -> ((full-pel mvx, mvy), cost)"""
+        L = self.L
+        L.orc_me_set_source(self.me, C.c_void_p(self.fenc_org), self.stride, y * self.stride + x, w, h, 4, 4, 4, 3)
+        bmv = MV(*start_mv)
+        cost = L.orc_sea_search_only(self.me, C.byref(self.rp), MV(*mvmin), MV(*mvmax), MV(*mvp), merange, C.byref(bmv),
+                                     start_cost)
+        return (bmv.x, bmv.y), cost
 
     def pred_sad(self, x, y, w, h, qmv):
         """SAD of the PU against the prediction at quarter-pel vector qmv (one candidate of Search::selectMVP)"""

@@ -670,6 +670,231 @@ static void full_search(srch* s, int merange)
             try_mv(s, tx, ty);
 }
 
+/* ---- successive elimination (X265_SEA) ---- */
+
+/* integral_init{4,8,12,16,24,32}h_c, source/encoder/framefilter.cpp:39-104: running sum of w pixels plus the
+ * entry one row up */
+static void integral_inith(int w, uint32_t* sum, const pixel* pix, intptr_t stride)
+{
+    int32_t v = 0;
+    for (int k = 0; k < w; k++)
+        v += pix[k];
+    for (int16_t x = 0; x < stride - w; x++)
+    {
+        sum[x] = v + sum[x - stride];
+        v += pix[x + w] - pix[x];
+    }
+}
+
+/* integral_init{4..32}v_c, framefilter.cpp:106-140 */
+static void integral_initv(int h, uint32_t* sum, intptr_t stride)
+{
+    for (int x = 0; x < stride; x++)
+        sum[x] = sum[x + h * stride] - sum[x];
+}
+
+static const int k_integralW[12] = { 32, 32, 32, 24, 16, 16, 16, 12, 8, 8, 4, 4 };
+static const int k_integralH[12] = { 32, 24, 8, 32, 16, 12, 4, 16, 32, 8, 16, 4 };
+
+/* FrameFilter::computeMEIntegral over every row of the padded picture at once: framefilter.cpp:760-828 */
+void orc_sea_integral(const pixel* picOrg, intptr_t stride, int padX, int padY, int height, uint32_t* const planes[12])
+{
+    for (int i = 0; i < 12; i++)
+        memset(planes[i] - padY * stride - padX, 0, stride * sizeof(uint32_t));
+    const int last = height + padY - 1;
+    for (int y = -padY; y < last; y++)
+    {
+        const pixel* pix = picOrg + y * stride - padX;
+        for (int i = 0; i < 12; i++)
+        {
+            uint32_t* sum = planes[i] + (y + 1) * stride - padX;
+            integral_inith(k_integralW[i], sum, pix, stride);
+            if (y >= k_integralH[i] - padY)
+                integral_initv(k_integralH[i], sum - k_integralH[i] * stride, stride);
+        }
+    }
+}
+
+void orc_me_set_integral(orc_me* me, uint32_t* const planes[12])
+{
+    for (int i = 0; i < 12; i++)
+        me->integral[i] = planes[i];
+}
+
+/* ads_x4 / ads_x2 / ads_x1, source/common/pixel.cpp:121-165; lx is the PU width */
+static int ads_n(int n, int lx, const int encDC[4], const uint32_t* sums, int delta, const uint16_t* costMvX,
+                 int16_t* mvs, int width, int thresh)
+{
+    int nmv = 0;
+    for (int16_t i = 0; i < width; i++, sums++)
+    {
+        int ads;
+        if (n == 4)
+            ads = (int)labs(encDC[0] - (long)sums[0]) + (int)labs(encDC[1] - (long)sums[lx >> 1]) +
+                  (int)labs(encDC[2] - (long)sums[delta]) + (int)labs(encDC[3] - (long)sums[delta + (lx >> 1)]) + costMvX[i];
+        else if (n == 2)
+            ads = (int)labs(encDC[0] - (long)sums[0]) + (int)labs(encDC[1] - (long)sums[delta]) + costMvX[i];
+        else
+            ads = (int)labs(encDC[0] - (long)sums[0]) + costMvX[i];
+        if (ads < thresh)
+            mvs[nmv++] = i;
+    }
+    return nmv;
+}
+
+static int is_size(const orc_me* me, int w, int h) { return me->bw == w && me->bh == h; }
+
+/* which ads primitive setSourcePU picks for the partition: source/common/pixel.cpp:1122-1146 */
+static int ads_arity(const orc_me* me)
+{
+    static const int four[][2] = { {16,16}, {32,32}, {64,64}, {32,24}, {24,32}, {32,8}, {8,32}, {64,48}, {48,64}, {64,16}, {16,64} };
+    static const int one[][2] = { {4,4}, {8,8}, {16,12}, {12,16}, {16,4}, {4,16} };
+    for (size_t i = 0; i < sizeof(four) / sizeof(four[0]); i++)
+        if (is_size(me, four[i][0], four[i][1]))
+            return 4;
+    for (size_t i = 0; i < sizeof(one) / sizeof(one[0]); i++)
+        if (is_size(me, one[i][0], one[i][1]))
+            return 1;
+    return 2;
+}
+
+/* sum of a tw x th block of the staged encode block = sad_x4 against a zero block, motion.cpp:1501-1507 */
+static int fenc_sum(const orc_me* me, int x, int y, int tw, int th)
+{
+    int s = 0;
+    for (int r = 0; r < th; r++)
+        for (int c = 0; c < tw; c++)
+            s += me->fenc[(y + r) * ORC_FENC_STRIDE + x + c];
+    return s;
+}
+
+/* Successive elimination: source/encoder/motion.cpp:1438-1591.  The DC of up to four sub-blocks is compared with
+ * block sums of the reference before a candidate's SAD is taken.  Four partitions (8x4, 4x8, 32x8, 8x32) make the
+ * reference compare DC terms taken over encode-buffer bytes outside the PU, left there by earlier PUs: those have
+ * no defined result. */
+static void sea_search(srch* s, int merange)
+{
+    orc_me* me = s->me;
+    const intptr_t stride = s->stride;
+    const orc_mv omv = s->bmv;
+    const int minX = imax(omv.x - merange, s->mvmin.x), minY = imax(omv.y - merange, s->mvmin.y);
+    const int maxX = imin(omv.x + merange, s->mvmax.x), maxY = imin(omv.y + merange, s->mvmax.y);
+    const uint16_t* p_cost_mvx = s->cx;
+    const uint16_t* p_cost_mvy = s->cy;
+    int16_t* scratch = (int16_t*)calloc(merange * 2 + 4, sizeof(int16_t));
+    const int meRangeWidth = (maxX - minX + 3) & ~3;
+    const int w = me->bw, h = me->bh;
+    if (is_size(me, 8, 4) || is_size(me, 4, 8) || is_size(me, 32, 8) || is_size(me, 8, 32))
+        abort();
+    int deltaX = w <= 8 ? w : w >> 1;
+    int deltaY = h <= 8 ? h : h >> 1;
+    const int smallRect = is_size(me, 4, 4) || is_size(me, 16, 12) || is_size(me, 12, 16) || is_size(me, 16, 4) || is_size(me, 4, 16);
+    const int verticalRect = is_size(me, 32, 64) || is_size(me, 16, 32) || is_size(me, 8, 16) || is_size(me, 4, 8);
+    const int horizontalRect = is_size(me, 64, 32) || is_size(me, 32, 16) || is_size(me, 16, 8) || is_size(me, 8, 4);
+    const int asymVertical = is_size(me, 12, 16) || is_size(me, 4, 16) || is_size(me, 24, 32) || is_size(me, 8, 32) ||
+                             is_size(me, 48, 64) || is_size(me, 16, 64);
+    const int asymHorizontal = is_size(me, 16, 12) || is_size(me, 16, 4) || is_size(me, 32, 24) || is_size(me, 32, 8) ||
+                               is_size(me, 64, 48) || is_size(me, 64, 16);
+    int tw, th;             /* the partition the four DC terms are taken over */
+    if (verticalRect)
+        tw = w, th = h >> 1;
+    else if (horizontalRect)
+        tw = w >> 1, th = h;
+    else if (asymVertical || asymHorizontal)
+        tw = smallRect ? w : w >> 1, th = smallRect ? h : h >> 1;
+    else
+        tw = w <= 8 ? w : w >> 1, th = w <= 8 ? h : h >> 1;
+    /* the four terms exactly where sad_x4 reads them, inside the 64x64 staging buffer; terms the partition's ads
+     * does not use may cover bytes outside the PU */
+    int encDC[4];
+    encDC[0] = fenc_sum(me, 0, 0, tw, th);
+    encDC[1] = deltaX + tw <= 64 ? fenc_sum(me, deltaX, 0, tw, th) : 0;
+    encDC[2] = deltaY + th <= 64 ? fenc_sum(me, 0, deltaY, tw, th) : 0;
+    encDC[3] = deltaX + tw <= 64 && deltaY + th <= 64 ? fenc_sum(me, deltaX, deltaY, tw, th) : 0;
+
+    int plane;
+    switch (deltaX)
+    {
+    case 32: plane = deltaY % 24 == 0 ? 1 : deltaY == 8 ? 2 : 0; break;
+    case 24: plane = 3; break;
+    case 16: plane = deltaY % 12 == 0 ? 5 : deltaY == 4 ? 6 : 4; break;
+    case 12: plane = 7; break;
+    case 8:  plane = deltaY == 32 ? 8 : 9; break;
+    case 4:  plane = deltaY == 16 ? 10 : 11; break;
+    default: plane = 11; break;
+    }
+    const uint32_t* sumsBase = me->integral[plane] + me->blockOffset;
+
+    const int scaled = is_size(me, 64, 64) || is_size(me, 32, 32) || is_size(me, 16, 16) || is_size(me, 32, 64) ||
+                       is_size(me, 16, 32) || is_size(me, 8, 16) || is_size(me, 4, 8) || is_size(me, 12, 16) ||
+                       is_size(me, 4, 16) || is_size(me, 24, 32) || is_size(me, 8, 32) || is_size(me, 48, 64) ||
+                       is_size(me, 16, 64);
+    if (scaled)
+        deltaY *= (int)stride;
+    if (verticalRect)
+        encDC[1] = encDC[2];
+    if (horizontalRect)
+        deltaY = deltaX;
+
+    /* fpelCostMvX + minX (motion.cpp:1460, :1574): m_fpelMvCosts[j][i] = cost[4 * i + j] (bitcost.cpp:70-73), so
+     * entry k of m_fpelMvCosts[-qmvp.x & 3] + (-qmvp.x >> 2) is cost[4 * k - qmvp.x] */
+    uint16_t* costMvX = (uint16_t*)malloc((meRangeWidth + 1) * sizeof(uint16_t));
+    for (int i = 0; i < meRangeWidth; i++)
+        costMvX[i] = p_cost_mvx[4 * (minX + i)];
+
+    const int arity = ads_arity(me);
+    for (int ty = minY; ty <= maxY; ty++)
+    {
+        int i;
+        const int ycost = p_cost_mvy[ty] << 2;       /* indexed by the full-pel row, as the reference does */
+        if (s->bcost <= ycost)
+            continue;
+        s->bcost -= ycost;
+        const int xn = ads_n(arity, w, encDC, sumsBase + minX + ty * stride, deltaY, costMvX, scratch, meRangeWidth, s->bcost);
+        /* COST_MV_X3_ABS (motion.cpp:325-338): SAD plus the x cost only, against the reduced bcost */
+        for (i = 0; i < xn - 2; i += 3)
+        {
+            int costs[3];
+            for (int k = 0; k < 3; k++)
+                costs[k] = fpel_sad(s, minX + scratch[i + k], ty) + p_cost_mvx[(minX + scratch[i + k]) * 4];
+            for (int k = 0; k < 3; k++)
+                if (costs[k] < s->bcost)
+                {
+                    s->bcost = costs[k];
+                    s->bmv.x = minX + scratch[i + k];
+                    s->bmv.y = ty;
+                }
+        }
+        s->bcost += ycost;
+        for (; i < xn; i++)
+            try_mv(s, minX + scratch[i], ty);
+    }
+    free(costMvX);
+    free(scratch);
+}
+
+/* the elimination search alone, from a given start (tests) */
+int orc_sea_search_only(orc_me* me, const orc_refplanes* ref, orc_mv mvmin, orc_mv mvmax, orc_mv qmvp, int merange,
+                        orc_mv* bmv, int bcost)
+{
+    srch S;
+    memset(&S, 0, sizeof(S));
+    S.me = me;
+    S.ref = ref;
+    S.stride = ref->stride;
+    S.fref = ref->plane[0] + me->blockOffset;
+    S.mvmin = mvmin;
+    S.mvmax = mvmax;
+    me->mvp = qmvp;
+    S.cx = me->cost - qmvp.x;
+    S.cy = me->cost - qmvp.y;
+    S.bmv = *bmv;
+    S.bcost = bcost;
+    sea_search(&S, merange);
+    *bmv = S.bmv;
+    return S.bcost;
+}
+
 /* MotionEstimate::subpelCompare for luma: source/encoder/motion.cpp:1775-1803.
  * Always addresses fpelPlane[0] with the full lumaStride, also when the search
  * itself ran on the quarter-res planes. */
@@ -917,8 +1142,11 @@ int orc_motion_estimate(orc_me* me, const orc_refplanes* ref, orc_mv mvmin, orc_
     case ORC_FULL:
         full_search(s, merange);
         break;
+    case ORC_SEA:
+        sea_search(s, merange);
+        break;
     default:
-        abort(); /* SEA needs integral planes; not on any measured configuration */
+        abort();
     }
 
     orc_mv bmv;

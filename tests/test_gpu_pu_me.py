@@ -78,6 +78,54 @@ def test_pu_motion_estimate(depth, method, merange, subpel):
     _run(depth, method, merange, subpel, 96, seed=100 + depth + merange)
 
 
+SEA_SHAPES = [s for s in PU_SHAPES if s not in ((8, 4), (4, 8), (32, 8), (8, 32))]
+
+
+@pytest.mark.parametrize("depth,merange,subpel,seed", [(8, 16, 2, 1), (8, 57, 3, 2), (10, 24, 3, 3), (12, 9, 1, 4), (8, 100, 0, 5)])
+def test_pu_successive_elimination(depth, merange, subpel, seed):
+    """--me sea: the block sums are made on the device from the reference slot; the oracle builds the reference's
+    twelve integral planes.  Windows stay 36 pixels inside the padding so that every sum the reference reads is one
+    it has computed."""
+    W, H, ctu = 416, 240, 64
+    clip, pads, mx, my, fw, fh = _pictures(W, H, depth, ctu, 300 + seed)
+    table, centre = orc.bitcost_table(depth)
+    ref = orc.FullResME(depth, table, centre, pads[1], pads[0], mx, my)
+    ref.build_integral()
+    rng = np.random.default_rng(seed)
+    jobs = []
+    while len(jobs) < 80:
+        w, h = SEA_SHAPES[rng.integers(len(SEA_SHAPES))]
+        x = int(rng.integers(0, (fw - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (fh - h) // 4 + 1)) * 4
+        mvp = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+        lo = (max((mvp[0] >> 2) - merange, -x - mx + 36), max((mvp[1] >> 2) - merange, -y - my + 36))
+        hi = (min((mvp[0] >> 2) + merange, fw - x - w + mx - 36), min((mvp[1] >> 2) + merange, fh - y - h + my - 36))
+        if lo[0] > hi[0] or lo[1] > hi[1]:
+            continue
+        mvc = [(int(rng.integers(-60, 61)), int(rng.integers(-60, 61))) for _ in range(int(rng.integers(0, 3)))]
+        jobs.append((x, y, w, h, mvp, lo, hi, mvc))
+    with api.Context(W, H, depth=depth, num_slots=2, ctu=ctu, keep_full_res=True) as ctx:
+        ctx.lowres_init(0, clip[0])
+        ctx.lowres_init(1, clip[1])
+        ctx.me_set_mvcost(table, centre)
+        got = ctx.pu_motion_estimate(1, 0, api.SEA_SEARCH, merange, subpel, jobs)
+        # the planes are kept per reference: a second call, and one after the reference was uploaded again
+        again = ctx.pu_motion_estimate(1, 0, api.SEA_SEARCH, merange, subpel, jobs[:16])
+        assert again == got[:16]
+        ctx.lowres_init(0, clip[1])
+        same = ctx.pu_motion_estimate(1, 0, api.SEA_SEARCH, merange, subpel, jobs[:16])
+    for j, g in zip(jobs, got):
+        want = ref.estimate(j[0], j[1], j[2], j[3], j[4], j[5], j[6], orc.SEA, merange, subpel, j[7])
+        assert g == want, (j, g, want)
+    ref.close()
+    ref = orc.FullResME(depth, table, centre, pads[1], pads[1], mx, my)
+    ref.build_integral()
+    for j, g in zip(jobs[:16], same):
+        want = ref.estimate(j[0], j[1], j[2], j[3], j[4], j[5], j[6], orc.SEA, merange, subpel, j[7])
+        assert g == want, (j, g, want)
+    ref.close()
+
+
 def test_pu_motion_estimate_12bit():
     _run(12, orc.STAR, 57, 3, 64, seed=1212)
     _run(12, orc.UMH, 24, 5, 48, seed=1213)
@@ -138,8 +186,16 @@ def test_pu_rejects_bad_jobs():
                     (0, 0, 8, 8, (0, 0), (-400, -4), (4, 4), [])]:           # vectors leave the padded plane
             with pytest.raises(api.X265GpuError):
                 ctx.pu_motion_estimate(0, 1, api.STAR_SEARCH, 57, 3, [bad])
-        with pytest.raises(api.X265GpuError):                    # SEA (4) is not offered on this path
-            ctx.pu_motion_estimate(0, 1, 4, 16, 2, [(0, 0, 8, 8, (0, 0), (-4, -4), (4, 4), [])])
+        ctx.lowres_init(0, np.zeros((240, 416), np.uint8))
+        ctx.lowres_init(1, np.zeros((240, 416), np.uint8))
+        ctx.pu_motion_estimate(0, 1, api.SEA_SEARCH, 16, 2, [(64, 64, 8, 8, (0, 0), (-4, -4), (4, 4), [])])
+        for w, h in [(8, 4), (4, 8), (32, 8), (8, 32)]:          # the elimination test of these reads outside the PU
+            with pytest.raises(api.X265GpuError):
+                ctx.pu_motion_estimate(0, 1, api.SEA_SEARCH, 16, 2, [(64, 64, w, h, (0, 0), (-4, -4), (4, 4), [])])
+        with pytest.raises(api.X265GpuError):                    # window wider than the survivor masks
+            ctx.pu_motion_estimate(0, 1, api.SEA_SEARCH, 200, 2, [(64, 64, 8, 8, (0, 0), (-4, -4), (4, 4), [])])
+        with pytest.raises(api.X265GpuError):                    # block sums would be read past the padded picture
+            ctx.pu_motion_estimate(0, 1, api.SEA_SEARCH, 16, 2, [(384, 64, 32, 24, (0, 0), (-4, -4), (110, 4), [])])
     finally:
         ctx.close()
 

@@ -59,6 +59,9 @@ def _run(W, H, depth, rows, method=api.STAR_SEARCH, merange=57, subpel=3, amp=Fa
         finally:
             tme.close()
     mes = [orc.FullResME(depth, table, centre, pads[cur], pads[f], mx, my) for f in ref_frames]
+    if method == api.SEA_SEARCH:
+        for m in mes:
+            m.build_integral()
     ser = SerialTME(mes, ref_frames, cur, W, H, bitsizes, (table, centre), lam, method=method, merange=merange,
                     subpel=subpel, amp=amp, rect=rect, ctu=ctu, min_cu=min_cu, lowres_mvs=lowres, median_mv=med)
     want = ser.run_rows(rows[0], rows[1])
@@ -105,6 +108,7 @@ def test_ctu_rows_4k_10bit():
     dict(method=api.HEX_SEARCH, merange=24, subpel=2, num_refs=2),
     dict(method=api.UMH_SEARCH, merange=32, subpel=5, amp=True),
     dict(lookahead=False),                                     # no lookahead vectors: a single search per PU
+    dict(method=api.SEA_SEARCH, merange=24, subpel=2, min_cu=16, num_refs=2),   # --me sea (block sums per reference)
     dict(median=True, amp=True),                               # CUData::getMedianColMV overriding the area vectors
     dict(second_picture=True),                                 # predictors from the reference picture's own table
     dict(ctu=32, min_cu=16, amp=True),
@@ -124,6 +128,10 @@ def test_generator_rejects_what_it_does_not_cover():
             api.ThreadedME(ctx, min_cu=4)
         with pytest.raises(api.X265GpuError):
             api.ThreadedME(ctx, subpel=9)
+        with pytest.raises(api.X265GpuError):                   # --me sea with PU shapes it has no defined result for
+            api.ThreadedME(ctx, search=api.SEA_SEARCH, merange=24, amp=True, min_cu=16)
+        with pytest.raises(api.X265GpuError):
+            api.ThreadedME(ctx, search=api.SEA_SEARCH, merange=24, min_cu=8)
         clip = synth.luma_clip(416, 240, 2, 8, seed=1)
         ctx.lowres_init(0, clip[0])
         ctx.lowres_init(1, clip[1])

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libx265gpu.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
-DIA_SEARCH, HEX_SEARCH, UMH_SEARCH, STAR_SEARCH, FULL_SEARCH = 0, 1, 2, 3, 5
+DIA_SEARCH, HEX_SEARCH, UMH_SEARCH, STAR_SEARCH, SEA_SEARCH, FULL_SEARCH = 0, 1, 2, 3, 4, 5
 AREA_DIAMOND_SEARCH = 16
 OP_SAD, OP_SATD, OP_SA8D = 0, 1, 2
 PHASES = ("lowres", "intra", "search", "cost")

@@ -138,11 +138,15 @@ struct PuFrame
     int method, merange, subpelRefine;
     int maxPasses;                     // largest ceil(tiles / 16) over the batch: sizes the LDS per wave
     int rowForm;                       // 1: SAD stages read the encode block in row form (pu_kernels.hip)
+    const uint32_t* seaSums[12];       // successive elimination: entry (0,0) of the reference's block-sum planes
 };
 struct BlockJob { int x, y, w, h; int qmvx, qmvy; int op; int reserved; };   // same layout as x265gpu_block_job
 hipError_t launch_block_compare(hipStream_t s, int bpp, const PuFrame& f, const BlockJob* dJobs, int n, int* dOut);
 hipError_t launch_interp_block(hipStream_t s, int bpp, const void* pic, int stride, int x, int y, int w, int h, int xf, int yf,
                                int depth, void* dOut);
+// block sums of a padded picture for the planes in `mask` (sea_shape.h); tmp holds stride * rows entries
+hipError_t launch_sea_planes(hipStream_t s, int bpp, const void* pic, int stride, int rows, unsigned mask, uint32_t* tmp,
+                             uint32_t* const planes[12]);
 hipError_t launch_pad_picture(hipStream_t s, int bpp, const void* src, long long srcStride, void* dst, int stride, int rows,
                               int width, int height, int marginX, int marginY);
 // Jobs sorted into size classes: order[] lists job indices class after class (PUs of at most 2, 4, 8 tiles of

@@ -21,12 +21,13 @@
 // block's pixels and across PUs.
 #include "device_common.h"
 #include "kernels.h"
+#include "sea_shape.h"
 
 #define XG_LDS __attribute__((address_space(3)))
 
 namespace xg {
 
-constexpr int PU_DIA = 0, PU_HEX = 1, PU_UMH = 2, PU_STAR = 3;   // x265gpu search method values (anything else: exhaustive)
+constexpr int PU_DIA = 0, PU_HEX = 1, PU_UMH = 2, PU_STAR = 3, PU_SEA = 4;   // x265gpu search method values (anything else: exhaustive)
 constexpr int PU_AREA_DIAMOND = 16;                  // MotionEstimate::diamondSearch instead of motionEstimate
 
 // luma interpolation taps, source/common/constants.cpp:250-256
@@ -683,6 +684,115 @@ template <typename P> __device__ __forceinline__ void full_search(PuCtx<P>& c)
             try_mv<P>(c, tx, ty);
 }
 
+// Successive elimination, motion.cpp:1438-1591, for a PU that owns its wave.  Rows of the window are visited in
+// order; in a row every lane takes one candidate column (two with a window wider than 64), adds up the absolute
+// DC differences of the partition's terms plus the column's vector cost, and the ballot of "below the row's
+// threshold" is the list ads() writes.  The survivors' SADs are then taken one after the other by the whole wave,
+// in list order, with the reference's bookkeeping: triples are compared without the row's vector cost against a
+// best cost reduced by `ycost`, the remainder as COST_MV; `ycost` is the cost table read at the full-pel row,
+// times four, as the reference has it.
+template <typename P>
+__device__ __forceinline__ void sea_search(PuCtx<P>& c, const PuFrame& f, int merange)
+{
+    SeaShape sh;
+    if (!sea_shape(c.w, c.h, sh))
+        return;                              // the host refuses such jobs
+    const int minX = max(c.bmx - merange, c.minx), minY = max(c.bmy - merange, c.miny);
+    const int maxX = min(c.bmx + merange, c.maxx), maxY = min(c.bmy + merange, c.maxy);
+    const int width = (maxX - minX + 3) & ~3;    // "fastest in multiples of 4": up to three columns past maxX
+    // DC of the encode sub-blocks
+    int encDC[4] = { 0, 0, 0, 0 };
+    const int cells = sh.tw * sh.th;
+#pragma unroll 1
+    for (int k = 0; k < sh.terms; k++)
+    {
+        const XG_GLOBAL P* src = c.fencPic + ((long long)(c.y + sh.encY[k]) * c.stride + c.x + sh.encX[k]);
+        int v = 0;
+        for (int i = c.phys; i < cells; i += 64)
+        {
+            const int r = i / sh.tw;
+            v += (int)src[r * c.stride + (i - r * sh.tw)];
+        }
+        encDC[k] = wave_sum(v);
+    }
+    const XG_GLOBAL uint32_t* sums = as_global<uint32_t>(f.seaSums[sh.plane]) + ((long long)c.y * c.stride + c.x);
+#pragma unroll 1
+    for (int ty = minY; ty <= maxY; ty++)
+    {
+        const int ycost = (int)c.cy[clampi(ty - c.mvpy, c.lo, c.hi) + c.mvpy] << 2;
+        if (c.bcost <= ycost)
+            continue;
+        int reduced = c.bcost - ycost;
+        const int thresh = reduced;
+        int bx = c.bmx, by = c.bmy;
+        int taken = 0;                        // survivors seen so far in this row
+        int total = 0;
+        // first pass over the row: how many survive (the split into triples and remainder needs the count)
+        unsigned long long keep[4] = { 0, 0, 0, 0 };
+#pragma unroll 1
+        for (int base = 0, chunk = 0; base < width && chunk < 4; base += 64, chunk++)
+        {
+            const int i = base + c.phys;
+            bool pass = false;
+            if (i < width)
+            {
+                const int mx = minX + i;
+                const XG_GLOBAL uint32_t* p = sums + ((long long)ty * c.stride + mx);
+                int ads = (int)c.cx[clampi(4 * mx - c.mvpx, c.lo, c.hi) + c.mvpx];
+#pragma unroll 1
+                for (int k = 0; k < sh.terms; k++)
+                    ads += abs(encDC[k] - (int)p[sh.sumY[k] * c.stride + sh.sumX[k]]);
+                pass = ads < thresh;
+            }
+            keep[chunk] = __builtin_amdgcn_ballot_w64(pass);
+            total += __builtin_popcountll(keep[chunk]);
+        }
+        const int triples = total >= 3 ? total - total % 3 : 0;
+#pragma unroll 1
+        for (int chunk = 0; chunk < 4; chunk++)
+        {
+            unsigned long long m = keep[chunk];
+            while (m)
+            {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                const int mx = minX + chunk * 64 + bit;
+                const int sad = block_cost<P, false>(c, mx * 4, ty * 4);
+                if (taken < triples)
+                {
+                    const int cost = sad + (int)c.cx[clampi(4 * mx - c.mvpx, c.lo, c.hi) + c.mvpx];
+                    if (cost < reduced)
+                    {
+                        reduced = cost;
+                        bx = mx;
+                        by = ty;
+                    }
+                }
+                else
+                {
+                    if (taken == triples)
+                    {
+                        c.bcost = reduced + ycost;      // the triples are done: bcost gets the row cost back
+                        reduced = -1;
+                    }
+                    const int cost = sad + mvcost<P>(c, mx * 4, ty * 4);
+                    if (cost < c.bcost)
+                    {
+                        c.bcost = cost;
+                        bx = mx;
+                        by = ty;
+                    }
+                }
+                taken++;
+            }
+        }
+        if (reduced >= 0)
+            c.bcost = reduced + ycost;
+        c.bmx = bx;
+        c.bmy = by;
+    }
+}
+
 // COST_MV_X4 as this fork defines it (motion.cpp:302-323): the offset is added to `o`, the
 // candidate is measured whatever its row, and accepted only when the row is in range.
 template <typename P> __device__ __forceinline__ void try_rel(PuCtx<P>& c, int ox, int oy, int dx, int dy)
@@ -1192,6 +1302,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XG_PU_
         }
         else if (f.method == PU_STAR)
             star_search<P>(c, f.merange);
+        else if (f.method == PU_SEA)
+        {
+            if constexpr (LPP == 64)
+                sea_search<P>(c, f, f.merange);
+        }
         else
             full_search<P>(c);
 
@@ -1428,6 +1543,60 @@ hipError_t launch_pad_picture(hipStream_t s, int bpp, const void* src, long long
     else
         hipLaunchKernelGGL(pad_picture_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)src, srcStride,
                            (uint16_t*)dst, stride, rows, width, height, marginX, marginY);
+    return hipGetLastError();
+}
+
+// ---- block-sum planes for the successive-elimination search ---------------------------
+// What FrameFilter::computeMEIntegral leaves in FrameData::m_meIntegral once a picture is finished
+// (source/encoder/framefilter.cpp:731-831): entry (x, y) of plane k is the sum of the bw x bh block of the padded
+// reference picture whose top-left pixel is (x, y).  Two separable passes over the whole padded plane.
+template <typename P>
+__global__ void __launch_bounds__(256) sea_row_sums_kernel(const P* pic, int stride, int rows, int bw, uint32_t* out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= stride || y >= rows)
+        return;
+    uint32_t v = 0;
+    if (x + bw <= stride)
+        for (int k = 0; k < bw; k++)
+            v += pic[(long long)y * stride + x + k];
+    out[(long long)y * stride + x] = v;
+}
+
+__global__ void __launch_bounds__(256) sea_col_sums_kernel(const uint32_t* rowSums, int stride, int rows, int bh, uint32_t* out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= stride || y >= rows)
+        return;
+    uint32_t v = 0;
+    if (y + bh <= rows)
+        for (int r = 0; r < bh; r++)
+            v += rowSums[(long long)(y + r) * stride + x];
+    out[(long long)y * stride + x] = v;
+}
+
+// planes[k] (k in mask) <- block sums of the padded picture starting at `pic`; `tmp` holds one plane
+hipError_t launch_sea_planes(hipStream_t s, int bpp, const void* pic, int stride, int rows, unsigned mask, uint32_t* tmp,
+                             uint32_t* const planes[SEA_PLANES])
+{
+    dim3 grid((stride + 255) / 256, rows);
+    int lastW = 0;
+    for (int k = 0; k < SEA_PLANES; k++)
+    {
+        if (!(mask & (1u << k)))
+            continue;
+        int bw, bh;
+        sea_plane_size(k, bw, bh);
+        if (bw != lastW)       // planes of one width follow each other and share the row pass
+        {
+            if (bpp == 1)
+                hipLaunchKernelGGL(sea_row_sums_kernel<uint8_t>, grid, dim3(256), 0, s, (const uint8_t*)pic, stride, rows, bw, tmp);
+            else
+                hipLaunchKernelGGL(sea_row_sums_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)pic, stride, rows, bw, tmp);
+            lastW = bw;
+        }
+        hipLaunchKernelGGL(sea_col_sums_kernel, grid, dim3(256), 0, s, (const uint32_t*)tmp, stride, rows, bh, planes[k]);
+    }
     return hipGetLastError();
 }
 

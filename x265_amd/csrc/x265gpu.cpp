@@ -2,6 +2,7 @@
 // See include/x265gpu.h for the contract of each entry point.
 #include "../../include/x265gpu.h"
 #include "kernels.h"
+#include "sea_shape.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,7 @@ struct Slot
     uint8_t* intraMode = nullptr;
     int32_t* invQscale = nullptr;
     bool hasAq = false;
+    unsigned long long fullSerial = 0;   // uploads of the full-resolution picture so far
     int32_t* aqStage = nullptr;    // page-locked staging copy of the caller's invQscaleFactor, allocated on first use
     hipEvent_t aqStaged = nullptr; // the last upload from aqStage
     unsigned long long* propagate = nullptr; // cuTree: unsaturated propagateCost totals, [n]
@@ -98,6 +100,10 @@ struct x265gpu_ctx
     int meMaxMvd = 0;
     char* puBuf = nullptr;            // device staging: jobs, then results
     size_t puBufSize = 0;
+    uint32_t* seaBuf = nullptr;       // successive elimination: 12 block-sum planes of one reference + one scratch plane
+    int seaSlot = -1;                 // whose picture the planes describe, which upload of it, and which planes exist
+    unsigned long long seaSerial = 0;
+    unsigned seaMask = 0;
     char* mcstfBuf = nullptr;         // MCSTF motion search: vector / error arrays of every reference
     size_t mcstfBufSize = 0;
     // The intra estimate runs on a stream of its own: the motion searches that usually follow it read
@@ -645,6 +651,7 @@ void x265gpu_close(x265gpu_ctx* ctx)
     if (ctx->meCostBuf) (void)hipFree(ctx->meCostBuf);
     if (ctx->puBuf) (void)hipFree(ctx->puBuf);
     if (ctx->mcstfBuf) (void)hipFree(ctx->mcstfBuf);
+    if (ctx->seaBuf) (void)hipFree(ctx->seaBuf);
     if (ctx->intraStream) (void)hipStreamSynchronize(ctx->intraStream);
     if (ctx->intraJobBuf) (void)hipFree(ctx->intraJobBuf);
     if (ctx->intraJobHost) (void)hipHostFree(ctx->intraJobHost);
@@ -779,8 +786,11 @@ int x265gpu_lowres_init_batch(x265gpu_ctx* ctx, int32_t n, const int32_t* slots,
         jobs[i].planes = s.planes;
         jobs[i].planes4 = s.planes4;
         if (s.full)
+        {
             HIPCHK(launch_pad_picture(ctx->stream, ctx->bpp, jobs[i].src, jobs[i].srcStride, s.full, ctx->fullStride,
                                       ctx->fullRows, g.srcWidth, g.srcHeight, ctx->fullMarginX, ctx->fullMarginY));
+            s.fullSerial++;
+        }
     }
     int rc = ensure_job_buf(ctx, sizeof(LowresJob) * n);
     if (rc)
@@ -1517,11 +1527,15 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
     if (!ctx->meCostCentre)
         return fail(ctx, X265GPU_ERR_STATE, "pu_motion_estimate: MV cost table not set");
     if (searchMethod != X265GPU_DIA_SEARCH && searchMethod != X265GPU_HEX_SEARCH && searchMethod != X265GPU_UMH_SEARCH &&
-        searchMethod != X265GPU_STAR_SEARCH &&
+        searchMethod != X265GPU_STAR_SEARCH && searchMethod != X265GPU_SEA_SEARCH &&
         searchMethod != X265GPU_FULL_SEARCH && searchMethod != X265GPU_AREA_DIAMOND_SEARCH)
         return fail(ctx, X265GPU_ERR_UNSUPPORTED, "pu_motion_estimate: search method");
     if (subpelRefine < 0 || subpelRefine > 7 || merange < 1 || merange > 32767)
         return fail(ctx, X265GPU_ERR_ARG, "pu_motion_estimate: subpelRefine or merange");
+    const bool sea = searchMethod == X265GPU_SEA_SEARCH;
+    if (sea && merange > 126)      // a row of the window is held as four 64-bit survivor masks
+        return fail(ctx, X265GPU_ERR_UNSUPPORTED, "pu_motion_estimate: successive elimination with merange above 126");
+    unsigned seaNeed = 0;
     // the jobs go up while the host checks and sorts them
     const size_t jobBytes = align256(sizeof(PuJob) * (size_t)n), outBytes = align256(sizeof(PuResult) * (size_t)n);
     const size_t orderBytes = sizeof(int) * (size_t)n;
@@ -1555,6 +1569,31 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
         const int passes = (tiles + 15) / 16;
         passesOf[i] = passes;
         cls[i] = !pack ? 4 : tiles <= 2 ? 0 : tiles <= 4 ? 1 : tiles <= 8 ? 2 : tiles <= 32 ? 3 : 4;
+        if (sea)
+        {
+            SeaShape sh;
+            if (!sea_shape(j.w, j.h, sh))
+            {
+                (void)hipStreamSynchronize(ctx->stream);
+                return fail(ctx, X265GPU_ERR_UNSUPPORTED, "pu_motion_estimate: no defined successive elimination for this PU shape");
+            }
+            // every block sum and every SAD the window can ask for (up to three columns past mvmaxX) lies inside
+            // the padded picture
+            int bw, bh, reachX = j.w + 16, reachY = j.h + 8;
+            sea_plane_size(sh.plane, bw, bh);
+            for (int k = 0; k < sh.terms; k++)
+            {
+                reachX = sh.sumX[k] + bw > reachX ? sh.sumX[k] + bw : reachX;
+                reachY = sh.sumY[k] + bh > reachY ? sh.sumY[k] + bh : reachY;
+            }
+            if (j.x + j.mvmaxX + 3 + reachX > ctx->fullW + ctx->fullMarginX || j.y + j.mvmaxY + reachY > ctx->fullH + ctx->fullMarginY)
+            {
+                (void)hipStreamSynchronize(ctx->stream);
+                return fail(ctx, X265GPU_ERR_ARG, "pu_motion_estimate: successive elimination window leaves the padded picture");
+            }
+            seaNeed |= 1u << sh.plane;
+            cls[i] = tiles <= 32 ? 3 : 4;          // the elimination pass works with the whole wave
+        }
         classes.count[cls[i]]++;
         if (cls[i] == 3)
             midPasses = passes > midPasses ? passes : midPasses;
@@ -1584,6 +1623,29 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
     f.merange = merange;
     f.subpelRefine = subpelRefine;
     f.maxPasses = maxPasses;
+    if (sea)
+    {
+        const size_t planeElems = (size_t)ctx->fullStride * ctx->fullRows;
+        if (!ctx->seaBuf)
+            HIPCHK(hipMalloc((void**)&ctx->seaBuf, (SEA_PLANES + 1) * planeElems * sizeof(uint32_t)));
+        if (ctx->seaSlot != slotRef || ctx->seaSerial != ctx->slots[slotRef].fullSerial)
+        {
+            ctx->seaSlot = slotRef;
+            ctx->seaSerial = ctx->slots[slotRef].fullSerial;
+            ctx->seaMask = 0;
+        }
+        uint32_t* planes[SEA_PLANES];
+        const size_t originElems = (size_t)ctx->fullMarginY * ctx->fullStride + ctx->fullMarginX;
+        for (int k = 0; k < SEA_PLANES; k++)
+        {
+            planes[k] = ctx->seaBuf + k * planeElems;
+            f.seaSums[k] = planes[k] + originElems;
+        }
+        if (seaNeed & ~ctx->seaMask)
+            HIPCHK(launch_sea_planes(ctx->stream, ctx->bpp, ctx->slots[slotRef].full, ctx->fullStride, ctx->fullRows,
+                                     seaNeed & ~ctx->seaMask, ctx->seaBuf + SEA_PLANES * planeElems, planes));
+        ctx->seaMask |= seaNeed;
+    }
     HIPCHK(launch_pu_search(ctx->stream, ctx->searchAux, ctx->bpp, f, (const PuJob*)ctx->puBuf, classes, ctx->meCostCentre, ctx->meMaxMvd,
                             (PuResult*)(ctx->puBuf + jobBytes)));
     HIPCHK(hipMemcpyAsync(out, ctx->puBuf + jobBytes, sizeof(PuResult) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

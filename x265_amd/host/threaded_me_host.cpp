@@ -159,6 +159,10 @@ ThreadedME::ThreadedME(x265gpu_ctx* ctx, const TmeParam& p)
         m_unsupported = "picture size must be a multiple of minCUSize";
     else if (p.searchRange < 1 || p.searchRange > 32767 || p.subpelRefine < 0 || p.subpelRefine > 7 || !(p.lambda > 0))
         m_unsupported = "searchRange, subpelRefine or lambda out of range";
+    else if (p.searchMethod == 4 /* X265_SEA */ && (p.bEnableAMP || (mn == 8 && p.bEnableRectInter) || p.searchRange > 126))
+        // the elimination test of 8x4, 4x8, 32x8 and 8x32 PUs reads encode-buffer bytes outside the PU, and the lower
+        // terms of 64x48, 64x16 and 32x24 are read up to 56 columns to the right, past the planes at the picture's edge
+        m_unsupported = "successive elimination needs --no-amp, rectangular PUs only from 16x16 CUs up, and merange <= 126";
     if (m_unsupported)
         return;
     m_numCuInWidth = (p.picWidth + ctu - 1) / ctu;

@@ -345,7 +345,7 @@ int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const v
                       int32_t memKind, uint32_t* energy, uint64_t wpSum[3], uint64_t wpSsd[3]);
 
 /* The whole of LookaheadTLD::calcAdaptiveQuantFrame (source/encoder/slicetype.cpp:454-704) for a 4:2:0
- * picture with rc.aqMode NONE / VARIANCE / AUTO_VARIANCE / AUTO_VARIANCE_BIASED: the block energies come from
+ * picture with rc.aqMode NONE / VARIANCE / AUTO_VARIANCE / AUTO_VARIANCE_BIASED / EDGE: the block energies come from
  * the device pass above, the double-precision mapping to QP offsets (:486-505, :539-643) and x265_exp2fix8
  * (source/common/common.cpp:96-103) run on the host in this call, in the reference's order of operations.
  * qgSize >= 16: arrays hold one entry per 16x16 block, ceil(w/16) per row.  qgSize 8: 8x8 luma + 4x4 chroma
@@ -371,7 +371,13 @@ int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const v
  * dCuTreeOffset (:303-337) with qpAdaptationRange.  The LAST layer listed is the one of minAQDepth: its
  * dQpOffset becomes invQscaleFactor through x265_exp2fix8 in visiting order (:441-447), and acEnergyCu runs
  * once per block for wp_sum / wp_ssd (:449).  qpAqOffset / qpCuTreeOffset are not written in this mode.
- * X265_AQ_EDGE is not covered: X265GPU_ERR_UNSUPPORTED. */
+ * X265_AQ_EDGE (aqMode 4, :529-606): edgeFilter's blurred picture, Sobel gradients and edge picture (:100-225) and
+ * edgeDensityCu's block sums (:227-263) are one more device pass; as in the reference, the edge picture's block
+ * sums are added to plane 0 of wp_sum / wp_ssd.  A pixel's gradient angle in whole degrees comes from the device
+ * wherever the degree is certain within the accuracy of the device's atan2f; the few pixels close to a whole
+ * degree are listed and get their angle from the host's atan2f in this call, so the angle sums are the ones a
+ * host-only run with this machine's libm gives.  The reference's other consumer of the edge picture
+ * (recursionSkipMode's m_edgeBitPic) and Lowres::edgeInclined are not outputs. */
 typedef struct x265gpu_hevc_aq_layer
 {
     int32_t aqPartWidth, aqPartHeight;            /* PicQPAdaptationLayer's fields of the same names */
@@ -383,7 +389,7 @@ typedef struct x265gpu_hevc_aq_layer
 } x265gpu_hevc_aq_layer;
 typedef struct x265gpu_aq_params
 {
-    int32_t aqMode;               /* param->rc.aqMode, 0..3 */
+    int32_t aqMode;               /* param->rc.aqMode, 0..4 */
     int32_t bWeightedPred;        /* param->bEnableWeightedPred || param->bEnableWeightedBiPred */
     int32_t bHDR10Opt;            /* param->bHDR10Opt: luma-average dependent offset (:613-635) */
     int32_t bSkipOffsets;

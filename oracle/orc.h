@@ -72,6 +72,8 @@ uint64_t orc_pixel_var(int size, const pixel* pix, intptr_t stride);
 void orc_aq_energy(const pixel* y, intptr_t sy, const pixel* u, const pixel* v, intptr_t sc, int w, int h,
                    uint32_t* energy, uint64_t* wp);
 int  orc_exp2fix8(double x);
+/* edgeFilter: edgePic / thetaPic are tight w x h planes */
+void orc_edge_filter(const pixel* src, intptr_t stride, int w, int h, pixel* edgePic, pixel* thetaPic);
 double orc_hevc_aq_layer(const pixel* src, intptr_t stride, int width, int height, int aqPartWidth, int aqPartHeight,
                          int numW, int numH, double qpAdaptationRange, double* dActivity, double* dQpOffset,
                          double* dCuTreeOffset);

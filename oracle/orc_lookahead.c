@@ -335,6 +335,78 @@ void orc_aq_energy(const pixel* y, intptr_t sy, const pixel* u, const pixel* v, 
         }
 }
 
+/* ---------------------------------------------------------------- AQ edge mode */
+
+/* edgeFilter (source/encoder/slicetype.cpp:191-225) on a tight w x h luma plane: gaussianBlur5x5 (:164-189), then
+ * computeEdge with bcalcTheta (:100-162).  edgePic starts as a copy of the source and thetaPic as zeros (:199-215),
+ * so the one-pixel frame the Sobel pass leaves out keeps source pixels in edgePic and 0 in thetaPic; the blurred
+ * picture keeps source pixels in its two-pixel frame.  The reference's pictures are followed by zeroed padding
+ * (:199-201); here everything beyond w x h is simply absent and readers treat it as 0. */
+void orc_edge_filter(const pixel* src, intptr_t stride, int w, int h, pixel* edgePic, pixel* thetaPic)
+{
+    pixel* blur = (pixel*)malloc((size_t)w * h * sizeof(pixel));
+    for (int y = 0; y < h; y++)
+    {
+        memcpy(edgePic + (size_t)y * w, src + y * stride, w * sizeof(pixel));
+        memcpy(blur + (size_t)y * w, src + y * stride, w * sizeof(pixel));
+        memset(thetaPic + (size_t)y * w, 0, w * sizeof(pixel));
+    }
+    static const int g[5][5] = { { 2, 4, 5, 4, 2 }, { 4, 9, 12, 9, 4 }, { 5, 12, 15, 12, 5 }, { 4, 9, 12, 9, 4 }, { 2, 4, 5, 4, 2 } };
+    for (int r = 2; r < h - 2; r++)
+        for (int c = 2; c < w - 2; c++)
+        {
+            int acc = 0;
+            for (int j = 0; j < 5; j++)
+                for (int i = 0; i < 5; i++)
+                    acc += g[j][i] * src[(r + j - 2) * stride + c + i - 2];
+            blur[(size_t)r * w + c] = (pixel)(acc / 159);
+        }
+#if ORC_DEPTH > 8
+    const float edgeThreshold = 1023.0f;            /* EDGE_THRESHOLD, source/encoder/slicetype.h:69-73 */
+#else
+    const float edgeThreshold = 255.0f;
+#endif
+    const pixel whitePixel = (pixel)edgeThreshold;
+    for (int r = 1; r < h - 1; r++)
+        for (int c = 1; c < w - 1; c++)
+        {
+            const pixel* p = blur + (size_t)r * w + c;
+            const float gradientH = (float)(-3 * p[-w - 1] + 3 * p[-w + 1] - 10 * p[-1] + 10 * p[1] - 3 * p[w - 1] + 3 * p[w + 1]);
+            const float gradientV = (float)(-3 * p[-w - 1] - 10 * p[-w] - 3 * p[-w + 1] + 3 * p[w - 1] + 10 * p[w] + 3 * p[w + 1]);
+            const float gradientMagnitude = sqrtf(gradientH * gradientH + gradientV * gradientV);
+            /* C++ picks the float overload of atan2 for two floats */
+            const float radians = atan2f(gradientV, gradientH);
+            float theta = (float)((radians * 180) / 3.14159265);       /* PI, slicetype.h:74 */
+            if (theta < 0)
+                theta = 180 + theta;
+            thetaPic[(size_t)r * w + c] = (pixel)theta;
+            edgePic[(size_t)r * w + c] = (pixel)(gradientMagnitude >= edgeThreshold ? whitePixel : 0);
+        }
+    free(blur);
+}
+
+/* LookaheadTLD::edgeDensityCu + findAvgAngle (source/encoder/slicetype.cpp:227-263): variance of the edge picture's
+ * block (acEnergyVar, adding the block's sums to plane 0 of wp_sum / wp_ssd as it does) and the mean angle */
+static uint32_t edge_density_cu(const pixel* edgePic, const pixel* thetaPic, int w, int h, int bx, int by, int size,
+                                uint32_t* avgAngle, uint64_t* wpSum, uint64_t* wpSsd)
+{
+    pixel blk[16 * 16];
+    int angle = 0;
+    for (int y = 0; y < size; y++)
+        for (int x = 0; x < size; x++)
+        {
+            const int in = by + y < h && bx + x < w;
+            blk[y * size + x] = in ? edgePic[(size_t)(by + y) * w + bx + x] : 0;
+            angle += in ? thetaPic[(size_t)(by + y) * w + bx + x] : 0;
+        }
+    *avgAngle = angle / (size * size);
+    uint64_t sum_ssd = orc_pixel_var(size, blk, size);
+    uint32_t sum = (uint32_t)sum_ssd, ssd = (uint32_t)(sum_ssd >> 32);
+    *wpSum += sum;
+    *wpSsd += ssd;
+    return ssd - (uint32_t)(((uint64_t)sum * sum) >> (size == 8 ? 6 : 8));
+}
+
 /* x265_exp2fix8, source/common/common.cpp:96-103; the fraction table is
  * x265_exp2_lut (source/common/constants.cpp:552-558) = round(256 * (2^(i/64) - 1)) */
 int orc_exp2fix8(double x)
@@ -355,7 +427,7 @@ int orc_exp2fix8(double x)
 }
 
 /* LookaheadTLD::calcAdaptiveQuantFrame, source/encoder/slicetype.cpp:454-704, for 4:2:0, without
- * hevcAq and the edge mode.  qgSize 8 measures 8x8 luma + 4x4 chroma blocks with modeOneConst 11.427f /
+ * hevcAq (aqMode 4 is the edge mode, :529-606).  qgSize 8 measures 8x8 luma + 4x4 chroma blocks with modeOneConst 11.427f /
  * modeTwoConst 8.f, everything else 16x16 + 8x8 with 14.427f / 11.f (:461-474).  Block by block in the
  * reference's order: acEnergyCu is called from the same places, so wp_sum / wp_ssd accumulate exactly
  * as they do there, including the second round of the bDynamicRefine / bEnableFades tail (:688-703).
@@ -422,13 +494,40 @@ void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, 
         {
             int k = 0;
             double avg_adj_pow2 = 0, avg_adj = 0, qp_adj = 0, bias_strength = 0, strength = 0;
-            if (aqMode == 2 || aqMode == 3)
+            pixel* edgePic = NULL;
+            pixel* thetaPic = NULL;
+            uint8_t* edgeInclined = NULL;
+            if (aqMode == 4)
+            {
+                edgePic = (pixel*)malloc((size_t)w * h * sizeof(pixel));
+                thetaPic = (pixel*)malloc((size_t)w * h * sizeof(pixel));
+                edgeInclined = (uint8_t*)calloc(blockCount, 1);
+                orc_edge_filter(y, sy, w, h, edgePic, thetaPic);
+            }
+            if (aqMode == 2 || aqMode == 3 || aqMode == 4)
             {
                 double bit_depth_correction = 1.f / (1 << (2 * (ORC_DEPTH - 8)));
                 for (int by = 0; by < maxRow; by += loopIncr)
                     for (int bx = 0; bx < maxCol; bx += loopIncr)
                     {
                         uint32_t energy = ORC_ENERGY(bx, by);
+                        if (aqMode == 4)
+                        {
+                            uint32_t avgAngle;
+                            uint32_t edgeDensity = edge_density_cu(edgePic, thetaPic, w, h, bx, by, loopIncr, &avgAngle, &wp[0], &wp[3]);
+                            if (edgeDensity)
+                            {
+                                qp_adj = pow(edgeDensity * bit_depth_correction + 1, 0.1);
+                                /* EDGE_INCLINATION 45 -+ 15 and 45 + 75 .. 45 + 105 */
+                                edgeInclined[k] = (avgAngle >= 30 && avgAngle <= 60) || (avgAngle >= 120 && avgAngle <= 150);
+                            }
+                            else
+                            {
+                                qp_adj = pow(energy * bit_depth_correction + 1, 0.1);
+                                edgeInclined[k] = 0;
+                            }
+                        }
+                        else
                         qp_adj = pow(energy * bit_depth_correction + 1, 0.1);
                         qpCuTreeOffset[k++] = qp_adj;
                         avg_adj += qp_adj;
@@ -457,6 +556,14 @@ void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, 
                         qp_adj = qpCuTreeOffset[k];
                         qp_adj = strength * (qp_adj - avg_adj);
                     }
+                    else if (aqMode == 4)
+                    {
+                        qp_adj = qpCuTreeOffset[k];
+                        if (edgeInclined[k] && (qp_adj - avg_adj > 0))
+                            qp_adj = ((strength + 0.5 /* AQ_EDGE_BIAS */) * (qp_adj - avg_adj));
+                        else
+                            qp_adj = strength * (qp_adj - avg_adj);
+                    }
                     else
                     {
                         uint32_t energy = ORC_ENERGY(bx, by);
@@ -484,6 +591,9 @@ void orc_calc_adaptive_quant_frame(const pixel* y, intptr_t sy, const pixel* u, 
                     qpCuTreeOffset[k] = qp_adj;
                     invQscaleFactor[k] = orc_exp2fix8(qp_adj);
                 }
+            free(edgePic);
+            free(thetaPic);
+            free(edgeInclined);
         }
         if (qgSize == 8 && invQscaleFactor && invQscaleFactor8x8)
         {

@@ -89,7 +89,60 @@ def test_aq_frame_rejects_uncovered_modes():
     u = v = np.zeros((H // 2, W // 2), np.uint8)
     with api.Context(W, H, depth=8, num_slots=1) as ctx:
         with pytest.raises(api.X265GpuError):
-            ctx.aq_frame(y, u, v, 4, 1.0)                           # X265_AQ_EDGE
+            ctx.aq_frame(y, u, v, 5, 1.0)                           # no such mode
+
+
+def _edgy_picture(W, H, depth, seed):
+    """Edges at many angles: bars, both diagonals at several slopes, discs, a ramp, noise and a flat band."""
+    rng = np.random.default_rng(seed)
+    top = (1 << depth) - 1
+    yy, xx = np.mgrid[0:H, 0:W]
+    y = np.zeros((H, W), np.int64)
+    y += ((xx // 23) % 2) * (top // 2) * (yy < H // 4)                                 # vertical bars
+    y += ((yy // 11) % 2) * (top // 3) * ((yy >= H // 4) & (yy < H // 2) & (xx < W // 3))   # horizontal bars
+    for k, slope in enumerate((1, -1, 2, -3, 0.5)):
+        band = (xx >= W // 3 + k * (W // 8)) & (xx < W // 3 + (k + 1) * (W // 8)) & (yy >= H // 4) & (yy < 3 * H // 4)
+        y += ((((xx + slope * yy) // 9).astype(np.int64)) % 2) * (top * 2 // 3) * band
+    y += (((xx - W // 6) ** 2 + (yy - 3 * H // 4) ** 2) < (H // 6) ** 2) * (top // 2)  # a disc: every angle
+    y += (xx * top // (4 * W)) * (yy >= 3 * H // 4)                                    # ramp
+    y += rng.integers(0, max(2, top // 40), (H, W)) * (xx > 3 * W // 4)                # mild noise on the right
+    y = np.clip(y, 0, top).astype(np.uint8 if depth == 8 else np.uint16)
+    dt = y.dtype
+    u = rng.integers(top // 3, top // 2, (H // 2, W // 2)).astype(dt)
+    v = rng.integers(0, top + 1, (H // 2, W // 2)).astype(dt)
+    return y, u, v
+
+
+@pytest.mark.parametrize("depth", [8, 10, 12])
+@pytest.mark.parametrize("size,qg", [((416, 240), 32), ((200, 120), 32), ((178, 94), 32), ((424, 248), 8), ((1920, 1080), 32)])
+def test_aq_edge_mode(depth, size, qg):
+    """X265_AQ_EDGE: blurred picture, Sobel gradients, edge density and mean angle per block, the offsets mapped from
+    them, and wp_sum / wp_ssd with the edge picture's sums added in, all equal to the oracle's."""
+    W, H = size
+    y, u, v = _edgy_picture(W, H, depth, 40 + depth)
+    names = ("qpAqOffset", "qpCuTreeOffset", "invQscaleFactor", "wp_sum", "wp_ssd", "invQscaleFactor8x8")
+    for weightp, strength in ((False, 1.0), (True, 0.7)):
+        want = orc.calc_adaptive_quant_frame(depth, y, u, v, 4, strength, weightp=weightp, qg_size=qg)
+        with api.Context(W, H, depth=depth, num_slots=1) as ctx:
+            got = ctx.aq_frame(y, u, v, 4, strength, weightp=weightp, slot=0, qg_size=qg)
+        assert len(got) == len(want)
+        for g, w_, name in zip(got, want, names):
+            np.testing.assert_array_equal(g, w_, err_msg="%s weightp %s" % (name, weightp))
+    # the edge term changes the outcome: same picture, plain auto-variance
+    plain = orc.calc_adaptive_quant_frame(depth, y, u, v, 2, 0.7, weightp=True, qg_size=qg)
+    assert (plain[0] != want[0]).mean() > 0.2
+
+
+def test_aq_edge_mode_in_bands(monkeypatch):
+    """The picture pass in bands of three tile rows (as a picture too large for one list of host-side angles runs)."""
+    monkeypatch.setenv("X265GPU_AQ_EDGE_BAND_ROWS", "3")
+    W, H, depth = 416, 240, 8
+    y, u, v = _edgy_picture(W, H, depth, 77)
+    want = orc.calc_adaptive_quant_frame(depth, y, u, v, 4, 1.0, weightp=True)
+    with api.Context(W, H, depth=depth, num_slots=1) as ctx:
+        got = ctx.aq_frame(y, u, v, 4, 1.0, weightp=True, slot=0)
+    for g, w_ in zip(got, want):
+        np.testing.assert_array_equal(g, w_)
 
 
 @pytest.mark.parametrize("depth", [8, 10])

@@ -386,6 +386,48 @@ def test_picture_statistics_oracle_pin(oracle_built):
     lr.close()
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+def test_edge_filter_against_numpy(oracle_built, depth):
+    """edgeFilter (5x5 blur, Sobel pair, threshold, angle in whole degrees) against array arithmetic.  numpy's own
+    float32 arctan2 may differ from libm's in the last bit, which can move an angle that sits on a whole degree:
+    gradients along a diagonal (exactly 45 or 135 degrees) land on either side depending on the library, and apart
+    from those at most a handful of pixels may differ, by one degree."""
+    from x265_amd import synth
+    W, H = 160, 96
+    src = synth.luma_clip(W, H, 1, depth, seed=9)[0]
+    src[20:40, 30:90] = (np.arange(60) * ((1 << depth) - 1) // 60).astype(src.dtype)       # a ramp: equal gradients
+    L = orc.lib(depth)
+    edge = np.zeros((H, W), src.dtype)
+    theta = np.zeros((H, W), src.dtype)
+    L.orc_edge_filter(orc.ptr(src), W, W, H, orc.ptr(edge), orc.ptr(theta))
+    s = src.astype(np.int64)
+    g = np.array([[2, 4, 5, 4, 2], [4, 9, 12, 9, 4], [5, 12, 15, 12, 5], [4, 9, 12, 9, 4], [2, 4, 5, 4, 2]])
+    blur = s.copy()
+    acc = np.zeros((H - 4, W - 4), np.int64)
+    for j in range(5):
+        for i in range(5):
+            acc += g[j, i] * s[j:H - 4 + j, i:W - 4 + i]
+    blur[2:H - 2, 2:W - 2] = acc // 159
+    b = blur
+    gh = (-3 * b[:-2, :-2] + 3 * b[:-2, 2:] - 10 * b[1:-1, :-2] + 10 * b[1:-1, 2:] - 3 * b[2:, :-2] + 3 * b[2:, 2:])
+    gv = (-3 * b[:-2, :-2] - 10 * b[:-2, 1:-1] - 3 * b[:-2, 2:] + 3 * b[2:, :-2] + 10 * b[2:, 1:-1] + 3 * b[2:, 2:])
+    white = 255 if depth == 8 else 1023
+    want_edge = s.copy()
+    want_edge[1:-1, 1:-1] = np.where(gh * gh + gv * gv >= white * white, white, 0)
+    np.testing.assert_array_equal(edge, want_edge)
+    rad = np.arctan2(gv.astype(np.float32), gh.astype(np.float32))
+    th = ((rad * np.float32(180)).astype(np.float64) / 3.14159265).astype(np.float32)
+    th = np.where(th < 0, np.float32(180) + th, th).astype(np.float32)
+    want_theta = np.zeros((H, W), np.int64)
+    want_theta[1:-1, 1:-1] = th.astype(np.int64)
+    diff = np.abs(theta.astype(np.int64) - want_theta)
+    diagonal = np.zeros((H, W), bool)
+    diagonal[1:-1, 1:-1] = np.abs(gv) == np.abs(gh)
+    assert diff.max() <= 1 and (diff[~diagonal] != 0).sum() <= 4
+    assert len(np.unique(theta)) > 60                             # a spread of angles, not a degenerate picture
+    assert (theta[0] == 0).all() and (theta[:, -1] == 0).all()
+
+
 def test_serial_threaded_me_fills_every_entry_once():
     """The serial restatement of Analysis::deriveMVsForCTU on one small picture: with AMP and rectangular PUs
     every one of the 593 entries of a 64x64 CTU's table is written, and a P slice leaves list 1 empty."""

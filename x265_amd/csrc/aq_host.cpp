@@ -12,6 +12,7 @@
 
 #include <math.h>
 #include <string.h>
+#include <vector>
 
 // every product and sum below rounds on its own, as the reference's scalar build does
 #pragma STDC FP_CONTRACT OFF
@@ -58,13 +59,29 @@ int aq_exp2fix8(double x)
     return (exp2Table.v[i & 63] + 256) << (i >> 6) >> 8;
 }
 
+// One pixel's gradient angle in whole degrees as computeEdge stores it (source/encoder/slicetype.cpp:145-153):
+// float atan2 (the overload C++ picks for two floats), times 180 in float, divided by the reference's PI constant in
+// double, back to float, negative angles folded by adding 180, truncated.
+int edge_theta(int gradientV, int gradientH)
+{
+    const float radians = atan2f((float)gradientV, (float)gradientH);
+    float theta = (float)((radians * 180) / 3.14159265);
+    if (theta < 0)
+        theta = 180 + theta;
+    return (int)theta;
+}
+
 void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy, const uint32_t* lumaSum,
-                      const float* quantOffsets, double* qpAqOffset, double* qpCuTreeOffset, int32_t* invQscale)
+                      const float* quantOffsets, double* qpAqOffset, double* qpCuTreeOffset, int32_t* invQscale,
+                      const uint32_t* edgeDensity, const uint32_t* avgAngle)
 {
     // slicetype.cpp:461-474
     const float modeOneConst = p.blockSize == 8 ? 11.427f : 14.427f, modeTwoConst = p.blockSize == 8 ? 8.f : 11.f;
     double strength, avg = 0, bias = 0;
-    const bool autoVariance = p.aqMode == 2 || p.aqMode == 3;
+    const bool autoVariance = p.aqMode == 2 || p.aqMode == 3 || p.aqMode == 4;
+    std::vector<unsigned char> inclined;
+    if (p.aqMode == 4)
+        inclined.assign((size_t)blocks, 0);
     if (autoVariance)
     {
         // first pass (:541-578): activity = (energy + 1)^0.1, kept in qpCuTreeOffset, and its first two moments
@@ -72,7 +89,15 @@ void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy
         double sum = 0, sumSq = 0;
         for (int i = 0; i < blocks; i++)
         {
-            const double a = pow(energy[i] * depthScale + 1, 0.1);
+            // edge mode (:548-565): a block with edges is rated by its edge density, and marked when its mean gradient
+            // angle lies within 15 degrees of a diagonal
+            uint32_t e = energy[i];
+            if (p.aqMode == 4 && edgeDensity[i])
+            {
+                e = edgeDensity[i];
+                inclined[i] = (avgAngle[i] >= 30 && avgAngle[i] <= 60) || (avgAngle[i] >= 120 && avgAngle[i] <= 150);
+            }
+            const double a = pow(e * depthScale + 1, 0.1);
             qpCuTreeOffset[i] = a;
             sum += a;
             sumSq += a * a;
@@ -97,6 +122,11 @@ void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy
         }
         else if (p.aqMode == 2)
             q = strength * (qpCuTreeOffset[i] - avg);
+        else if (p.aqMode == 4)
+        {
+            const double a = qpCuTreeOffset[i];                 // :598-606, AQ_EDGE_BIAS 0.5
+            q = inclined[i] && (a - avg > 0) ? (strength + 0.5) * (a - avg) : strength * (a - avg);
+        }
         else
         {
             const uint32_t e = energy[i] > 1 ? energy[i] : 1;

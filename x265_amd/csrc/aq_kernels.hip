@@ -207,4 +207,130 @@ hipError_t launch_aq_energy(hipStream_t s, int bpp, const AqJob& job)
     return hipGetLastError();
 }
 
+// ---- edge mode -------------------------------------------------------------------------
+// edgeFilter (source/encoder/slicetype.cpp:191-225) and edgeDensityCu's two block sums (:227-263) in one pass:
+// a workgroup takes a 16x16 tile of the picture, stages the 22x22 source pixels around it, blurs the 18x18 it needs
+// (gaussianBlur5x5, :164-189: the two-pixel frame of the picture keeps source pixels) and applies computeEdge's
+// Sobel pair (:100-162) to its own pixels.  The edge picture is the source on the one-pixel frame, the threshold
+// test inside, zero beyond the picture; the angle picture is zero on the frame and beyond.  The threshold test on
+// sqrtf(gH^2 + gV^2) is done on the integer sum of squares: both thresholds' squares are below 2^24, where the
+// float sum is exact and sqrtf is monotonic.
+template <typename P>
+__global__ void __launch_bounds__(256) aq_edge_kernel(AqEdgeJob job, int threshold)
+{
+    __shared__ int src[22][23];
+    __shared__ int blur[18][19];
+    __shared__ uint32_t acc[4][3];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int x0 = blockIdx.x * 16, y0 = (job.tileRow0 + blockIdx.y) * 16;
+    const int w = job.width, h = job.height;
+    if (tid < 12)
+        acc[tid / 3][tid % 3] = 0;
+    for (int i = tid; i < 22 * 22; i += 256)
+    {
+        const int r = i / 22, c = i - r * 22;
+        const int y = min(max(y0 + r - 3, 0), h - 1), x = min(max(x0 + c - 3, 0), w - 1);
+        src[r][c] = (int)((const P*)job.luma)[(long long)y * job.lumaStride + x];
+    }
+    __syncthreads();
+    for (int i = tid; i < 18 * 18; i += 256)
+    {
+        const int r = i / 18, c = i - r * 18;
+        const int y = y0 + r - 1, x = x0 + c - 1;           // picture position of blur[r][c]; src[r + 2][c + 2] is its centre
+        int v = src[r + 2][c + 2];
+        if (y >= 2 && y < h - 2 && x >= 2 && x < w - 2)
+        {
+            const int s0 = 2 * src[r][c] + 4 * src[r][c + 1] + 5 * src[r][c + 2] + 4 * src[r][c + 3] + 2 * src[r][c + 4];
+            const int s1 = 4 * src[r + 1][c] + 9 * src[r + 1][c + 1] + 12 * src[r + 1][c + 2] + 9 * src[r + 1][c + 3] + 4 * src[r + 1][c + 4];
+            const int s2 = 5 * src[r + 2][c] + 12 * src[r + 2][c + 1] + 15 * src[r + 2][c + 2] + 12 * src[r + 2][c + 3] + 5 * src[r + 2][c + 4];
+            const int s3 = 4 * src[r + 3][c] + 9 * src[r + 3][c + 1] + 12 * src[r + 3][c + 2] + 9 * src[r + 3][c + 3] + 4 * src[r + 3][c + 4];
+            const int s4 = 2 * src[r + 4][c] + 4 * src[r + 4][c + 1] + 5 * src[r + 4][c + 2] + 4 * src[r + 4][c + 3] + 2 * src[r + 4][c + 4];
+            v = (s0 + s1 + s2 + s3 + s4) / 159;
+        }
+        blur[r][c] = v;
+    }
+    __syncthreads();
+    const int x = x0 + tx, y = y0 + ty;
+    uint32_t edge = 0, theta = 0;
+    bool listed = false;
+    int gV = 0, gH = 0;
+    if (x < w && y < h)
+    {
+        if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1)
+        {
+            const int r = ty + 1, c = tx + 1;
+            gH = -3 * blur[r - 1][c - 1] + 3 * blur[r - 1][c + 1] - 10 * blur[r][c - 1] + 10 * blur[r][c + 1] - 3 * blur[r + 1][c - 1] + 3 * blur[r + 1][c + 1];
+            gV = -3 * blur[r - 1][c - 1] - 10 * blur[r - 1][c] - 3 * blur[r - 1][c + 1] + 3 * blur[r + 1][c - 1] + 10 * blur[r + 1][c] + 3 * blur[r + 1][c + 1];
+            edge = gH * gH + gV * gV >= threshold * threshold ? (uint32_t)threshold : 0u;
+            if (gV == 0)
+                theta = gH >= 0 ? 0 : job.theta180;        // atan2(+0, x): +0 for x >= 0, pi for x < 0
+            else if (gH == 0)
+                theta = gV > 0 ? job.theta90pos : job.theta90neg;
+            else
+            {
+                // the device's atan2f and the host's may differ in the last bits: take the whole degree only when
+                // both ends of a generous error interval agree on it
+                const float radians = atan2f((float)gV, (float)gH);
+                const float slack = fabsf(radians) * 1.5e-6f;
+                int deg[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+                {
+                    const float rk = k ? radians + slack : radians - slack;
+                    float t = (float)((double)(rk * 180.0f) / 3.14159265);
+                    if (t < 0)
+                        t = 180.0f + t;
+                    deg[k] = (int)t;
+                }
+                if (deg[0] == deg[1])
+                    theta = deg[0];
+                else
+                    listed = true;
+            }
+        }
+        else
+            edge = src[ty + 3][tx + 3];
+    }
+    const int sub = job.blockSize == 8 ? (ty >> 3) * 2 + (tx >> 3) : 0;
+    if (edge)
+    {
+        atomicAdd(&acc[sub][0], edge);
+        atomicAdd(&acc[sub][1], edge * edge);
+    }
+    if (theta)
+        atomicAdd(&acc[sub][2], theta);
+    const int blocksPerTile = job.blockSize == 8 ? 2 : 1;
+    const int bx = blockIdx.x * blocksPerTile + (job.blockSize == 8 ? tx >> 3 : 0);
+    const int by = (job.tileRow0 + blockIdx.y) * blocksPerTile + (job.blockSize == 8 ? ty >> 3 : 0);
+    if (listed)
+    {
+        const uint32_t at = atomicAdd(job.listCount, 1u);
+        job.list[2 * at] = (uint32_t)(by * job.blocksX + bx);
+        job.list[2 * at + 1] = ((uint32_t)gV & 0xffffu) | ((uint32_t)gH << 16);
+    }
+    __syncthreads();
+    if (tid < 4 * 3)
+    {
+        const int sb = tid / 3, what = tid % 3;
+        const int obx = blockIdx.x * blocksPerTile + (sb & 1), oby = (job.tileRow0 + blockIdx.y) * blocksPerTile + (sb >> 1);
+        const bool exists = (job.blockSize == 8 || sb == 0) && obx * job.blockSize < w && oby * job.blockSize < h;
+        if (exists)
+        {
+            uint32_t* out = what == 0 ? job.edgeSum : what == 1 ? job.edgeSsd : job.thetaSum;
+            out[oby * job.blocksX + obx] = acc[sb][what];
+        }
+    }
+}
+
+hipError_t launch_aq_edge(hipStream_t s, int bpp, int depth, const AqEdgeJob& job, int tileRows)
+{
+    dim3 grid((job.width + 15) / 16, tileRows);
+    const int threshold = depth > 8 ? 1023 : 255;        // EDGE_THRESHOLD, source/encoder/slicetype.h:69-73
+    if (bpp == 1)
+        hipLaunchKernelGGL(aq_edge_kernel<uint8_t>, grid, dim3(256), 0, s, job, threshold);
+    else
+        hipLaunchKernelGGL(aq_edge_kernel<uint16_t>, grid, dim3(256), 0, s, job, threshold);
+    return hipGetLastError();
+}
+
 } // namespace xg

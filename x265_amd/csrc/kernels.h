@@ -187,9 +187,31 @@ double hevc_aq_layer(int width, int height, int partW, int partH, int numPartInW
                      double* dCuTreeOffset);
 
 // Host half of calcAdaptiveQuantFrame: block energies -> QP offsets (aq_host.cpp).
+// The edge mode's picture pass (X265_AQ_EDGE): per AQ block the sum and the sum of squares of the edge picture and
+// the sum of the per-pixel gradient angles.  A pixel whose angle in whole degrees cannot be told apart from its
+// neighbour within the accuracy of the device's atan2f is left out of the sum and listed instead, for the host to
+// add with its own atan2f (edge_theta).
+struct AqEdgeJob
+{
+    const void* luma;
+    long long lumaStride;                    // pixels
+    int width, height;
+    int blockSize;                           // 16 or 8
+    int blocksX;
+    int tileRow0;                            // first row of 16x16 tiles this launch covers
+    int theta180, theta90pos, theta90neg;    // the host's angles for gradients along the axes
+    uint32_t* edgeSum;                       // [blocks], zeroed by the caller
+    uint32_t* edgeSsd;
+    uint32_t* thetaSum;
+    uint32_t* listCount;                     // one counter, zeroed per launch
+    uint32_t* list;                          // pairs { block index, gradientV | gradientH << 16 }, capacity = pixels of the launch
+};
+hipError_t launch_aq_edge(hipStream_t s, int bpp, int depth, const AqEdgeJob& job, int tileRows);
+int edge_theta(int gradientV, int gradientH);    // aq_host.cpp
+
 struct AqFrameParams
 {
-    int aqMode;          // 1 variance, 2 auto-variance, 3 auto-variance biased
+    int aqMode;          // 1 variance, 2 auto-variance, 3 auto-variance biased, 4 edge
     int depth;
     int hdr10;
     double strength;     // rc.aqStrength
@@ -197,8 +219,10 @@ struct AqFrameParams
     int blockCount;      // what the activity moments are divided by (can exceed the visited blocks with qgSize 8)
 };
 int aq_exp2fix8(double x);
+// edgeDensity / avgAngle: per block, edge mode only (else null)
 void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy, const uint32_t* lumaSum,
-                      const float* quantOffsets, double* qpAqOffset, double* qpCuTreeOffset, int32_t* invQscale);
+                      const float* quantOffsets, double* qpAqOffset, double* qpCuTreeOffset, int32_t* invQscale,
+                      const uint32_t* edgeDensity = nullptr, const uint32_t* avgAngle = nullptr);
 void aq_finish_wp(int width, int height, unsigned long long sum[3], unsigned long long ssd[3]);
 // cuTreeFinish for qgSize > 8 (aq_host.cpp): propagate totals -> qpCuTreeOffset
 void cutree_finish_offsets(int blocks, const int32_t* intraCost, const int32_t* invQscale, const unsigned long long* totals,

@@ -2072,6 +2072,83 @@ int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const v
     return X265GPU_OK;
 }
 
+namespace {
+// The edge mode's picture pass (edgeFilter + edgeDensityCu, source/encoder/slicetype.cpp:191-263) over a staged
+// picture, in bands of tile rows so that the list of pixels left to the host's atan2f always fits its buffer.
+// edgeDensityCu runs the edge picture's blocks through acEnergyVar, which adds their sums to plane 0 of wp_sum /
+// wp_ssd: wp[0] and wp[3] receive those as well.
+int aq_edge_pass(x265gpu_ctx* ctx, const YuvOnDevice& pic, int B, int w, int h, int cols, int blocks,
+                 std::vector<uint32_t>& edgeDensity, std::vector<uint32_t>& avgAngle, unsigned long long wp[6])
+{
+    const int tileRowsAll = (h + 15) / 16, tileCols = (w + 15) / 16;
+    const size_t listCap = (size_t)1 << 21;                                  // records per band
+    int bandRows = (int)(listCap / ((size_t)tileCols * 256));
+    if (const char* e = getenv("X265GPU_AQ_EDGE_BAND_ROWS"))      // smaller bands (tests)
+        bandRows = atoi(e) < bandRows ? atoi(e) : bandRows;
+    bandRows = bandRows < 1 ? 1 : bandRows;
+    const size_t arrayBytes = align256(sizeof(uint32_t) * (size_t)blocks);
+    const size_t bandPixels = (size_t)bandRows * tileCols * 256;
+    const size_t total = 3 * arrayBytes + 256 + bandPixels * 2 * sizeof(uint32_t);
+    int rc = ensure_pu_buf(ctx, total);
+    if (rc)
+        return rc;
+    AqEdgeJob job;
+    memset(&job, 0, sizeof(job));
+    job.luma = pic.y;
+    job.lumaStride = pic.strideY;
+    job.width = w;
+    job.height = h;
+    job.blockSize = B;
+    job.blocksX = cols;
+    job.theta180 = edge_theta(0, -1);
+    job.theta90pos = edge_theta(1, 0);
+    job.theta90neg = edge_theta(-1, 0);
+    job.edgeSum = (uint32_t*)ctx->puBuf;
+    job.edgeSsd = (uint32_t*)(ctx->puBuf + arrayBytes);
+    job.thetaSum = (uint32_t*)(ctx->puBuf + 2 * arrayBytes);
+    job.listCount = (uint32_t*)(ctx->puBuf + 3 * arrayBytes);
+    job.list = (uint32_t*)(ctx->puBuf + 3 * arrayBytes + 256);
+    std::vector<uint32_t> extra((size_t)blocks, 0), records;
+    for (int row0 = 0; row0 < tileRowsAll; row0 += bandRows)
+    {
+        const int rows = bandRows < tileRowsAll - row0 ? bandRows : tileRowsAll - row0;
+        job.tileRow0 = row0;
+        HIPCHK(hipMemsetAsync(job.listCount, 0, sizeof(uint32_t), ctx->stream));
+        HIPCHK(launch_aq_edge(ctx->stream, ctx->bpp, ctx->cfg.internalBitDepth, job, rows));
+        uint32_t count = 0;
+        HIPCHK(hipMemcpyAsync(&count, job.listCount, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (!count)
+            continue;
+        records.resize(2 * (size_t)count);
+        HIPCHK(hipMemcpyAsync(records.data(), job.list, 2 * (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (uint32_t i = 0; i < count; i++)
+        {
+            const uint32_t g = records[2 * (size_t)i + 1];
+            extra[records[2 * (size_t)i]] += (uint32_t)edge_theta((int16_t)(g & 0xffff), (int16_t)(g >> 16));
+        }
+    }
+    std::vector<uint32_t> sums(3 * (size_t)blocks);
+    for (int k = 0; k < 3; k++)
+        HIPCHK(hipMemcpyAsync(sums.data() + (size_t)k * blocks, ctx->puBuf + k * arrayBytes, sizeof(uint32_t) * (size_t)blocks,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    edgeDensity.resize((size_t)blocks);
+    avgAngle.resize((size_t)blocks);
+    const int shift = B == 8 ? 6 : 8;
+    for (int i = 0; i < blocks; i++)
+    {
+        const uint32_t sum = sums[i], ssd = sums[(size_t)blocks + i];
+        wp[0] += sum;
+        wp[3] += ssd;
+        edgeDensity[i] = ssd - (uint32_t)(((unsigned long long)sum * sum) >> shift);      // acEnergyVar, :51-59
+        avgAngle[i] = (sums[2 * (size_t)blocks + i] + extra[i]) / (uint32_t)(B * B);        // findAvgAngle, :228-240
+    }
+    return X265GPU_OK;
+}
+} // namespace
+
 int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t strideY, const void* u, const void* v,
                      intptr_t strideC, int32_t memKind, const x265gpu_aq_params* params, const float* quantOffsets,
                      double* qpAqOffset, double* qpCuTreeOffset, int32_t* invQscaleFactor, uint64_t wpSum[3],
@@ -2081,8 +2158,8 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
     FINISH_AQ(ctx);
     if (!ctx || !params || !y || !u || !v || !wpSum || !wpSsd)
         return X265GPU_ERR_ARG;
-    if (params->aqMode < 0 || params->aqMode > 3)
-        return fail(ctx, X265GPU_ERR_UNSUPPORTED, "aq_frame: aqMode must be 0..3 (the edge-based mode is not covered)");
+    if (params->aqMode < 0 || params->aqMode > 4)
+        return fail(ctx, X265GPU_ERR_ARG, "aq_frame: aqMode must be 0..4");
     if (params->qgSize != 0 && params->qgSize != 8 && params->qgSize != 16 && params->qgSize != 32 && params->qgSize != 64)
         return fail(ctx, X265GPU_ERR_ARG, "aq_frame: qgSize must be 8, 16, 32 or 64 (0 = 32)");
     if (slot >= 0 && !slot_ok(ctx, slot))
@@ -2166,6 +2243,13 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
         }
         else if (mapped)
         {
+            std::vector<uint32_t> edgeDensity, avgAngle;
+            if (params->aqMode == 4)
+            {
+                rc = aq_edge_pass(ctx, pic, B, w, h, cols, visited, edgeDensity, avgAngle, wp);
+                if (rc)
+                    return rc;
+            }
             AqFrameParams p;
             p.aqMode = params->aqMode;
             p.depth = ctx->cfg.internalBitDepth;
@@ -2174,7 +2258,8 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
             p.blockSize = B;
             p.blockCount = blockCount;
             aq_frame_offsets(p, visited, energy.data(), lumaSum.empty() ? nullptr : lumaSum.data(), quantOffsets,
-                             qpAqOffset, qpCuTreeOffset, invQscaleFactor);
+                             qpAqOffset, qpCuTreeOffset, invQscaleFactor, params->aqMode == 4 ? edgeDensity.data() : nullptr,
+                             params->aqMode == 4 ? avgAngle.data() : nullptr);
         }
     }
     if (offsets && !mapped)

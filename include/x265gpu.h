@@ -529,6 +529,19 @@ typedef struct x265gpu_block_job
 } x265gpu_block_job;
 int x265gpu_block_compare(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t n, const x265gpu_block_job* jobs,
                           int32_t* costs);
+/* The bidirectional candidate of Search::puMotionEstimation (source/encoder/search.cpp:440-448, 482-486): each PU
+ * predicted from two reference pictures at its own quarter-pel vector (Predict::predInterLumaPixel,
+ * source/common/predict.cpp:279-300), the two predictions averaged (pixelavg_pp, (a + b + 1) >> 1) and compared
+ * with the source PU by SATD (bufSATD).  costs[i] receives the SATD of job i; the zero-vector form of :482-486 is
+ * the same job with both vectors zero. */
+typedef struct x265gpu_bipred_job
+{
+    int32_t x, y, w, h;
+    int32_t qmv0X, qmv0Y;      /* vector into slotRef0, quarter pixels */
+    int32_t qmv1X, qmv1Y;      /* vector into slotRef1 */
+} x265gpu_bipred_job;
+int x265gpu_bipred_satd(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef0, int32_t slotRef1, int32_t n,
+                        const x265gpu_bipred_job* jobs, int32_t* costs);
 /* out receives w*h pixels, rows tight; (xFrac,yFrac) in quarter pixels, 0..3 each */
 int x265gpu_interp_luma(x265gpu_ctx* ctx, int32_t slot, int32_t x, int32_t y, int32_t w, int32_t h, int32_t xFrac,
                         int32_t yFrac, void* out);

@@ -138,6 +138,7 @@ void orc_me_set_vert_restriction(orc_me* me, int on);
 /* SAD of the source PU against the prediction at a quarter-pel vector: predInterLumaPixel + bufSAD as
  * Search::selectMVP measures a candidate (source/encoder/search.cpp:2372-2379) */
 int  orc_me_pred_sad(orc_me* me, const orc_refplanes* ref, orc_mv qmv);
+int  orc_me_bipred_satd(orc_me* me, const orc_refplanes* ref0, orc_mv qmv0, const orc_refplanes* ref1, orc_mv qmv1);
 /* the X265_SEA stage of motionEstimate alone, from the start (*bmv, bcost); returns the cost, *bmv the vector */
 int  orc_sea_search_only(orc_me* me, const orc_refplanes* ref, orc_mv mvmin, orc_mv mvmax, orc_mv qmvp, int merange,
                          orc_mv* bmv, int bcost);

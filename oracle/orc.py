@@ -155,6 +155,8 @@ def lib(depth=8):
     L.orc_diamond_search.restype = i
     L.orc_me_pred_sad.argtypes = [vp, C.POINTER(RefPlanes), MV]
     L.orc_me_pred_sad.restype = i
+    L.orc_me_bipred_satd.argtypes = [vp, C.POINTER(RefPlanes), MV, C.POINTER(RefPlanes), MV]
+    L.orc_me_bipred_satd.restype = i
     L.orc_me_set_vert_restriction.argtypes = [vp, i]
     L.orc_sea_integral.argtypes = [vp, ip, i, i, i, vp]
     L.orc_me_set_integral.argtypes = [vp, vp]
@@ -448,6 +450,13 @@ class FullResME:
         cost = L.orc_sea_search_only(self.me, C.byref(self.rp), MV(*mvmin), MV(*mvmax), MV(*mvp), merange, C.byref(bmv),
                                      start_cost)
         return (bmv.x, bmv.y), cost
+
+    def bipred_satd(self, x, y, w, h, qmv0, other, qmv1):
+        """SATD of the PU against the average of its prediction from this reference at qmv0 and from `other`'s
+        reference at qmv1 (the bidirectional candidate of Search::puMotionEstimation)"""
+        L = self.L
+        L.orc_me_set_source(self.me, C.c_void_p(self.fenc_org), self.stride, y * self.stride + x, w, h, 3, 3, 3, 3)
+        return L.orc_me_bipred_satd(self.me, C.byref(self.rp), MV(*qmv0), C.byref(other.rp), MV(*qmv1))
 
     def pred_sad(self, x, y, w, h, qmv):
         """SAD of the PU against the prediction at quarter-pel vector qmv (one candidate of Search::selectMVP)"""

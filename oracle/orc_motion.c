@@ -929,6 +929,35 @@ int orc_me_pred_sad(orc_me* me, const orc_refplanes* ref, orc_mv qmv)
     return subpel_compare(&S, qmv, 0);
 }
 
+/* Predict::predInterLumaPixel (source/common/predict.cpp:279-300) into a tight bw x bh buffer */
+static void pred_luma_pixel(const orc_me* me, const orc_refplanes* ref, orc_mv qmv, pixel* dst)
+{
+    const intptr_t rs = ref->stride;
+    const pixel* src = ref->plane[0] + me->blockOffset + (qmv.x >> 2) + (qmv.y >> 2) * rs;
+    const int xf = qmv.x & 3, yf = qmv.y & 3;
+    if (!(xf | yf))
+        for (int y = 0; y < me->bh; y++)
+            memcpy(dst + y * me->bw, src + y * rs, me->bw * sizeof(pixel));
+    else if (!yf)
+        orc_luma_hpp(me->bw, me->bh, src, rs, dst, me->bw, xf);
+    else if (!xf)
+        orc_luma_vpp(me->bw, me->bh, src, rs, dst, me->bw, yf);
+    else
+        orc_luma_hvpp(me->bw, me->bh, src, rs, dst, me->bw, xf, yf);
+}
+
+/* The bidirectional candidate of Search::puMotionEstimation (source/encoder/search.cpp:440-448): both predictions,
+ * pixelavg_pp with weight 32, bufSATD against the source PU.  With zero vectors this is also :482-486, which
+ * averages the two reference blocks in place. */
+int orc_me_bipred_satd(orc_me* me, const orc_refplanes* ref0, orc_mv qmv0, const orc_refplanes* ref1, orc_mv qmv1)
+{
+    pixel p0[64 * 64], p1[64 * 64], avg[64 * 64];
+    pred_luma_pixel(me, ref0, qmv0, p0);
+    pred_luma_pixel(me, ref1, qmv1, p1);
+    orc_pixelavg_pp(me->bw, me->bh, avg, me->bw, p0, me->bw, p1, me->bw);
+    return cmp_satd(me, avg, me->bw);
+}
+
 /* MotionEstimate::diamondSearch, source/encoder/motion.cpp:631-788: the coarse
  * search Search::puMotionEstimation runs for an area's starting vector
  * (isMVP, source/encoder/search.cpp:360-364).  Full-pel in, full-pel out.

@@ -62,6 +62,45 @@ def test_sad_satd_all_partitions(depth, kind):
         ctx.close()
 
 
+@pytest.mark.parametrize("depth", [8, 10, 12])
+def test_bipred_satd_all_partitions(depth):
+    """SATD against the average of two predictions (the bidirectional candidate of puMotionEstimation): every
+    partition, full-pel and fractional vectors in any mix, three pictures."""
+    W, H, ctu = 320, 192, 64
+    clip = synth.luma_clip(W, H, 3, depth, seed=70 + depth)
+    mx, my = ctu + 32, ctu + 16
+    pads = [np.ascontiguousarray(np.pad(f, ((my, my), (mx, mx)), mode="edge")) for f in clip]
+    table, centre = orc.bitcost_table(depth)
+    me0 = orc.FullResME(depth, table, centre, pads[1], pads[0], mx, my)
+    me1 = orc.FullResME(depth, table, centre, pads[1], pads[2], mx, my)
+    rng = np.random.default_rng(depth)
+    jobs, want = [], []
+    for (w, h) in PARTITIONS[1:]:
+        for k in range(6):
+            x = int(rng.integers(0, (W - w) // 4 + 1)) * 4
+            y = int(rng.integers(0, (H - h) // 4 + 1)) * 4
+            q0 = (int(rng.integers(-80, 81)), int(rng.integers(-80, 81)))
+            q1 = (int(rng.integers(-80, 81)), int(rng.integers(-80, 81)))
+            if k == 0:
+                q0 = q1 = (0, 0)
+            elif k == 1:
+                q0 = (q0[0] & ~3, q0[1] & ~3)
+            jobs.append((x, y, w, h, q0, q1))
+            want.append(me0.bipred_satd(x, y, w, h, q0, me1, q1))
+    with api.Context(W, H, depth=depth, num_slots=3, ctu=ctu, keep_full_res=True) as ctx:
+        for k in range(3):
+            ctx.lowres_init(k, clip[k])
+        got = ctx.bipred_satd(1, 0, 2, jobs)
+        np.testing.assert_array_equal(got, np.array(want, np.int32))
+        same = ctx.bipred_satd(1, 0, 0, [(j[0], j[1], j[2], j[3], j[4], j[4]) for j in jobs])
+        plain = ctx.block_compare(1, 0, [(j[0], j[1], j[2], j[3], j[4][0], j[4][1], api.OP_SATD) for j in jobs])
+        np.testing.assert_array_equal(same, plain)           # averaging a prediction with itself changes nothing
+        with pytest.raises(api.X265GpuError):
+            ctx.bipred_satd(1, 0, 2, [(0, 0, 8, 8, (0, 0), (-800, 0))])
+    me0.close()
+    me1.close()
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_sa8d(depth):
     ctx, pads, mx, my, fw, fh = _setup(depth, 77, "random")

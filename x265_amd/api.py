@@ -22,7 +22,7 @@ EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_estimate_sums_device", "x265gpu_weight_cost", "x265gpu_weight_costs", "x265gpu_weight_cost_static", "x265gpu_weight_planes",
-    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_aq_frames", "x265gpu_aq_frames_begin", "x265gpu_aq_frames_finish", "x265gpu_get_frame_costs", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_bipred_satd", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_aq_frames", "x265gpu_aq_frames_begin", "x265gpu_aq_frames_finish", "x265gpu_get_frame_costs", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
     "x265gpu_cutree_clear", "x265gpu_cutree_swap", "x265gpu_cutree_propagate", "x265gpu_cutree_get_propagate_cost",
     "x265gpu_cutree_finish", "x265gpu_hist_stats", "x265gpu_mcstf_motion_search",
     "x265gpu_profile_enable", "x265gpu_profile_read",
@@ -154,6 +154,7 @@ def load_library(path=None):
     L.x265gpu_pu_motion_estimate.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
     L.x265gpu_get_full_plane.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.x265gpu_block_compare.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.x265gpu_bipred_satd.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     L.x265gpu_aq_energy.argtypes = [vp, vp, ip, vp, vp, ip, i32, vp, vp, vp]
     L.x265gpu_cutree_clear.argtypes = [vp, i32]
     L.x265gpu_cutree_swap.argtypes = [vp, i32, i32]
@@ -395,6 +396,17 @@ class Context:
             arr[k].x, arr[k].y, arr[k].w, arr[k].h, arr[k].qmvX, arr[k].qmvY, arr[k].op = x, y, w, h, qx, qy, op
         out = np.empty(len(jobs), np.int32)
         self._chk(self.L.x265gpu_block_compare(self.h, slot_fenc, slot_ref, len(jobs), arr, _ptr(out)))
+        return out
+
+    def bipred_satd(self, slot_fenc, slot_ref0, slot_ref1, jobs):
+        """jobs: iterable of (x, y, w, h, (qmv0x, qmv0y), (qmv1x, qmv1y)); SATD of each PU against the average of its
+        two predictions."""
+        jobs = list(jobs)
+        arr = np.zeros((len(jobs), 8), np.int32)
+        for k, (x, y, w, h, q0, q1) in enumerate(jobs):
+            arr[k] = (x, y, w, h, q0[0], q0[1], q1[0], q1[1])
+        out = np.empty(len(jobs), np.int32)
+        self._chk(self.L.x265gpu_bipred_satd(self.h, slot_fenc, slot_ref0, slot_ref1, len(jobs), _ptr(arr), _ptr(out)))
         return out
 
     def interp_luma(self, slot, x, y, w, h, xfrac, yfrac):

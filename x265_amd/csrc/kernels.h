@@ -142,6 +142,8 @@ struct PuFrame
 };
 struct BlockJob { int x, y, w, h; int qmvx, qmvy; int op; int reserved; };   // same layout as x265gpu_block_job
 hipError_t launch_block_compare(hipStream_t s, int bpp, const PuFrame& f, const BlockJob* dJobs, int n, int* dOut);
+// SATD against the average of two predictions (x265gpu_bipred_job layout); ref1 = pixel (0,0) of the second padded reference
+hipError_t launch_bipred_satd(hipStream_t s, int bpp, const PuFrame& f, const void* ref1, const void* dJobs, int n, int* dOut);
 hipError_t launch_interp_block(hipStream_t s, int bpp, const void* pic, int stride, int x, int y, int w, int h, int xf, int yf,
                                int depth, void* dOut);
 // block sums of a padded picture for the planes in `mask` (sea_shape.h); tmp holds stride * rows entries

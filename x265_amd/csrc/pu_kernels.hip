@@ -1497,6 +1497,81 @@ __global__ void __launch_bounds__(256) block_compare_kernel(const BlockJob* jobs
         out[idx] = cost;
 }
 
+// One wave per job: SATD of a PU against the average of two predictions, one from each of two reference pictures at
+// its own quarter-pel vector - the bidirectional candidate of Search::puMotionEstimation (source/encoder/search.cpp:
+// 440-448: Predict::predInterLumaPixel twice, pixelavg_pp with weight 32 = (a + b + 1) >> 1, bufSATD; and :482-486,
+// the same average at the zero vectors).
+struct BipredJob { int x, y, w, h; int qmv0x, qmv0y, qmv1x, qmv1y; };     // same layout as x265gpu_bipred_job
+
+template <typename P>
+__global__ void __launch_bounds__(256) bipred_satd_kernel(const BipredJob* jobs, int n, PuFrame f, const void* ref1, int* out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t puLds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + wave;
+    if (idx >= n)
+        return;
+    const BipredJob& job = jobs[idx];
+    XG_LDS uint32_t* rec = (XG_LDS uint32_t*)puLds + wave * (f.maxPasses * 64 * PU_REC_DW);
+    PuCtx<P> c;
+    c.ref = as_global<P>(f.ref);
+    c.stride = f.stride;
+    c.x = job.x;
+    c.y = job.y;
+    c.w = job.w;
+    c.h = job.h;
+    c.minX = -f.marginX + 4;
+    c.maxX = f.width + f.marginX - job.w - 16;
+    c.minY = -f.marginY + 4;
+    c.maxY = f.height + f.marginY - job.h - 5;
+    c.lane = lane;
+    c.phys = lane;
+    c.lpp = 64;
+    c.rec = rec;
+    c.depth = f.depth;
+    stage_encode_block<P>(c, as_global<P>(f.fenc), f.stride, rec);
+    const XG_GLOBAL P* base0 = block_at<P>(c, job.qmv0x >> 2, job.qmv0y >> 2);
+    const XG_GLOBAL P* base1 = as_global<P>(ref1) + (block_at<P>(c, job.qmv1x >> 2, job.qmv1y >> 2) - c.ref);
+    const int xf0 = job.qmv0x & 3, yf0 = job.qmv0y & 3, xf1 = job.qmv1x & 3, yf1 = job.qmv1y & 3;
+    uint32_t acc = 0;
+#pragma unroll 1
+    for (int k = 0; k < c.passes; k++)
+    {
+        const XG_LDS uint32_t* r = c.rec + (k * 64 + c.phys) * PU_REC_DW;
+        const uint32_t f0 = r[0], f1 = r[1], f2 = r[2], f3 = r[3], mask = r[5];
+        const int off = (int)r[4];
+        const Row<P> row0 = (xf0 | yf0) ? interp_row<P>(base0 + off, c.stride, xf0, yf0, c.depth) : load_row_g<P>(base0, off);
+        const Row<P> row1 = (xf1 | yf1) ? interp_row<P>(base1 + off, c.stride, xf1, yf1, c.depth) : load_row_g<P>(base1, off);
+        int a[8], b[8];
+        unpack_row<P>(row0, a);
+        unpack_row<P>(row1, b);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            a[i] = (a[i] + b[i] + 1) >> 1;
+        const Cols d = pair_cols<P>(pack_row<P>(a));
+        acc += (uint32_t)satd8x4_cols(as_s16x2(f0) - as_s16x2(d.q[0] & mask), as_s16x2(f1) - as_s16x2(d.q[1] & mask),
+                                      as_s16x2(f2) - as_s16x2(d.q[2] & mask), as_s16x2(f3) - as_s16x2(d.q[3] & mask), lane & 3);
+    }
+    acc = (lane & 3) ? 0u : acc;
+    const int cost = wave_sum((int)acc);
+    if (lane == 0)
+        out[idx] = cost;
+}
+
+hipError_t launch_bipred_satd(hipStream_t s, int bpp, const PuFrame& f, const void* ref1, const void* dJobs, int n, int* dOut)
+{
+    if (n <= 0)
+        return hipSuccess;
+    const size_t lds = (size_t)4 * f.maxPasses * 64 * PU_REC_DW * sizeof(uint32_t);
+    dim3 grid((n + 3) / 4);
+    if (bpp == 1)
+        hipLaunchKernelGGL(bipred_satd_kernel<uint8_t>, grid, dim3(256), lds, s, (const BipredJob*)dJobs, n, f, ref1, dOut);
+    else
+        hipLaunchKernelGGL(bipred_satd_kernel<uint16_t>, grid, dim3(256), lds, s, (const BipredJob*)dJobs, n, f, ref1, dOut);
+    return hipGetLastError();
+}
+
 // luma_hpp / luma_vpp / luma_hvpp of one block (filter_pp_t, filter_hv_pp_t): one thread per
 // 8-pixel row segment, output tight (stride = w)
 template <typename P>

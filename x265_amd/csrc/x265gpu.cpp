@@ -2604,6 +2604,49 @@ int x265gpu_hist_stats(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t s
     return X265GPU_OK;
 }
 
+int x265gpu_bipred_satd(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef0, int32_t slotRef1, int32_t n,
+                        const x265gpu_bipred_job* jobs, int32_t* costs)
+{
+    DeviceScope deviceScope(ctx);
+    if (!ctx || n < 0 || (n && (!jobs || !costs)))
+        return X265GPU_ERR_ARG;
+    if (!n)
+        return X265GPU_OK;
+    if (!slot_ok(ctx, slotFenc) || !slot_ok(ctx, slotRef0) || !slot_ok(ctx, slotRef1))
+        return fail(ctx, X265GPU_ERR_ARG, "bipred_satd: bad slot");
+    if (!ctx->fullStride)
+        return fail(ctx, X265GPU_ERR_STATE, "bipred_satd: context opened without bKeepFullRes");
+    PuFrame f = pu_frame(ctx, slotFenc, slotRef0);
+    for (int i = 0; i < n; i++)
+    {
+        const x265gpu_bipred_job& j = jobs[i];
+        bool ok = j.w >= 4 && j.h >= 4 && j.w <= 64 && j.h <= 64 && !(j.w & 3) && !(j.h & 3) && j.x >= 0 && j.y >= 0 &&
+                  j.x + j.w <= ctx->fullW && j.y + j.h <= ctx->fullH;
+        for (int k = 0; k < 2 && ok; k++)
+        {
+            const int fx = j.x + ((k ? j.qmv1X : j.qmv0X) >> 2), fy = j.y + ((k ? j.qmv1Y : j.qmv0Y) >> 2);
+            ok = fx >= -ctx->fullMarginX + 8 && fx + j.w <= ctx->fullW + ctx->fullMarginX - 16 &&
+                 fy >= -ctx->fullMarginY + 8 && fy + j.h <= ctx->fullH + ctx->fullMarginY - 8;
+        }
+        if (!ok)
+            return fail(ctx, X265GPU_ERR_ARG, "bipred_satd: bad job");
+        const int segW = (j.w & 7) ? 4 : 8;
+        const int passes = ((j.w / segW) * (j.h / 4) + 15) / 16;
+        f.maxPasses = passes > f.maxPasses ? passes : f.maxPasses;
+    }
+    const size_t jobBytes = align256(sizeof(x265gpu_bipred_job) * (size_t)n), outBytes = sizeof(int32_t) * (size_t)n;
+    int rc = ensure_pu_buf(ctx, jobBytes + outBytes);
+    if (rc)
+        return rc;
+    const size_t origin = ((size_t)ctx->fullMarginY * ctx->fullStride + ctx->fullMarginX) * ctx->bpp;
+    HIPCHK(hipMemcpyAsync(ctx->puBuf, jobs, sizeof(x265gpu_bipred_job) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(launch_bipred_satd(ctx->stream, ctx->bpp, f, ctx->slots[slotRef1].full + origin, ctx->puBuf, n,
+                              (int*)(ctx->puBuf + jobBytes)));
+    HIPCHK(hipMemcpyAsync(costs, ctx->puBuf + jobBytes, outBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return X265GPU_OK;
+}
+
 int x265gpu_block_compare(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t n, const x265gpu_block_job* jobs,
                           int32_t* costs)
 {

@@ -17,19 +17,20 @@ def _padded(clip, W, H, ctu):
 
 
 def _run(W, H, depth, rows, method=api.STAR_SEARCH, merange=57, subpel=3, amp=False, rect=True, min_cu=8, ctu=64,
-         num_refs=1, lam=4.0, lookahead=True, seed=3, median=False, second_picture=False):
-    nframes = num_refs + 1 + int(second_picture)
+         num_refs=1, lam=4.0, lookahead=True, seed=3, median=False, second_picture=False, num_l1=0):
+    nframes = num_refs + 1 + max(int(second_picture), num_l1)
     clip = synth.luma_clip(W, H, nframes, depth, seed=seed, scene_cut=False)
     pads, mx, my = _padded(clip, W, H, ctu)
     cur = num_refs                                            # the P picture; references are the frames before it
     ref_frames = [cur - 1 - r for r in range(num_refs)]       # list 0, nearest first
+    l1_frames = [cur + 1 + r for r in range(num_l1)]          # list 1 of a B picture: the frames after it
     bitsizes = orc.bitsizes(depth)
     table, centre = orc.bitcost_table(depth, lam)
     la_table, la_centre = orc.bitcost_table(depth)
     with api.Context(W, H, depth=depth, num_slots=nframes, ctu=ctu, keep_full_res=True, bframes=4) as ctx:
         for k in range(nframes):
             ctx.lowres_init(k, clip[k], poc=k)
-        lowres = [None] * num_refs
+        lowres = [None] * (num_refs + num_l1)
         if lookahead:
             # the lookahead's own vectors for the P picture: what Search::getLowresMV reads
             ctx.set_mvcost(la_table, la_centre)
@@ -38,18 +39,23 @@ def _run(W, H, depth, rows, method=api.STAR_SEARCH, merange=57, subpel=3, amp=Fa
                 if cur - f <= 5:
                     ctx.estimate([(f, cur, cur, f, cur, cur, 1, 0)])
                     lowres[r] = ctx.get_mvs(cur, 0, cur - f)[0]
+            for r, f in enumerate(l1_frames):
+                if f - cur <= 4:
+                    ctx.estimate([(cur - 1, cur, f, cur - 1, cur, f, 0, 1)])
+                    lowres[num_refs + r] = ctx.get_mvs(cur, 1, f - cur)[0]
         cols, nrows = -(-W // ctu), -(-H // ctu)
         med = None
         if median:
             rng = np.random.default_rng(seed)
-            med = np.zeros((cols * nrows, num_refs, 3), np.int32)
-            med[:, :, 0] = rng.integers(0, 2, (cols * nrows, num_refs))
-            med[:, :, 1:] = rng.integers(-24, 25, (cols * nrows, num_refs, 2))
+            med = np.zeros((cols * nrows, num_refs + num_l1, 3), np.int32)
+            med[:, :, 0] = rng.integers(0, 2, (cols * nrows, num_refs + num_l1))
+            med[:, :, 1:] = rng.integers(-24, 25, (cols * nrows, num_refs + num_l1, 2))
         tme = api.ThreadedME(ctx, search=method, merange=merange, subpel=subpel, amp=amp, rect=rect, min_cu=min_cu, lam=lam)
         try:
             got = tme.new_table()
             refs = [(f, f, True, None, lowres[r]) for r, f in enumerate(ref_frames)]
-            tme.estimate_rows(cur, cur, refs, rows[0], rows[1], got, median_mv=med)
+            refs_l1 = [(f, f, True, None, lowres[num_refs + r]) for r, f in enumerate(l1_frames)]
+            tme.estimate_rows(cur, cur, refs, rows[0], rows[1], got, median_mv=med, refs_l1=refs_l1)
             counts = tme.counts()
             got2 = None
             if second_picture:
@@ -58,12 +64,13 @@ def _run(W, H, depth, rows, method=api.STAR_SEARCH, merange=57, subpel=3, amp=Fa
                 tme.estimate_rows(cur + 1, cur + 1, [(cur, cur, False, got, None)], rows[0], rows[1], got2)
         finally:
             tme.close()
-    mes = [orc.FullResME(depth, table, centre, pads[cur], pads[f], mx, my) for f in ref_frames]
+    mes = [orc.FullResME(depth, table, centre, pads[cur], pads[f], mx, my) for f in ref_frames + l1_frames]
     if method == api.SEA_SEARCH:
         for m in mes:
             m.build_integral()
-    ser = SerialTME(mes, ref_frames, cur, W, H, bitsizes, (table, centre), lam, method=method, merange=merange,
-                    subpel=subpel, amp=amp, rect=rect, ctu=ctu, min_cu=min_cu, lowres_mvs=lowres, median_mv=med)
+    ser = SerialTME(mes, ref_frames + l1_frames, cur, W, H, bitsizes, (table, centre), lam, method=method, merange=merange,
+                    subpel=subpel, amp=amp, rect=rect, ctu=ctu, min_cu=min_cu, lowres_mvs=lowres, median_mv=med,
+                    num_l0=num_refs)
     want = ser.run_rows(rows[0], rows[1])
     for m in mes:
         m.close()
@@ -97,6 +104,13 @@ def test_ctu_rows_4k_star_57():
     _run(3840, 2160, 8, (33, 34), seed=4)
 
 
+def test_ctu_rows_4k_b_picture():
+    """A B picture at 3840x2160: one reference each way, the bidirectional candidate of every rectangular PU."""
+    got, _ = _run(3840, 2160, 8, (20, 21), num_l1=1, seed=6)
+    row = got[20 * 60:21 * 60]
+    assert ((row["ref"][:, :, 0] >= 0) & (row["ref"][:, :, 1] >= 0)).any()
+
+
 def test_ctu_rows_4k_10bit():
     _run(3840, 2160, 10, (16, 17), lam=16.0, seed=5)
 
@@ -111,6 +125,9 @@ def test_ctu_rows_4k_10bit():
     dict(method=api.SEA_SEARCH, merange=24, subpel=2, min_cu=16, num_refs=2),   # --me sea (block sums per reference)
     dict(median=True, amp=True),                               # CUData::getMedianColMV overriding the area vectors
     dict(second_picture=True),                                 # predictors from the reference picture's own table
+    dict(num_l1=1),                                            # a B picture: one reference each way
+    dict(num_l1=2, num_refs=2, amp=True, lam=9.5),            # B, two references per list, every shape
+    dict(num_l1=1, method=api.HEX_SEARCH, merange=24, subpel=5, median=True, lookahead=False),
     dict(ctu=32, min_cu=16, amp=True),
     dict(ctu=16, min_cu=8),
     dict(min_cu=64, size=(448, 256)),                          # one CU per CTU
@@ -119,7 +136,13 @@ def test_ctu_rows_shapes_and_settings(kw):
     kw = dict(kw)
     W, H = kw.pop("size", (416, 240))
     ctu = kw.get("ctu", 64)
-    _run(W, H, 8, (0, -(-H // ctu)), **kw)
+    got, _ = _run(W, H, 8, (0, -(-H // ctu)), **kw)
+    if kw.get("num_l1"):
+        ref = got["ref"]
+        used = (ref[:, :, 0] >= 0) | (ref[:, :, 1] >= 0)
+        both = (ref[:, :, 0] >= 0) & (ref[:, :, 1] >= 0)
+        only1 = (ref[:, :, 0] < 0) & (ref[:, :, 1] >= 0)
+        assert both.sum() > 0.02 * used.sum() and only1.sum() > 0.02 * used.sum()    # all three outcomes occur
 
 
 def test_generator_rejects_what_it_does_not_cover():

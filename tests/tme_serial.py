@@ -2,7 +2,7 @@
 over the CPU oracle's searches (parity unpinned: the reference tree holds no output fixture for this path).
 
 Follows Analysis::deriveMVsForCTU / computeMVForPUs (source/encoder/analysis.cpp:161-306) and
-Search::puMotionEstimation (source/encoder/search.cpp:226-560) statement by statement for a P slice: one CTU
+Search::puMotionEstimation (source/encoder/search.cpp:226-560) statement by statement for a P or B slice: one CTU
 after another, children before parents, one search at a time, each reading the CTU's result table as the calls
 before it left it.  The host layer under test reorders the same calls into dependency levels over many CTUs."""
 import numpy as np
@@ -58,10 +58,14 @@ def scale_mv_by_poc_dist(mv, cur_poc, cur_ref_poc, col_poc, col_ref_poc):
 class SerialTME:
     def __init__(self, me_per_ref, ref_pocs, poc, pic_w, pic_h, bitsizes, cost_table, lam, method=3, merange=57,
                  subpel=3, amp=False, rect=True, ctu=64, min_cu=8, bframes=4, lowres_mvs=None, ref_is_intra=None,
-                 ref_tables=None, median_mv=None, ref_lag_pixels=None):
+                 ref_tables=None, median_mv=None, ref_lag_pixels=None, num_l0=None):
         """me_per_ref: one oracle FullResME (source PU in the current picture, searches in that reference) per
-        reference of list 0; bitsizes / cost_table: (array, centre) pairs; lowres_mvs[r]: (blocks, 2) or None."""
+        reference, list 0's first (num_l0 of them; all of them for a P slice), then list 1's; bitsizes / cost_table:
+        (array, centre) pairs; lowres_mvs[r]: (blocks, 2) or None."""
         self.me, self.ref_pocs, self.poc = me_per_ref, list(ref_pocs), poc
+        self.num_l0 = len(self.ref_pocs) if num_l0 is None else num_l0
+        self.is_p = self.num_l0 == len(self.ref_pocs)
+        self.list_pocs = [self.ref_pocs[:self.num_l0], self.ref_pocs[self.num_l0:]]
         self.pic_w, self.pic_h = pic_w, pic_h
         self.bs, self.bs0 = bitsizes
         self.ct, self.ct0 = cost_table
@@ -117,18 +121,24 @@ class SerialTME:
         mx = (mx[0], max(min(mx[1], self.ref_lag), mn[1]))
         return mn, mx
 
-    def get_pmv(self, neighbours, ref_idx):
-        """CUData::getPMV for list 0 of a P slice, temporal candidate unavailable (cudata.cpp:1845-1905, 1980-1983);
-        neighbours[dir] = (mv of list 0, refIdx of list 0) or None"""
-        cur_ref_poc = self.ref_pocs[ref_idx]
+    def get_pmv(self, neighbours, pic_list, ref_idx):
+        """CUData::getPMV, temporal candidate unavailable (cudata.cpp:1845-1905, 1980-1983), with getDirectPMV /
+        getIndirectPMV (:2110-2156): the asked list of the neighbour first, then the other one;
+        neighbours[dir] = ((mv of list 0, mv of list 1), (refIdx of list 0, refIdx of list 1)) or None"""
+        cur_ref_poc = self.list_pocs[pic_list][ref_idx]
         direct, indirect = {}, {}
         for d in range(MD_ABOVE_LEFT + 1):
             nb = neighbours[d]
-            if nb is None or nb[1] < 0:
+            if nb is None:
                 continue
-            if self.ref_pocs[nb[1]] == cur_ref_poc:
-                direct[d] = nb[0]
-            indirect[d] = scale_mv_by_poc_dist(nb[0], self.poc, cur_ref_poc, self.poc, self.ref_pocs[nb[1]])
+            for pl in (pic_list, 1 - pic_list):
+                if nb[1][pl] >= 0 and self.list_pocs[pl][nb[1][pl]] == cur_ref_poc:
+                    direct[d] = nb[0][pl]
+                    break
+            for pl in (pic_list, 1 - pic_list):
+                if nb[1][pl] >= 0:
+                    indirect[d] = scale_mv_by_poc_dist(nb[0][pl], self.poc, cur_ref_poc, self.poc, self.list_pocs[pl][nb[1][pl]])
+                    break
         amvp = []
         for src, d in ((direct, MD_BELOW_LEFT), (direct, MD_LEFT), (indirect, MD_BELOW_LEFT), (indirect, MD_LEFT)):
             if d in src:
@@ -156,6 +166,16 @@ class SerialTME:
             amvp.append((0, 0))
         return amvp, mvc
 
+    def get_blk_bits(self, part, pu_idx, last_mode):
+        """Search::getBlkBits (search.cpp:4894-4940)"""
+        if part in (SIZE_2Nx2N, SIZE_NxN):
+            return [1 if self.is_p else 3, 3, 5]
+        if self.is_p:
+            return [3, 0, 0]
+        if part in (SIZE_2NxN, SIZE_2NxnU, SIZE_2NxnD):
+            return [[[0, 0, 3], [0, 0, 0], [0, 0, 0]], [[5, 7, 7], [7, 5, 7], [6, 6, 6]]][pu_idx][last_mode]
+        return [[[0, 2, 3], [0, 0, 0], [0, 0, 0]], [[5, 7, 7], [5, 5, 7], [6, 6, 6]]][pu_idx][last_mode]
+
     def get_lowres_mv(self, bx, by, ref):
         """Search::getLowresMV (search.cpp:2323-2343)"""
         if abs(self.poc - self.ref_pocs[ref]) > self.bframes + 1 or self.lowres_mvs[ref] is None:
@@ -169,15 +189,20 @@ class SerialTME:
         search_range = 32 if is_mvp else self.merange
         num_refs = len(self.ref_pocs)
         mvp = (0, 0)
-        best = dict(cost=MAX_UINT)                         # declared outside the loop over the parts
+        best = [dict(cost=MAX_UINT), dict(cost=MAX_UINT)]  # bestME[2], declared outside the loop over the parts
+        last_mode = 0
         entries = self.table[addr]
         for pu_idx in range(1 if part == SIZE_2Nx2N else 2):
             rx, ry, w, h = part_rect(part, pu_idx, cu_size)
             x, y = cu_x + rx, cu_y + ry
             pos = final_idx + pu_idx * pu_offset
-            for ref in range(num_refs):
+            for ref in range(num_refs):                    # list 0's references, then list 1's
+                pic_list = 0 if ref < self.num_l0 else 1
+                ref_idx = ref - pic_list * self.num_l0
+                num_idx = len(self.list_pocs[pic_list])
                 me = self.me[ref]
-                bits = (1 if part == SIZE_2Nx2N else 3) + 1 + ref + (ref < num_refs - 1)
+                sel_bits = self.get_blk_bits(part, pu_idx, last_mode)
+                bits = sel_bits[pic_list] + 1 + ref_idx + (ref_idx < num_idx - 1)
                 if not is_mvp:
                     mvp = self.area_best[area_idx][ref]
                 amvp, mvp_idx, mvc = [(0, 0), (0, 0)], 0, []
@@ -187,10 +212,11 @@ class SerialTME:
                         n = neighbor_idx[d]
                         e = entries[n] if n >= 0 else None
                         if e is not None and (e["ref"][0] >= 0 or e["ref"][1] >= 0):
-                            neighbours.append(((int(e["mv"][0][0]), int(e["mv"][0][1])), int(e["ref"][0])))
+                            neighbours.append((((int(e["mv"][0][0]), int(e["mv"][0][1])), (int(e["mv"][1][0]), int(e["mv"][1][1]))),
+                                               (int(e["ref"][0]), int(e["ref"][1]))))
                         else:
                             neighbours.append(None)
-                    cand, mvc = self.get_pmv(neighbours, ref)
+                    cand, mvc = self.get_pmv(neighbours, pic_list, ref_idx)
                     if mvc:
                         amvp = cand
                         if amvp[0] != amvp[1]:              # Search::selectMVP (search.cpp:2347-2383)
@@ -200,7 +226,9 @@ class SerialTME:
                     elif not self.ref_is_intra[ref] and self.ref_tables[ref] is not None:
                         md = self.ref_tables[ref][addr][pos]
                         r0, r1 = int(md["ref"][0]), int(md["ref"][1])
-                        if r0 >= 0:                          # uni-L0, or bi with list 0
+                        if r0 >= 0 and r1 >= 0:
+                            mvp = (int(md["mv"][pic_list][0]), int(md["mv"][pic_list][1]))
+                        elif r0 >= 0:
                             mvp = (int(md["mv"][0][0]), int(md["mv"][0][1]))
                         elif r1 >= 0:
                             mvp = (int(md["mv"][1][0]), int(md["mv"][1][1]))
@@ -248,17 +276,57 @@ class SerialTME:
                     bits = (orig + diff) & U32
                     cost = (cost - self.get_cost(orig) + self.get_cost(bits)) & U32
                 mvp = amvp[mvp_idx]
-                if cost < best["cost"]:
-                    best = dict(mv=outmv, mvp=mvp, cost=cost, bits=bits, mvCost=mv_cost, ref=ref)
+                if cost < best[pic_list]["cost"]:
+                    best[pic_list] = dict(mv=outmv, mvp=mvp, cost=cost, bits=bits, mvCost=mv_cost, ref=ref_idx)
             if is_mvp:
                 return
+            # the bidirectional candidate (search.cpp:415-511)
+            sel_bits = self.get_blk_bits(part, pu_idx, last_mode)
+            bidir_cost, bidir_bits, bidir_mv = MAX_UINT, 0, None
+            restricted = cu_size == 8 and part != SIZE_2Nx2N            # CUData::isBipredRestriction
+            if (not self.is_p and not restricted and part != SIZE_2Nx2N and best[0]["cost"] != MAX_UINT
+                    and best[1]["cost"] != MAX_UINT):
+                me0, me1 = self.me[best[0]["ref"]], self.me[self.num_l0 + best[1]["ref"]]
+                bidir_mv = [best[0]["mv"], best[1]["mv"]]
+                satd = me0.bipred_satd(x, y, w, h, best[0]["mv"], me1, best[1]["mv"])
+                bidir_bits = best[0]["bits"] + best[1]["bits"] + sel_bits[2] - (sel_bits[0] + sel_bits[1])
+                bidir_cost = (satd + self.get_cost(bidir_bits & U32)) & U32
+                try_zero = best[0]["mv"] != (0, 0) or best[1]["mv"] != (0, 0)
+                if try_zero:
+                    mn, mx = self.set_search_range(cu_x, cu_y, (0, 0), max(self.pic_w, self.pic_h))
+                    mx = (mx[0], mx[1] + 2)
+                    for l in (0, 1):
+                        p = best[l]["mvp"]
+                        try_zero = try_zero and mn[0] * 4 <= p[0] <= mx[0] * 4 and mn[1] * 4 <= p[1] <= mx[1] * 4
+                if try_zero:
+                    satd = me0.bipred_satd(x, y, w, h, (0, 0), me1, (0, 0))
+                    bits0 = (best[0]["bits"] - self.bitcost(best[0]["mv"], best[0]["mvp"]) + self.bitcost((0, 0), best[0]["mvp"])) & U32
+                    bits1 = (best[1]["bits"] - self.bitcost(best[1]["mv"], best[1]["mvp"]) + self.bitcost((0, 0), best[1]["mvp"])) & U32
+                    cost = (satd + self.get_cost(bits0) + self.get_cost(bits1)) & U32
+                    if cost < bidir_cost:
+                        bidir_mv = [(0, 0), (0, 0)]
+                        bidir_cost = cost
+                        bidir_bits = bits0 + bits1 + sel_bits[2] - (sel_bits[0] + sel_bits[1])
             o = entries[pos]
-            o["ref"] = (best["ref"], -1)
-            o["mv"][0] = best["mv"]
-            o["mvp"][0] = best["mvp"]
-            o["mvCost"][0] = best["mvCost"]
-            o["cost"] = best["cost"]
-            o["bits"] = best["bits"]
+            o["ref"] = (-1, -1)
+            if bidir_cost < best[0]["cost"] and bidir_cost < best[1]["cost"]:
+                last_mode = 2
+                for l in (0, 1):
+                    o["mv"][l] = bidir_mv[l]
+                    o["mvp"][l] = best[l]["mvp"]
+                    o["mvCost"][l] = best[l]["mvCost"]
+                    o["ref"][l] = best[l]["ref"]
+                o["bits"] = ((bidir_bits + (1 << 31)) & U32) - (1 << 31)     # int bidirBits: unsigned sums, kept as int
+                o["cost"] = bidir_cost
+            else:
+                l = 0 if best[0]["cost"] <= best[1]["cost"] else 1
+                last_mode = l
+                o["mv"][l] = best[l]["mv"]
+                o["mvp"][l] = best[l]["mvp"]
+                o["mvCost"][l] = best[l]["mvCost"]
+                o["cost"] = best[l]["cost"]
+                o["bits"] = best[l]["bits"]
+                o["ref"][l] = best[l]["ref"]
 
     # ---- Analysis::computeMVForPUs ----
     def compute_mv_for_pus(self, addr, ctu_x, ctu_y, rel_x, rel_y, cu_size):

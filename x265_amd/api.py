@@ -568,7 +568,7 @@ HOST_EXPORTS = (
     "xgh_lookahead_get_decided", "xgh_lookahead_trace", "xgh_lookahead_cost_est", "xgh_lookahead_cost_est_aq",
     "xgh_lookahead_intra_mbs", "xgh_lookahead_slot", "xgh_lookahead_qp_offsets", "xgh_lookahead_inv_qscale",
     "xgh_lookahead_planned_satd", "xgh_lookahead_recalc_row_satds", "xgh_lookahead_decide_calls", "xgh_lookahead_presearch_hits", "xgh_lookahead_precost_hits", "xgh_lookahead_seconds",
-    "xgh_tme_create", "xgh_tme_destroy", "xgh_tme_unsupported", "xgh_tme_estimate_rows", "xgh_tme_counts",
+    "xgh_tme_create", "xgh_tme_destroy", "xgh_tme_unsupported", "xgh_tme_estimate_rows", "xgh_tme_estimate_rows_b", "xgh_tme_counts",
 )
 
 
@@ -679,6 +679,7 @@ def load_host_library():
     H.xgh_tme_unsupported.argtypes = [vp]
     H.xgh_tme_unsupported.restype = C.c_char_p
     H.xgh_tme_estimate_rows.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp]
+    H.xgh_tme_estimate_rows_b.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, vp, vp]
     H.xgh_tme_counts.argtypes = [vp, C.POINTER(i64 * 6)]
     H.xgh_tme_counts.restype = None
     _libs[HOST_LIB_PATH] = H
@@ -924,7 +925,8 @@ ME_DATA = np.dtype([("mv", np.int32, (2, 2)), ("mvp", np.int32, (2, 2)), ("mvCos
 class TmeParam(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "searchMethod", "searchRange", "subpelRefine", "bEnableAMP", "bEnableRectInter", "maxCUSize", "minCUSize",
-        "bframes", "picWidth", "picHeight", "refLagPixels")] + [("pad", C.c_int32), ("lambda_", C.c_double)]
+        "bframes", "picWidth", "picHeight", "refLagPixels")] + [("pad", C.c_int32), ("lambda_", C.c_double),
+                                                                 ("sourceWidth", C.c_int32), ("sourceHeight", C.c_int32)]
 
 
 class TmeRef(C.Structure):
@@ -972,9 +974,12 @@ class ThreadedME:
         t["ref"] = -1
         return t
 
-    def estimate_rows(self, slot_fenc, poc, refs, row_begin, row_end, out, median_mv=None):
-        """refs: [(slot, poc, is_intra_slice, ctuMV table or None, lowres (cuCount, 2) int32 vectors or None)];
-        fills `out` (new_table()) for the CTU rows [row_begin, row_end)."""
+    def estimate_rows(self, slot_fenc, poc, refs, row_begin, row_end, out, median_mv=None, refs_l1=()):
+        """refs: [(slot, poc, is_intra_slice, ctuMV table or None, lowres (cuCount, 2) int32 vectors or None)], the
+        references of list 0; refs_l1: those of list 1 (a B picture).  Fills `out` (new_table()) for the CTU rows
+        [row_begin, row_end)."""
+        num_l0 = len(refs)
+        refs = list(refs) + list(refs_l1)
         arr = (TmeRef * len(refs))()
         keep = []
         for k, (slot, rpoc, intra, table, lowres) in enumerate(refs):
@@ -990,8 +995,8 @@ class ThreadedME:
         if median_mv is not None:
             med = np.ascontiguousarray(median_mv, np.int32)
         assert out.dtype == ME_DATA and out.flags.c_contiguous
-        rc = self.H.xgh_tme_estimate_rows(self.h, slot_fenc, poc, len(refs), arr, row_begin, row_end,
-                                          None if med is None else med.ctypes.data, out.ctypes.data)
+        rc = self.H.xgh_tme_estimate_rows_b(self.h, slot_fenc, poc, num_l0, len(refs) - num_l0, arr, row_begin, row_end,
+                                            None if med is None else med.ctypes.data, out.ctypes.data)
         if rc:
             raise X265GpuError("xgh_tme_estimate_rows failed with status %d" % rc)
         return out

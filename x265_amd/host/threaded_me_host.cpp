@@ -141,8 +141,30 @@ int getPMV(const SliceRefs& s, const Neighbour* nb, int picList, int refIdx, MV 
     return numMvc;
 }
 
-// Search::getBlkBits for a P slice (search.cpp:4894-4940): list-selection bits of list 0
-int listSelBitsP(int partSize) { return partSize == SIZE_2Nx2N || partSize == SIZE_NxN ? 1 : 3; }
+// Search::getBlkBits (search.cpp:4894-4940): list-selection bits of list 0, list 1 and both, which in a B slice
+// depend on the part's index and on what the part before it chose (lastMode)
+void getBlkBits(int partSize, bool bPSlice, int partIdx, int lastMode, uint32_t blockBit[3])
+{
+    if (partSize == SIZE_2Nx2N || partSize == SIZE_NxN)
+    {
+        blockBit[0] = bPSlice ? 1 : 3;
+        blockBit[1] = 3;
+        blockBit[2] = 5;
+        return;
+    }
+    if (bPSlice)
+    {
+        blockBit[0] = 3;
+        blockBit[1] = blockBit[2] = 0;
+        return;
+    }
+    static const uint32_t horizontal[2][3][3] = { { { 0, 0, 3 }, { 0, 0, 0 }, { 0, 0, 0 } },
+                                                  { { 5, 7, 7 }, { 7, 5, 7 }, { 9 - 3, 9 - 3, 9 - 3 } } };
+    static const uint32_t vertical[2][3][3] = { { { 0, 2, 3 }, { 0, 0, 0 }, { 0, 0, 0 } },
+                                                { { 5, 7, 7 }, { 7 - 2, 7 - 2, 9 - 2 }, { 9 - 3, 9 - 3, 9 - 3 } } };
+    const bool horz = partSize == SIZE_2NxN || partSize == SIZE_2NxnU || partSize == SIZE_2NxnD;
+    memcpy(blockBit, (horz ? horizontal : vertical)[partIdx][lastMode], 3 * sizeof(uint32_t));
+}
 
 inline int getTUBits(int idx, int numIdx) { return idx + (idx < numIdx - 1); }   // search.h:252-255
 
@@ -344,7 +366,14 @@ struct RefPass
     int cmpJob, job0, job1;
 };
 
-struct RefOut { MV mv, mvp; uint32_t bits, cost, mvCost; };
+// one reference's search as it comes back, before any bits are counted
+struct RefRaw { MV outmv, meMvp; int satdCost; bool bLowresMVP; MV mvp, mvpLowres, amvp[2]; int mvpIdx; };
+
+// MotionData (source/encoder/search.h:97-117), the fields this path reads
+struct BestME { MV mv, mvp; uint32_t bits, cost, mvCost; int ref; };
+
+// the bidirectional candidate of one PU, waiting for its SATDs
+struct BiReq { size_t item; int r0, r1; bool tryZero; int job, jobZero; };
 
 inline x265gpu_pu_job makeJob(const Item& it, MV mvp, MV mvmin, MV mvmax, int numMvc, const MV* mvc)
 {
@@ -374,18 +403,30 @@ inline x265gpu_pu_job makeJob(const Item& it, MV mvp, MV mvmin, MV mvmax, int nu
 int ThreadedME::estimateRows(int slotFenc, int poc, int numRefs, const TmeRef* refs, int rowBegin, int rowEnd,
                              const int32_t* medianMv, MEData* out)
 {
-    if (m_unsupported || !m_ctx || !refs || !out || numRefs < 1 || numRefs > 16 || rowBegin < 0 || rowEnd > m_numCuInHeight ||
-        rowBegin >= rowEnd)
+    return estimateRowsB(slotFenc, poc, numRefs, 0, refs, rowBegin, rowEnd, medianMv, out);
+}
+
+int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL1, const TmeRef* refs, int rowBegin,
+                              int rowEnd, const int32_t* medianMv, MEData* out)
+{
+    if (m_unsupported || !m_ctx || !refs || !out || numRefsL0 < 1 || numRefsL0 > 16 || numRefsL1 < 0 || numRefsL1 > 16 ||
+        rowBegin < 0 || rowEnd > m_numCuInHeight || rowBegin >= rowEnd)
         return X265GPU_ERR_ARG;
+    // list 0's references, then list 1's: the order puMotionEstimation visits them in (search.cpp:264-267)
+    const int numRefs = numRefsL0 + numRefsL1;
+    const bool isP = numRefsL1 == 0;
+    auto listOf = [&](int r) { return r < numRefsL0 ? 0 : 1; };
+    auto idxOf = [&](int r) { return r < numRefsL0 ? r : r - numRefsL0; };
     SliceRefs slice;
     memset(&slice, 0, sizeof(slice));
     slice.poc = poc;
-    slice.numRefIdx[0] = numRefs;
+    slice.numRefIdx[0] = numRefsL0;
+    slice.numRefIdx[1] = numRefsL1;
     for (int r = 0; r < numRefs; r++)
     {
         if (refs[r].poc == poc)
             return X265GPU_ERR_UNSUPPORTED;          // the current picture as its own reference (screen content)
-        slice.refPOC[0][r] = refs[r].poc;
+        slice.refPOC[listOf(r)][idxOf(r)] = refs[r].poc;
     }
     const int ctu = m_p.maxCUSize;
     const int numCtus = (rowEnd - rowBegin) * m_numCuInWidth, firstCtu = rowBegin * m_numCuInWidth;
@@ -452,7 +493,12 @@ int ThreadedME::estimateRows(int slotFenc, int poc, int numRefs, const TmeRef* r
     // ---- computeMVForPUs, one dependency level at a time over all CTUs ----
     std::vector<Item> items;
     std::vector<RefPass> pass;
-    std::vector<RefOut> refOut;
+    std::vector<RefRaw> raw;
+    std::vector<BestME> bestOf;          // per item: bestME[0], bestME[1] after that part
+    std::vector<int> modeOf;             // per item: lastMode after that part
+    std::vector<BiReq> biReqs;
+    std::vector<x265gpu_bipred_job> biJobs;
+    std::vector<int32_t> biCosts, biAll;
     std::vector<x265gpu_block_job> cmpJobs;
     std::vector<int32_t> cmpCosts;
     for (int level = 0; level < m_numLevels; level++)
@@ -471,9 +517,10 @@ int ThreadedME::estimateRows(int slotFenc, int poc, int numRefs, const TmeRef* r
                                           ctuX + t.cuX, ctuY + t.cuY });
             }
         }
-        refOut.assign(items.size() * numRefs, RefOut());
+        raw.assign(items.size() * numRefs, RefRaw());
         for (int r = 0; r < numRefs; r++)
         {
+            const int list = listOf(r), refIdx = idxOf(r);
             pass.assign(items.size(), RefPass());
             cmpJobs.clear();
             // predictors (search.cpp:269-330)
@@ -505,7 +552,7 @@ int ThreadedME::estimateRows(int slotFenc, int poc, int numRefs, const TmeRef* r
                     }
                 }
                 MV cand[2];
-                ps.numMvc = getPMV(slice, nb, 0, r, cand, ps.mvc);
+                ps.numMvc = getPMV(slice, nb, list, refIdx, cand, ps.mvc);
                 if (ps.numMvc > 0)
                 {
                     ps.amvp[0] = cand[0];
@@ -537,7 +584,7 @@ int ThreadedME::estimateRows(int slotFenc, int poc, int numRefs, const TmeRef* r
                     else if (uniL1)
                         ps.mvp = md.mv[1];
                     else if (bi)
-                        ps.mvp = md.mv[0];
+                        ps.mvp = md.mv[list];
                 }
             }
             if (!cmpJobs.empty())
@@ -597,90 +644,229 @@ int ThreadedME::estimateRows(int slotFenc, int poc, int numRefs, const TmeRef* r
                 return rc;
             m_deviceCalls++;
             m_searches += (int64_t)jobs.size();
-            // bits and cost of this reference's vector (search.cpp:366-398)
+            // what each search left (search.cpp:366-386); bits are counted once every reference is back
+            for (size_t i = 0; i < items.size(); i++)
+            {
+                const RefPass& ps = pass[i];
+                RefRaw& rr = raw[i * numRefs + r];
+                rr.outmv = MV{ results[ps.job0].mvX, results[ps.job0].mvY };
+                rr.satdCost = results[ps.job0].cost;
+                rr.meMvp = ps.mvp;                    // the predictor MotionEstimate holds after its last search
+                rr.bLowresMVP = ps.bLowresMVP;
+                if (ps.job1 >= 0)
+                {
+                    rr.bLowresMVP = false;
+                    rr.meMvp = ps.mvpLowres;
+                    if (results[ps.job1].cost < rr.satdCost)
+                    {
+                        rr.outmv = MV{ results[ps.job1].mvX, results[ps.job1].mvY };
+                        rr.satdCost = results[ps.job1].cost;
+                        rr.bLowresMVP = true;
+                    }
+                }
+                rr.mvp = ps.mvp;
+                rr.mvpLowres = ps.mvpLowres;
+                rr.amvp[0] = ps.amvp[0];
+                rr.amvp[1] = ps.amvp[1];
+                rr.mvpIdx = ps.mvpIdx;
+            }
+        }
+
+        // ---- bits, costs, the best reference of each list, the bidirectional candidate, the table entry
+        //      (search.cpp:269-272, 388-556).  The first parts of all partitions, then the second parts: a second
+        //      part starts from the first part's bestME (declared outside the loop over the parts) and, in a B
+        //      slice, its list-selection bits depend on what the first part chose. ----
+        bestOf.assign(items.size() * 2, BestME());
+        modeOf.assign(items.size(), 0);
+        for (int phase = 0; phase < 2; phase++)
+        {
+            biReqs.clear();
             for (size_t i = 0; i < items.size(); i++)
             {
                 const Item& it = items[i];
+                if (it.puIdx != phase)
+                    continue;
                 const PuTask& t = m_tasks[it.task];
-                RefPass& ps = pass[i];
-                uint32_t bits = (uint32_t)(listSelBitsP(t.partSize) + MVP_IDX_BITS + getTUBits(r, numRefs));
-                MV outmv = { results[ps.job0].mvX, results[ps.job0].mvY };
-                int satdCost = results[ps.job0].cost;
-                MV meMvp = ps.mvp;                    // the predictor MotionEstimate holds after its last search
-                bool bLowresMVP = ps.bLowresMVP;
-                if (ps.job1 >= 0)
+                BestME best[2];
+                int lastMode = 0;
+                if (phase)
                 {
-                    bLowresMVP = false;
-                    meMvp = ps.mvpLowres;
-                    if (results[ps.job1].cost < satdCost)
+                    best[0] = bestOf[(i - 1) * 2];
+                    best[1] = bestOf[(i - 1) * 2 + 1];
+                    lastMode = modeOf[i - 1];
+                }
+                else
+                {
+                    memset(best, 0, sizeof(best));
+                    best[0].cost = best[1].cost = 0xFFFFFFFFu;
+                }
+                uint32_t listSelBits[3];
+                getBlkBits(t.partSize, isP, it.puIdx, lastMode, listSelBits);
+                for (int r = 0; r < numRefs; r++)
+                {
+                    const int list = listOf(r), refIdx = idxOf(r);
+                    const RefRaw& rr = raw[i * numRefs + r];
+                    uint32_t bits = listSelBits[list] + MVP_IDX_BITS + (uint32_t)getTUBits(refIdx, slice.numRefIdx[list]);
+                    bits += bitcost(rr.outmv, rr.meMvp);
+                    const uint32_t mvCost = mvcost(rr.outmv, rr.meMvp);
+                    uint32_t cost = ((uint32_t)rr.satdCost - mvCost) + getCost(bits);
+                    if (rr.bLowresMVP)
                     {
-                        outmv = MV{ results[ps.job1].mvX, results[ps.job1].mvY };
-                        satdCost = results[ps.job1].cost;
-                        bLowresMVP = true;
+                        // Search::updateMVP (search.cpp:4961-4967)
+                        const int diffBits = (int)bitcost(rr.outmv, rr.mvp) - (int)bitcost(rr.outmv, rr.mvpLowres);
+                        const uint32_t origBits = bits;
+                        bits = origBits + diffBits;
+                        cost = (cost - getCost(origBits)) + getCost(bits);
+                    }
+                    // Search::checkBestMVP (search.cpp:4947-4958)
+                    int mvpIdx = rr.mvpIdx;
+                    const int diffBits = (int)bitcost(rr.outmv, rr.amvp[!mvpIdx]) - (int)bitcost(rr.outmv, rr.amvp[mvpIdx]);
+                    if (diffBits < 0)
+                    {
+                        mvpIdx = !mvpIdx;
+                        const uint32_t origBits = bits;
+                        bits = origBits + diffBits;
+                        cost = (cost - getCost(origBits)) + getCost(bits);
+                    }
+                    if (cost < best[list].cost)
+                    {
+                        best[list].mv = rr.outmv;
+                        best[list].mvp = rr.amvp[mvpIdx];
+                        best[list].cost = cost;
+                        best[list].bits = bits;
+                        best[list].mvCost = mvCost;
+                        best[list].ref = refIdx;
                     }
                 }
-                bits += bitcost(outmv, meMvp);
-                const uint32_t mvCost = mvcost(outmv, meMvp);
-                uint32_t cost = ((uint32_t)satdCost - mvCost) + getCost(bits);
-                if (bLowresMVP)
+                bestOf[i * 2] = best[0];
+                bestOf[i * 2 + 1] = best[1];
+                // the bidirectional candidate (search.cpp:421-422): B slice, not an 8x8 CU split in two
+                // (CUData::isBipredRestriction), not 2Nx2N, a winner in both lists
+                if (!isP && !(t.cuSize == 8 && t.partSize != SIZE_2Nx2N) && t.partSize != SIZE_2Nx2N &&
+                    best[0].cost != 0xFFFFFFFFu && best[1].cost != 0xFFFFFFFFu)
                 {
-                    // Search::updateMVP (search.cpp:4961-4967)
-                    const int diffBits = (int)bitcost(outmv, ps.mvp) - (int)bitcost(outmv, ps.mvpLowres);
-                    const uint32_t origBits = bits;
-                    bits = origBits + diffBits;
-                    cost = (cost - getCost(origBits)) + getCost(bits);
+                    BiReq q;
+                    q.item = i;
+                    q.r0 = best[0].ref;
+                    q.r1 = numRefsL0 + best[1].ref;
+                    q.tryZero = notZero(best[0].mv) || notZero(best[1].mv);
+                    if (q.tryZero)
+                    {
+                        // search.cpp:455-466: both predictors inside the picture-wide window around zero
+                        MV mvmin, mvmax;
+                        const int merange = std::max(m_p.sourceWidth ? m_p.sourceWidth : m_p.picWidth,
+                                                     m_p.sourceHeight ? m_p.sourceHeight : m_p.picHeight);
+                        setSearchRange(it.cuPelX, it.cuPelY, MV{ 0, 0 }, merange, mvmin, mvmax);
+                        mvmax.y += 2;
+                        mvmin = MV{ mvmin.x * 4, mvmin.y * 4 };
+                        mvmax = MV{ mvmax.x * 4, mvmax.y * 4 };
+                        for (int l = 0; l < 2; l++)
+                            q.tryZero = q.tryZero && best[l].mvp.x >= mvmin.x && best[l].mvp.x <= mvmax.x &&
+                                        best[l].mvp.y >= mvmin.y && best[l].mvp.y <= mvmax.y;
+                    }
+                    q.job = q.jobZero = -1;
+                    biReqs.push_back(q);
                 }
-                // Search::checkBestMVP (search.cpp:4947-4958)
-                int mvpIdx = ps.mvpIdx;
-                const int diffBits = (int)bitcost(outmv, ps.amvp[!mvpIdx]) - (int)bitcost(outmv, ps.amvp[mvpIdx]);
-                if (diffBits < 0)
-                {
-                    mvpIdx = !mvpIdx;
-                    const uint32_t origBits = bits;
-                    bits = origBits + diffBits;
-                    cost = (cost - getCost(origBits)) + getCost(bits);
-                }
-                RefOut& ro = refOut[i * numRefs + r];
-                ro.mv = outmv;
-                ro.mvp = ps.amvp[mvpIdx];
-                ro.bits = bits;
-                ro.cost = cost;
-                ro.mvCost = mvCost;
             }
-        }
-        // best reference per PU (search.cpp:399-408, 512-545).  bestME is declared outside the loop over the parts
-        // of the partition, so the second part starts from the first part's winner.
-        uint32_t bestCost = 0xFFFFFFFFu;
-        RefOut best = RefOut();
-        int bestRef = 0;
-        for (size_t i = 0; i < items.size(); i++)
-        {
-            const Item& it = items[i];
-            const PuTask& t = m_tasks[it.task];
-            if (it.puIdx == 0)
+            // the SATDs, one device call per pair of reference pictures
+            biAll.assign(biReqs.size() * 2, 0);
+            for (size_t first = 0; first < biReqs.size(); first++)
             {
-                bestCost = 0xFFFFFFFFu;
-                best = RefOut();
-                bestRef = 0;
-            }
-            for (int r = 0; r < numRefs; r++)
-            {
-                const RefOut& ro = refOut[i * numRefs + r];
-                if (ro.cost < bestCost)
+                if (biReqs[first].job >= 0)
+                    continue;
+                const int r0 = biReqs[first].r0, r1 = biReqs[first].r1;
+                biJobs.clear();
+                for (size_t k = first; k < biReqs.size(); k++)
                 {
-                    bestCost = ro.cost;
-                    best = ro;
-                    bestRef = r;
+                    BiReq& q = biReqs[k];
+                    if (q.job >= 0 || q.r0 != r0 || q.r1 != r1)
+                        continue;
+                    const Item& it = items[q.item];
+                    const BestME* best = &bestOf[q.item * 2];
+                    q.job = (int)biJobs.size();
+                    biJobs.push_back(x265gpu_bipred_job{ it.x, it.y, it.w, it.h, best[0].mv.x, best[0].mv.y, best[1].mv.x, best[1].mv.y });
+                    if (q.tryZero)
+                    {
+                        q.jobZero = (int)biJobs.size();
+                        biJobs.push_back(x265gpu_bipred_job{ it.x, it.y, it.w, it.h, 0, 0, 0, 0 });
+                    }
+                }
+                biCosts.resize(biJobs.size());
+                rc = x265gpu_bipred_satd(m_ctx, slotFenc, refs[r0].slot, refs[r1].slot, (int)biJobs.size(), biJobs.data(), biCosts.data());
+                if (rc)
+                    return rc;
+                m_deviceCalls++;
+                for (size_t k = first; k < biReqs.size(); k++)
+                {
+                    const BiReq& q = biReqs[k];
+                    if (q.r0 != r0 || q.r1 != r1)
+                        continue;
+                    biAll[k * 2] = biCosts[q.job];
+                    if (q.jobZero >= 0)
+                        biAll[k * 2 + 1] = biCosts[q.jobZero];
                 }
             }
-            MEData& o = out[(size_t)it.ctuAddr * MAX_NUM_PUS_PER_CTU + t.finalIdx + it.puIdx * t.puOffset];
-            o.mv[0] = best.mv;
-            o.mvp[0] = best.mvp;
-            o.mvCost[0] = best.mvCost;
-            o.cost = bestCost;
-            o.bits = (int32_t)best.bits;
-            o.ref[0] = bestRef;
-            o.ref[1] = REF_NOT_VALID;
+            // the table entries (search.cpp:451-556)
+            size_t nextBi = 0;
+            for (size_t i = 0; i < items.size(); i++)
+            {
+                const Item& it = items[i];
+                if (it.puIdx != phase)
+                    continue;
+                const PuTask& t = m_tasks[it.task];
+                const BestME* best = &bestOf[i * 2];
+                uint32_t listSelBits[3];
+                getBlkBits(t.partSize, isP, it.puIdx, phase ? modeOf[i - 1] : 0, listSelBits);
+                uint32_t bidirCost = 0xFFFFFFFFu;
+                int bidirBits = 0;
+                MV bidirMv[2] = { best[0].mv, best[1].mv };
+                if (nextBi < biReqs.size() && biReqs[nextBi].item == i)
+                {
+                    const BiReq& q = biReqs[nextBi];
+                    bidirBits = (int)(best[0].bits + best[1].bits + listSelBits[2] - (listSelBits[0] + listSelBits[1]));
+                    bidirCost = (uint32_t)biAll[nextBi * 2] + getCost((uint32_t)bidirBits);
+                    if (q.tryZero)
+                    {
+                        const MV zero = { 0, 0 };
+                        const uint32_t bits0 = best[0].bits - bitcost(best[0].mv, best[0].mvp) + bitcost(zero, best[0].mvp);
+                        const uint32_t bits1 = best[1].bits - bitcost(best[1].mv, best[1].mvp) + bitcost(zero, best[1].mvp);
+                        const uint32_t cost = (uint32_t)biAll[nextBi * 2 + 1] + getCost(bits0) + getCost(bits1);
+                        if (cost < bidirCost)
+                        {
+                            bidirMv[0] = bidirMv[1] = zero;
+                            bidirCost = cost;
+                            bidirBits = (int)(bits0 + bits1 + listSelBits[2] - (listSelBits[0] + listSelBits[1]));
+                        }
+                    }
+                    nextBi++;
+                }
+                MEData& o = out[(size_t)it.ctuAddr * MAX_NUM_PUS_PER_CTU + t.finalIdx + it.puIdx * t.puOffset];
+                o.ref[0] = o.ref[1] = REF_NOT_VALID;
+                if (bidirCost < best[0].cost && bidirCost < best[1].cost)
+                {
+                    modeOf[i] = 2;
+                    for (int l = 0; l < 2; l++)
+                    {
+                        o.mv[l] = bidirMv[l];
+                        o.mvp[l] = best[l].mvp;
+                        o.mvCost[l] = best[l].mvCost;
+                        o.ref[l] = best[l].ref;
+                    }
+                    o.bits = bidirBits;
+                    o.cost = bidirCost;
+                }
+                else
+                {
+                    const int l = best[0].cost <= best[1].cost ? 0 : 1;
+                    modeOf[i] = l;
+                    o.mv[l] = best[l].mv;
+                    o.mvp[l] = best[l].mvp;
+                    o.mvCost[l] = best[l].mvCost;
+                    o.cost = best[l].cost;
+                    o.bits = (int32_t)best[l].bits;
+                    o.ref[l] = best[l].ref;
+                }
+            }
         }
     }
     return X265GPU_OK;
@@ -711,6 +897,15 @@ int xgh_tme_estimate_rows(xgh_tme* t, int32_t slotFenc, int32_t poc, int32_t num
     if (!t)
         return X265GPU_ERR_ARG;
     return t->me.estimateRows(slotFenc, poc, numRefs, refs, rowBegin, rowEnd, medianMv, out);
+}
+
+int xgh_tme_estimate_rows_b(xgh_tme* t, int32_t slotFenc, int32_t poc, int32_t numRefsL0, int32_t numRefsL1,
+                            const xgh_tme_ref* refs, int32_t rowBegin, int32_t rowEnd, const int32_t* medianMv,
+                            xgh_me_data* out)
+{
+    if (!t)
+        return X265GPU_ERR_ARG;
+    return t->me.estimateRowsB(slotFenc, poc, numRefsL0, numRefsL1, refs, rowBegin, rowEnd, medianMv, out);
 }
 
 void xgh_tme_counts(const xgh_tme* t, int64_t counts[6])

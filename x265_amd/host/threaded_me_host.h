@@ -11,10 +11,11 @@
 // the predictor logic (CUData::getPMV, Search::setSearchRange, getLowresMV, updateMVP, checkBestMVP and the
 // bit accounting) kept here, as x265 keeps it on the host.  Pixels never come here.
 //
-// Covered: P slices (list 0, any number of references), every shape of g_puLookup
-// (source/encoder/threadedme.h:67-92) under bEnableAMP / bEnableRectInter, one slice QP for the picture
-// (no per-CU delta QP), one slice, no frame-parallel lag window beyond refLagPixels.  B slices need the
-// bidirectional average of search.cpp:415-511 and are reported as unsupported.  The temporal candidate
+// Covered: P and B slices (any number of references per list; in a B slice the bidirectional candidate of
+// search.cpp:415-511 through x265gpu_bipred_satd, and the list-selection bits that depend on what the
+// partition's first part chose), every shape of g_puLookup (source/encoder/threadedme.h:67-92) under
+// bEnableAMP / bEnableRectInter, one slice QP for the picture (no per-CU delta QP), one slice, no
+// frame-parallel lag window beyond refLagPixels.  The temporal candidate
 // (neighbours[MD_COLLOCATED]) and CUData::getMedianColMV read the reference picture's coded CUs, which
 // only the encoder has: the median vector is an optional input, the temporal candidate is taken as
 // unavailable (--no-temporal-mvp).
@@ -64,16 +65,18 @@ struct TmeParam
     int32_t picHeight;           //   padded to a multiple of minCUSize
     int32_t refLagPixels;        // Search::m_refLagPixels (search.cpp:96): sourceHeight without frame threads
     double  lambda;              // x265_lambda_tab[slice QP]: MV cost table and RDCost::getCost
+    int32_t sourceWidth;         // param->sourceWidth / sourceHeight (the zero-vector test of the bidirectional
+    int32_t sourceHeight;        //   candidate, search.cpp:458); 0: picWidth / picHeight
 };
 
-// one entry of slice->m_refPOCList[0] / m_mref[0]
+// one entry of slice->m_refPOCList[list] / m_mref[list]
 struct TmeRef
 {
     int32_t slot;                // device slot holding the reference picture (its full-resolution plane)
     int32_t poc;
     int32_t isIntraSlice;        // the reference picture was coded as an I slice (search.cpp:315)
     const MEData* ctuMV;         // that picture's own result table (all CTUs), or NULL
-    const int32_t* lowresMvs;    // m_frame->m_lowres.lowresMvs[0][|poc - ref poc|] as x,y pairs, or NULL when that
+    const int32_t* lowresMvs;    // m_frame->m_lowres.lowresMvs[list][|poc - ref poc|] as x,y pairs, or NULL when that
                                  //   distance was never searched (the 0x7FFF sentinel of search.cpp:2331)
 };
 
@@ -102,6 +105,10 @@ public:
     // (FrameData::reinit, source/common/framedata.cpp:93-102) and filled.
     int estimateRows(int slotFenc, int poc, int numRefs, const TmeRef* refs, int rowBegin, int rowEnd,
                      const int32_t* medianMv, MEData* out);
+    // The same for a B picture: refs holds list 0's numRefsL0 references, then list 1's numRefsL1 (medianMv in
+    // that order too).  numRefsL1 = 0 is the P form above.
+    int estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL1, const TmeRef* refs, int rowBegin, int rowEnd,
+                      const int32_t* medianMv, MEData* out);
 
     const std::vector<PuTask>& tasks() const { return m_tasks; }
     int numLevels() const { return m_numLevels; }
@@ -146,6 +153,10 @@ void xgh_tme_destroy(xgh_tme* t);
 const char* xgh_tme_unsupported(const xgh_tme* t);
 int xgh_tme_estimate_rows(xgh_tme* t, int32_t slotFenc, int32_t poc, int32_t numRefs, const xgh_tme_ref* refs,
                           int32_t rowBegin, int32_t rowEnd, const int32_t* medianMv, xgh_me_data* out);
+// B picture: refs = list 0's numRefsL0 references, then list 1's numRefsL1
+int xgh_tme_estimate_rows_b(xgh_tme* t, int32_t slotFenc, int32_t poc, int32_t numRefsL0, int32_t numRefsL1,
+                            const xgh_tme_ref* refs, int32_t rowBegin, int32_t rowEnd, const int32_t* medianMv,
+                            xgh_me_data* out);
 // counts: {tasks per CTU, dependency levels, CTUs per row, CTU rows, searches so far, device calls so far}
 void xgh_tme_counts(const xgh_tme* t, int64_t counts[6]);
 }

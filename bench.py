@@ -215,7 +215,9 @@ def recorded_issue_rates():
 def rates_from(d, source):
     k = d["kinds"]
     valu = [k[n]["waves_per_simd_8"]["cycles_per_instruction_per_simd"] for n in ("v_sad_u8", "v_pk_add_i16", "v_min_i32", "v_alignbyte_b32")]
+    fastest = min(v["waves_per_simd_8"]["cycles_per_instruction_per_simd"] for n, v in k.items() if n.startswith("v_"))
     return {"valu_cycles_per_inst_per_simd_8_waves": sum(valu) / len(valu),
+            "valu_cycles_per_inst_per_simd_8_waves_fastest_kind": fastest,
             "valu_cycles_per_inst_per_simd_1_wave": k["v_sad_u8"]["waves_per_simd_1"]["cycles_per_instruction_per_simd"],
             "salu_cycles_per_inst_per_simd_8_waves": k["s_add_u32"]["waves_per_simd_8"]["cycles_per_instruction_per_simd"],
             "clock_GHz": d["clock_GHz_at_8_waves"], "source": source}
@@ -531,8 +533,12 @@ def rank_main(args):
 
     # Vector-issue fraction of every phase whose kernel has a counter pass for this configuration: wave64 VALU
     # instructions per step (counted per dispatch by rocprofv3, times the launches of a step) over the phase time,
-    # against 1024 SIMDs x measured clock / measured cycles per instruction.
-    valu_peak = SIMDS * rates["clock_GHz"] / rates["valu_cycles_per_inst_per_simd_8_waves"] if rates else None
+    # against 1024 SIMDs x measured clock / measured cycles per instruction.  Two measured rates: the fastest kind of
+    # vector instruction (plain 32-bit adds) is the ceiling no kernel can pass and the one fractions are quoted against;
+    # the SAD / packed / DPP kind these kernels are mostly made of issues more slowly, and the fraction against that
+    # rate says how much of the issue slots a kernel of this mix could still use.
+    valu_peak = SIMDS * rates["clock_GHz"] / rates["valu_cycles_per_inst_per_simd_8_waves_fastest_kind"] if rates else None
+    valu_peak_packed = SIMDS * rates["clock_GHz"] / rates["valu_cycles_per_inst_per_simd_8_waves"] if rates else None
     for k, v in kernels.items():
         c = pmc_kernel(args, names[k])
         if not c or not valu_peak or not c.get("dispatches") or "SQ_INSTS_VALU" not in c:
@@ -545,6 +551,7 @@ def rank_main(args):
         insts = c["SQ_INSTS_VALU"] / c["dispatches"] * launches
         v["valu_G_insts_per_s"] = insts / (v["ms_per_step"] * 1e-3) / 1e9
         v["valu_frac"] = v["valu_G_insts_per_s"] / valu_peak
+        v["valu_frac_at_sad_class_rate"] = v["valu_G_insts_per_s"] / valu_peak_packed
         t = pmc_traffic_per_launch(c)
         if t is not None:
             v["pmc_traffic_bytes_per_step"] = t * launches
@@ -564,11 +571,14 @@ def rank_main(args):
         units = n_search * n                                            # block searches per step
         achieved = per_wave * units / (dom["ms_per_step"] * 1e-3) / 1e9
         roofline.update({"bound": "valu", "achieved": achieved, "peak": valu_peak, "unit": "G wave64-instructions/s",
-                         "frac": achieved / valu_peak, "valu_insts_per_block_search": per_wave,
+                         "frac": achieved / valu_peak, "frac_at_sad_class_rate": achieved / valu_peak_packed,
+                         "peak_at_sad_class_rate": valu_peak_packed, "valu_insts_per_block_search": per_wave,
                          "salu_insts_per_block_search": pmc.get("SQ_INSTS_SALU", 0) / pmc["SQ_WAVES"],
                          "block_searches_per_step": units, "hbm": hbm,
                          "note": "vector-issue roofline: measured instructions per 8x8 block search x block searches / phase time, "
-                                 "against 1024 SIMDs x measured clock / measured cycles per wave64 instruction; the rest of a "
+                                 "against 1024 SIMDs x measured clock / measured cycles per wave64 instruction of the fastest kind "
+                                 "(32-bit add); frac_at_sad_class_rate uses the measured rate of v_sad_u8 / v_pk_add_i16 / v_min_i32 / "
+                                 "v_alignbyte_b32, which the search is mostly made of and which issue 1.8x more slowly; the rest of a "
                                  "wave's life is latency (memory round trips, LDS, scalar chain) that eight waves per SIMD do not cover"})
     elif dominant == "search":
         roofline["note"] = ("no counter pass committed for this configuration (profiles/pmc_%s.json): the vector-issue "

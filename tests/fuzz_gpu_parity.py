@@ -97,13 +97,16 @@ def one_round(cfg):
 
 
 def draw_pu(rng):
-    return dict(depth=int(rng.choice([8, 10, 12])), method=int(rng.choice([orc.DIA, orc.HEX, orc.UMH, orc.STAR, orc.FULL])),
+    return dict(depth=int(rng.choice([8, 10, 12])), method=int(rng.choice([orc.DIA, orc.HEX, orc.UMH, orc.STAR, orc.FULL, orc.SEA])),
                 merange=int(rng.choice([4, 8, 16, 24, 57])), subpel=int(rng.integers(0, 8)),
                 size=(int(rng.integers(20, 70)) * 8 + int(rng.integers(0, 4)) * 2, int(rng.integers(12, 40)) * 8 + int(rng.integers(0, 4)) * 2),
                 lam=float(rng.choice([0, 0, 2.5, 9.5, 40.0])), seed=int(rng.integers(1, 1 << 30)))
 
 
 def pu_round(cfg):
+    if cfg["method"] == orc.SEA:
+        TP.test_pu_successive_elimination(cfg["depth"], cfg["merange"], cfg["subpel"], cfg["seed"] % 100000)
+        return
     merange = min(cfg["merange"], 6) if cfg["method"] == orc.FULL else cfg["merange"]
     TP._run(cfg["depth"], cfg["method"], merange, cfg["subpel"], 24, cfg["seed"], size=cfg["size"], lam=cfg["lam"] or None)
 
@@ -141,11 +144,11 @@ def mcstf_round(cfg):
 
 def draw_aq(rng):
     return dict(depth=int(rng.choice([8, 10, 12])), W=int(rng.integers(16, 140)) * 4 + int(rng.integers(0, 2)) * 2,
-                H=int(rng.integers(16, 90)) * 4 + int(rng.integers(0, 2)) * 2, mode=int(rng.integers(0, 4)),
+                H=int(rng.integers(16, 90)) * 4 + int(rng.integers(0, 2)) * 2, mode=int(rng.integers(0, 5)),
                 strength=float(rng.choice([0.0, 0.4, 1.0, 1.7])), qg=int(rng.choice([8, 16, 32, 64])),
                 weightp=bool(rng.integers(0, 2)), hdr=bool(rng.integers(0, 2)), qo=bool(rng.integers(0, 2)),
                 var=bool(rng.integers(0, 2)), hevc=bool(rng.integers(0, 3) == 0), skip=bool(rng.integers(0, 8) == 0),
-                kind=str(rng.choice(["noise", "mixed", "flat"])), seed=int(rng.integers(1, 1 << 30)))
+                kind=str(rng.choice(["noise", "mixed", "flat", "edges"])), seed=int(rng.integers(1, 1 << 30)))
 
 
 def aq_round(cfg):
@@ -154,7 +157,10 @@ def aq_round(cfg):
     rng = np.random.default_rng(cfg["seed"])
     dt = np.uint8 if depth == 8 else np.uint16
     top = (1 << depth) - 1
-    if cfg["kind"] == "flat":
+    if cfg["kind"] == "edges":
+        import test_gpu_aq as TA
+        y = TA._edgy_picture(W, H, depth, cfg["seed"] % 1000)[0]
+    elif cfg["kind"] == "flat":
         y = np.full((H, W), int(rng.integers(0, top + 1)), dt)
         y[H // 2:, W // 3:] = int(rng.integers(0, top + 1))
     else:
@@ -168,7 +174,7 @@ def aq_round(cfg):
     qg8 = cfg["qg"] == 8
     nblocks = 4 * w8 * h8 if qg8 else w8 * h8
     qo = rng.normal(0, 1.5, nblocks).astype(np.float32) if cfg["qo"] else None
-    hevc = cfg["hevc"] and cfg["mode"] != 0 and cfg["strength"] != 0 and not cfg["skip"]
+    hevc = cfg["hevc"] and cfg["mode"] not in (0, 4) and cfg["strength"] != 0 and not cfg["skip"]
     kw = dict(weightp=cfg["weightp"], hdr10=cfg["hdr"], skip_offsets=cfg["skip"], quant_offsets=qo, qg_size=cfg["qg"],
               block_variance=cfg["var"])
     with api.Context(W, H, depth=depth, num_slots=1) as ctx:
@@ -210,18 +216,24 @@ def main():
     rng = np.random.default_rng(a.seed)
     drawer, runner = {"lookahead": (draw, one_round), "pu": (draw_pu, pu_round), "mcstf": (draw_mcstf, mcstf_round),
                       "aq": (draw_aq, aq_round)}[a.what]
-    t0, rounds = time.time(), 0
+    t0, rounds, refused = time.time(), 0, 0
     while time.time() - t0 < a.seconds:
         cfg = drawer(rng)
         try:
             runner(cfg)
+        except api.X265GpuError as e:
+            if "x265gpu_open failed with status -5" not in str(e):
+                print("FAILED in round %d: %r" % (rounds, cfg), flush=True)
+                raise
+            refused += 1            # a size the library declines (lowres grid of the padded picture one block larger)
+            continue
         except Exception:
             print("MISMATCH in round %d: %r" % (rounds, cfg), flush=True)
             raise
         rounds += 1
         if rounds % 10 == 0:
             print("%d rounds ok, %.0f s" % (rounds, time.time() - t0), flush=True)
-    print("fuzz ok: %d rounds in %.0f s" % (rounds, time.time() - t0), flush=True)
+    print("fuzz ok: %d rounds in %.0f s (%d draws with a refused size)" % (rounds, time.time() - t0, refused), flush=True)
 
 
 if __name__ == "__main__":

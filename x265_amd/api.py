@@ -568,7 +568,7 @@ HOST_EXPORTS = (
     "xgh_lookahead_get_decided", "xgh_lookahead_trace", "xgh_lookahead_cost_est", "xgh_lookahead_cost_est_aq",
     "xgh_lookahead_intra_mbs", "xgh_lookahead_slot", "xgh_lookahead_qp_offsets", "xgh_lookahead_inv_qscale",
     "xgh_lookahead_planned_satd", "xgh_lookahead_recalc_row_satds", "xgh_lookahead_decide_calls", "xgh_lookahead_presearch_hits", "xgh_lookahead_precost_hits", "xgh_lookahead_seconds",
-    "xgh_tme_create", "xgh_tme_destroy", "xgh_tme_unsupported", "xgh_tme_estimate_rows", "xgh_tme_estimate_rows_b", "xgh_tme_counts",
+    "xgh_tme_create", "xgh_tme_destroy", "xgh_tme_unsupported", "xgh_tme_estimate_rows", "xgh_tme_estimate_rows_b", "xgh_tme_seconds", "xgh_tme_counts",
 )
 
 
@@ -679,6 +679,7 @@ def load_host_library():
     H.xgh_tme_unsupported.argtypes = [vp]
     H.xgh_tme_unsupported.restype = C.c_char_p
     H.xgh_tme_estimate_rows.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp]
+    H.xgh_tme_seconds.argtypes = [vp, vp]
     H.xgh_tme_estimate_rows_b.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, vp, vp]
     H.xgh_tme_counts.argtypes = [vp, C.POINTER(i64 * 6)]
     H.xgh_tme_counts.restype = None
@@ -967,6 +968,12 @@ class ThreadedME:
         c = (C.c_int64 * 6)()
         self.H.xgh_tme_counts(self.h, C.byref(c))
         return dict(zip(("tasks", "levels", "cols", "rows", "searches", "device_calls"), list(c)))
+
+    def seconds(self):
+        """wall-clock seconds so far: host logic, inside device calls, whole estimate_rows calls"""
+        s = (C.c_double * 3)()
+        self.H.xgh_tme_seconds(self.h, C.byref(s))
+        return dict(zip(("host", "device", "total"), list(s)))
 
     def new_table(self):
         c = self.counts()

@@ -6,7 +6,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 
 namespace x265gpu_host {
 
@@ -172,8 +178,9 @@ inline int getTUBits(int idx, int numIdx) { return idx + (idx < numIdx - 1); }  
 
 ThreadedME::ThreadedME(x265gpu_ctx* ctx, const TmeParam& p)
     : m_ctx(ctx), m_p(p), m_unsupported(NULL), m_numCuInWidth(0), m_numCuInHeight(0), m_numLevels(0), m_lambdaFix8(0),
-      m_searches(0), m_deviceCalls(0)
+      m_searches(0), m_deviceCalls(0), m_jobs(NULL), m_results(NULL), m_jobCap(0), m_pool(NULL)
 {
+    m_seconds[0] = m_seconds[1] = m_seconds[2] = 0;
     const int ctu = p.maxCUSize, mn = p.minCUSize;
     if ((ctu != 16 && ctu != 32 && ctu != 64) || (mn != 8 && mn != 16 && mn != 32 && mn != 64) || mn > ctu)
         m_unsupported = "maxCUSize must be 16, 32 or 64 and minCUSize 8..maxCUSize";
@@ -345,7 +352,107 @@ void ThreadedME::setSearchRange(int cuPelX, int cuPelY, MV mvp, int merange, MV&
     mvmax.y = std::max(mvmax.y, mvmin.y);
 }
 
+// Host threads for the per-PU predictor and bookkeeping loops: the PUs of a level are independent, x265 itself
+// spreads this work over its ThreadedME workers.  run(n, fn) calls fn(begin, end) over [0, n) in chunks.
+class ThreadedME::Pool
+{
+public:
+    explicit Pool(int threads)
+    {
+        for (int i = 1; i < threads; i++)
+            m_threads.emplace_back([this]() { loop(); });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> lock(m_mutex);
+            m_stop = true;
+            m_generation++;
+        }
+        m_wake.notify_all();
+        for (std::thread& t : m_threads)
+            t.join();
+    }
+    void run(size_t n, const std::function<void(size_t, size_t)>& fn)
+    {
+        const size_t grain = 2048;
+        if (m_threads.empty() || n <= grain)
+        {
+            if (n)
+                fn(0, n);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lock(m_mutex);
+            m_fn = &fn;
+            m_n = n;
+            m_grain = grain;
+            m_next.store(0);
+            m_busy = (int)m_threads.size();
+            m_generation++;
+        }
+        m_wake.notify_all();
+        work();
+        std::unique_lock<std::mutex> lock(m_mutex);
+        m_done.wait(lock, [this]() { return m_busy == 0; });
+        m_fn = nullptr;
+    }
+
+private:
+    void work()
+    {
+        for (size_t b = m_next.fetch_add(m_grain); b < m_n; b = m_next.fetch_add(m_grain))
+            (*m_fn)(b, std::min(m_n, b + m_grain));
+    }
+    void loop()
+    {
+        unsigned long long seen = 0;
+        for (;;)
+        {
+            {
+                std::unique_lock<std::mutex> lock(m_mutex);
+                m_wake.wait(lock, [&]() { return m_generation != seen; });
+                seen = m_generation;
+                if (m_stop)
+                    return;
+            }
+            work();
+            {
+                std::lock_guard<std::mutex> lock(m_mutex);
+                m_busy--;
+            }
+            m_done.notify_one();
+        }
+    }
+    std::vector<std::thread> m_threads;
+    std::mutex m_mutex;
+    std::condition_variable m_wake, m_done;
+    unsigned long long m_generation = 0;
+    bool m_stop = false;
+    const std::function<void(size_t, size_t)>* m_fn = nullptr;
+    size_t m_n = 0, m_grain = 1;
+    std::atomic<size_t> m_next{ 0 };
+    int m_busy = 0;
+};
+
+ThreadedME::~ThreadedME()
+{
+    delete m_pool;
+    if (m_jobs)
+        x265gpu_host_free(m_ctx, m_jobs);
+    if (m_results)
+        x265gpu_host_free(m_ctx, m_results);
+}
+
 namespace {
+
+struct Stopwatch
+{
+    double& acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit Stopwatch(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~Stopwatch() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 // one puIdx of one puMotionEstimation call of one CTU
 struct Item
@@ -364,6 +471,8 @@ struct RefPass
     MV mvc[14];
     bool bLowresMVP;
     int cmpJob, job0, job1;
+    MV cmpMv[2];                 // the two AMVP candidates as selectMVP measures them
+    MV mvmin[2], mvmax[2];       // windows of the search from the predictor and of the one from the lookahead's vector
 };
 
 // one reference's search as it comes back, before any bits are counted
@@ -412,6 +521,7 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
     if (m_unsupported || !m_ctx || !refs || !out || numRefsL0 < 1 || numRefsL0 > 16 || numRefsL1 < 0 || numRefsL1 > 16 ||
         rowBegin < 0 || rowEnd > m_numCuInHeight || rowBegin >= rowEnd)
         return X265GPU_ERR_ARG;
+    Stopwatch whole(m_seconds[2]);
     // list 0's references, then list 1's: the order puMotionEstimation visits them in (search.cpp:264-267)
     const int numRefs = numRefsL0 + numRefsL1;
     const bool isP = numRefsL1 == 0;
@@ -448,11 +558,29 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
     //      its four quadrants from the zero vector, per reference; their full-pel results become predictors ----
     const int numAreas = ctu != m_p.minCUSize ? 5 : 1;
     std::vector<MV> areaBest((size_t)numCtus * 5 * numRefs, MV{ 0, 0 });
-    std::vector<x265gpu_pu_job> jobs;
-    std::vector<x265gpu_pu_result> results;
+    // job and result arrays in page-locked memory, kept between calls and only ever grown
+    auto ensureJobs = [&](size_t n) -> int {
+        if (n <= m_jobCap)
+            return X265GPU_OK;
+        if (m_jobs)
+            x265gpu_host_free(m_ctx, m_jobs);
+        if (m_results)
+            x265gpu_host_free(m_ctx, m_results);
+        m_jobs = NULL;
+        m_results = NULL;
+        m_jobCap = 0;
+        const size_t cap = n + n / 4;
+        int e = x265gpu_host_alloc(m_ctx, cap * sizeof(x265gpu_pu_job), (void**)&m_jobs);
+        if (e == X265GPU_OK)
+            e = x265gpu_host_alloc(m_ctx, cap * sizeof(x265gpu_pu_result), (void**)&m_results);
+        if (e == X265GPU_OK)
+            m_jobCap = cap;
+        return e;
+    };
     for (int r = 0; r < numRefs; r++)
     {
-        jobs.clear();
+        std::vector<x265gpu_pu_job> jobs;
+        std::vector<x265gpu_pu_result> results;
         for (int c = 0; c < numCtus; c++)
         {
             const int addr = firstCtu + c, ctuX = (addr % m_numCuInWidth) * ctu, ctuY = (addr / m_numCuInWidth) * ctu;
@@ -468,8 +596,11 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
             }
         }
         results.resize(jobs.size());
-        rc = x265gpu_pu_motion_estimate(m_ctx, slotFenc, refs[r].slot, X265GPU_AREA_DIAMOND_SEARCH, AREA_SEARCH_RANGE, 0,
-                                        (int)jobs.size(), jobs.data(), results.data());
+        {
+            Stopwatch sw(m_seconds[1]);
+            rc = x265gpu_pu_motion_estimate(m_ctx, slotFenc, refs[r].slot, X265GPU_AREA_DIAMOND_SEARCH, AREA_SEARCH_RANGE, 0,
+                                            (int)jobs.size(), jobs.data(), results.data());
+        }
         if (rc)
             return rc;
         m_deviceCalls++;
@@ -491,11 +622,23 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
     }
 
     // ---- computeMVForPUs, one dependency level at a time over all CTUs ----
+    if (!m_pool)
+    {
+        const char* env = getenv("X265GPU_HOST_THREADS");
+        const unsigned hw = std::thread::hardware_concurrency();
+        int threads = env ? atoi(env) : (int)(hw ? (hw < 16 ? hw : 16) : 4);
+        m_pool = new Pool(threads < 1 ? 1 : threads);
+    }
+    std::vector<std::vector<int> > tasksOfLevel(m_numLevels);
+    for (size_t ti = 0; ti < m_tasks.size(); ti++)
+        tasksOfLevel[m_tasks[ti].level].push_back((int)ti);
     std::vector<Item> items;
     std::vector<RefPass> pass;
     std::vector<RefRaw> raw;
     std::vector<BestME> bestOf;          // per item: bestME[0], bestME[1] after that part
     std::vector<int> modeOf;             // per item: lastMode after that part
+    std::vector<int> biOf;               // per item: its entry in biReqs, or -1
+    std::vector<unsigned char> biWant;   // per item: 0 no bidirectional candidate, 1 candidate, 2 with the zero-vector form
     std::vector<BiReq> biReqs;
     std::vector<x265gpu_bipred_job> biJobs;
     std::vector<int32_t> biCosts, biAll;
@@ -503,271 +646,330 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
     std::vector<int32_t> cmpCosts;
     for (int level = 0; level < m_numLevels; level++)
     {
-        items.clear();
-        for (int c = 0; c < numCtus; c++)
-        {
-            const int addr = firstCtu + c, ctuX = (addr % m_numCuInWidth) * ctu, ctuY = (addr / m_numCuInWidth) * ctu;
-            for (size_t ti = 0; ti < m_tasks.size(); ti++)
+        // the level's parts of one CTU, in call order; every CTU of the rows has the same
+        std::vector<std::pair<int, int> > parts;
+        for (int ti : tasksOfLevel[level])
+            for (int k = 0; k < m_tasks[ti].numPart; k++)
+                parts.push_back(std::make_pair(ti, k));
+        const size_t perCtu = parts.size(), numItems = perCtu * numCtus;
+        if (items.size() < numItems)
+            items.resize(numItems);
+        m_pool->run(numItems, [&](size_t begin, size_t end) {
+            for (size_t i = begin; i < end; i++)
             {
+                const int c = (int)(i / perCtu), ti = parts[i % perCtu].first, k = parts[i % perCtu].second;
+                const int addr = firstCtu + c, ctuX = (addr % m_numCuInWidth) * ctu, ctuY = (addr / m_numCuInWidth) * ctu;
                 const PuTask& t = m_tasks[ti];
-                if (t.level != level)
-                    continue;
-                for (int k = 0; k < t.numPart; k++)
-                    items.push_back(Item{ addr, c, (int)ti, k, ctuX + t.pu[k].x, ctuY + t.pu[k].y, t.pu[k].w, t.pu[k].h,
-                                          ctuX + t.cuX, ctuY + t.cuY });
+                items[i] = Item{ addr, c, ti, k, ctuX + t.pu[k].x, ctuY + t.pu[k].y, t.pu[k].w, t.pu[k].h, ctuX + t.cuX, ctuY + t.cuY };
             }
-        }
-        raw.assign(items.size() * numRefs, RefRaw());
+        });
+        if (raw.size() < numItems * numRefs)
+            raw.resize(numItems * numRefs);
+        if (pass.size() < numItems)
+            pass.resize(numItems);
         for (int r = 0; r < numRefs; r++)
         {
             const int list = listOf(r), refIdx = idxOf(r);
-            pass.assign(items.size(), RefPass());
-            cmpJobs.clear();
             // predictors (search.cpp:269-330)
-            for (size_t i = 0; i < items.size(); i++)
-            {
-                const Item& it = items[i];
-                const PuTask& t = m_tasks[it.task];
-                RefPass& ps = pass[i];
-                ps.mvp = areaBest[((size_t)it.ctuLocal * 5 + t.areaId) * numRefs + r];
-                ps.amvp[0] = ps.amvp[1] = MV{ 0, 0 };
-                ps.mvpIdx = 0;
-                ps.cmpJob = ps.job0 = ps.job1 = -1;
-                Neighbour nb[MD_ABOVE_LEFT + 1];
-                for (int dir = MD_LEFT; dir <= MD_ABOVE_LEFT; dir++)
+            m_pool->run(numItems, [&](size_t begin, size_t end) {
+                for (size_t i = begin; i < end; i++)
                 {
-                    if (t.nb[dir] >= 0)
+                    const Item& it = items[i];
+                    const PuTask& t = m_tasks[it.task];
+                    RefPass& ps = pass[i];
+                    ps.mvp = areaBest[((size_t)it.ctuLocal * 5 + t.areaId) * numRefs + r];
+                    ps.amvp[0] = ps.amvp[1] = MV{ 0, 0 };
+                    ps.mvpIdx = 0;
+                    ps.cmpJob = ps.job0 = ps.job1 = -1;
+                    Neighbour nb[MD_ABOVE_LEFT + 1];
+                    for (int dir = MD_LEFT; dir <= MD_ABOVE_LEFT; dir++)
                     {
-                        const MEData& nd = out[(size_t)it.ctuAddr * MAX_NUM_PUS_PER_CTU + t.nb[dir]];
-                        for (int l = 0; l < 2; l++)
+                        if (t.nb[dir] >= 0)
                         {
-                            nb[dir].mv[l] = nd.mv[l];
-                            nb[dir].refIdx[l] = nd.ref[l];
+                            const MEData& nd = out[(size_t)it.ctuAddr * MAX_NUM_PUS_PER_CTU + t.nb[dir]];
+                            for (int l = 0; l < 2; l++)
+                            {
+                                nb[dir].mv[l] = nd.mv[l];
+                                nb[dir].refIdx[l] = nd.ref[l];
+                            }
+                        }
+                        else
+                        {
+                            nb[dir].mv[0] = nb[dir].mv[1] = MV{ 0, 0 };
+                            nb[dir].refIdx[0] = nb[dir].refIdx[1] = -1;
                         }
                     }
-                    else
+                    MV cand[2];
+                    ps.numMvc = getPMV(slice, nb, list, refIdx, cand, ps.mvc);
+                    if (ps.numMvc > 0)
                     {
-                        nb[dir].mv[0] = nb[dir].mv[1] = MV{ 0, 0 };
-                        nb[dir].refIdx[0] = nb[dir].refIdx[1] = -1;
-                    }
-                }
-                MV cand[2];
-                ps.numMvc = getPMV(slice, nb, list, refIdx, cand, ps.mvc);
-                if (ps.numMvc > 0)
-                {
-                    ps.amvp[0] = cand[0];
-                    ps.amvp[1] = cand[1];
-                    if (cand[0] != cand[1])
-                    {
-                        // Search::selectMVP (search.cpp:2347-2383): SAD of the prediction at each clipped candidate
-                        ps.cmpJob = (int)cmpJobs.size();
-                        for (int k = 0; k < 2; k++)
+                        ps.amvp[0] = cand[0];
+                        ps.amvp[1] = cand[1];
+                        if (cand[0] != cand[1])
                         {
-                            MV mvCand = cand[k];
-                            clipMv(it.cuPelX, it.cuPelY, mvCand);
-                            x265gpu_block_job bj = { it.x, it.y, it.w, it.h, mvCand.x, mvCand.y, X265GPU_OP_SAD, 0 };
-                            cmpJobs.push_back(bj);
+                            // Search::selectMVP (search.cpp:2347-2383): SAD of the prediction at each clipped candidate
+                            ps.cmpJob = 0;                    // numbered below
+                            for (int k = 0; k < 2; k++)
+                            {
+                                ps.cmpMv[k] = cand[k];
+                                clipMv(it.cuPelX, it.cuPelY, ps.cmpMv[k]);
+                            }
                         }
+                        else
+                            ps.mvp = cand[0];
                     }
-                    else
-                        ps.mvp = cand[0];
+                    else if (!refs[r].isIntraSlice && refs[r].ctuMV)
+                    {
+                        const int pos = t.finalIdx + it.puIdx * t.puOffset;
+                        const MEData& md = refs[r].ctuMV[(size_t)it.ctuAddr * MAX_NUM_PUS_PER_CTU + pos];
+                        const bool bi = md.ref[0] >= 0 && md.ref[1] >= 0;
+                        const bool uniL0 = md.ref[0] >= 0 && md.ref[1] == REF_NOT_VALID;
+                        const bool uniL1 = md.ref[1] >= 0 && md.ref[0] == REF_NOT_VALID;
+                        if (uniL0)
+                            ps.mvp = md.mv[0];
+                        else if (uniL1)
+                            ps.mvp = md.mv[1];
+                        else if (bi)
+                            ps.mvp = md.mv[list];
+                    }
                 }
-                else if (!refs[r].isIntraSlice && refs[r].ctuMV)
+            });
+            int numCmp = 0;
+            for (size_t i = 0; i < numItems; i++)
+                if (pass[i].cmpJob == 0)
                 {
-                    const int pos = t.finalIdx + it.puIdx * t.puOffset;
-                    const MEData& md = refs[r].ctuMV[(size_t)it.ctuAddr * MAX_NUM_PUS_PER_CTU + pos];
-                    const bool bi = md.ref[0] >= 0 && md.ref[1] >= 0;
-                    const bool uniL0 = md.ref[0] >= 0 && md.ref[1] == REF_NOT_VALID;
-                    const bool uniL1 = md.ref[1] >= 0 && md.ref[0] == REF_NOT_VALID;
-                    if (uniL0)
-                        ps.mvp = md.mv[0];
-                    else if (uniL1)
-                        ps.mvp = md.mv[1];
-                    else if (bi)
-                        ps.mvp = md.mv[list];
+                    pass[i].cmpJob = numCmp;
+                    numCmp += 2;
                 }
-            }
-            if (!cmpJobs.empty())
+            if (numCmp)
             {
-                cmpCosts.resize(cmpJobs.size());
-                rc = x265gpu_block_compare(m_ctx, slotFenc, refs[r].slot, (int)cmpJobs.size(), cmpJobs.data(), cmpCosts.data());
+                if (cmpJobs.size() < (size_t)numCmp)
+                {
+                    cmpJobs.resize(numCmp);
+                    cmpCosts.resize(numCmp);
+                }
+                m_pool->run(numItems, [&](size_t begin, size_t end) {
+                    for (size_t i = begin; i < end; i++)
+                        if (pass[i].cmpJob >= 0)
+                            for (int k = 0; k < 2; k++)
+                                cmpJobs[pass[i].cmpJob + k] = x265gpu_block_job{ items[i].x, items[i].y, items[i].w, items[i].h,
+                                                                                 pass[i].cmpMv[k].x, pass[i].cmpMv[k].y, X265GPU_OP_SAD, 0 };
+                });
+                Stopwatch sw(m_seconds[1]);
+                rc = x265gpu_block_compare(m_ctx, slotFenc, refs[r].slot, numCmp, cmpJobs.data(), cmpCosts.data());
                 if (rc)
                     return rc;
                 m_deviceCalls++;
             }
             // lookahead candidate, search windows, search jobs (search.cpp:332-386)
-            jobs.clear();
             const int diffPoc = abs(poc - refs[r].poc);
             const int32_t* lowresMvs = diffPoc > m_p.bframes + 1 ? NULL : refs[r].lowresMvs;
-            for (size_t i = 0; i < items.size(); i++)
+            m_pool->run(numItems, [&](size_t begin, size_t end) {
+                for (size_t i = begin; i < end; i++)
+                {
+                    const Item& it = items[i];
+                    RefPass& ps = pass[i];
+                    if (ps.cmpJob >= 0)
+                    {
+                        ps.mvpIdx = (uint32_t)cmpCosts[ps.cmpJob] <= (uint32_t)cmpCosts[ps.cmpJob + 1] ? 0 : 1;
+                        ps.mvp = ps.amvp[ps.mvpIdx];
+                    }
+                    ps.bLowresMVP = false;
+                    ps.mvpLowres = MV{ 0, 0 };
+                    const int blockX = it.x + (it.w >> 1), blockY = it.y + (it.h >> 1);
+                    if (blockX < m_p.picWidth && blockY < m_p.picHeight)
+                    {
+                        MV lmv = { 0, 0 };
+                        if (lowresMvs)       // Search::getLowresMV (search.cpp:2323-2343)
+                        {
+                            const size_t idx = (size_t)(blockY >> 4) * lowresBlocksInRow + (blockX >> 4);
+                            lmv = MV{ lowresMvs[2 * idx] * 2, lowresMvs[2 * idx + 1] * 2 };
+                        }
+                        if (notZero(lmv))
+                        {
+                            ps.mvc[ps.numMvc++] = lmv;
+                            ps.bLowresMVP = true;
+                        }
+                        ps.mvpLowres = lmv;
+                    }
+                    setSearchRange(it.cuPelX, it.cuPelY, ps.mvp, m_p.searchRange, ps.mvmin[0], ps.mvmax[0]);
+                    ps.job0 = 0;
+                    ps.job1 = -1;
+                    if (ps.bLowresMVP && notZero(ps.mvpLowres) && ps.mvpLowres != ps.mvp)
+                    {
+                        setSearchRange(it.cuPelX, it.cuPelY, ps.mvpLowres, m_p.searchRange, ps.mvmin[1], ps.mvmax[1]);
+                        ps.job1 = 0;
+                    }
+                }
+            });
+            int numJobs = 0;
+            for (size_t i = 0; i < numItems; i++)
             {
-                const Item& it = items[i];
-                RefPass& ps = pass[i];
-                if (ps.cmpJob >= 0)
-                {
-                    ps.mvpIdx = (uint32_t)cmpCosts[ps.cmpJob] <= (uint32_t)cmpCosts[ps.cmpJob + 1] ? 0 : 1;
-                    ps.mvp = ps.amvp[ps.mvpIdx];
-                }
-                ps.bLowresMVP = false;
-                ps.mvpLowres = MV{ 0, 0 };
-                const int blockX = it.x + (it.w >> 1), blockY = it.y + (it.h >> 1);
-                if (blockX < m_p.picWidth && blockY < m_p.picHeight)
-                {
-                    MV lmv = { 0, 0 };
-                    if (lowresMvs)       // Search::getLowresMV (search.cpp:2323-2343)
-                    {
-                        const size_t idx = (size_t)(blockY >> 4) * lowresBlocksInRow + (blockX >> 4);
-                        lmv = MV{ lowresMvs[2 * idx] * 2, lowresMvs[2 * idx + 1] * 2 };
-                    }
-                    if (notZero(lmv))
-                    {
-                        ps.mvc[ps.numMvc++] = lmv;
-                        ps.bLowresMVP = true;
-                    }
-                    ps.mvpLowres = lmv;
-                }
-                MV mvmin, mvmax;
-                setSearchRange(it.cuPelX, it.cuPelY, ps.mvp, m_p.searchRange, mvmin, mvmax);
-                ps.job0 = (int)jobs.size();
-                jobs.push_back(makeJob(it, ps.mvp, mvmin, mvmax, ps.numMvc, ps.mvc));
-                if (ps.bLowresMVP && notZero(ps.mvpLowres) && ps.mvpLowres != ps.mvp)
-                {
-                    setSearchRange(it.cuPelX, it.cuPelY, ps.mvpLowres, m_p.searchRange, mvmin, mvmax);
-                    ps.job1 = (int)jobs.size();
-                    jobs.push_back(makeJob(it, ps.mvpLowres, mvmin, mvmax, ps.numMvc, ps.mvc));
-                }
+                pass[i].job0 = numJobs++;
+                if (pass[i].job1 == 0)
+                    pass[i].job1 = numJobs++;
             }
-            results.resize(jobs.size());
-            rc = x265gpu_pu_motion_estimate(m_ctx, slotFenc, refs[r].slot, m_p.searchMethod, m_p.searchRange, m_p.subpelRefine,
-                                            (int)jobs.size(), jobs.data(), results.data());
+            rc = ensureJobs((size_t)numJobs);
+            if (rc)
+                return rc;
+            x265gpu_pu_job* jobs = m_jobs;
+            const x265gpu_pu_result* results = m_results;
+            m_pool->run(numItems, [&](size_t begin, size_t end) {
+                for (size_t i = begin; i < end; i++)
+                {
+                    const RefPass& ps = pass[i];
+                    jobs[ps.job0] = makeJob(items[i], ps.mvp, ps.mvmin[0], ps.mvmax[0], ps.numMvc, ps.mvc);
+                    if (ps.job1 >= 0)
+                        jobs[ps.job1] = makeJob(items[i], ps.mvpLowres, ps.mvmin[1], ps.mvmax[1], ps.numMvc, ps.mvc);
+                }
+            });
+            {
+                Stopwatch sw(m_seconds[1]);
+                rc = x265gpu_pu_motion_estimate(m_ctx, slotFenc, refs[r].slot, m_p.searchMethod, m_p.searchRange, m_p.subpelRefine,
+                                                numJobs, m_jobs, m_results);
+            }
             if (rc)
                 return rc;
             m_deviceCalls++;
-            m_searches += (int64_t)jobs.size();
+            m_searches += (int64_t)numJobs;
             // what each search left (search.cpp:366-386); bits are counted once every reference is back
-            for (size_t i = 0; i < items.size(); i++)
-            {
-                const RefPass& ps = pass[i];
-                RefRaw& rr = raw[i * numRefs + r];
-                rr.outmv = MV{ results[ps.job0].mvX, results[ps.job0].mvY };
-                rr.satdCost = results[ps.job0].cost;
-                rr.meMvp = ps.mvp;                    // the predictor MotionEstimate holds after its last search
-                rr.bLowresMVP = ps.bLowresMVP;
-                if (ps.job1 >= 0)
+            m_pool->run(numItems, [&](size_t begin, size_t end) {
+                for (size_t i = begin; i < end; i++)
                 {
-                    rr.bLowresMVP = false;
-                    rr.meMvp = ps.mvpLowres;
-                    if (results[ps.job1].cost < rr.satdCost)
+                    const RefPass& ps = pass[i];
+                    RefRaw& rr = raw[i * numRefs + r];
+                    rr.outmv = MV{ results[ps.job0].mvX, results[ps.job0].mvY };
+                    rr.satdCost = results[ps.job0].cost;
+                    rr.meMvp = ps.mvp;                    // the predictor MotionEstimate holds after its last search
+                    rr.bLowresMVP = ps.bLowresMVP;
+                    if (ps.job1 >= 0)
                     {
-                        rr.outmv = MV{ results[ps.job1].mvX, results[ps.job1].mvY };
-                        rr.satdCost = results[ps.job1].cost;
-                        rr.bLowresMVP = true;
+                        rr.bLowresMVP = false;
+                        rr.meMvp = ps.mvpLowres;
+                        if (results[ps.job1].cost < rr.satdCost)
+                        {
+                            rr.outmv = MV{ results[ps.job1].mvX, results[ps.job1].mvY };
+                            rr.satdCost = results[ps.job1].cost;
+                            rr.bLowresMVP = true;
+                        }
                     }
+                    rr.mvp = ps.mvp;
+                    rr.mvpLowres = ps.mvpLowres;
+                    rr.amvp[0] = ps.amvp[0];
+                    rr.amvp[1] = ps.amvp[1];
+                    rr.mvpIdx = ps.mvpIdx;
                 }
-                rr.mvp = ps.mvp;
-                rr.mvpLowres = ps.mvpLowres;
-                rr.amvp[0] = ps.amvp[0];
-                rr.amvp[1] = ps.amvp[1];
-                rr.mvpIdx = ps.mvpIdx;
-            }
+            });
         }
 
         // ---- bits, costs, the best reference of each list, the bidirectional candidate, the table entry
         //      (search.cpp:269-272, 388-556).  The first parts of all partitions, then the second parts: a second
         //      part starts from the first part's bestME (declared outside the loop over the parts) and, in a B
         //      slice, its list-selection bits depend on what the first part chose. ----
-        bestOf.assign(items.size() * 2, BestME());
-        modeOf.assign(items.size(), 0);
+        if (bestOf.size() < numItems * 2)
+            bestOf.resize(numItems * 2);
+        modeOf.assign(numItems, 0);
+        biOf.assign(numItems, -1);
+        biWant.assign(numItems, 0);
+        const int zeroRange = std::max(m_p.sourceWidth ? m_p.sourceWidth : m_p.picWidth,
+                                       m_p.sourceHeight ? m_p.sourceHeight : m_p.picHeight);
         for (int phase = 0; phase < 2; phase++)
         {
+            m_pool->run(numItems, [&](size_t begin, size_t end) {
+                for (size_t i = begin; i < end; i++)
+                {
+                    const Item& it = items[i];
+                    if (it.puIdx != phase)
+                        continue;
+                    const PuTask& t = m_tasks[it.task];
+                    BestME best[2];
+                    int lastMode = 0;
+                    if (phase)
+                    {
+                        best[0] = bestOf[(i - 1) * 2];
+                        best[1] = bestOf[(i - 1) * 2 + 1];
+                        lastMode = modeOf[i - 1];
+                    }
+                    else
+                    {
+                        memset(best, 0, sizeof(best));
+                        best[0].cost = best[1].cost = 0xFFFFFFFFu;
+                    }
+                    uint32_t listSelBits[3];
+                    getBlkBits(t.partSize, isP, it.puIdx, lastMode, listSelBits);
+                    for (int r = 0; r < numRefs; r++)
+                    {
+                        const int list = listOf(r), refIdx = idxOf(r);
+                        const RefRaw& rr = raw[i * numRefs + r];
+                        uint32_t bits = listSelBits[list] + MVP_IDX_BITS + (uint32_t)getTUBits(refIdx, slice.numRefIdx[list]);
+                        bits += bitcost(rr.outmv, rr.meMvp);
+                        const uint32_t mvCost = mvcost(rr.outmv, rr.meMvp);
+                        uint32_t cost = ((uint32_t)rr.satdCost - mvCost) + getCost(bits);
+                        if (rr.bLowresMVP)
+                        {
+                            // Search::updateMVP (search.cpp:4961-4967)
+                            const int diffBits = (int)bitcost(rr.outmv, rr.mvp) - (int)bitcost(rr.outmv, rr.mvpLowres);
+                            const uint32_t origBits = bits;
+                            bits = origBits + diffBits;
+                            cost = (cost - getCost(origBits)) + getCost(bits);
+                        }
+                        // Search::checkBestMVP (search.cpp:4947-4958)
+                        int mvpIdx = rr.mvpIdx;
+                        const int diffBits = (int)bitcost(rr.outmv, rr.amvp[!mvpIdx]) - (int)bitcost(rr.outmv, rr.amvp[mvpIdx]);
+                        if (diffBits < 0)
+                        {
+                            mvpIdx = !mvpIdx;
+                            const uint32_t origBits = bits;
+                            bits = origBits + diffBits;
+                            cost = (cost - getCost(origBits)) + getCost(bits);
+                        }
+                        if (cost < best[list].cost)
+                        {
+                            best[list].mv = rr.outmv;
+                            best[list].mvp = rr.amvp[mvpIdx];
+                            best[list].cost = cost;
+                            best[list].bits = bits;
+                            best[list].mvCost = mvCost;
+                            best[list].ref = refIdx;
+                        }
+                    }
+                    bestOf[i * 2] = best[0];
+                    bestOf[i * 2 + 1] = best[1];
+                    // the bidirectional candidate (search.cpp:421-422): B slice, not an 8x8 CU split in two
+                    // (CUData::isBipredRestriction), not 2Nx2N, a winner in both lists
+                    if (!isP && !(t.cuSize == 8 && t.partSize != SIZE_2Nx2N) && t.partSize != SIZE_2Nx2N &&
+                        best[0].cost != 0xFFFFFFFFu && best[1].cost != 0xFFFFFFFFu)
+                    {
+                        bool tryZero = notZero(best[0].mv) || notZero(best[1].mv);
+                        if (tryZero)
+                        {
+                            // search.cpp:455-466: both predictors inside the picture-wide window around zero
+                            MV mvmin, mvmax;
+                            setSearchRange(it.cuPelX, it.cuPelY, MV{ 0, 0 }, zeroRange, mvmin, mvmax);
+                            mvmax.y += 2;
+                            mvmin = MV{ mvmin.x * 4, mvmin.y * 4 };
+                            mvmax = MV{ mvmax.x * 4, mvmax.y * 4 };
+                            for (int l = 0; l < 2; l++)
+                                tryZero = tryZero && best[l].mvp.x >= mvmin.x && best[l].mvp.x <= mvmax.x &&
+                                          best[l].mvp.y >= mvmin.y && best[l].mvp.y <= mvmax.y;
+                        }
+                        biWant[i] = tryZero ? 2 : 1;
+                    }
+                }
+            });
             biReqs.clear();
-            for (size_t i = 0; i < items.size(); i++)
-            {
-                const Item& it = items[i];
-                if (it.puIdx != phase)
-                    continue;
-                const PuTask& t = m_tasks[it.task];
-                BestME best[2];
-                int lastMode = 0;
-                if (phase)
-                {
-                    best[0] = bestOf[(i - 1) * 2];
-                    best[1] = bestOf[(i - 1) * 2 + 1];
-                    lastMode = modeOf[i - 1];
-                }
-                else
-                {
-                    memset(best, 0, sizeof(best));
-                    best[0].cost = best[1].cost = 0xFFFFFFFFu;
-                }
-                uint32_t listSelBits[3];
-                getBlkBits(t.partSize, isP, it.puIdx, lastMode, listSelBits);
-                for (int r = 0; r < numRefs; r++)
-                {
-                    const int list = listOf(r), refIdx = idxOf(r);
-                    const RefRaw& rr = raw[i * numRefs + r];
-                    uint32_t bits = listSelBits[list] + MVP_IDX_BITS + (uint32_t)getTUBits(refIdx, slice.numRefIdx[list]);
-                    bits += bitcost(rr.outmv, rr.meMvp);
-                    const uint32_t mvCost = mvcost(rr.outmv, rr.meMvp);
-                    uint32_t cost = ((uint32_t)rr.satdCost - mvCost) + getCost(bits);
-                    if (rr.bLowresMVP)
-                    {
-                        // Search::updateMVP (search.cpp:4961-4967)
-                        const int diffBits = (int)bitcost(rr.outmv, rr.mvp) - (int)bitcost(rr.outmv, rr.mvpLowres);
-                        const uint32_t origBits = bits;
-                        bits = origBits + diffBits;
-                        cost = (cost - getCost(origBits)) + getCost(bits);
-                    }
-                    // Search::checkBestMVP (search.cpp:4947-4958)
-                    int mvpIdx = rr.mvpIdx;
-                    const int diffBits = (int)bitcost(rr.outmv, rr.amvp[!mvpIdx]) - (int)bitcost(rr.outmv, rr.amvp[mvpIdx]);
-                    if (diffBits < 0)
-                    {
-                        mvpIdx = !mvpIdx;
-                        const uint32_t origBits = bits;
-                        bits = origBits + diffBits;
-                        cost = (cost - getCost(origBits)) + getCost(bits);
-                    }
-                    if (cost < best[list].cost)
-                    {
-                        best[list].mv = rr.outmv;
-                        best[list].mvp = rr.amvp[mvpIdx];
-                        best[list].cost = cost;
-                        best[list].bits = bits;
-                        best[list].mvCost = mvCost;
-                        best[list].ref = refIdx;
-                    }
-                }
-                bestOf[i * 2] = best[0];
-                bestOf[i * 2 + 1] = best[1];
-                // the bidirectional candidate (search.cpp:421-422): B slice, not an 8x8 CU split in two
-                // (CUData::isBipredRestriction), not 2Nx2N, a winner in both lists
-                if (!isP && !(t.cuSize == 8 && t.partSize != SIZE_2Nx2N) && t.partSize != SIZE_2Nx2N &&
-                    best[0].cost != 0xFFFFFFFFu && best[1].cost != 0xFFFFFFFFu)
+            for (size_t i = 0; i < numItems; i++)
+                if (items[i].puIdx == phase && biWant[i])
                 {
                     BiReq q;
                     q.item = i;
-                    q.r0 = best[0].ref;
-                    q.r1 = numRefsL0 + best[1].ref;
-                    q.tryZero = notZero(best[0].mv) || notZero(best[1].mv);
-                    if (q.tryZero)
-                    {
-                        // search.cpp:455-466: both predictors inside the picture-wide window around zero
-                        MV mvmin, mvmax;
-                        const int merange = std::max(m_p.sourceWidth ? m_p.sourceWidth : m_p.picWidth,
-                                                     m_p.sourceHeight ? m_p.sourceHeight : m_p.picHeight);
-                        setSearchRange(it.cuPelX, it.cuPelY, MV{ 0, 0 }, merange, mvmin, mvmax);
-                        mvmax.y += 2;
-                        mvmin = MV{ mvmin.x * 4, mvmin.y * 4 };
-                        mvmax = MV{ mvmax.x * 4, mvmax.y * 4 };
-                        for (int l = 0; l < 2; l++)
-                            q.tryZero = q.tryZero && best[l].mvp.x >= mvmin.x && best[l].mvp.x <= mvmax.x &&
-                                        best[l].mvp.y >= mvmin.y && best[l].mvp.y <= mvmax.y;
-                    }
+                    q.r0 = bestOf[i * 2].ref;
+                    q.r1 = numRefsL0 + bestOf[i * 2 + 1].ref;
+                    q.tryZero = biWant[i] == 2;
                     q.job = q.jobZero = -1;
+                    biOf[i] = (int)biReqs.size();
                     biReqs.push_back(q);
                 }
-            }
             // the SATDs, one device call per pair of reference pictures
             biAll.assign(biReqs.size() * 2, 0);
             for (size_t first = 0; first < biReqs.size(); first++)
@@ -792,7 +994,10 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
                     }
                 }
                 biCosts.resize(biJobs.size());
-                rc = x265gpu_bipred_satd(m_ctx, slotFenc, refs[r0].slot, refs[r1].slot, (int)biJobs.size(), biJobs.data(), biCosts.data());
+                {
+                    Stopwatch sw(m_seconds[1]);
+                    rc = x265gpu_bipred_satd(m_ctx, slotFenc, refs[r0].slot, refs[r1].slot, (int)biJobs.size(), biJobs.data(), biCosts.data());
+                }
                 if (rc)
                     return rc;
                 m_deviceCalls++;
@@ -807,66 +1012,66 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
                 }
             }
             // the table entries (search.cpp:451-556)
-            size_t nextBi = 0;
-            for (size_t i = 0; i < items.size(); i++)
-            {
-                const Item& it = items[i];
-                if (it.puIdx != phase)
-                    continue;
-                const PuTask& t = m_tasks[it.task];
-                const BestME* best = &bestOf[i * 2];
-                uint32_t listSelBits[3];
-                getBlkBits(t.partSize, isP, it.puIdx, phase ? modeOf[i - 1] : 0, listSelBits);
-                uint32_t bidirCost = 0xFFFFFFFFu;
-                int bidirBits = 0;
-                MV bidirMv[2] = { best[0].mv, best[1].mv };
-                if (nextBi < biReqs.size() && biReqs[nextBi].item == i)
+            m_pool->run(numItems, [&](size_t begin, size_t end) {
+                for (size_t i = begin; i < end; i++)
                 {
-                    const BiReq& q = biReqs[nextBi];
-                    bidirBits = (int)(best[0].bits + best[1].bits + listSelBits[2] - (listSelBits[0] + listSelBits[1]));
-                    bidirCost = (uint32_t)biAll[nextBi * 2] + getCost((uint32_t)bidirBits);
-                    if (q.tryZero)
+                    const Item& it = items[i];
+                    if (it.puIdx != phase)
+                        continue;
+                    const PuTask& t = m_tasks[it.task];
+                    const BestME* best = &bestOf[i * 2];
+                    uint32_t listSelBits[3];
+                    getBlkBits(t.partSize, isP, it.puIdx, phase ? modeOf[i - 1] : 0, listSelBits);
+                    uint32_t bidirCost = 0xFFFFFFFFu;
+                    int bidirBits = 0;
+                    MV bidirMv[2] = { best[0].mv, best[1].mv };
+                    if (biOf[i] >= 0)
                     {
-                        const MV zero = { 0, 0 };
-                        const uint32_t bits0 = best[0].bits - bitcost(best[0].mv, best[0].mvp) + bitcost(zero, best[0].mvp);
-                        const uint32_t bits1 = best[1].bits - bitcost(best[1].mv, best[1].mvp) + bitcost(zero, best[1].mvp);
-                        const uint32_t cost = (uint32_t)biAll[nextBi * 2 + 1] + getCost(bits0) + getCost(bits1);
-                        if (cost < bidirCost)
+                        const size_t k = (size_t)biOf[i];
+                        bidirBits = (int)(best[0].bits + best[1].bits + listSelBits[2] - (listSelBits[0] + listSelBits[1]));
+                        bidirCost = (uint32_t)biAll[k * 2] + getCost((uint32_t)bidirBits);
+                        if (biReqs[k].tryZero)
                         {
-                            bidirMv[0] = bidirMv[1] = zero;
-                            bidirCost = cost;
-                            bidirBits = (int)(bits0 + bits1 + listSelBits[2] - (listSelBits[0] + listSelBits[1]));
+                            const MV zero = { 0, 0 };
+                            const uint32_t bits0 = best[0].bits - bitcost(best[0].mv, best[0].mvp) + bitcost(zero, best[0].mvp);
+                            const uint32_t bits1 = best[1].bits - bitcost(best[1].mv, best[1].mvp) + bitcost(zero, best[1].mvp);
+                            const uint32_t cost = (uint32_t)biAll[k * 2 + 1] + getCost(bits0) + getCost(bits1);
+                            if (cost < bidirCost)
+                            {
+                                bidirMv[0] = bidirMv[1] = zero;
+                                bidirCost = cost;
+                                bidirBits = (int)(bits0 + bits1 + listSelBits[2] - (listSelBits[0] + listSelBits[1]));
+                            }
                         }
                     }
-                    nextBi++;
-                }
-                MEData& o = out[(size_t)it.ctuAddr * MAX_NUM_PUS_PER_CTU + t.finalIdx + it.puIdx * t.puOffset];
-                o.ref[0] = o.ref[1] = REF_NOT_VALID;
-                if (bidirCost < best[0].cost && bidirCost < best[1].cost)
-                {
-                    modeOf[i] = 2;
-                    for (int l = 0; l < 2; l++)
+                    MEData& o = out[(size_t)it.ctuAddr * MAX_NUM_PUS_PER_CTU + t.finalIdx + it.puIdx * t.puOffset];
+                    o.ref[0] = o.ref[1] = REF_NOT_VALID;
+                    if (bidirCost < best[0].cost && bidirCost < best[1].cost)
                     {
-                        o.mv[l] = bidirMv[l];
+                        modeOf[i] = 2;
+                        for (int l = 0; l < 2; l++)
+                        {
+                            o.mv[l] = bidirMv[l];
+                            o.mvp[l] = best[l].mvp;
+                            o.mvCost[l] = best[l].mvCost;
+                            o.ref[l] = best[l].ref;
+                        }
+                        o.bits = bidirBits;
+                        o.cost = bidirCost;
+                    }
+                    else
+                    {
+                        const int l = best[0].cost <= best[1].cost ? 0 : 1;
+                        modeOf[i] = l;
+                        o.mv[l] = best[l].mv;
                         o.mvp[l] = best[l].mvp;
                         o.mvCost[l] = best[l].mvCost;
+                        o.cost = best[l].cost;
+                        o.bits = (int32_t)best[l].bits;
                         o.ref[l] = best[l].ref;
                     }
-                    o.bits = bidirBits;
-                    o.cost = bidirCost;
                 }
-                else
-                {
-                    const int l = best[0].cost <= best[1].cost ? 0 : 1;
-                    modeOf[i] = l;
-                    o.mv[l] = best[l].mv;
-                    o.mvp[l] = best[l].mvp;
-                    o.mvCost[l] = best[l].mvCost;
-                    o.cost = best[l].cost;
-                    o.bits = (int32_t)best[l].bits;
-                    o.ref[l] = best[l].ref;
-                }
-            }
+            });
         }
     }
     return X265GPU_OK;
@@ -906,6 +1111,14 @@ int xgh_tme_estimate_rows_b(xgh_tme* t, int32_t slotFenc, int32_t poc, int32_t n
     if (!t)
         return X265GPU_ERR_ARG;
     return t->me.estimateRowsB(slotFenc, poc, numRefsL0, numRefsL1, refs, rowBegin, rowEnd, medianMv, out);
+}
+
+void xgh_tme_seconds(const xgh_tme* t, double seconds[3])
+{
+    const double* s = t->me.seconds();
+    seconds[0] = s[2] - s[1];
+    seconds[1] = s[1];
+    seconds[2] = s[2];
 }
 
 void xgh_tme_counts(const xgh_tme* t, int64_t counts[6])

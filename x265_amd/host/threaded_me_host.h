@@ -95,6 +95,9 @@ class ThreadedME
 {
 public:
     ThreadedME(x265gpu_ctx* ctx, const TmeParam& p);
+    ~ThreadedME();
+    ThreadedME(const ThreadedME&) = delete;
+    ThreadedME& operator=(const ThreadedME&) = delete;
 
     // Why this configuration cannot be run, or NULL
     const char* unsupported() const { return m_unsupported; }
@@ -116,6 +119,8 @@ public:
     int numCuInHeight() const { return m_numCuInHeight; }
     int64_t searches() const { return m_searches; }        // PU searches issued so far (area searches included)
     int64_t deviceCalls() const { return m_deviceCalls; }
+    // wall-clock seconds so far: [1] inside device calls (upload + kernels + download), [2] inside estimateRows
+    const double* seconds() const { return m_seconds; }
 
 private:
     void buildTasks();
@@ -137,6 +142,12 @@ private:
     std::vector<uint16_t> m_costTable;              // BitCost::m_cost, centred
     uint64_t m_lambdaFix8;                          // RDCost::m_lambda
     int64_t m_searches, m_deviceCalls;
+    double m_seconds[3];
+    class Pool;
+    x265gpu_pu_job* m_jobs;                         // page-locked job / result arrays of the level batches
+    x265gpu_pu_result* m_results;
+    size_t m_jobCap;
+    Pool* m_pool;                                   // host threads for the per-PU loops (X265GPU_HOST_THREADS, default up to 16)
 };
 
 }  // namespace x265gpu_host
@@ -157,6 +168,8 @@ int xgh_tme_estimate_rows(xgh_tme* t, int32_t slotFenc, int32_t poc, int32_t num
 int xgh_tme_estimate_rows_b(xgh_tme* t, int32_t slotFenc, int32_t poc, int32_t numRefsL0, int32_t numRefsL1,
                             const xgh_tme_ref* refs, int32_t rowBegin, int32_t rowEnd, const int32_t* medianMv,
                             xgh_me_data* out);
+// seconds so far: {host logic, inside device calls (upload + kernels + download), whole estimateRows calls}
+void xgh_tme_seconds(const xgh_tme* t, double seconds[3]);
 // counts: {tasks per CTU, dependency levels, CTUs per row, CTU rows, searches so far, device calls so far}
 void xgh_tme_counts(const xgh_tme* t, int64_t counts[6]);
 }

@@ -24,7 +24,7 @@ namespace xg {
 // blockX < visitWidth and blockY < visitHeight (normally the picture size; the variance tail of
 // calcAdaptiveQuantFrame walks a picture rounded to 16, :674-675, :692-694); results are stored in loop order.
 template <typename P, int B>
-__global__ void __launch_bounds__(256) aq_energy_kernel(AqJob job)
+__device__ __forceinline__ void aq_energy_block_rows(const AqJob& job)
 {
     constexpr int PER_WAVE = 64 / B, HALF = B / 2;
     const int lane = threadIdx.x & 63, k = lane & (B - 1);
@@ -119,6 +119,36 @@ __global__ void __launch_bounds__(256) aq_energy_kernel(AqJob job)
     }
 }
 
+template <typename P, int B>
+__global__ void __launch_bounds__(256) aq_energy_kernel(AqJob job)
+{
+    aq_energy_block_rows<P, B>(job);
+}
+
+// the pictures of a batch in one launch: blockIdx.z = picture
+template <typename P, int B>
+__global__ void __launch_bounds__(256) aq_energy_batch_kernel(const AqJob* jobs)
+{
+    const AqJob job = jobs[blockIdx.z];
+    aq_energy_block_rows<P, B>(job);
+}
+
+// dst[i][k] = src[i][k], k < count: the scale factors of a batch of pictures from one staging buffer to their slots
+__global__ void __launch_bounds__(256) scatter_i32_kernel(const int32_t* const* src, int32_t* const* dst, int count)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < count)
+        dst[blockIdx.y][k] = src[blockIdx.y][k];
+}
+
+hipError_t launch_scatter_i32(hipStream_t s, const int32_t* const* dSrc, int32_t* const* dDst, int count, int n)
+{
+    if (n <= 0 || count <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(scatter_i32_kernel, dim3((count + 255) / 256, n), dim3(256), 0, s, dSrc, dDst, count);
+    return hipGetLastError();
+}
+
 // Quadrant statistics of LookaheadTLD::xPreanalyze (source/encoder/slicetype.cpp:359-398): the picture is cut
 // into parts of partW x partH luma samples (clipped at the right / bottom edge), each part into four quadrants
 // at half its clipped width and height, and every quadrant gets its sum and sum of squares.  One wave per part;
@@ -179,6 +209,20 @@ hipError_t launch_aq_quadrants(hipStream_t s, int bpp, const void* luma, long lo
     else
         hipLaunchKernelGGL(aq_quadrant_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)luma, stride, width, height,
                            partW, partH, partsX, parts, out);
+    return hipGetLastError();
+}
+
+// n pictures of one size with 16x16 blocks, jobs on the device
+hipError_t launch_aq_energy_batch(hipStream_t s, int bpp, const AqJob* dJobs, int n, int visitWidth, int visitHeight)
+{
+    const int blocksX = (visitWidth + 15) / 16, blocksY = (visitHeight + 15) / 16;
+    if (blocksX < 1 || blocksY < 1 || n < 1)
+        return hipSuccess;
+    dim3 grid((blocksX + 15) / 16, blocksY, n);
+    if (bpp == 1)
+        hipLaunchKernelGGL((aq_energy_batch_kernel<uint8_t, 16>), grid, dim3(256), 0, s, dJobs);
+    else
+        hipLaunchKernelGGL((aq_energy_batch_kernel<uint16_t, 16>), grid, dim3(256), 0, s, dJobs);
     return hipGetLastError();
 }
 

@@ -184,7 +184,7 @@ hipError_t launch_cost(hipStream_t s, const Geometry& g, int bpp, const CostJob*
 // of min(SATD(ref, fenc), intraCost).  The uint32 total wraps like the
 // reference's accumulator; one atomic per workgroup.
 template <typename P>
-__global__ void __launch_bounds__(256) weight_cost_kernel(WeightCostJob job, Geometry g)
+__device__ __forceinline__ void weight_cost_rows(const WeightCostJob& job, const Geometry& g)
 {
     __shared__ unsigned int red[4];
     const int cuY = blockIdx.x;
@@ -210,6 +210,48 @@ __global__ void __launch_bounds__(256) weight_cost_kernel(WeightCostJob job, Geo
     __syncthreads();
     if (threadIdx.x == 0)
         atomicAdd(job.out, red[0] + red[1] + red[2] + red[3]);
+}
+
+template <typename P>
+__global__ void __launch_bounds__(256) weight_cost_kernel(WeightCostJob job, Geometry g)
+{
+    weight_cost_rows<P>(job, g);
+}
+
+// every pair of a batch in one launch: blockIdx.y = pair
+template <typename P>
+__global__ void __launch_bounds__(256) weight_cost_batch_kernel(const WeightCostJob* jobs, Geometry g)
+{
+    const WeightCostJob job = jobs[blockIdx.y];
+    weight_cost_rows<P>(job, g);
+}
+
+hipError_t launch_weight_cost_batch(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJobs, int n)
+{
+    if (n <= 0)
+        return hipSuccess;
+    dim3 grid(g.H, n);
+    if (bpp == 1)
+        hipLaunchKernelGGL(weight_cost_batch_kernel<uint8_t>, grid, dim3(256), 0, s, dJobs, g);
+    else
+        hipLaunchKernelGGL(weight_cost_batch_kernel<uint16_t>, grid, dim3(256), 0, s, dJobs, g);
+    return hipGetLastError();
+}
+
+// dst[3 * i + k] = src[i][k]: the three frame totals of n (slot, d0, d1) entries in one pass
+__global__ void __launch_bounds__(256) gather_totals_kernel(const long long* const* src, long long* dst, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 3 * n)
+        dst[i] = src[i / 3][i % 3];
+}
+
+hipError_t launch_gather_totals(hipStream_t s, const long long* const* dSrc, long long* dDst, int n)
+{
+    if (n <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(gather_totals_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, s, dSrc, dDst, n);
+    return hipGetLastError();
 }
 
 hipError_t launch_weight_cost(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* job)

@@ -88,6 +88,8 @@ struct WeightCostJob
 };
 
 // launchers (defined in the .hip files); bytesPerPixel is 1 or 2
+hipError_t launch_gather_totals(hipStream_t s, const long long* const* dSrc, long long* dDst, int n);
+hipError_t launch_weight_cost_batch(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJobs, int n);
 hipError_t launch_lowres_init(hipStream_t s, const Geometry& g, int bpp, const LowresJob* dJobs, int n);
 hipError_t launch_intra(hipStream_t s, const Geometry& g, int bpp, int depth, int lambda, const IntraJob* dJobs, int n);
 // Side streams the search may spread independent jobs over so that the drain of
@@ -180,6 +182,8 @@ struct AqJob
 constexpr int AQ_WP_SHARDS = 64, AQ_WP_SHARD_STRIDE = 16;    // one 128-byte line per shard
 constexpr size_t AQ_WP_BYTES = (size_t)AQ_WP_SHARDS * AQ_WP_SHARD_STRIDE * sizeof(unsigned long long);
 hipError_t launch_aq_energy(hipStream_t s, int bpp, const AqJob& job);
+hipError_t launch_aq_energy_batch(hipStream_t s, int bpp, const AqJob* dJobs, int n, int visitWidth, int visitHeight);
+hipError_t launch_scatter_i32(hipStream_t s, const int32_t* const* dSrc, int32_t* const* dDst, int count, int n);
 // xPreanalyze's quadrant sums: out holds 8 values per part (4 sums, 4 sums of squares), parts in raster order
 hipError_t launch_aq_quadrants(hipStream_t s, int bpp, const void* luma, long long stride, int width, int height, int partW,
                                int partH, unsigned long long* out);

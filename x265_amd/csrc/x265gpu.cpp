@@ -123,12 +123,16 @@ struct x265gpu_ctx
     {
         std::vector<x265gpu_aq_picture> pics;
         x265gpu_aq_params params;
-        char* host = nullptr;          // page-locked copy of the energy arrays
+        char* host = nullptr;          // page-locked copy of the energy arrays (the context's aqHost / aqDev)
         char* dev = nullptr;
+        size_t perPic = 0, ptrsAt = 0; // layout of those arrays: bytes per picture, where the scatter's pointers go
         std::vector<std::thread> workers;
         std::atomic<int>* next = nullptr;
     };
     std::vector<AqPending*> aqPending;
+    char* aqDev = nullptr;              // the batched AQ pass's device arrays and their page-locked mirror, kept between
+    char* aqHost = nullptr;             //   calls and grown when a larger batch comes
+    size_t aqBufBytes = 0;
     std::vector<int32_t> intraDeferred;    // slots whose intra estimate waits for those batches' scale factors
     int flowGridPad = 1;
     uint32_t* flowChunks[2] = { nullptr, nullptr };   // chunk tables of the half-res and the quarter-res block grid
@@ -652,6 +656,8 @@ void x265gpu_close(x265gpu_ctx* ctx)
     if (ctx->puBuf) (void)hipFree(ctx->puBuf);
     if (ctx->mcstfBuf) (void)hipFree(ctx->mcstfBuf);
     if (ctx->seaBuf) (void)hipFree(ctx->seaBuf);
+    if (ctx->aqDev) (void)hipFree(ctx->aqDev);
+    if (ctx->aqHost) (void)hipHostFree(ctx->aqHost);
     if (ctx->intraStream) (void)hipStreamSynchronize(ctx->intraStream);
     if (ctx->intraJobBuf) (void)hipFree(ctx->intraJobBuf);
     if (ctx->intraJobHost) (void)hipHostFree(ctx->intraJobHost);
@@ -1259,18 +1265,20 @@ int x265gpu_weight_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_weight_job* 
     int rc = ensure_src_stage(ctx, planeBytes * (weightedJobs > 0 ? weightedJobs : 1));
     if (rc)
         return rc;
-    rc = ensure_pu_buf(ctx, align256(sizeof(unsigned int) * (size_t)n));
+    const size_t accBytes = align256(sizeof(unsigned int) * (size_t)n);
+    rc = ensure_pu_buf(ctx, accBytes + sizeof(WeightCostJob) * (size_t)n);
     if (rc)
         return rc;
     unsigned int* acc = (unsigned int*)ctx->puBuf;
     HIPCHK(hipMemsetAsync(acc, 0, sizeof(unsigned int) * (size_t)n, ctx->stream));
+    std::vector<WeightCostJob> batch((size_t)n);
     int w = 0;
     for (int i = 0; i < n; i++)
     {
         const x265gpu_weight_job& j = jobs[i];
         Slot& sf = ctx->slots[j.slotFenc];
         Slot& sr = ctx->slots[j.slotRef];
-        WeightCostJob job;
+        WeightCostJob& job = batch[i];
         job.fencPlane0 = plane_origin(ctx, sf.planes);
         job.refPlane0 = plane_origin(ctx, sr.planes);
         job.intraCost = sf.intraCost;
@@ -1284,8 +1292,11 @@ int x265gpu_weight_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_weight_job* 
                                         j.log2Denom + corr, j.offset * (1 << (depth - 8))));
             job.refPlane0 = plane_origin(ctx, stage);
         }
-        HIPCHK(launch_weight_cost(ctx->stream, g, ctx->bpp, &job));
     }
+    // one launch for every pair (the weighted copies above are in place by then: same stream)
+    WeightCostJob* dBatch = (WeightCostJob*)(ctx->puBuf + accBytes);
+    HIPCHK(hipMemcpyAsync(dBatch, batch.data(), sizeof(WeightCostJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(launch_weight_cost_batch(ctx->stream, g, ctx->bpp, dBatch, n));
     HIPCHK(hipMemcpyAsync(costs, acc, sizeof(unsigned int) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return X265GPU_OK;
@@ -2370,26 +2381,49 @@ int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pic
         if (p.slot >= 0 && blocks != ctx->g.cuCount)
             return fail(ctx, X265GPU_ERR_ARG, "aq_frames: 16x16 block grid differs from the slot's 8x8 lowres grid");
     }
+    // one batch at a time shares the context's arrays
+    {
+        int frc = aq_finish_pending(ctx);
+        if (frc)
+            return frc;
+    }
     const bool hdr = params->bHDR10Opt && mapped;
     const size_t arrayBytes = align256(sizeof(uint32_t) * (size_t)blocks);
     const size_t perPic = (hdr ? 2 : 1) * arrayBytes + AQ_WP_BYTES;
+    // after the pictures' arrays: the job structs, then the pointer pairs of the scatter that installs the factors
+    const size_t jobsAt = perPic * n, ptrsAt = jobsAt + align256(sizeof(AqJob) * (size_t)n);
+    const size_t total = ptrsAt + align256(2 * sizeof(void*) * (size_t)n);
+    if (total > ctx->aqBufBytes)
+    {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ctx->intraStream)
+            HIPCHK(hipStreamSynchronize(ctx->intraStream));
+        if (ctx->aqDev) (void)hipFree(ctx->aqDev);
+        if (ctx->aqHost) (void)hipHostFree(ctx->aqHost);
+        ctx->aqDev = ctx->aqHost = nullptr;
+        ctx->aqBufBytes = 0;
+        if (hipMalloc((void**)&ctx->aqDev, total) != hipSuccess ||
+            hipHostMalloc((void**)&ctx->aqHost, total, hipHostMallocDefault) != hipSuccess)
+        {
+            if (ctx->aqDev) (void)hipFree(ctx->aqDev);
+            ctx->aqDev = nullptr;
+            return fail(ctx, X265GPU_ERR_NOMEM, "aq_frames: out of memory");
+        }
+        ctx->aqBufBytes = total;
+    }
     x265gpu_ctx::AqPending* b = new (std::nothrow) x265gpu_ctx::AqPending;
     if (!b)
         return X265GPU_ERR_NOMEM;
-    if (hipMalloc((void**)&b->dev, perPic * n) != hipSuccess || hipHostMalloc((void**)&b->host, perPic * n, hipHostMallocDefault) != hipSuccess)
-    {
-        if (b->dev) (void)hipFree(b->dev);
-        delete b;
-        return fail(ctx, X265GPU_ERR_NOMEM, "aq_frames: out of memory");
-    }
-    auto drop = [&]() { (void)hipFree(b->dev); (void)hipHostFree(b->host); delete b; };
-    // every picture's energy pass, then one transfer and one wait
-    hipError_t e = hipMemsetAsync(b->dev, 0, perPic * n, ctx->stream);
-    for (int i = 0; i < n && e == hipSuccess; i++)
+    b->dev = ctx->aqDev;
+    b->host = ctx->aqHost;
+    auto drop = [&]() { delete b; };
+    // every picture's energy pass in one launch, then one transfer and one wait
+    AqJob* hostJobs = (AqJob*)(b->host + jobsAt);
+    for (int i = 0; i < n; i++)
     {
         const x265gpu_aq_picture& p = pics[i];
         char* base = b->dev + perPic * i;
-        AqJob job;
+        AqJob& job = hostJobs[i];
         memset(&job, 0, sizeof(job));
         job.width = job.visitWidth = w;
         job.height = job.visitHeight = h;
@@ -2402,8 +2436,12 @@ int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pic
         job.energy = (uint32_t*)base;
         job.lumaSum = hdr ? (uint32_t*)(base + arrayBytes) : nullptr;
         job.wp = (unsigned long long*)(base + (hdr ? 2 : 1) * arrayBytes);
-        e = launch_aq_energy(ctx->stream, ctx->bpp, job);
     }
+    hipError_t e = hipMemsetAsync(b->dev, 0, perPic * n, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(b->dev + jobsAt, hostJobs, sizeof(AqJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = launch_aq_energy_batch(ctx->stream, ctx->bpp, (const AqJob*)(b->dev + jobsAt), n, w, h);
     if (e == hipSuccess)
         e = hipMemcpyAsync(b->host, b->dev, perPic * n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess)
@@ -2435,6 +2473,8 @@ int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pic
     // the way x265's pool workers share the frames of PreLookaheadGroup (slicetype.cpp:1843-1859).
     b->pics.assign(pics, pics + n);
     b->params = *params;
+    b->perPic = perPic;
+    b->ptrsAt = ptrsAt;
     AqFrameParams ap;
     ap.aqMode = params->aqMode;
     ap.depth = ctx->cfg.internalBitDepth;
@@ -2480,11 +2520,36 @@ static int aq_finish_pending(x265gpu_ctx* ctx)
     {
         for (std::thread& th : b->workers)
             th.join();
-        for (const x265gpu_aq_picture& p : b->pics)
-            if (p.slot >= 0 && rc == X265GPU_OK)
-                rc = set_aq_staged(ctx, p.slot, p.invQscaleFactor, up);
-        (void)hipFree(b->dev);
-        (void)hipHostFree(b->host);
+        // The scale factors of every picture that has a slot: into the page-locked arrays (each picture's energy
+        // array has served its purpose and is exactly as large), one transfer, one pass that hands them to the slots.
+        const size_t bytes = sizeof(int32_t) * ctx->g.cuCount;
+        const int32_t** src = (const int32_t**)(b->host + b->ptrsAt);
+        int32_t** dst = (int32_t**)(b->host + b->ptrsAt) + b->pics.size();
+        int count = 0;
+        for (size_t i = 0; i < b->pics.size(); i++)
+        {
+            const x265gpu_aq_picture& p = b->pics[i];
+            if (p.slot < 0)
+                continue;
+            memcpy(b->host + b->perPic * i, p.invQscaleFactor, bytes);
+            src[count] = (const int32_t*)(b->dev + b->perPic * i);
+            dst[count] = ctx->slots[p.slot].invQscale;
+            ctx->slots[p.slot].hasAq = true;
+            count++;
+        }
+        if (count && rc == X265GPU_OK)
+        {
+            // pointer pairs packed behind each other for the device: count sources, then count destinations
+            memmove((void*)(src + count), (const void*)dst, sizeof(void*) * (size_t)count);
+            hipError_t e = hipMemcpyAsync(b->dev, b->host, b->perPic * b->pics.size(), hipMemcpyHostToDevice, up);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(b->dev + b->ptrsAt, b->host + b->ptrsAt, 2 * sizeof(void*) * (size_t)count, hipMemcpyHostToDevice, up);
+            if (e == hipSuccess)
+                e = launch_scatter_i32(up, (const int32_t* const*)(b->dev + b->ptrsAt),
+                                       (int32_t* const*)(b->dev + b->ptrsAt) + count, (int)ctx->g.cuCount, count);
+            if (e != hipSuccess)
+                rc = X265GPU_ERR_DEVICE;
+        }
         delete b->next;
         delete b;
     }
@@ -2533,13 +2598,26 @@ int x265gpu_get_frame_costs(x265gpu_ctx* ctx, int32_t n, const int32_t* slots, c
     if (!n)
         return X265GPU_OK;
     std::vector<long long> sums((size_t)3 * n);
+    std::vector<const long long*> where((size_t)n);
     for (int i = 0; i < n; i++)
     {
         const int a = d0 ? d0[i] : 0, b = d1 ? d1[i] : 0;
         if (!slot_ok(ctx, slots[i]) || a < 0 || a >= ctx->D || b < 0 || b >= ctx->D)
             return X265GPU_ERR_ARG;
-        HIPCHK(hipMemcpyAsync(&sums[3 * (size_t)i], ctx->slots[slots[i]].sums + ((size_t)a * ctx->D + b) * 3, 3 * sizeof(long long),
-                              hipMemcpyDeviceToHost, ctx->stream));
+        where[i] = ctx->slots[slots[i]].sums + ((size_t)a * ctx->D + b) * 3;
+    }
+    if (n == 1)
+        HIPCHK(hipMemcpyAsync(sums.data(), where[0], 3 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    else
+    {
+        // the totals sit in n different slots: gathered on the device, one transfer each way
+        const size_t ptrBytes = align256(sizeof(long long*) * (size_t)n);
+        int rc = ensure_pu_buf(ctx, ptrBytes + 3 * sizeof(long long) * (size_t)n);
+        if (rc)
+            return rc;
+        HIPCHK(hipMemcpyAsync(ctx->puBuf, where.data(), sizeof(long long*) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(launch_gather_totals(ctx->stream, (const long long* const*)ctx->puBuf, (long long*)(ctx->puBuf + ptrBytes), n));
+        HIPCHK(hipMemcpyAsync(sums.data(), ctx->puBuf + ptrBytes, 3 * sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n; i++)

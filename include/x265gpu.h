@@ -472,7 +472,13 @@ int x265gpu_aq_frames_finish(x265gpu_ctx* ctx);
  *                             invQscaleFactor8x8.  Every part must reach into the picture (a part without
  *                             a block divides by zero in the reference).
  * The uint16 saturation of the reference's CLIP_ADD is order independent (all addends >= 0), so the
- * device adds with atomics into wide cells and clamps on read; results are bit-exact. */
+ * device adds with atomics into wide cells and clamps on read; results are bit-exact.
+ * x265gpu_cutree_clear and x265gpu_cutree_propagate only queue their pass.  The queue is launched by the next call
+ * that reads totals or waits (the finish calls, _get_propagate_cost, _swap, x265gpu_sync, the estimate calls): passes
+ * that do not depend on each other - adds into one array commute, so all that orders them is a clear of an array
+ * they touch and every add into the array they read - go out as one launch per dependency level (the unreferenced
+ * B frames of a whole cuTree walk together, then the chain from each P frame to the one before it).  The outcome is
+ * that of the calls in their order. */
 int x265gpu_cutree_clear(x265gpu_ctx* ctx, int32_t slot);
 int x265gpu_cutree_swap(x265gpu_ctx* ctx, int32_t slotA, int32_t slotB);
 int x265gpu_cutree_propagate(x265gpu_ctx* ctx, int32_t slotP0, int32_t slotP1, int32_t slotB, int32_t d0, int32_t d1,

@@ -23,6 +23,35 @@ namespace xg {
 // slicetype.cpp:62-86).  B lanes per block, 64 / B blocks per wave.  The block loop runs while
 // blockX < visitWidth and blockY < visitHeight (normally the picture size; the variance tail of
 // calcAdaptiveQuantFrame walks a picture rounded to 16, :674-675, :692-694); results are stored in loop order.
+// sum and sum of squares of N consecutive pixels (N * sizeof(P) a multiple of 8 bytes), read as 8-byte pieces
+template <typename P, int N>
+__device__ __forceinline__ void sum_pixels(const P* p, uint32_t& sum, uint32_t& sqr)
+{
+    constexpr int PIECES = N * (int)sizeof(P) / 8;
+#pragma unroll
+    for (int q = 0; q < PIECES; q++)
+    {
+        const u32x2_unaligned v = *(const u32x2_unaligned*)((const char*)p + 8 * q);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+            const uint32_t w = h ? v.y : v.x;
+            if (sizeof(P) == 1)
+            {
+                const uint32_t b0 = w & 0xffu, b1 = (w >> 8) & 0xffu, b2 = (w >> 16) & 0xffu, b3 = w >> 24;
+                sum = __builtin_amdgcn_sad_u8(w, 0u, sum);
+                sqr += b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3;
+            }
+            else
+            {
+                const uint32_t lo = w & 0xffffu, hi = w >> 16;
+                sum += lo + hi;
+                sqr += lo * lo + hi * hi;
+            }
+        }
+    }
+}
+
 template <typename P, int B>
 __device__ __forceinline__ void aq_energy_block_rows(const AqJob& job)
 {
@@ -39,13 +68,16 @@ __device__ __forceinline__ void aq_energy_block_rows(const AqJob& job)
     {
         const int y = min(B * by + k, job.height - 1);
         const P* row = (const P*)job.luma + (long long)y * job.lumaStride;
+        if (B * cbx + B <= job.width)                 // the whole row segment lies inside the picture: wide loads
+            sum_pixels<P, B>(row + B * cbx, sumY, sqrY);
+        else
 #pragma unroll
-        for (int i = 0; i < B; i++)
-        {
-            const uint32_t v = row[min(B * cbx + i, job.width - 1)];
-            sumY += v;
-            sqrY += v * v;
-        }
+            for (int i = 0; i < B; i++)
+            {
+                const uint32_t v = row[min(B * cbx + i, job.width - 1)];
+                sumY += v;
+                sqrY += v * v;
+            }
     }
     // chroma: the lower half of the lanes take the U rows, the upper half the V rows
     uint32_t sC = 0, qC = 0;
@@ -54,13 +86,16 @@ __device__ __forceinline__ void aq_energy_block_rows(const AqJob& job)
         const P* plane = (const P*)(k < HALF ? job.u : job.v);
         const int y = min(HALF * by + (k & (HALF - 1)), ch - 1);
         const P* row = plane + (long long)y * job.chromaStride;
+        if (HALF * sizeof(P) >= 8 && HALF * cbx + HALF <= cw)
+            sum_pixels<P, (HALF * sizeof(P) >= 8 ? HALF : 8)>(row + HALF * cbx, sC, qC);
+        else
 #pragma unroll
-        for (int i = 0; i < HALF; i++)
-        {
-            const uint32_t v = row[min(HALF * cbx + i, cw - 1)];
-            sC += v;
-            qC += v * v;
-        }
+            for (int i = 0; i < HALF; i++)
+            {
+                const uint32_t v = row[min(HALF * cbx + i, cw - 1)];
+                sC += v;
+                qC += v * v;
+            }
     }
     // luma over the B lanes of the block; U total in the lower half, V total in the upper half
     sumY += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sumY, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]

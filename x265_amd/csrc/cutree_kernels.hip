@@ -23,7 +23,7 @@ __device__ __forceinline__ void clip_add(unsigned long long* cell, int x)
         atomicAdd(cell, (unsigned long long)min(x, 65535));
 }
 
-__global__ void __launch_bounds__(256) cutree_propagate_kernel(PropagateJob job)
+__device__ __forceinline__ void propagate_block(const PropagateJob& job)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= job.W * job.H)
@@ -69,6 +69,42 @@ __global__ void __launch_bounds__(256) cutree_propagate_kernel(PropagateJob job)
                 clip_add(ref + ty * job.W + tx, (share * w + 512) >> 10);
         }
     }
+}
+
+__global__ void __launch_bounds__(256) cutree_propagate_kernel(PropagateJob job)
+{
+    propagate_block(job);
+}
+
+// several frames whose passes do not depend on each other, in one launch: blockIdx.y = frame
+__global__ void __launch_bounds__(256) cutree_propagate_batch_kernel(const PropagateJob* jobs)
+{
+    const PropagateJob job = jobs[blockIdx.y];
+    propagate_block(job);
+}
+
+hipError_t launch_cutree_propagate_batch(hipStream_t s, const PropagateJob* dJobs, int count, int W, int H)
+{
+    if (count <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(cutree_propagate_batch_kernel, dim3((W * H + 255) / 256, count), dim3(256), 0, s, dJobs);
+    return hipGetLastError();
+}
+
+// cells[k][0 .. counts[k]) = 0 for each array of the list
+__global__ void __launch_bounds__(256) cutree_clear_batch_kernel(unsigned long long* const* cells, const int* counts)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < counts[blockIdx.y])
+        cells[blockIdx.y][i] = 0;
+}
+
+hipError_t launch_cutree_clear_batch(hipStream_t s, unsigned long long* const* dCells, const int* dCounts, int arrays, int maxCount)
+{
+    if (arrays <= 0 || maxCount <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(cutree_clear_batch_kernel, dim3((maxCount + 255) / 256, arrays), dim3(256), 0, s, dCells, dCounts);
+    return hipGetLastError();
 }
 
 hipError_t launch_cutree_propagate(hipStream_t s, const PropagateJob& job)

@@ -256,6 +256,8 @@ struct PropagateJob
     double fps;                              // fpsFactor / 256
 };
 hipError_t launch_cutree_propagate(hipStream_t s, const PropagateJob& job);
+hipError_t launch_cutree_propagate_batch(hipStream_t s, const PropagateJob* dJobs, int count, int W, int H);
+hipError_t launch_cutree_clear_batch(hipStream_t s, unsigned long long* const* dCells, const int* dCounts, int arrays, int maxCount);
 
 // Histogram scene-cut statistics of one 4:2:0 picture.
 struct HistJob

@@ -130,6 +130,11 @@ struct x265gpu_ctx
         std::atomic<int>* next = nullptr;
     };
     std::vector<AqPending*> aqPending;
+    // cuTree passes queued by x265gpu_cutree_clear / _propagate and not launched yet (cutree_flush)
+    struct CuTreeOp { bool clear; unsigned long long* cells; int count; PropagateJob job; };
+    std::vector<CuTreeOp> cutreeOps;
+    char* cutreeBuf = nullptr;
+    size_t cutreeBufBytes = 0;
     char* aqDev = nullptr;              // the batched AQ pass's device arrays and their page-locked mirror, kept between
     char* aqHost = nullptr;             //   calls and grown when a larger batch comes
     size_t aqBufBytes = 0;
@@ -145,7 +150,10 @@ struct x265gpu_ctx
 // x265gpu_aq_frames_begin batches still on host threads: joined, uploaded, and the intra estimates that waited for
 // them launched, before anything reads scale factors or intra results
 static int aq_finish_pending(x265gpu_ctx* ctx);
-#define FINISH_AQ(ctx) do { if (ctx) { const int rcAq_ = aq_finish_pending(ctx); if (rcAq_) return rcAq_; } } while (0)
+static int cutree_flush(x265gpu_ctx* ctx);
+// work the library holds back (the AQ mapping running on host threads, queued cuTree passes) is brought up to date
+// before anything that reads its results
+#define FINISH_AQ(ctx) do { if (ctx) { int rcAq_ = aq_finish_pending(ctx); if (!rcAq_) rcAq_ = cutree_flush(ctx); if (rcAq_) return rcAq_; } } while (0)
 
 namespace {
 
@@ -657,6 +665,7 @@ void x265gpu_close(x265gpu_ctx* ctx)
     if (ctx->mcstfBuf) (void)hipFree(ctx->mcstfBuf);
     if (ctx->seaBuf) (void)hipFree(ctx->seaBuf);
     if (ctx->aqDev) (void)hipFree(ctx->aqDev);
+    if (ctx->cutreeBuf) (void)hipFree(ctx->cutreeBuf);
     if (ctx->aqHost) (void)hipHostFree(ctx->aqHost);
     if (ctx->intraStream) (void)hipStreamSynchronize(ctx->intraStream);
     if (ctx->intraJobBuf) (void)hipFree(ctx->intraJobBuf);
@@ -1799,7 +1808,12 @@ int x265gpu_cutree_clear(x265gpu_ctx* ctx, int32_t slot)
     DeviceScope deviceScope(ctx);
     if (!ctx || !slot_ok(ctx, slot))
         return X265GPU_ERR_ARG;
-    HIPCHK(hipMemsetAsync(ctx->slots[slot].propagate, 0, sizeof(unsigned long long) * ctx->g.cuCount, ctx->stream));
+    x265gpu_ctx::CuTreeOp op;
+    memset(&op, 0, sizeof(op));
+    op.clear = true;
+    op.cells = ctx->slots[slot].propagate;
+    op.count = (int)ctx->g.cuCount;
+    ctx->cutreeOps.push_back(op);
     return X265GPU_OK;
 }
 
@@ -1807,6 +1821,10 @@ int x265gpu_cutree_swap(x265gpu_ctx* ctx, int32_t slotA, int32_t slotB)
 {
     if (!ctx || !slot_ok(ctx, slotA) || !slot_ok(ctx, slotB))
         return X265GPU_ERR_ARG;
+    DeviceScope deviceScope(ctx);
+    int rc = cutree_flush(ctx);            // queued passes hold the arrays' addresses
+    if (rc)
+        return rc;
     std::swap(ctx->slots[slotA].propagate, ctx->slots[slotB].propagate);
     return X265GPU_OK;
 }
@@ -1815,7 +1833,12 @@ int x265gpu_cutree_propagate(x265gpu_ctx* ctx, int32_t slotP0, int32_t slotP1, i
                              int32_t referenced, double fpsFactor, int32_t bipredWeight)
 {
     DeviceScope deviceScope(ctx);
-    FINISH_AQ(ctx);
+    if (ctx)
+    {
+        const int rcAq = aq_finish_pending(ctx);      // the scale factors this pass reads
+        if (rcAq)
+            return rcAq;
+    }
     if (!ctx || !slot_ok(ctx, slotP0) || !slot_ok(ctx, slotP1) || !slot_ok(ctx, slotB) || d0 < 1 || d0 >= ctx->D ||
         d1 < 0 || d1 >= ctx->D || bipredWeight < 0 || bipredWeight > 64)
         return X265GPU_ERR_ARG;
@@ -1839,9 +1862,123 @@ int x265gpu_cutree_propagate(x265gpu_ctx* ctx, int32_t slotP0, int32_t slotP1, i
     job.fps = fpsFactor / 256;
     // an unreferenced frame's own cells are a zeroed row in the reference (slicetype.cpp:3784-3785):
     // nothing reads them again before the next clear, but keep the visible state the same
+    x265gpu_ctx::CuTreeOp op;
+    memset(&op, 0, sizeof(op));
     if (!referenced)
-        HIPCHK(hipMemsetAsync(sb.propagate, 0, sizeof(unsigned long long) * ctx->g.W, ctx->stream));
-    HIPCHK(launch_cutree_propagate(ctx->stream, job));
+    {
+        op.clear = true;
+        op.cells = sb.propagate;
+        op.count = ctx->g.W;
+        ctx->cutreeOps.push_back(op);
+    }
+    op.clear = false;
+    op.cells = nullptr;
+    op.count = 0;
+    op.job = job;
+    ctx->cutreeOps.push_back(op);
+    return X265GPU_OK;
+}
+
+// Launches the queued cuTree passes.  A pass reads its own frame's totals and adds to its references' totals; adds to
+// one array commute, so passes only have to wait for the clears of the arrays they touch, for every add into the
+// array they read, and (a clear) for everything that touched the array before.  Each pass gets the lowest level its
+// predecessors allow and a level is one launch: the unreferenced B frames of a whole walk go together, and what
+// remains is the chain from each P frame to the one before it.
+static int cutree_flush(x265gpu_ctx* ctx)
+{
+    std::vector<x265gpu_ctx::CuTreeOp>& ops = ctx->cutreeOps;
+    if (ops.empty())
+        return X265GPU_OK;
+    const size_t n = ops.size();
+    std::vector<int> level(n, 0);
+    int levels = 0;
+    for (size_t j = 0; j < n; j++)
+    {
+        const x265gpu_ctx::CuTreeOp& b = ops[j];
+        int lv = 0;
+        for (size_t i = 0; i < j; i++)
+        {
+            const x265gpu_ctx::CuTreeOp& a = ops[i];
+            bool after;
+            if (a.clear && b.clear)
+                after = a.cells == b.cells;
+            else if (a.clear)
+                after = a.cells == b.job.propagateIn || a.cells == b.job.refCosts[0] || a.cells == b.job.refCosts[1];
+            else if (b.clear)
+                after = b.cells == a.job.propagateIn || b.cells == a.job.refCosts[0] || b.cells == a.job.refCosts[1];
+            else
+                after = (b.job.propagateIn && (b.job.propagateIn == a.job.refCosts[0] || b.job.propagateIn == a.job.refCosts[1])) ||
+                        (a.job.propagateIn && (a.job.propagateIn == b.job.refCosts[0] || a.job.propagateIn == b.job.refCosts[1]));
+            if (after && level[i] + 1 > lv)
+                lv = level[i] + 1;
+        }
+        level[j] = lv;
+        levels = lv + 1 > levels ? lv + 1 : levels;
+    }
+    // device copies, level after level: the passes' jobs, then the clears' arrays and lengths
+    std::vector<PropagateJob> jobs;
+    std::vector<unsigned long long*> cells;
+    std::vector<int> counts;
+    std::vector<int> jobAt(levels + 1, 0), clearAt(levels + 1, 0);
+    for (int lv = 0; lv < levels; lv++)
+    {
+        jobAt[lv] = (int)jobs.size();
+        clearAt[lv] = (int)cells.size();
+        for (size_t i = 0; i < n; i++)
+            if (level[i] == lv)
+            {
+                if (ops[i].clear)
+                {
+                    cells.push_back(ops[i].cells);
+                    counts.push_back(ops[i].count);
+                }
+                else
+                    jobs.push_back(ops[i].job);
+            }
+    }
+    jobAt[levels] = (int)jobs.size();
+    clearAt[levels] = (int)cells.size();
+    const size_t jobBytes = align256(sizeof(PropagateJob) * jobs.size()), cellBytes = align256(sizeof(void*) * cells.size());
+    const size_t total = jobBytes + cellBytes + align256(sizeof(int) * counts.size());
+    if (total > ctx->cutreeBufBytes)
+    {
+        if (ctx->cutreeBuf)
+        {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipFree(ctx->cutreeBuf));
+            ctx->cutreeBuf = nullptr;
+            ctx->cutreeBufBytes = 0;
+        }
+        HIPCHK(hipMalloc((void**)&ctx->cutreeBuf, 2 * total));
+        ctx->cutreeBufBytes = 2 * total;
+    }
+    ops.clear();
+    if (!jobs.empty())
+        HIPCHK(hipMemcpyAsync(ctx->cutreeBuf, jobs.data(), sizeof(PropagateJob) * jobs.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (!cells.empty())
+    {
+        HIPCHK(hipMemcpyAsync(ctx->cutreeBuf + jobBytes, cells.data(), sizeof(void*) * cells.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->cutreeBuf + jobBytes + cellBytes, counts.data(), sizeof(int) * counts.size(), hipMemcpyHostToDevice,
+                              ctx->stream));
+    }
+    const PropagateJob* dJobs = (const PropagateJob*)ctx->cutreeBuf;
+    unsigned long long* const* dCells = (unsigned long long* const*)(ctx->cutreeBuf + jobBytes);
+    const int* dCounts = (const int*)(ctx->cutreeBuf + jobBytes + cellBytes);
+    for (int lv = 0; lv < levels; lv++)
+    {
+        const int nc = clearAt[lv + 1] - clearAt[lv], nj = jobAt[lv + 1] - jobAt[lv];
+        if (nc)
+        {
+            int maxCount = 0;
+            for (int k = clearAt[lv]; k < clearAt[lv + 1]; k++)
+                maxCount = counts[k] > maxCount ? counts[k] : maxCount;
+            HIPCHK(launch_cutree_clear_batch(ctx->stream, dCells + clearAt[lv], dCounts + clearAt[lv], nc, maxCount));
+        }
+        if (nj)
+            HIPCHK(launch_cutree_propagate_batch(ctx->stream, dJobs + jobAt[lv], nj, ctx->g.W, ctx->g.H));
+    }
+    // the uploads above read these vectors
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return X265GPU_OK;
 }
 
@@ -1860,6 +1997,7 @@ int x265gpu_cutree_get_propagate_cost(x265gpu_ctx* ctx, int32_t slot, uint16_t* 
     DeviceScope deviceScope(ctx);
     if (!ctx || !slot_ok(ctx, slot) || !propagateCost)
         return X265GPU_ERR_ARG;
+    FINISH_AQ(ctx);
     std::vector<unsigned long long> acc;
     int rc = fetch_propagate(ctx, slot, acc);
     if (rc)

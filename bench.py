@@ -24,6 +24,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -326,7 +327,7 @@ def rank_main(args):
     # Everything that starts another process (the issue-rate microbenchmark, the worker pool of the all-cores CPU
     # baseline) runs before this process initialises the GPU.
     rates = (issue_rates() if not args.no_micro else None) or recorded_issue_rates() if rank == 0 else None
-    cpu = cpu_baselines(args) if rank == 0 and args.cpu_frames > 0 else {}
+    cpu = cpu_baselines(args) if rank == 0 and world == 1 and args.cpu_frames > 0 else {}
 
     import ctypes as C
     import torch
@@ -355,22 +356,9 @@ def rank_main(args):
     u_ptrs = [dev_u.data_ptr() + i * cb for i in range(F)]
     v_ptrs = [dev_v.data_ptr() + i * cb for i in range(F)]
 
-    stream = torch.cuda.current_stream().cuda_stream
     hme_kw = dict(hme=True) if args.hme else {}
-    ctx = api.Context(W, H, depth=D, bframes=args.bframes, num_slots=F, device=local_rank, stream=stream, **hme_kw)
     table, centre = api.bitcost_table(D)
-    ctx.set_mvcost(table, centre)
-    n = ctx.geom.cuCount
-
-    # ---- segment workload through xgh_window ----
     Hlib = api.load_host_library()
-    win = api.HostWindow(ctx, F, weightp=True)
-    offs = [(np.zeros(n), np.zeros(n)) for _ in range(F)]
-    invs = [np.zeros(n, np.int32) for _ in range(F)]
-    for i in range(F):
-        win.set_qp_offsets(i, *offs[i])
-    for k, t in enumerate(segment_slice_types(F, args.bframes)):
-        win.set_slice_type(k, t)
     b1, b2 = batch_requests(F, args.bframes)
     a1 = np.ascontiguousarray(np.array(b1, np.int32).reshape(-1, 3))
     a2 = np.ascontiguousarray(np.array(b2, np.int32).reshape(-1, 3))
@@ -381,7 +369,44 @@ def rank_main(args):
     ys, us, vs = vpn(*y_ptrs), vpn(*u_ptrs), vpn(*v_ptrs)
     sy, sc = (C.c_ssize_t * F)(*[W] * F), (C.c_ssize_t * F)(*[W // 2] * F)
     aqp = api.AqParams(2, 1, 0, 0, 1.0, 32, 0, None, None, None, 0, 0, 0.0, None)
-    iq = vpn(*[a.ctypes.data for a in invs])
+
+    class Pipeline:
+        """One lookahead instance (library context, host-layer window) working on segments one after the other.  With
+        --in-flight P, P of them take the steps in turn from P host threads, each on a stream of its own: one
+        segment's host phases (weight analysis, AQ mapping, cuTree) then run beside another's searches."""
+
+        def __init__(self, own_stream):
+            self.stream = torch.cuda.Stream() if own_stream else torch.cuda.current_stream()
+            self.ctx = api.Context(W, H, depth=D, bframes=args.bframes, num_slots=F, device=local_rank,
+                                   stream=self.stream.cuda_stream, **hme_kw)
+            self.ctx.set_mvcost(table, centre)
+            n_ = self.ctx.geom.cuCount
+            self.win = api.HostWindow(self.ctx, F, weightp=True)
+            self.offs = [(np.zeros(n_), np.zeros(n_)) for _ in range(F)]
+            self.invs = [np.zeros(n_, np.int32) for _ in range(F)]
+            for i in range(F):
+                self.win.set_qp_offsets(i, *self.offs[i])
+            for k, t in enumerate(segment_slice_types(F, args.bframes)):
+                self.win.set_slice_type(k, t)
+            self.iq = vpn(*[a.ctypes.data for a in self.invs])
+
+        def step(self):
+            win = self.win
+            win._chk(Hlib.xgh_pre_lookahead_aq(win.h, F, frames_arr, ys, us, vs, sy, sc, C.byref(aqp), self.iq, api.MEM_DEVICE))
+            Hlib.xgh_add_many(win.h, len(a1), a1.ctypes.data_as(C.c_void_p))
+            win.finish_batch()
+            Hlib.xgh_add_many(win.h, len(a2), a2.ctypes.data_as(C.c_void_p))
+            win.finish_batch()
+            win.cu_tree(F - 1, False, b_pyramid=True)
+
+        def close(self):
+            self.win.close()
+            self.ctx.close()
+
+    in_flight = max(1, args.in_flight)
+    pipes = [Pipeline(own_stream=in_flight > 1) for _ in range(in_flight)]
+    ctx, win = pipes[0].ctx, pipes[0].win
+    n = ctx.geom.cuCount
 
     gather = None
     if distributed:
@@ -392,36 +417,56 @@ def rank_main(args):
         req_all = np.ascontiguousarray(np.concatenate([a1, a2]))
         pin_np = pinned.numpy()
 
-        def gather():
+        def gather(pipe):
             # this rank's per-request scalars (already on its host, where its own decisions read them) go to the
             # other ranks in one collective; rank 0 also brings the whole set back to its host
-            Hlib.xgh_collect_costs(win.h, len(req_all), req_all.ctypes.data_as(C.c_void_p), pin_np.ctypes.data_as(C.c_void_p))
+            Hlib.xgh_collect_costs(pipe.win.h, len(req_all), req_all.ctypes.data_as(C.c_void_p), pin_np.ctypes.data_as(C.c_void_p))
             local.copy_(pinned, non_blocking=True)
             dist.all_gather_into_tensor(gathered, local)
             if rank == 0:
                 gathered_host.copy_(gathered, non_blocking=True)
 
-    def segment_step():
-        win._chk(Hlib.xgh_pre_lookahead_aq(win.h, F, frames_arr, ys, us, vs, sy, sc, C.byref(aqp), iq, api.MEM_DEVICE))
-        Hlib.xgh_add_many(win.h, len(a1), a1.ctypes.data_as(C.c_void_p))
-        win.finish_batch()
-        Hlib.xgh_add_many(win.h, len(a2), a2.ctypes.data_as(C.c_void_p))
-        win.finish_batch()
-        win.cu_tree(F - 1, False, b_pyramid=True)
+    def segment_step(pipe=None):
+        pipe = pipe or pipes[0]
+        pipe.step()
         if gather is not None:
-            gather()
+            with gather_lock:
+                gather(pipe)
+
+    gather_lock = threading.Lock()
+
+    def run_steps(count):
+        """`count` segment steps: in turn on the pipelines, each pipeline driven by a host thread of its own."""
+        if in_flight == 1:
+            for _ in range(count):
+                segment_step()
+            return
+        errs = []
+
+        def work(k):
+            try:
+                with torch.cuda.stream(pipes[k].stream):
+                    for _ in range(k, count, in_flight):
+                        segment_step(pipes[k])
+            except Exception as e:      # noqa: BLE001 - reported by the caller
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(k,)) for k in range(in_flight)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
 
     def fence():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        segment_step()
+    run_steps(max(args.warmup, in_flight if args.warmup else 0))
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        segment_step()
+    run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if distributed:
@@ -601,8 +646,8 @@ def rank_main(args):
     if steady:
         out["steady_state"] = steady
     out.update(cpu)
-    win.close()
-    ctx.close()
+    for pipe in pipes:
+        pipe.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -623,6 +668,8 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--frames", type=int, default=60, help="frames per step (one segment)")
     ap.add_argument("--bframes", type=int, default=4)
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="segments in flight per GPU: lookahead instances (context, stream, host thread) that take the steps in turn")
     ap.add_argument("--steady-steps", type=int, default=3, help="repetitions of the steady (slicetypeDecide loop) workload, 0 = skip")
     ap.add_argument("--cpu-frames", type=int, default=60, help="frames in the bounded CPU baseline samples (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=16, help="host cores for the all-cores CPU baseline")

@@ -182,3 +182,75 @@ def test_pre_lookahead_with_adaptive_quant(depth):
         win.close()
         ctx.close()
         ref.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_window_on_device_pictures_weights_follow_intra(depth):
+    """Device-resident pictures take the batched pre-lookahead: the AQ mapping runs on host threads and is only joined
+    by the first call that reads its results.  A weighted batch right behind it, on a context whose arrays have never
+    held an intra estimate: weightCostLuma reads the per-block intra costs, so the estimate must have run by then
+    although its AQ-weighted sums cannot have.  Everything against the oracle: weights, costs, vectors, and the
+    intra totals once the scale factors are in."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")        # the runtime the library under test already runs on
+    held = []
+
+    def to_device(a):
+        a = np.ascontiguousarray(a)
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(a.nbytes)) == 0
+        held.append(p)
+        assert hip.hipMemcpy(p, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), 1) == 0     # hipMemcpyHostToDevice
+        return p.value
+    W, H, N = 384, 208, 6
+    top = (1 << depth) - 1
+    base = synth.luma_clip(W, H, N, depth, seed=19)[0]
+    rng = np.random.default_rng(5)
+    dt = base.dtype
+    clip = [np.clip(np.roll(base, i, axis=1).astype(np.int32) * (64 - 6 * i) // 64 + (2 * i << (depth - 8)) +
+                    rng.integers(-1, 2, base.shape), 0, top).astype(dt) for i in range(N)]
+    chroma = [(rng.integers(0, top + 1, (H // 2, W // 2)).astype(dt), rng.integers(0, top + 1, (H // 2, W // 2)).astype(dt))
+              for _ in range(N)]
+    ref = orc.Lookahead(depth, orc.make_param(W, H, weightp=True), with_aq=True)
+    ctx = api.Context(W, H, depth=depth, num_slots=N)
+    win = api.HostWindow(ctx, N, weightp=True)
+    try:
+        n = ctx.geom.cuCount
+        want = [orc.calc_adaptive_quant_frame(depth, clip[i], chroma[i][0], chroma[i][1], 2, 1.0, weightp=True) for i in range(N)]
+        for i in range(N):
+            lr = ref.add_frame(clip[i], want[i][2])
+            s, d = lr.wp()
+            s[:], d[:] = want[i][3], want[i][4]
+        ctx.set_mvcost(ref.table, ref.centre)
+        offs = [(np.full(n, np.nan), np.full(n, np.nan)) for _ in range(N)]
+        for i in range(N):
+            win.set_qp_offsets(i, *offs[i])
+        ptrs = [(to_device(clip[i]), to_device(chroma[i][0]), to_device(chroma[i][1]), W, W // 2) for i in range(N)]
+        invs = win.pre_lookahead_aq(None, 2, 1.0, weightp=True, device_ptrs=ptrs, resolve=False)
+        batch = [(0, 1, 1), (0, 2, 2), (0, 2, 1), (1, 3, 3), (1, 3, 2), (0, 5, 5), (2, 5, 3), (3, 4, 4), (2, 4, 4)]
+        for r in batch:
+            win.add(*r)
+        win.finish_batch()
+        nweighted = 0
+        for (p0, p1, b) in batch:
+            assert win.cost_est(b, b - p0, p1 - b) == ref.frame_cost(p0, p1, b), (p0, p1, b)
+            _check(ref, ctx, p0, p1, b)
+            if (p0, p1, b) == (0, 2, 1):
+                continue        # finds the list-0 search of (0, 1, 1) done: the flag it leaves depends on request order
+            weighted = bool(ref.frames[b].i64("isWeighted", b - p0))
+            assert win.is_weighted(b, b - p0) == weighted, (p0, p1, b)
+            nweighted += weighted
+        assert nweighted >= 3
+        for i in range(N):
+            np.testing.assert_array_equal(invs[i], want[i][2])
+            assert win.cost_est(i, 0, 0) == ref.frames[i].i64("costEst", 0, 0)
+            np.testing.assert_array_equal(ctx.get_intra(i)[0], ref.frames[i].intra_cost())
+            lc, rs, fc = ctx.get_costs(i, 0, 0)
+            assert fc[:2] == (ref.frames[i].i64("costEst", 0, 0), ref.frames[i].i64("costEstAq", 0, 0))
+            np.testing.assert_array_equal(rs, ref.frames[i].row_satds(0, 0))
+    finally:
+        win.close()
+        ctx.close()
+        ref.close()
+        for p in held:
+            hip.hipFree(p)

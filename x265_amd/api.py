@@ -732,23 +732,33 @@ class HostWindow:
         iq = None if invs is None else (C.c_void_p * n)(*[a.ctypes.data for a in invs])
         self._chk(self.H.xgh_pre_lookahead(self.h, n, frames, ptrs, strides, iq))
 
-    def pre_lookahead_aq(self, pictures, aq_mode, strength, weightp=False, qg_size=32):
+    def pre_lookahead_aq(self, pictures, aq_mode, strength, weightp=False, qg_size=32, device_ptrs=None, resolve=True):
         """The whole pre-lookahead task for 4:2:0 pictures [(y, u, v), ...] -> the frames' invQscaleFactor arrays
-        (offsets go to the arrays given with set_qp_offsets, wp sums are kept in the window: get_wp)."""
-        n = len(pictures)
-        pics = [[np.ascontiguousarray(p, self.ctx.pix) for p in pic] for pic in pictures]
+        (offsets go to the arrays given with set_qp_offsets, wp sums are kept in the window: get_wp).
+        device_ptrs: [(y, u, v, strideY, strideC), ...] device addresses of the same pictures; the task then reads
+        them there (the batched form whose AQ mapping runs on host threads).  resolve=False returns while that
+        mapping may still be running: the arrays are complete after the next call that reads its results."""
+        n = len(pictures) if device_ptrs is None else len(device_ptrs)
         blocks = self.ctx.geom.cuCount
         invs = [np.full(blocks, -1, np.int32) for _ in range(n)]
         self._keep += invs
         frames = (C.c_int32 * n)(*range(n))
         vpn = C.c_void_p * n
-        ys, us, vs = (vpn(*[pic[k].ctypes.data for pic in pics]) for k in range(3))
-        sy = (C.c_ssize_t * n)(*[pic[0].shape[1] for pic in pics])
-        sc = (C.c_ssize_t * n)(*[pic[1].shape[1] for pic in pics])
+        if device_ptrs is None:
+            pics = [[np.ascontiguousarray(p, self.ctx.pix) for p in pic] for pic in pictures]
+            ys, us, vs = (vpn(*[pic[k].ctypes.data for pic in pics]) for k in range(3))
+            sy = (C.c_ssize_t * n)(*[pic[0].shape[1] for pic in pics])
+            sc = (C.c_ssize_t * n)(*[pic[1].shape[1] for pic in pics])
+        else:
+            ys, us, vs = (vpn(*[d[k] for d in device_ptrs]) for k in range(3))
+            sy = (C.c_ssize_t * n)(*[d[3] for d in device_ptrs])
+            sc = (C.c_ssize_t * n)(*[d[4] for d in device_ptrs])
         prm = AqParams(int(aq_mode), int(weightp), 0, 0, float(strength), int(qg_size), 0, None, None, None, 0, 0, 0.0, None)
         iq = vpn(*[a.ctypes.data for a in invs])
-        self._chk(self.H.xgh_pre_lookahead_aq(self.h, n, frames, ys, us, vs, sy, sc, C.byref(prm), iq, MEM_HOST))
-        self._chk(self.H.xgh_resolve(self.h))       # the arrays returned here are complete
+        self._chk(self.H.xgh_pre_lookahead_aq(self.h, n, frames, ys, us, vs, sy, sc, C.byref(prm), iq,
+                                              MEM_HOST if device_ptrs is None else MEM_DEVICE))
+        if resolve:
+            self._chk(self.H.xgh_resolve(self.h))       # the arrays returned here are complete
         return invs
 
     def new_group(self, weightp=False):

@@ -301,6 +301,47 @@ __global__ void intra_finalize_kernel(const IntraJob* jobs, int H)
     }
 }
 
+// The AQ-weighted sums of an intra estimate whose costs are in place, redone with the scale factors the job points
+// at now: the row totals (all blocks) and the frame partial (scored blocks) of slicetype.cpp:798-811, then the frame
+// totals.  One 64-lane workgroup per block row.  Lets the estimate itself run before the factors exist.
+__global__ void __launch_bounds__(64) intra_aq_rows_kernel(const IntraJob* jobs, Geometry g)
+{
+    const IntraJob job = jobs[blockIdx.y];
+    const int W = g.W, H = g.H, cuY = blockIdx.x;
+    long long accRow = 0, accAq = 0;
+    for (int cuX = threadIdx.x; cuX < W; cuX += 64)
+    {
+        const int cuXY = cuX + cuY * W;
+        const int ic = job.intraCost[cuXY];
+        const bool scored = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
+        int icAq = ic;
+        if (scored && job.invQscale)
+            icAq = (ic * job.invQscale[cuXY] + 128) >> 8;
+        accRow += icAq;
+        if (scored)
+            accAq += icAq;
+    }
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        accRow += __shfl_down(accRow, o);
+        accAq += __shfl_down(accAq, o);
+    }
+    if (threadIdx.x == 0)
+    {
+        job.rowSatds[cuY] = (int32_t)accRow;
+        job.rowPartials[2 * cuY + 1] = accAq;
+    }
+}
+
+hipError_t launch_intra_aq_sums(hipStream_t s, const Geometry& g, const IntraJob* dJobs, int n)
+{
+    if (n <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(intra_aq_rows_kernel, dim3(g.H, n), dim3(64), 0, s, dJobs, g);
+    hipLaunchKernelGGL(intra_finalize_kernel, dim3(n), dim3(64), 0, s, dJobs, g.H);
+    return hipGetLastError();
+}
+
 hipError_t launch_intra(hipStream_t s, const Geometry& g, int bpp, int depth, int lambda, const IntraJob* dJobs, int n)
 {
     if (n <= 0)

@@ -92,6 +92,8 @@ hipError_t launch_gather_totals(hipStream_t s, const long long* const* dSrc, lon
 hipError_t launch_weight_cost_batch(hipStream_t s, const Geometry& g, int bpp, const WeightCostJob* dJobs, int n);
 hipError_t launch_lowres_init(hipStream_t s, const Geometry& g, int bpp, const LowresJob* dJobs, int n);
 hipError_t launch_intra(hipStream_t s, const Geometry& g, int bpp, int depth, int lambda, const IntraJob* dJobs, int n);
+// redo the AQ-weighted row and frame sums of finished intra estimates with the jobs' current scale factors
+hipError_t launch_intra_aq_sums(hipStream_t s, const Geometry& g, const IntraJob* dJobs, int n);
 // Side streams the search may spread independent jobs over so that the drain of
 // one anti-diagonal launch overlaps the body of another job group's launch.
 struct SearchStreams

@@ -377,6 +377,25 @@ int ensure_src_stage(x265gpu_ctx* ctx, size_t bytes)
     return X265GPU_OK;
 }
 
+// Job descriptors of the side-stream intra work: two halves of `intraJobBufSize` bytes each (device, and a
+// page-locked mirror), the first for the estimate's launch, the second for the pass that redoes its AQ sums.
+// Both record intraDone when they have been queued, so waiting for it frees both halves.
+int ensure_intra_job_buf(x265gpu_ctx* ctx, size_t bytes)
+{
+    HIPCHK(hipEventSynchronize(ctx->intraDone));
+    if (bytes <= ctx->intraJobBufSize)
+        return X265GPU_OK;
+    if (ctx->intraJobBuf) HIPCHK(hipFree(ctx->intraJobBuf));
+    if (ctx->intraJobHost) HIPCHK(hipHostFree(ctx->intraJobHost));
+    ctx->intraJobBuf = ctx->intraJobHost = nullptr;
+    ctx->intraJobBufSize = 0;
+    const size_t sz = align256(bytes * 2);
+    HIPCHK(hipMalloc((void**)&ctx->intraJobBuf, 2 * sz));
+    HIPCHK(hipHostMalloc((void**)&ctx->intraJobHost, 2 * sz, hipHostMallocDefault));
+    ctx->intraJobBufSize = sz;
+    return X265GPU_OK;
+}
+
 struct PhaseTimer
 {
     x265gpu_ctx* c;
@@ -591,16 +610,17 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
         {
             // X265GPU_INTRA_STREAM=0 keeps the intra estimate on the main stream
             const char* e = getenv("X265GPU_INTRA_STREAM");
-            if (!e || atoi(e) != 0)
+            if (hipEventCreateWithFlags(&ctx->intraFork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->intraDone, hipEventDisableTiming) != hipSuccess ||
+                hipEventRecord(ctx->intraDone, ctx->stream) != hipSuccess)
             {
-                if (hipStreamCreateWithFlags(&ctx->intraStream, hipStreamNonBlocking) != hipSuccess ||
-                    hipEventCreateWithFlags(&ctx->intraFork, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&ctx->intraDone, hipEventDisableTiming) != hipSuccess ||
-                    hipEventRecord(ctx->intraDone, ctx->intraStream) != hipSuccess)
-                {
-                    rc = X265GPU_ERR_DEVICE;
-                    break;
-                }
+                rc = X265GPU_ERR_DEVICE;
+                break;
+            }
+            if ((!e || atoi(e) != 0) && hipStreamCreateWithFlags(&ctx->intraStream, hipStreamNonBlocking) != hipSuccess)
+            {
+                rc = X265GPU_ERR_DEVICE;
+                break;
             }
         }
         ctx->slots.resize(cfg->numSlots);
@@ -874,19 +894,18 @@ int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots)
     for (int i = 0; i < n; i++)
         if (!slot_ok(ctx, slots[i]))
             return fail(ctx, X265GPU_ERR_ARG, "intra_estimate: bad slot");
-    if (!ctx->aqPending.empty())
-    {
-        // the AQ-weighted sums of the intra estimate need scale factors that host threads are still computing:
-        // the launch is made when they are done (aq_finish_pending), ahead of whatever reads its results
+    // Scale factors that host threads are still computing (x265gpu_aq_frames_begin) only enter the AQ-weighted sums:
+    // the estimate itself starts now, so that what reads its per-block costs (weight analysis, cost passes) finds
+    // them, and the sums are redone when the factors are installed (aq_finish_pending), ahead of whatever reads those.
+    const bool aqLater = !ctx->aqPending.empty();
+    if (aqLater)
         ctx->intraDeferred.insert(ctx->intraDeferred.end(), slots, slots + n);
-        return X265GPU_OK;
-    }
     std::vector<IntraJob> jobs(n);
     for (int i = 0; i < n; i++)
     {
         Slot& s = ctx->slots[slots[i]];
         jobs[i].plane0 = plane_origin(ctx, s.planes);
-        jobs[i].invQscale = s.hasAq ? s.invQscale : nullptr;
+        jobs[i].invQscale = (s.hasAq && !aqLater) ? s.invQscale : nullptr;
         jobs[i].intraCost = s.intraCost;
         jobs[i].intraMode = s.intraMode;
         jobs[i].lowresCosts = s.lowresCosts;   // [0][0]
@@ -898,18 +917,9 @@ int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots)
     {
         // side stream: starts after everything queued on the main stream so far (planes, AQ factors)
         const size_t bytes = sizeof(IntraJob) * n;
-        HIPCHK(hipEventSynchronize(ctx->intraDone));        // the previous launch is done with the job buffers
-        if (bytes > ctx->intraJobBufSize)
-        {
-            if (ctx->intraJobBuf) HIPCHK(hipFree(ctx->intraJobBuf));
-            if (ctx->intraJobHost) HIPCHK(hipHostFree(ctx->intraJobHost));
-            ctx->intraJobBuf = ctx->intraJobHost = nullptr;
-            ctx->intraJobBufSize = 0;
-            const size_t sz = align256(bytes * 2);
-            HIPCHK(hipMalloc((void**)&ctx->intraJobBuf, sz));
-            HIPCHK(hipHostMalloc((void**)&ctx->intraJobHost, sz, hipHostMallocDefault));
-            ctx->intraJobBufSize = sz;
-        }
+        int rcBuf = ensure_intra_job_buf(ctx, bytes);       // waits until the previous launch is done with the buffers
+        if (rcBuf)
+            return rcBuf;
         memcpy(ctx->intraJobHost, jobs.data(), bytes);
         if (!ctx->intraNoFork)
         {
@@ -2637,6 +2647,11 @@ int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pic
             }
         });
     ctx->aqPending.push_back(b);
+    // Job descriptors built from now on point at the slots' factor arrays; the contents are installed by
+    // aq_finish_pending, which every pass that reads them goes through before it is launched.
+    for (int i = 0; i < n; i++)
+        if (pics[i].slot >= 0)
+            ctx->slots[pics[i].slot].hasAq = true;
     return X265GPU_OK;
 }
 
@@ -2693,11 +2708,40 @@ static int aq_finish_pending(x265gpu_ctx* ctx)
     }
     if (rc == X265GPU_OK && !ctx->intraDeferred.empty())
     {
+        // the intra estimates launched while the factors were still being computed: their AQ-weighted sums, redone
+        // behind the estimate (same stream) and behind the factors' installation just queued
         std::vector<int32_t> slots;
         slots.swap(ctx->intraDeferred);
-        ctx->intraNoFork = side;
-        rc = x265gpu_intra_estimate(ctx, (int)slots.size(), slots.data());
-        ctx->intraNoFork = false;
+        std::sort(slots.begin(), slots.end());
+        slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+        std::vector<IntraJob> jobs(slots.size());
+        for (size_t i = 0; i < slots.size(); i++)
+        {
+            Slot& s = ctx->slots[slots[i]];
+            memset(&jobs[i], 0, sizeof(IntraJob));
+            jobs[i].invQscale = s.hasAq ? s.invQscale : nullptr;
+            jobs[i].intraCost = s.intraCost;
+            jobs[i].rowSatds = s.rowSatds;
+            jobs[i].rowPartials = s.rowPartials;
+            jobs[i].sums = s.sums;
+        }
+        const size_t bytes = sizeof(IntraJob) * jobs.size();
+        rc = ensure_intra_job_buf(ctx, bytes);
+        if (rc == X265GPU_OK)
+        {
+            char* host = ctx->intraJobHost + ctx->intraJobBufSize;
+            char* dev = ctx->intraJobBuf + ctx->intraJobBufSize;
+            memcpy(host, jobs.data(), bytes);
+            hipError_t e = hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, up);
+            if (e == hipSuccess)
+                e = launch_intra_aq_sums(up, ctx->g, (const IntraJob*)dev, (int)jobs.size());
+            if (e == hipSuccess)
+                e = hipEventRecord(ctx->intraDone, up);
+            if (e != hipSuccess)
+                rc = X265GPU_ERR_DEVICE;
+            else if (side)
+                ctx->intraPending = true;
+        }
     }
     else if (rc == X265GPU_OK && side && !batches.empty())
     {

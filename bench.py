@@ -8,7 +8,11 @@ Two workloads per run, both through the C++ host layer (x265_amd/host) over the 
            calcAdaptiveQuantFrame (AQ mode 2) and the intra estimate; batch 1 = every motion search (both lists,
            distances 1..bframes+1) with weightsAnalyse in front of each L0 search; batch 2 = every (p0, p1, b)
            frame cost; then one cuTree pass over the segment (B-pyramid mini-GOPs).  This is the throughput with
-           many frames in flight, e.g. GOP segments of one or several encodes.
+           many frames in flight, e.g. GOP segments of one or several encodes.  By default two lookahead
+           instances per GPU (--in-flight 2: a library context, a stream and a host thread each) take the steps
+           in turn, so that one segment's host phases (AQ mapping, weight analysis, cuTree) run beside the
+           other's searches; every step is still a whole segment, and `single_instance` is the same step on one
+           instance alone.
   steady   (`steady_state`): the real decision loop, Lookahead::slicetypeDecide with rc-lookahead 20 and a pool
            (batches per decision), fed picture by picture and drained as Encoder::encode does; frames/s and
            milliseconds per slicetypeDecide call are what ONE encoder instance sees.
@@ -337,6 +341,8 @@ def rank_main(args):
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)       # --force-dist outside a launcher: a world of one
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from x265_amd import api
@@ -408,28 +414,30 @@ def rank_main(args):
     ctx, win = pipes[0].ctx, pipes[0].win
     n = ctx.geom.cuCount
 
-    gather = None
+    req_all = np.ascontiguousarray(np.concatenate([a1, a2]))
     if distributed:
-        pinned = torch.zeros((n_cost, 3), dtype=torch.int64).pin_memory()
-        local = torch.zeros((n_cost, 3), dtype=torch.int64, device="cuda")
-        gathered = torch.zeros((world * n_cost, 3), dtype=torch.int64, device="cuda")
-        gathered_host = torch.zeros((world * n_cost, 3), dtype=torch.int64).pin_memory()
-        req_all = np.ascontiguousarray(np.concatenate([a1, a2]))
-        pin_np = pinned.numpy()
+        # per pipeline: the step's records in page-locked memory, their device copy, the gathered set
+        for pipe in pipes:
+            pipe.pinned = torch.zeros((n_cost, 3), dtype=torch.int64).pin_memory()
+            pipe.pin_np = pipe.pinned.numpy()
+            pipe.local = torch.zeros((n_cost, 3), dtype=torch.int64, device="cuda")
+            pipe.gathered = torch.zeros((world * n_cost, 3), dtype=torch.int64, device="cuda")
+            pipe.gathered_host = torch.zeros((world * n_cost, 3), dtype=torch.int64).pin_memory()
 
-        def gather(pipe):
-            # this rank's per-request scalars (already on its host, where its own decisions read them) go to the
-            # other ranks in one collective; rank 0 also brings the whole set back to its host
-            Hlib.xgh_collect_costs(pipe.win.h, len(req_all), req_all.ctypes.data_as(C.c_void_p), pin_np.ctypes.data_as(C.c_void_p))
-            local.copy_(pinned, non_blocking=True)
-            dist.all_gather_into_tensor(gathered, local)
-            if rank == 0:
-                gathered_host.copy_(gathered, non_blocking=True)
+    def gather(pipe):
+        # this rank's per-request scalars (already on its host, where its own decisions read them) go to the
+        # other ranks in one collective; rank 0 also brings the whole set back to its host
+        Hlib.xgh_collect_costs(pipe.win.h, len(req_all), req_all.ctypes.data_as(C.c_void_p), pipe.pin_np.ctypes.data_as(C.c_void_p))
+        pipe.local.copy_(pipe.pinned, non_blocking=True)
+        dist.all_gather_into_tensor(pipe.gathered, pipe.local)
+        if rank == 0:
+            pipe.gathered_host.copy_(pipe.gathered, non_blocking=True)
 
     def segment_step(pipe=None):
         pipe = pipe or pipes[0]
         pipe.step()
-        if gather is not None:
+        if distributed:
+            # one collective at a time, in the same count on every rank
             with gather_lock:
                 gather(pipe)
 
@@ -475,6 +483,18 @@ def rank_main(args):
         dt = float(t.item())
     ms_per_step = 1000.0 * dt / args.steps
     fps = F * world * args.steps / dt
+
+    # one lookahead instance on its own (a segment's phases strictly one after the other), for comparison
+    single = None
+    if in_flight > 1:
+        ssteps = max(1, min(args.steps, 20))
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(ssteps):
+            segment_step()
+        fence()
+        sdt = time.perf_counter() - t0
+        single = {"ms_per_step": 1000.0 * sdt / ssteps, "frames_per_s_per_gpu": F * ssteps / sdt, "steps": ssteps}
 
     # ---- per-phase kernel time with HIP events on the library's stream (separate, untimed pass) ----
     ctx.profile_enable(True)
@@ -636,13 +656,18 @@ def rank_main(args):
         "scaling": "weak", "vs_baseline": None, "dtype": "u8" if D == 8 else "u16", "data": "synthetic",
         "config": {"workload": "%dx%d %d-bit lookahead%s, preset medium per segment: Lowres::init + AQ mode 2 + intra per frame, "
                                "batch 1 (all searches, weightp analysis) + batch 2 (all frame costs) in b-adapt 2 batch order, one cuTree "
-                               "pass; %d-frame segment per step" % (W, H, D, " with --hme (hex / umh)" if args.hme else "", F),
+                               "pass; %d-frame segment per step%s" % (W, H, D, " with --hme (hex / umh)" if args.hme else "", F,
+                                                                   ", %d lookahead instances per GPU taking the steps in turn" % in_flight
+                                                                   if in_flight > 1 else ""),
                    "frames_per_step": F, "search_requests_per_step": n_search, "cost_requests_per_step": n_cost,
                    "blocks_per_frame": n, "bframes": args.bframes,
+                   "segments_in_flight_per_gpu": in_flight,
                    "sharding": "one frame segment per rank, RCCL all_gather of the per-request cost scalars" if distributed else "single GPU"},
         "roofline": roofline, "kernels": kernels, "machine": rates,
         "step_wall_ms_with_event_timers": prof_wall_ms,
     }
+    if single:
+        out["single_instance"] = single
     if steady:
         out["steady_state"] = steady
     out.update(cpu)
@@ -668,7 +693,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--frames", type=int, default=60, help="frames per step (one segment)")
     ap.add_argument("--bframes", type=int, default=4)
-    ap.add_argument("--in-flight", type=int, default=1,
+    ap.add_argument("--in-flight", type=int, default=2,
                     help="segments in flight per GPU: lookahead instances (context, stream, host thread) that take the steps in turn")
     ap.add_argument("--steady-steps", type=int, default=3, help="repetitions of the steady (slicetypeDecide loop) workload, 0 = skip")
     ap.add_argument("--cpu-frames", type=int, default=60, help="frames in the bounded CPU baseline samples (0 = skip)")

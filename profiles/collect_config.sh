@@ -4,6 +4,7 @@
 #   e.g. bash profiles/collect_config.sh 3840x2160_10bit_hme --width 3840 --height 2160 --depth 10 --hme
 # Leaves gpurun_out/<key>/kernel_stats.csv, gpurun_out/<key>/pmc.json and one log per pass; copy the two files to
 # profiles/r<round>_kernel_stats_<key>.csv and profiles/pmc_<key>.json (the name bench.py looks for).
+# One lookahead instance (--in-flight 1), so that no kernel of another instance runs beside the one being measured.
 # The bench runs without its child processes (microbenchmark, CPU baseline pool) and without the steady workload:
 # a program under rocprofv3 must not start other programs, and the steady loop launches the same kernels with
 # other job counts, which would blur the per-launch averages.
@@ -14,7 +15,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$KEY
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--cpu-frames 0 --no-micro --steady-steps 0 $*"
+ARGS="--cpu-frames 0 --no-micro --steady-steps 0 --in-flight 1 $*"
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 5 --warmup 2 $ARGS > $OUT/bench_traced.json 2> $OUT/trace.log || { echo "kernel trace failed"; tail -5 $OUT/trace.log; exit 1; }
 find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 echo "trace ok"

@@ -10,6 +10,7 @@
 #include "kernels.h"
 #include "../../include/x265gpu.h"
 
+#include <limits>
 #include <math.h>
 #include <string.h>
 #include <vector>
@@ -200,6 +201,26 @@ void aq_finish_wp(int width, int height, unsigned long long sum[3], unsigned lon
     }
 }
 
+// log2 of a non-negative integer, exactly as the host's libm returns it: the value is computed by log2() the first
+// time it is asked for and remembered per host thread.  The cuTree ratios take two logarithms per block and frame
+// of small integers (scaled intra and propagated costs) that recur from frame to frame; the memo turns most of them
+// into a load without changing one bit of the result.
+static inline double log2_of_int(int x)
+{
+    constexpr unsigned MEMO = 1u << 18;
+    static thread_local std::vector<double> memo;
+    if (memo.empty())
+        memo.assign(MEMO, std::numeric_limits<double>::quiet_NaN());
+    if ((unsigned)x < MEMO)
+    {
+        double r = memo[(unsigned)x];
+        if (r != r)
+            memo[(unsigned)x] = r = log2((double)x);
+        return r;
+    }
+    return log2((double)x);
+}
+
 // Lookahead::cuTreeFinish, the qgSize > 8 loop (source/encoder/slicetype.cpp:4052-4061): blocks
 // whose scaled intra cost is zero keep their previous offset.
 void cutree_finish_offsets(int blocks, const int32_t* intraCost, const int32_t* invQscale, const unsigned long long* totals,
@@ -213,7 +234,7 @@ void cutree_finish_offsets(int blocks, const int32_t* intraCost, const int32_t* 
             continue;
         const int inherited = (int)(totals[i] < 65535 ? totals[i] : 65535);
         const int propagated = (inherited * fpsFactor + 128) >> 8;
-        const double ratio = log2((double)(intra + propagated)) - log2((double)intra) + weightDelta;
+        const double ratio = log2_of_int(intra + propagated) - log2_of_int(intra) + weightDelta;
         qpCuTreeOffset[i] = qpAqOffset[i] - strength * ratio;
     }
 }
@@ -235,7 +256,7 @@ void cutree_finish_offsets_qg8(int W, int H, const int32_t* intraCost, const int
                 continue;
             const int inherited = (int)(totals[i] < 65535 ? totals[i] : 65535);
             const int propagated = (inherited / 4 * fpsFactor + 128) >> 8;
-            const double ratio = log2((double)(intra + propagated)) - log2((double)intra) + weightDelta;
+            const double ratio = log2_of_int(intra + propagated) - log2_of_int(intra) + weightDelta;
             const int at = cuX * 2 + cuY * W * 4;
             qpCuTreeOffset[at] = qpAqOffset[at] - strength * ratio;
             qpCuTreeOffset[at + 1] = qpAqOffset[at + 1] - strength * ratio;
@@ -267,7 +288,7 @@ void cutree_finish_hevc(int W, int H, int widthFullRes, int heightFullRes, bool 
                     continue;
                 const int inherited = (int)(totals[i] < 65535 ? totals[i] : 65535);
                 const int propagated = ((inherited / 4) * fpsFactor + 128) >> 8;
-                const double ratio = log2((double)(intra + propagated)) - log2((double)intra) + weightDelta;
+                const double ratio = log2_of_int(intra + propagated) - log2_of_int(intra) + weightDelta;
                 const int at = cuX * 2 + cuY * W * 4;
                 ratio8x8[at] = ratio8x8[at + 1] = ratio8x8[at + maxCols] = ratio8x8[at + maxCols + 1] = ratio;
             }
@@ -293,7 +314,7 @@ void cutree_finish_hevc(int W, int H, int widthFullRes, int heightFullRes, bool 
                             const int intra = (intraCost[idx] * invQscale[idx] + 128) >> 8;
                             const int inherited = (int)(totals[idx] < 65535 ? totals[idx] : 65535);
                             const int propagated = (inherited * fpsFactor + 128) >> 8;
-                            sum += (log2((double)(intra + propagated)) - log2((double)intra) + weightDelta);
+                            sum += (log2_of_int(intra + propagated) - log2_of_int(intra) + weightDelta);
                         }
                         count++;
                     }

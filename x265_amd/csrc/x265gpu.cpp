@@ -135,6 +135,8 @@ struct x265gpu_ctx
     std::vector<CuTreeOp> cutreeOps;
     char* cutreeBuf = nullptr;
     size_t cutreeBufBytes = 0;
+    char* finishHost = nullptr;         // page-locked landing area of cuTreeFinish's three per-block arrays
+    size_t finishHostBytes = 0;
     char* aqDev = nullptr;              // the batched AQ pass's device arrays and their page-locked mirror, kept between
     char* aqHost = nullptr;             //   calls and grown when a larger batch comes
     size_t aqBufBytes = 0;
@@ -688,6 +690,7 @@ void x265gpu_close(x265gpu_ctx* ctx)
     if (ctx->cutreeBuf) (void)hipFree(ctx->cutreeBuf);
     if (ctx->aqHost) (void)hipHostFree(ctx->aqHost);
     if (ctx->intraStream) (void)hipStreamSynchronize(ctx->intraStream);
+    if (ctx->finishHost) (void)hipHostFree(ctx->finishHost);
     if (ctx->intraJobBuf) (void)hipFree(ctx->intraJobBuf);
     if (ctx->intraJobHost) (void)hipHostFree(ctx->intraJobHost);
     if (ctx->intraFork) (void)hipEventDestroy(ctx->intraFork);
@@ -2020,6 +2023,34 @@ int x265gpu_cutree_get_propagate_cost(x265gpu_ctx* ctx, int32_t slot, uint16_t* 
 
 namespace {
 
+// What cuTreeFinish reads of a frame: propagated totals, intra costs and scale factors of every block, brought to
+// the context's page-locked landing area in three transfers and one wait.
+int fetch_finish_inputs(x265gpu_ctx* ctx, int32_t slot, const unsigned long long** acc, const int32_t** intra, const int32_t** invQ)
+{
+    Slot& s = ctx->slots[slot];
+    const size_t nb = ctx->g.cuCount;
+    const size_t accBytes = align256(sizeof(unsigned long long) * nb), arrBytes = align256(sizeof(int32_t) * nb);
+    const size_t total = accBytes + 2 * arrBytes;
+    if (total > ctx->finishHostBytes)
+    {
+        if (ctx->finishHost)
+            HIPCHK(hipHostFree(ctx->finishHost));
+        ctx->finishHost = nullptr;
+        ctx->finishHostBytes = 0;
+        HIPCHK(hipHostMalloc((void**)&ctx->finishHost, total, hipHostMallocDefault));
+        ctx->finishHostBytes = total;
+    }
+    char* h = ctx->finishHost;
+    HIPCHK(hipMemcpyAsync(h, s.propagate, sizeof(unsigned long long) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h + accBytes, s.intraCost, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h + accBytes + arrBytes, s.invQscale, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *acc = (const unsigned long long*)h;
+    *intra = (const int32_t*)(h + accBytes);
+    *invQ = (const int32_t*)(h + accBytes + arrBytes);
+    return X265GPU_OK;
+}
+
 int cutree_finish(x265gpu_ctx* ctx, int32_t slot, bool qg8, int32_t fpsFactor, double weightDelta, double cuTreeStrength,
                   const double* qpAqOffset, double* qpCuTreeOffset)
 {
@@ -2029,20 +2060,16 @@ int cutree_finish(x265gpu_ctx* ctx, int32_t slot, bool qg8, int32_t fpsFactor, d
     if (!s.hasAq)
         return fail(ctx, X265GPU_ERR_STATE, "cutree_finish: the frame has no invQscaleFactor (x265gpu_lowres_set_aq)");
     const size_t nb = ctx->g.cuCount;
-    std::vector<unsigned long long> acc;
-    std::vector<int32_t> intra(nb), invQ(nb);
-    int rc = fetch_propagate(ctx, slot, acc);
+    const unsigned long long* acc;
+    const int32_t *intra, *invQ;
+    int rc = fetch_finish_inputs(ctx, slot, &acc, &intra, &invQ);
     if (rc)
         return rc;
-    HIPCHK(hipMemcpyAsync(intra.data(), s.intraCost, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(invQ.data(), s.invQscale, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
     if (qg8)
-        cutree_finish_offsets_qg8(ctx->g.W, ctx->g.H, intra.data(), invQ.data(), acc.data(), fpsFactor, weightDelta,
-                                  cuTreeStrength, qpAqOffset, qpCuTreeOffset);
+        cutree_finish_offsets_qg8(ctx->g.W, ctx->g.H, intra, invQ, acc, fpsFactor, weightDelta, cuTreeStrength, qpAqOffset,
+                                  qpCuTreeOffset);
     else
-        cutree_finish_offsets((int)nb, intra.data(), invQ.data(), acc.data(), fpsFactor, weightDelta, cuTreeStrength,
-                              qpAqOffset, qpCuTreeOffset);
+        cutree_finish_offsets((int)nb, intra, invQ, acc, fpsFactor, weightDelta, cuTreeStrength, qpAqOffset, qpCuTreeOffset);
     return X265GPU_OK;
 }
 
@@ -2096,16 +2123,12 @@ int x265gpu_cutree_finish_hevc(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor
         qp[d] = l.dQpOffset;
         out[d] = l.dCuTreeOffset;
     }
-    const size_t nb = ctx->g.cuCount;
-    std::vector<unsigned long long> acc;
-    std::vector<int32_t> intra(nb), invQ(nb);
-    int rc = fetch_propagate(ctx, slot, acc);
+    const unsigned long long* acc;
+    const int32_t *intra, *invQ;
+    int rc = fetch_finish_inputs(ctx, slot, &acc, &intra, &invQ);
     if (rc)
         return rc;
-    HIPCHK(hipMemcpyAsync(intra.data(), s.intraCost, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(invQ.data(), s.invQscale, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    cutree_finish_hevc(ctx->g.W, ctx->g.H, ctx->cfg.sourceWidth, ctx->cfg.sourceHeight, qg8, intra.data(), invQ.data(), acc.data(),
+    cutree_finish_hevc(ctx->g.W, ctx->g.H, ctx->cfg.sourceWidth, ctx->cfg.sourceHeight, qg8, intra, invQ, acc,
                        fpsFactor, weightDelta, cuTreeStrength, numLayers, partW, partH, numW, numH, qp, out, dCuTreeOffset8x8);
     return X265GPU_OK;
 }

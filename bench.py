@@ -453,6 +453,7 @@ def rank_main(args):
 
         def work(k):
             try:
+                torch.cuda.set_device(local_rank)          # the current device is a per-thread setting
                 with torch.cuda.stream(pipes[k].stream):
                     for _ in range(k, count, in_flight):
                         segment_step(pipes[k])

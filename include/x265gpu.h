@@ -431,10 +431,12 @@ int x265gpu_aq_frames(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int
  * x265gpu_aq_frames_begin runs the energy pass, waits for it and fills wpSum / wpSsd (what LookaheadTLD::weightsAnalyse
  * reads); qpAqOffset, qpCuTreeOffset and invQscaleFactor are being written by library threads when it returns and
  * the arrays (and `quantOffsets`) must stay where they are.  x265gpu_aq_frames_finish joins those threads and installs
- * the scale factors; after it the arrays are the caller's again.  Until then x265gpu_intra_estimate calls are held
- * back (their AQ-weighted sums need the factors), and every call that reads scale factors or intra results - the cost
- * pass of an estimate call (after its searches have been queued), the cuTree calls, the getters, x265gpu_sync -
- * finishes the pending batches first, so only the caller's own reads of the three arrays need the explicit call. */
+ * the scale factors; after it the arrays are the caller's again.  An x265gpu_intra_estimate call made until then
+ * starts at once (the per-block intra costs and modes, which the weight analysis and the cost passes read, do not
+ * depend on AQ); only its AQ-weighted row and frame sums are redone when the factors are installed.  Every call that
+ * reads scale factors or those sums - the cost pass of an estimate call (after its searches have been queued), the
+ * cuTree calls, the getters, x265gpu_sync - finishes the pending batches first, so only the caller's own reads of the
+ * three arrays need the explicit call. */
 int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int32_t memKind, const x265gpu_aq_params* params);
 int x265gpu_aq_frames_finish(x265gpu_ctx* ctx);
 

@@ -20,8 +20,10 @@ __global__ void __launch_bounds__(256) cost_rows_kernel(const CostJob* jobs, Geo
 {
     __shared__ long long red[4][4];
 
-    const CostJob job = jobs[blockIdx.y];
-    const int cuY = blockIdx.x;
+    // grid (requests, block rows), the request fastest: the requests of a batch move down the picture together, so
+    // the rows of a frame that several of them read (as encode frame or as reference) are fetched from memory once
+    const CostJob job = jobs[blockIdx.x];
+    const int cuY = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = lane >> 3, r = lane & 7;
     const int W = g.W, H = g.H;
@@ -171,7 +173,7 @@ hipError_t launch_cost(hipStream_t s, const Geometry& g, int bpp, const CostJob*
 {
     if (n <= 0)
         return hipSuccess;
-    dim3 grid(g.H, n);
+    dim3 grid(n, g.H);
     if (bpp == 1)
         hipLaunchKernelGGL(cost_rows_kernel<uint8_t>, grid, dim3(256), 0, s, dJobs, g);
     else

@@ -201,7 +201,21 @@ __device__ __forceinline__ void weight_cost_rows(const WeightCostJob& job, const
         const int cuX = min(cuXraw, W - 1);
         const long long off = (long long)(8 * cuY + r) * g.stride + 8 * cuX;
         const Cols f = pair_cols<P>(load_row<P>((const P*)job.fencPlane0 + off));
-        const int satd = satd8x8<P>(f, load_row<P>((const P*)job.refPlane0 + off), r);
+        Row<P> ref = load_row<P>((const P*)job.refPlane0 + off);
+        if (job.weighted)       // uniform over the launch's y slice
+        {
+            // weight_pp (source/common/pixel.cpp:510-535) on the row just read
+            int v[8];
+            unpack_row<P>(ref, v);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+            {
+                const int val = (int)(short)(v[k] << job.correction);
+                v[k] = clampi(((job.w0 * val + job.round) >> job.shift) + job.offset, 0, job.pixelMax);
+            }
+            ref = pack_row<P>(v);
+        }
+        const int satd = satd8x8<P>(f, ref, r);
         if (cuXraw < W && r == 0)
             acc += (unsigned int)min(satd, job.intraCost[cuX + cuY * W]);
     }

@@ -85,6 +85,9 @@ struct WeightCostJob
     const void* refPlane0;      // origin of (possibly weighted) plane 0
     const int32_t* intraCost;
     unsigned int* out;          // single accumulator, zeroed by the host beforehand
+    // weighted != 0: refPlane0 is the unweighted reference and weight_pp (w0, round, shift, offset; `correction`
+    // = 14 - depth, clip to pixelMax) is applied to each row as it is read, instead of to a copy of the plane
+    int weighted, w0, round, shift, offset, correction, pixelMax, pad;
 };
 
 // launchers (defined in the .hip files); bytesPerPixel is 1 or 2

@@ -1239,7 +1239,7 @@ int x265gpu_weight_cost(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int
     Slot& sf = ctx->slots[slotFenc];
     Slot& sr = ctx->slots[slotRef];
     const int depth = ctx->cfg.internalBitDepth;
-    WeightCostJob job;
+    WeightCostJob job{};
     job.fencPlane0 = plane_origin(ctx, sf.planes);
     job.refPlane0 = plane_origin(ctx, sr.planes);
     job.intraCost = sf.intraCost;
@@ -1276,46 +1276,43 @@ int x265gpu_weight_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_weight_job* 
         return X265GPU_OK;
     const Geometry& g = ctx->g;
     const int depth = ctx->cfg.internalBitDepth;
-    const size_t planeBytes = align256((size_t)g.planeSize * ctx->bpp);
-    int weightedJobs = 0;
     for (int i = 0; i < n; i++)
-    {
         if (!slot_ok(ctx, jobs[i].slotFenc) || !slot_ok(ctx, jobs[i].slotRef))
             return fail(ctx, X265GPU_ERR_ARG, "weight_costs: bad slot");
-        weightedJobs += jobs[i].wtPresent != 0;
-    }
-    int rc = ensure_src_stage(ctx, planeBytes * (weightedJobs > 0 ? weightedJobs : 1));
-    if (rc)
-        return rc;
     const size_t accBytes = align256(sizeof(unsigned int) * (size_t)n);
-    rc = ensure_pu_buf(ctx, accBytes + sizeof(WeightCostJob) * (size_t)n);
+    int rc = ensure_pu_buf(ctx, accBytes + sizeof(WeightCostJob) * (size_t)n);
     if (rc)
         return rc;
     unsigned int* acc = (unsigned int*)ctx->puBuf;
     HIPCHK(hipMemsetAsync(acc, 0, sizeof(unsigned int) * (size_t)n, ctx->stream));
     std::vector<WeightCostJob> batch((size_t)n);
-    int w = 0;
     for (int i = 0; i < n; i++)
     {
         const x265gpu_weight_job& j = jobs[i];
         Slot& sf = ctx->slots[j.slotFenc];
         Slot& sr = ctx->slots[j.slotRef];
         WeightCostJob& job = batch[i];
+        memset(&job, 0, sizeof(job));
         job.fencPlane0 = plane_origin(ctx, sf.planes);
         job.refPlane0 = plane_origin(ctx, sr.planes);
         job.intraCost = sf.intraCost;
         job.out = acc + i;
         if (j.wtPresent)
         {
-            char* stage = ctx->srcStage + planeBytes * w++;
+            // the weighted reference (slicetype.cpp:822-834) is never written out: the kernel weights each row as
+            // it reads it
             const int corr = 14 - depth;
             const int round = j.log2Denom ? 1 << (j.log2Denom - 1) : 0;
-            HIPCHK(launch_weight_planes(ctx->stream, g, ctx->bpp, depth, 1, sr.planes, stage, j.scale, round << corr,
-                                        j.log2Denom + corr, j.offset * (1 << (depth - 8))));
-            job.refPlane0 = plane_origin(ctx, stage);
+            job.weighted = 1;
+            job.w0 = j.scale;
+            job.round = round << corr;
+            job.shift = j.log2Denom + corr;
+            job.offset = j.offset * (1 << (depth - 8));
+            job.correction = corr;
+            job.pixelMax = (1 << depth) - 1;
         }
     }
-    // one launch for every pair (the weighted copies above are in place by then: same stream)
+    // one launch for every pair
     WeightCostJob* dBatch = (WeightCostJob*)(ctx->puBuf + accBytes);
     HIPCHK(hipMemcpyAsync(dBatch, batch.data(), sizeof(WeightCostJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(launch_weight_cost_batch(ctx->stream, g, ctx->bpp, dBatch, n));
@@ -1346,7 +1343,7 @@ int x265gpu_weight_cost_static(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
     const int depth = ctx->cfg.internalBitDepth;
     unsigned int* acc = (unsigned int*)ctx->staticScratch;
     char* plane = ctx->staticScratch + STATIC_SCRATCH_PLANE;
-    WeightCostJob job;
+    WeightCostJob job{};
     job.fencPlane0 = plane_origin(ctx, sf.planes);
     job.refPlane0 = plane_origin(ctx, sr.planes);
     job.intraCost = sf.intraCost;

@@ -173,7 +173,10 @@ int x265gpu_lowres_init_batch(x265gpu_ctx* ctx, int32_t n, const int32_t* slots,
  * array is copied before the call returns (the upload itself stays asynchronous). */
 int x265gpu_lowres_set_aq(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQscaleFactor);
 
-/* LookaheadTLD::lowresIntraEstimate (slicetype.cpp:706-815) for n slots. */
+/* LookaheadTLD::lowresIntraEstimate (slicetype.cpp:706-815) for n slots.  It may be called before or after the
+ * slot's scale factors are given (x265gpu_lowres_set_aq, the x265gpu_aq_frame* calls): the per-block costs and modes
+ * do not depend on them, and the AQ-weighted row and frame sums are redone with whatever factors are installed
+ * after the estimate was launched, before any call reads them. */
 int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots);
 
 /* ---- cost estimation: CostEstimateGroup::add/finishBatch/singleCost

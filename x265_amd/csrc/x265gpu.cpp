@@ -28,6 +28,7 @@ struct Slot
     uint8_t* intraMode = nullptr;
     int32_t* invQscale = nullptr;
     bool hasAq = false;
+    bool intraFresh = false;       // an intra estimate of the picture now in the slot has been launched
     unsigned long long fullSerial = 0;   // uploads of the full-resolution picture so far
     int32_t* aqStage = nullptr;    // page-locked staging copy of the caller's invQscaleFactor, allocated on first use
     hipEvent_t aqStaged = nullptr; // the last upload from aqStage
@@ -140,7 +141,8 @@ struct x265gpu_ctx
     char* aqDev = nullptr;              // the batched AQ pass's device arrays and their page-locked mirror, kept between
     char* aqHost = nullptr;             //   calls and grown when a larger batch comes
     size_t aqBufBytes = 0;
-    std::vector<int32_t> intraDeferred;    // slots whose intra estimate waits for those batches' scale factors
+    std::vector<int32_t> intraDeferred;    // slots whose intra estimate ran ahead of their scale factors: AQ sums to redo
+    bool aqInstalledOnMain = false;        // some of those factors were uploaded on the main stream (x265gpu_lowres_set_aq)
     int flowGridPad = 1;
     uint32_t* flowChunks[2] = { nullptr, nullptr };   // chunk tables of the half-res and the quarter-res block grid
     int flowChunkCount[2] = { 0, 0 };
@@ -808,6 +810,7 @@ int x265gpu_lowres_init_batch(x265gpu_ctx* ctx, int32_t n, const int32_t* slots,
     {
         Slot& s = ctx->slots[slots[i]];
         s.poc = pocs ? pocs[i] : 0;
+        s.intraFresh = false;
         if (memKind == X265GPU_MEM_HOST)
         {
             char* dst = ctx->srcStage + frameBytes * i;
@@ -854,6 +857,13 @@ static int set_aq_staged(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQscal
     if (!stream)
         stream = ctx->stream;
     Slot& s = ctx->slots[slot];
+    // Factors that arrive after the picture's intra estimate: its AQ-weighted sums are redone (aq_finish_pending)
+    // before anything reads them, behind this upload.
+    if (s.intraFresh)
+    {
+        ctx->intraDeferred.push_back(slot);
+        ctx->aqInstalledOnMain = true;
+    }
     if (!invQscaleFactor)
     {
         s.hasAq = false;
@@ -909,6 +919,7 @@ int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots)
         Slot& s = ctx->slots[slots[i]];
         jobs[i].plane0 = plane_origin(ctx, s.planes);
         jobs[i].invQscale = (s.hasAq && !aqLater) ? s.invQscale : nullptr;
+        s.intraFresh = true;
         jobs[i].intraCost = s.intraCost;
         jobs[i].intraMode = s.intraMode;
         jobs[i].lowresCosts = s.lowresCosts;   // [0][0]
@@ -2514,7 +2525,8 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
 // mapping of the offsets to host threads.  Returns with those threads running when there is a mapping to do.
 int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int32_t memKind, const x265gpu_aq_params* params)
 {
-    DeviceScope deviceScope(ctx);
+    // reads nothing an intra estimate writes: one that was launched just before keeps running beside the energy pass
+    DeviceScope deviceScope(ctx, false);
     if (!ctx || !params || n < 0 || (n && !pics))
         return X265GPU_ERR_ARG;
     if (!n)
@@ -2671,7 +2683,12 @@ int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pic
     // aq_finish_pending, which every pass that reads them goes through before it is launched.
     for (int i = 0; i < n; i++)
         if (pics[i].slot >= 0)
-            ctx->slots[pics[i].slot].hasAq = true;
+        {
+            Slot& s = ctx->slots[pics[i].slot];
+            s.hasAq = true;
+            if (s.intraFresh)       // estimated before this call: the AQ-weighted sums follow the factors
+                ctx->intraDeferred.push_back(pics[i].slot);
+        }
     return X265GPU_OK;
 }
 
@@ -2687,6 +2704,14 @@ static int aq_finish_pending(x265gpu_ctx* ctx)
     // the searches; the main stream joins before its next pass that reads them.
     const bool side = ctx->intraStream && !ctx->prof;
     hipStream_t up = side ? ctx->intraStream : ctx->stream;
+    if (ctx->aqInstalledOnMain)
+    {
+        // factors uploaded on the main stream (x265gpu_lowres_set_aq) must be in place before the sums are redone
+        if (side && (hipEventRecord(ctx->intraFork, ctx->stream) != hipSuccess ||
+                     hipStreamWaitEvent(up, ctx->intraFork, 0) != hipSuccess))
+            rc = X265GPU_ERR_DEVICE;
+        ctx->aqInstalledOnMain = false;
+    }
     std::vector<x265gpu_ctx::AqPending*> batches;
     batches.swap(ctx->aqPending);
     for (x265gpu_ctx::AqPending* b : batches)

@@ -244,10 +244,14 @@ int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const Picture*
         a.qpCuTreeOffset = fr.qpCuTreeOffset;
         a.invQscaleFactor = fr.invQscaleFactor;
     }
+    // The intra estimate goes first: its per-block costs need no AQ (weightsAnalyse reads them), so it runs on the
+    // library's side stream beside the AQ energy pass; its AQ-weighted sums follow the scale factors by themselves.
+    rc = x265gpu_intra_estimate(m_ctx, n, slots.data());
+    if (rc != X265GPU_OK)
+        return rc;
     // pictures of one batch live in one kind of memory.  The sums that weightsAnalyse reads are back when this
-    // returns; the offsets are still being mapped on the library's host threads, the intra estimate (whose AQ-weighted
-    // sums need them) is held back with them, and both are finished from inside the next estimate call, after its
-    // searches have been queued: resolveIntraTotals() then reads the frames' intra totals.
+    // returns; the offsets are still being mapped on the library's host threads and are finished from inside the
+    // next estimate call, after its searches have been queued: resolveIntraTotals() then reads the frames' intra totals.
     rc = x265gpu_aq_frames_begin(m_ctx, n, ap.data(), pics[0].memKind, &aq);
     if (rc != X265GPU_OK)
         return rc;
@@ -255,12 +259,8 @@ int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const Picture*
     {
         frames[i]->wp_sum = ap[i].wpSum[0];
         frames[i]->wp_ssd = ap[i].wpSsd[0];
-    }
-    rc = x265gpu_intra_estimate(m_ctx, n, slots.data());
-    if (rc != X265GPU_OK)
-        return rc;
-    for (int i = 0; i < n; i++)
         frames[i]->intraTotalsPending = true;
+    }
     return X265GPU_OK;
 }
 

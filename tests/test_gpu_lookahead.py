@@ -83,6 +83,31 @@ def test_lowres_planes_and_intra(depth, size):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
+def test_scale_factors_after_the_intra_estimate(depth):
+    """The intra estimate's per-block costs do not depend on AQ; its AQ-weighted row and frame sums do.  Factors
+    installed after the estimate was launched (also a second set, and their removal) must show in those sums."""
+    W, H = 392, 216
+    clip = synth.luma_clip(W, H, 1, depth, seed=23)
+    rng = np.random.default_rng(24)
+    with api.Context(W, H, depth=depth, num_slots=1) as ctx:
+        n = ctx.geom.cuCount
+        ctx.lowres_init(0, clip[0])
+        ctx.intra_estimate([0])
+        for inv in (rng.integers(128, 513, size=n).astype(np.int32), rng.integers(64, 300, size=n).astype(np.int32), None):
+            ref = orc.Lookahead(depth, orc.make_param(W, H), with_aq=inv is not None)
+            try:
+                fr = ref.add_frame(clip[0], inv) if inv is not None else ref.add_frame(clip[0])
+                ctx.set_aq(0, inv)
+                lc, rs, (ce, ceaq, _) = ctx.get_costs(0, 0, 0)
+                np.testing.assert_array_equal(ctx.get_intra(0)[0], fr.intra_cost())
+                np.testing.assert_array_equal(lc, fr.lowres_costs(0, 0))
+                np.testing.assert_array_equal(rs, fr.row_satds(0, 0))
+                assert (ce, ceaq) == (fr.i64("costEst", 0, 0), fr.i64("costEstAq", 0, 0))
+            finally:
+                ref.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
 def test_mcstf_downscale_filter(depth):
     """--mcstf: rounded 2x2 mean instead of cascaded averages, and quarter-res planes without HME."""
     W, H = 424, 242

@@ -241,10 +241,19 @@ def pmc_kernel(args, kernel_name):
             summary = json.load(f)
     except (OSError, ValueError):
         return None
-    for name, counters in summary.items():
-        if kernel_name in name:
-            return counters
-    return None
+    found = [c for name, c in summary.items() if kernel_name in name and c.get("dispatches")]
+    if not found:
+        return None
+    if len(found) == 1:
+        return found[0]
+    # several instantiations of one kernel in a step (--hme: the quarter-res and the half-res search, one launch
+    # each): per-step totals, every counter divided by its kernel's dispatch count first
+    total = {"dispatches": 1.0}
+    for c in found:
+        for k, v in c.items():
+            if k != "dispatches":
+                total[k] = total.get(k, 0.0) + v / c["dispatches"]
+    return total
 
 
 def pmc_traffic_per_launch(c):
@@ -614,6 +623,8 @@ def rank_main(args):
         launches = v["launches_per_step"]
         if k in ("intra", "cost") or (k == "search" and mode == "flow"):
             launches /= 2
+        if k == "search" and mode == "flow" and args.hme:
+            launches = 1        # the two levels' kernels come back from pmc_kernel() summed per step
         insts = c["SQ_INSTS_VALU"] / c["dispatches"] * launches
         v["valu_G_insts_per_s"] = insts / (v["ms_per_step"] * 1e-3) / 1e9
         v["valu_frac"] = v["valu_G_insts_per_s"] / valu_peak
@@ -634,7 +645,7 @@ def rank_main(args):
         # not HBM.  Instructions per block search come from the counter passes of this configuration, cycles per
         # instruction and the clock from the microbenchmark.
         per_wave = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"]
-        units = n_search * n                                            # block searches per step
+        units = pmc["SQ_WAVES"] / pmc["dispatches"]                    # block searches per step (a wave each; with --hme both levels)
         achieved = per_wave * units / (dom["ms_per_step"] * 1e-3) / 1e9
         roofline.update({"bound": "valu", "achieved": achieved, "peak": valu_peak, "unit": "G wave64-instructions/s",
                          "frac": achieved / valu_peak, "frac_at_sad_class_rate": achieved / valu_peak_packed,

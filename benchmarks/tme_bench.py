@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--amp", action="store_true")
     ap.add_argument("--b-picture", action="store_true")
     ap.add_argument("--cpu-ctus", type=int, default=2)
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="generator instances (library context + ThreadedME + host thread each) that take the row groups of a "
+                         "picture in turn: one's host stages run beside another's device calls (CTUs are independent)")
     a = ap.parse_args()
     W, H, ctu, lam = a.width, a.height, 64, 4.0
     n = 3 if a.b_picture else 2
@@ -37,35 +40,56 @@ def main():
     cur = 1
     from oracle import orc          # host-built input tables, as BitCost makes them
     la_table, la_centre = orc.bitcost_table(a.depth)
-    ctx = api.Context(W, H, depth=a.depth, num_slots=n, ctu=ctu, keep_full_res=True, bframes=4)
-    for k in range(n):
-        ctx.lowres_init(k, clip[k], poc=k)
-    ctx.set_mvcost(la_table, la_centre)
-    ctx.intra_estimate(list(range(n)))
-    ctx.estimate([(0, cur, cur, 0, cur, cur, 1, 0)])
+    import threading
+    P = max(1, a.in_flight)
+    ctxs, tmes = [], []
+    for _ in range(P):
+        c = api.Context(W, H, depth=a.depth, num_slots=n, ctu=ctu, keep_full_res=True, bframes=4)
+        for k in range(n):
+            c.lowres_init(k, clip[k], poc=k)
+        c.set_mvcost(la_table, la_centre)
+        c.intra_estimate(list(range(n)))
+        c.estimate([(0, cur, cur, 0, cur, cur, 1, 0)])
+        if a.b_picture:
+            c.estimate([(0, cur, 2, 0, cur, 2, 0, 1)])
+        ctxs.append(c)
+        tmes.append(api.ThreadedME(c, search=api.STAR_SEARCH, merange=57, subpel=3, amp=a.amp, rect=True, min_cu=8, lam=lam))
+    ctx, tme = ctxs[0], tmes[0]
     lowres0 = ctx.get_mvs(cur, 0, 1)[0]
     refs = [(0, 0, True, None, lowres0)]
-    refs_l1 = []
-    if a.b_picture:
-        ctx.estimate([(0, cur, 2, 0, cur, 2, 0, 1)])
-        refs_l1 = [(2, 2, True, None, ctx.get_mvs(cur, 1, 1)[0])]
-    tme = api.ThreadedME(ctx, search=api.STAR_SEARCH, merange=57, subpel=3, amp=a.amp, rect=True, min_cu=8, lam=lam)
+    refs_l1 = [(2, 2, True, None, ctx.get_mvs(cur, 1, 1)[0])] if a.b_picture else []
     counts = tme.counts()
     rows_total = counts["rows"]
-    step = a.rows or rows_total
+    step = a.rows or -(-rows_total // P)
     table = tme.new_table()
-    tme.estimate_rows(cur, cur, refs, 0, 1, table, refs_l1=refs_l1)          # warm-up
+    for t in tmes:
+        t.estimate_rows(cur, cur, refs, 0, 1, table, refs_l1=refs_l1)          # warm-up
+    groups = list(range(0, rows_total, step))
+
+    def work(k):
+        for r in groups[k::P]:
+            tmes[k].estimate_rows(cur, cur, refs, r, min(rows_total, r + step), table, refs_l1=refs_l1)
     times = []
     for _ in range(a.reps):
-        s0, sec0 = tme.counts(), tme.seconds()
+        s0 = [t.counts() for t in tmes]
+        sec0 = [t.seconds() for t in tmes]
         t0 = time.perf_counter()
-        for r in range(0, rows_total, step):
-            tme.estimate_rows(cur, cur, refs, r, min(rows_total, r + step), table, refs_l1=refs_l1)
+        if P == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(k,)) for k in range(P)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
         times.append(time.perf_counter() - t0)
-        s1, sec1 = tme.counts(), tme.seconds()
+        s1 = [t.counts() for t in tmes]
+        sec1 = [t.seconds() for t in tmes]
     dt = sorted(times)[len(times) // 2]
-    searches = s1["searches"] - s0["searches"]
-    calls = s1["device_calls"] - s0["device_calls"]
+    searches = sum(b["searches"] - a_["searches"] for a_, b in zip(s0, s1))
+    calls = sum(b["device_calls"] - a_["device_calls"] for a_, b in zip(s0, s1))
+    sec0 = {k: sum(x[k] for x in sec0) for k in sec0[0]}
+    sec1 = {k: sum(x[k] for x in sec1) for k in sec1[0]}
     ctus = counts["cols"] * rows_total
     out = {"metric": "--threaded-me pictures per second (star, merange 57, subme 3)", "value": 1.0 / dt, "unit": "pictures/s",
            "seconds_per_picture": dt, "ctus": ctus, "pu_searches_per_picture": searches, "pu_searches_per_s": searches / dt,
@@ -73,7 +97,8 @@ def main():
            "inside_device_calls_s": sec1["device"] - sec0["device"], "tasks_per_ctu": counts["tasks"], "dependency_levels": counts["levels"],
            "config": {"workload": "%dx%d %d-bit %s picture, %s PU shapes, min CU 8, %d CTU rows per call"
                                   % (W, H, a.depth, "B (one reference each way)" if a.b_picture else "P (one reference)",
-                                     "all 24" if a.amp else "square and rectangular", step)},
+                                     "all 24" if a.amp else "square and rectangular", step),
+                      "generator_instances": P},
            "note": "wall time of ThreadedME::estimateRows over the whole picture: host predictor logic, job upload, kernels, "
                    "result download, level after level"}
     if a.cpu_ctus > 0:
@@ -101,8 +126,10 @@ def main():
                                          "the bookkeeping Python), checked equal to the GPU table" % (a.cpu_ctus, row)}
         for m in mes:
             m.close()
-    tme.close()
-    ctx.close()
+    for t in tmes:
+        t.close()
+    for c in ctxs:
+        c.close()
     print(json.dumps(out))
 
 

@@ -483,15 +483,15 @@ __device__ __forceinline__ void hex_search(BlockCtx<P>& c, int merange, int& bmx
 
 // Up to eight full-pel candidates, one per group, accepted in group order with
 // the reference's strict '<' (COST_MV / COST_MV_X4 semantics, motion.cpp:263-323).
-// `mask` (wave-uniform) says which groups hold a candidate that may be accepted;
-// the others are neither loaded nor compared.
+// `active` (per lane, uniform within a group) says whether the group holds a candidate that may be
+// accepted; the others are neither loaded nor compared.  Callers form it from the lane's own candidate
+// (a couple of vector compares) rather than as a wave-uniform bit mask over all eight candidates.
 // When every candidate of the pass (block and both MV-cost entries) lies inside what is staged in
 // LDS, the pass reads it there; the long-range steps, which no window covers, go to global memory.
 template <typename P>
-__device__ __forceinline__ void try_points(const BlockCtx<P>& c, int mx, int my, unsigned mask, int& bmx, int& bmy,
+__device__ __forceinline__ void try_points(const BlockCtx<P>& c, int mx, int my, bool active, int& bmx, int& bmy,
                                            int& bcost)
 {
-    const bool active = ((mask >> c.g) & 1u) != 0;
     const bool staged = (unsigned)(c.relX + mx) <= (unsigned)(WIN - 8) && (unsigned)(c.relY + my) <= (unsigned)(WIN - 8) &&
                         (unsigned)(4 * mx + c.tabBiasX) < (unsigned)TAB_N &&
                         (unsigned)(4 * my + c.tabBiasY - TAB_N) < (unsigned)TAB_N;
@@ -510,19 +510,8 @@ __device__ __forceinline__ void try_points(const BlockCtx<P>& c, int mx, int my,
     take_winner(wave_min(active ? make_key(cost, c.g + 1, c.g) : KEY_INVALID), mx, my, bmx, bmy, bcost);
 }
 
-// COST_MV_X4 around (ox,oy) with offsets from nibble tables: all four are
-// accepted subject to their row being in range (motion.cpp:302-323); a second
-// independent x4 (other origin, same offsets) may ride in groups 4..7.
-template <typename P>
-__device__ __forceinline__ unsigned x4_mask(const BlockCtx<P>& c, int oy, uint32_t tabY, int first)
-{
-    unsigned m = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (y_ok<P>(c, oy + nib(tabY, first + k)))
-            m |= 1u << k;
-    return m;
-}
+// COST_MV_X4 (motion.cpp:302-323) accepts each of its four points subject to the point's own row being inside
+// mvmin.y..mvmax.y: for a lane that is y_ok() of its own candidate.
 
 // CROSS(start, x_max, y_max) around (ox,oy): motion.cpp:361-385
 template <typename P>
@@ -538,46 +527,26 @@ __device__ __forceinline__ void umh_cross(const BlockCtx<P>& c, int ox, int oy, 
         if (lim <= room)
         {
             // x4 passes (i, -i, i+2, -i-2); two reference iterations per pass
-            const unsigned rowok = dirY ? 0u : (y_ok<P>(c, oy) ? 0xFu : 0u);
             while (i < lim - 2)
             {
                 const bool two = i + 4 < lim - 2;
                 const int ii = i + ((c.g >= 4) ? 4 : 0);
                 const int sel = c.g & 3;
                 const int d = (sel == 0) ? ii : (sel == 1) ? -ii : (sel == 2) ? ii + 2 : -ii - 2;
-                unsigned m;
-                if (dirY)
-                {
-                    m = (y_ok<P>(c, oy + i) ? 1u : 0u) | (y_ok<P>(c, oy - i) ? 2u : 0u) |
-                        (y_ok<P>(c, oy + i + 2) ? 4u : 0u) | (y_ok<P>(c, oy - i - 2) ? 8u : 0u);
-                    if (two)
-                        m |= (y_ok<P>(c, oy + i + 4) ? 16u : 0u) | (y_ok<P>(c, oy - i - 4) ? 32u : 0u) |
-                             (y_ok<P>(c, oy + i + 6) ? 64u : 0u) | (y_ok<P>(c, oy - i - 6) ? 128u : 0u);
-                }
-                else
-                    m = rowok | (two ? rowok << 4 : 0u);
-                try_points<P>(c, dirY ? ox : ox + d, dirY ? oy + d : oy, m, bmx, bmy, bcost);
+                const int mx = dirY ? ox : ox + d, my = dirY ? oy + d : oy;
+                try_points<P>(c, mx, my, (c.g < 4 || two) && y_ok<P>(c, my), bmx, bmy, bcost);
                 i += two ? 8 : 4;
             }
         }
         // checked single points, (+i, -i) per reference iteration; four iterations per pass
         while (i < lim)
         {
-            const int it = c.g >> 1;                 // 0..3
-            const int ii = i + 2 * it;
-            const int d = (c.g & 1) ? -ii : ii;
-            unsigned m = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-            {
-                const int ik = i + 2 * k;
-                if (ik < lim)
-                {
-                    if (dirY ? (oy + ik <= c.maxy) : (ox + ik <= c.maxx)) m |= 1u << (2 * k);
-                    if (dirY ? (oy - ik >= c.miny) : (ox - ik >= c.minx)) m |= 2u << (2 * k);
-                }
-            }
-            try_points<P>(c, dirY ? ox : ox + d, dirY ? oy + d : oy, m, bmx, bmy, bcost);
+            const int ii = i + 2 * (c.g >> 1);
+            const bool neg = (c.g & 1) != 0;
+            const int d = neg ? -ii : ii;
+            const int at = (dirY ? oy : ox) + d;       // the coordinate that moves
+            const bool ok = ii < lim && (neg ? at >= (dirY ? c.miny : c.minx) : at <= (dirY ? c.maxy : c.maxx));
+            try_points<P>(c, dirY ? ox : ox + d, dirY ? oy + d : oy, ok, bmx, bmy, bcost);
             i += 8;
         }
     }
@@ -606,17 +575,15 @@ __device__ __forceinline__ bool umh_search(BlockCtx<P>& c, int pmx, int pmy, int
     {
         // DIA1 around the rounded predictor, and around (0,0) when the predictor is not zero
         const int sel = c.g & 3;
-        const int ox = (c.g < 4) ? pmx : 0, oy = (c.g < 4) ? pmy : 0;
-        unsigned m = x4_mask<P>(c, pmy, DIA1_Y, 0);
-        if (pnz)
-            m |= x4_mask<P>(c, 0, DIA1_Y, 0) << 4;
-        try_points<P>(c, ox + nib(DIA1_X, sel), oy + nib(DIA1_Y, sel), m, bmx, bmy, bcost);
+        const int mx = ((c.g < 4) ? pmx : 0) + nib(DIA1_X, sel), my = ((c.g < 4) ? pmy : 0) + nib(DIA1_Y, sel);
+        try_points<P>(c, mx, my, (c.g < 4 || pnz) && y_ok<P>(c, my), bmx, bmy, bcost);
     }
     const int ucost2 = bcost;
     if ((bmx | bmy) && (bmx != pmx || bmy != pmy))
     {
         const int sel = c.g & 3;
-        try_points<P>(c, bmx + nib(DIA1_X, sel), bmy + nib(DIA1_Y, sel), x4_mask<P>(c, bmy, DIA1_Y, 0), bmx, bmy, bcost);
+        const int my = bmy + nib(DIA1_Y, sel);
+        try_points<P>(c, bmx + nib(DIA1_X, sel), my, c.g < 4 && y_ok<P>(c, my), bmx, bmy, bcost);
     }
     if (bcost == ucost2)
         cross_start = 3;
@@ -624,16 +591,20 @@ __device__ __forceinline__ bool umh_search(BlockCtx<P>& c, int pmx, int pmy, int
     const int ox = bmx, oy = bmy;   // the later cross stays centred here (motion.cpp:1238)
     if (bcost == ucost2 && UMH_THRESH(2000))
     {
-        try_points<P>(c, ox + nib(OCT_X, c.g), oy + nib(OCT_Y, c.g),
-                      x4_mask<P>(c, oy, OCT_Y, 0) | (x4_mask<P>(c, oy, OCT_Y, 4) << 4), bmx, bmy, bcost);
+        {
+            const int my = oy + nib(OCT_Y, c.g);
+            try_points<P>(c, ox + nib(OCT_X, c.g), my, y_ok<P>(c, my), bmx, bmy, bcost);
+        }
         if (bcost == ucost1 && UMH_THRESH(500))
             return false;
         if (bcost == ucost2)
         {
             const int range = (short)((merange >> 1) | 1);
             umh_cross<P>(c, ox, oy, 3, range, range, bmx, bmy, bcost);
-            try_points<P>(c, ox + nib(RING_X, c.g), oy + nib(RING_Y, c.g),
-                          x4_mask<P>(c, oy, RING_Y, 0) | (x4_mask<P>(c, oy, RING_Y, 4) << 4), bmx, bmy, bcost);
+            {
+                const int my = oy + nib(RING_Y, c.g);
+                try_points<P>(c, ox + nib(RING_X, c.g), my, y_ok<P>(c, my), bmx, bmy, bcost);
+            }
             if (bcost == ucost2)
                 return false;
             cross_start = range + 2;
@@ -641,7 +612,10 @@ __device__ __forceinline__ bool umh_search(BlockCtx<P>& c, int pmx, int pmy, int
     }
 
     umh_cross<P>(c, ox, oy, cross_start, merange, merange >> 1, bmx, bmy, bcost);
-    try_points<P>(c, ox + nib(CORN_X, c.g & 3), oy + nib(CORN_Y, c.g & 3), x4_mask<P>(c, oy, CORN_Y, 0), bmx, bmy, bcost);
+    {
+        const int my = oy + nib(CORN_Y, c.g & 3);
+        try_points<P>(c, ox + nib(CORN_X, c.g & 3), my, c.g < 4 && y_ok<P>(c, my), bmx, bmy, bcost);
+    }
 
     // hexagon grid of growing radius around the best so far; its first three radii (up to +-12) fit a
     // window centred here
@@ -658,19 +632,11 @@ __device__ __forceinline__ bool umh_search(BlockCtx<P>& c, int pmx, int pmy, int
             const uint32_t ty = half ? H4Y1 : H4Y0;
             const int dx = nib(tx, c.g);
             const int dy = nib(ty, c.g);
-            unsigned m = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-            {
-                const int kdx = nib(tx, k);
-                const int kdy = nib(ty, k);
-                // near the border every point is range-checked; otherwise only the row of the
-                // UNSCALED pattern offset is tested (MIN_MV, motion.cpp:1274)
-                const bool ok = near ? in_range<P>(c, hx + kdx * (int)i, hy + kdy * (int)i) : y_ok<P>(c, hy + kdy);
-                if (ok)
-                    m |= 1u << k;
-            }
-            try_points<P>(c, hx + dx * (int)i, hy + dy * (int)i, m, bmx, bmy, bcost);
+            const int mx = hx + dx * (int)i, my = hy + dy * (int)i;
+            // near the border every point is range-checked; otherwise only the row of the
+            // UNSCALED pattern offset is tested (MIN_MV, motion.cpp:1274)
+            const bool ok = near ? in_range<P>(c, mx, my) : y_ok<P>(c, hy + dy);
+            try_points<P>(c, mx, my, ok, bmx, bmy, bcost);
         }
     }
     while (++i <= (unsigned)(merange >> 2));

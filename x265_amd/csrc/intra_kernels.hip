@@ -72,7 +72,7 @@ __device__ __forceinline__ void predict_row(const int* nb, int* ext, int mode, i
             else if (i == -1)
                 v = s[0];
             else
-                v = s[sideBase - 1 + ((128 + (-1 - i) * inv) >> 8)];     // ref[i] = side[(i * invAngle + 128) >> 8] mirrored
+                v = s[sideBase - 1 + ((128 + __mul24(-1 - i, inv)) >> 8)];     // ref[i] = side[(i * invAngle + 128) >> 8] mirrored
             ext[j] = v;
         }
     }
@@ -84,10 +84,11 @@ __device__ __forceinline__ void predict_row(const int* nb, int* ext, int mode, i
         {
             // (yy, xx): position in the un-transposed prediction
             const int yy = hor ? x : r, xx = hor ? r : x;
-            const int angSum = (yy + 1) * angle;
+            // small operands throughout: 24-bit multiplies issue at full rate, 32-bit ones at a quarter of it
+            const int angSum = __mul24(yy + 1, angle);
             const int idx = (angSum >> 5) + xx + 8, frac = angSum & 31;
             const int a = ext[idx], b = ext[idx + 1];
-            p[x] = ((32 - frac) * a + frac * b + 16) >> 5;
+            p[x] = (__mul24(frac, b - a) + (a << 5) + 16) >> 5;      // = ((32 - frac) * a + frac * b + 16) >> 5
         }
         if (angle == 0)
         {
@@ -125,7 +126,7 @@ __device__ __forceinline__ void predict_row(const int* nb, int* ext, int mode, i
         const int tr = s[9], bl = s[25], lf = s[17 + r];
 #pragma unroll
         for (int x = 0; x < 8; x++)
-            p[x] = ((7 - x) * lf + (7 - r) * s[1 + x] + (x + 1) * tr + (r + 1) * bl + 8) >> 4;
+            p[x] = (__mul24(7 - x, lf) + __mul24(7 - r, s[1 + x]) + __mul24(x + 1, tr) + __mul24(r + 1, bl) + 8) >> 4;
     }
     lds_handover();     // `ext` is rewritten by the next call
 }

@@ -132,7 +132,7 @@ __device__ __forceinline__ void predict_row(const int* nb, int* ext, int mode, i
 }
 
 template <typename P>
-__global__ void __launch_bounds__(256) intra_kernel(const IntraJob* jobs, Geometry g, int lambda, int pixelMax)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) intra_kernel(const IntraJob* jobs, Geometry g, int lambda, int pixelMax)
 {
     __shared__ int nbr[4][4][80];          // [wave][block][raw 0..32, smoothed 40..72]
     __shared__ int extRef[4][8][32];       // [wave][group]: the angular reference array being used

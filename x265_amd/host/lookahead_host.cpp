@@ -734,14 +734,10 @@ int CuTree::cuTree(Lowres* const* frames, int numframes, bool bIntra)
 // whose entries are round(256 * (2^(i/64) - 1)); inside x265 this is the function itself
 static int exp2fix8(double x)
 {
-    static int lut[64];
-    static bool ready = false;
-    if (!ready)
-    {
-        for (int k = 0; k < 64; k++)
-            lut[k] = (int)lround(256.0 * (exp2(k / 64.0) - 1.0));
-        ready = true;
-    }
+    // filled once, by whichever thread comes first (instances on several host threads share it)
+    struct Lut { int v[64]; Lut() { for (int k = 0; k < 64; k++) v[k] = (int)lround(256.0 * (exp2(k / 64.0) - 1.0)); } };
+    static const Lut table;
+    const int* lut = table.v;
     const int i = (int)(x * (-64.f / 6.f) + 512.5f);
     if (i < 0)
         return 0;

@@ -206,7 +206,8 @@ int x265gpu_estimate_sums_device(x265gpu_ctx* ctx, int32_t n, const x265gpu_requ
 
 /* weightCostLuma (slicetype.cpp:817-850): sum over 8x8 blocks of
  * min(SATD(ref [weighted], fenc), intraCost).  wtPresent == 0 measures the
- * unweighted reference.  The result is written to *cost after a sync. */
+ * unweighted reference.  The result is written to *cost after a sync.  Reads slotFenc's per-block intra costs:
+ * x265gpu_intra_estimate for that slot must have been issued (it need not have been given its AQ factors yet). */
 int x265gpu_weight_cost(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t wtPresent,
                         int32_t scale, int32_t log2Denom, int32_t offset, uint32_t* cost);
 /* n x265gpu_weight_cost measurements with one wait at the end (the weight analyses of a batch of requests are

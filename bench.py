@@ -655,8 +655,9 @@ def rank_main(args):
                          "note": "vector-issue roofline: measured instructions per 8x8 block search x block searches / phase time, "
                                  "against 1024 SIMDs x measured clock / measured cycles per wave64 instruction of the fastest kind "
                                  "(32-bit add); frac_at_sad_class_rate uses the measured rate of v_sad_u8 / v_pk_add_i16 / v_min_i32 / "
-                                 "v_alignbyte_b32, which the search is mostly made of and which issue 1.8x more slowly; the rest of a "
-                                 "wave's life is latency (memory round trips, LDS, scalar chain) that eight waves per SIMD do not cover"})
+                                 "v_alignbyte_b32, which the search is mostly made of and which issue 1.8x more slowly, measured for an "
+                                 "independent stream; the kernel's stream is dependent (SAD, DPP adds, DPP minima, lane read per step) and "
+                                 "by an occupancy test (8 -> 6 waves per SIMD costs 12 %) the phase is mostly at its issue limit"})
     elif dominant == "search":
         roofline["note"] = ("no counter pass committed for this configuration (profiles/pmc_%s.json): the vector-issue "
                             "fraction is not reported; the HBM fraction is small by construction (integer search out of LDS)"

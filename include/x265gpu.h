@@ -14,7 +14,10 @@
  * code; nothing throws; all host buffers are caller-owned; strides are in
  * PIXELS as in x265; `pixel` is uint8_t when bitDepth == 8 and uint16_t
  * otherwise (source/common/common.h:127-141).  A context is bound to one
- * device and one HIP stream; calls on one context must not overlap.
+ * device and one HIP stream.  Every entry point holds the context's lock while
+ * it runs, so calls on one context from several host threads take turns; what
+ * a begin/finish pair or x265gpu_last_error means across threads stays the
+ * caller's business.  Different contexts run side by side.
  * There is no CPU fallback: if no gfx950 device or no kernel image is
  * available, x265gpu_open fails.
  */

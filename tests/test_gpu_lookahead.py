@@ -107,6 +107,47 @@ def test_scale_factors_after_the_intra_estimate(depth):
                 ref.close()
 
 
+def test_two_host_threads_on_one_context():
+    """Calls on one context take turns under the context's lock: two host threads, each preparing and reading back
+    its own pictures (shared staging buffers, job lists and streams underneath), both get the oracle's numbers."""
+    import threading
+    W, H, N = 392, 216, 8
+    clip = synth.luma_clip(W, H, N, 8, seed=31)
+    ref = orc.Lookahead(8, orc.make_param(W, H))
+    for f in clip:
+        ref.add_frame(f)
+    got, errors = {}, []
+    with api.Context(W, H, depth=8, num_slots=N) as ctx:
+        def worker(slots):
+            try:
+                for rep in range(3):
+                    for i in slots:
+                        ctx.lowres_init(i, clip[i], poc=i)
+                        ctx.intra_estimate([i])
+                        got[i] = ([ctx.get_plane(i, p) for p in range(4)], ctx.get_intra(i), ctx.get_costs(i, 0, 0))
+            except Exception as e:      # noqa: BLE001 - reported by the parent thread
+                errors.append(e)
+        threads = [threading.Thread(target=worker, args=(range(k, N, 2),)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    try:
+        assert not errors, errors
+        for i in range(N):
+            planes, (cost, mode), (lc, rs, (ce, ceaq, _)) = got[i]
+            fr = ref.frames[i]
+            for p in range(4):
+                np.testing.assert_array_equal(planes[p], fr.buffer(p), err_msg="frame %d plane %d" % (i, p))
+            np.testing.assert_array_equal(cost, fr.intra_cost())
+            np.testing.assert_array_equal(mode, fr.intra_mode())
+            np.testing.assert_array_equal(lc, fr.lowres_costs(0, 0))
+            np.testing.assert_array_equal(rs, fr.row_satds(0, 0))
+            assert (ce, ceaq) == (fr.i64("costEst", 0, 0), fr.i64("costEstAq", 0, 0))
+    finally:
+        ref.close()
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_mcstf_downscale_filter(depth):
     """--mcstf: rounded 2x2 mean instead of cascaded averages, and quarter-res planes without HME."""

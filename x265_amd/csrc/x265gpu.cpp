@@ -12,6 +12,7 @@
 #include <utility>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -67,6 +68,7 @@ struct x265gpu_ctx
     int D = 0;
     int numCoopSlices = 1;            // Lookahead::m_numCoopSlices / m_numRowsPerSlice (slicetype.cpp:1122-1133)
     int numRowsPerSlice = 0;
+    std::recursive_mutex mu;          // held for the length of every entry point: calls on one context from several threads take turns
     hipStream_t stream = nullptr;
     bool ownStream = false;
     std::vector<Slot> slots;
@@ -188,10 +190,19 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // Makes the context's device current for the duration of an entry point and puts the caller's
 // device back afterwards: a process may drive several contexts (one per GPU) from one thread.
 // Unless told otherwise it also orders the main stream behind an intra estimate still running on its side stream.
+// It also holds the context's lock, so that entry points called on one context from several host threads run one
+// after the other (entry points call each other: the lock is recursive).
 struct DeviceScope
 {
     int prev = -1;
+    std::unique_lock<std::recursive_mutex> lock;
     explicit DeviceScope(x265gpu_ctx* ctx, bool joinIntra = true);
+    void release()                      // before the context, and its lock with it, is destroyed
+    {
+        if (lock.owns_lock())
+            lock.unlock();
+        lock.release();
+    }
     ~DeviceScope()
     {
         if (prev >= 0)
@@ -249,6 +260,8 @@ void join_intra(x265gpu_ctx* ctx)
 
 DeviceScope::DeviceScope(x265gpu_ctx* ctx, bool joinIntra)
 {
+    if (ctx)
+        lock = std::unique_lock<std::recursive_mutex>(ctx->mu);
     int cur = -1;
     if (ctx && hipGetDevice(&cur) == hipSuccess && cur != ctx->cfg.deviceId && hipSetDevice(ctx->cfg.deviceId) == hipSuccess)
         prev = cur;
@@ -705,6 +718,7 @@ void x265gpu_close(x265gpu_ctx* ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    deviceScope.release();
     delete ctx;
 }
 

@@ -229,8 +229,9 @@ int x265gpu_weight_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_weight_job* 
  * Limit: with wtPresent the padded half-res plane (stride x (lines + 2 marginY) pixels) plus 256 bytes
  * must fit the array - up to 3840x2160 at 10 bit; larger pictures return X265GPU_ERR_ARG with a message
  * in x265gpu_last_error.  Every context on one GPU shares that GPU's array and the array keeps the last
- * call's contents (the call clears what must start at zero): calls that overlap on one GPU race, so
- * serialise them. */
+ * call's contents (the call clears what must start at zero).  Calls made through this library in one
+ * process take turns on a per-GPU lock; calls from different processes on one GPU use different copies
+ * of the array.  Anything else that touched the array while a call runs would race with it. */
 int x265gpu_weight_cost_static(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t wtPresent,
                                int32_t scale, int32_t log2Denom, int32_t offset, uint32_t* cost);
 /* weight_pp over all four padded planes of slotRef (slicetype.cpp:957-969);

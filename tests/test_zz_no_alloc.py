@@ -47,6 +47,38 @@ def test_static_scratch_matches_allocating_entry_point(depth):
         small.close()
 
 
+def test_static_scratch_calls_from_two_contexts_take_turns():
+    """Two contexts on one GPU share the array; their calls, made from two host threads at once, hold the GPU's lock
+    until the result is back, so each still gets the allocating entry point's numbers."""
+    import threading
+    big = api.Context(1280, 720, depth=8, num_slots=2)
+    small = api.Context(416, 240, depth=8, num_slots=2)
+    try:
+        _prepare(big, 1280, 720, 8, 7)
+        _prepare(small, 416, 240, 8, 8)
+        want = {id(c): [c.weight_cost(1, 0, *w) for w in WEIGHTS] for c in (big, small)}
+        bad = []
+
+        def worker(c):
+            try:
+                for rep in range(25):
+                    for w, expect in zip(WEIGHTS, want[id(c)]):
+                        got = c.weight_cost_static(1, 0, *w)
+                        if got != expect:
+                            bad.append((rep, w, got, expect))
+            except Exception as e:      # noqa: BLE001 - reported by the parent thread
+                bad.append(e)
+        threads = [threading.Thread(target=worker, args=(c,)) for c in (big, small)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not bad, bad[:4]
+    finally:
+        big.close()
+        small.close()
+
+
 def test_static_scratch_rejects_oversized_plane():
     """7680x4320 at 10 bit: the padded half-res plane (18.7 MB) is beyond the 8 MiB array."""
     ctx = api.Context(7680, 4320, depth=10, num_slots=2)

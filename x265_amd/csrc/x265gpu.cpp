@@ -55,6 +55,9 @@ constexpr size_t STATIC_SCRATCH_BYTES = (size_t)8 << 20;
 constexpr size_t STATIC_SCRATCH_PLANE = 256;
 constexpr int STATIC_SCRATCH_MAX_DEVICES = 64;
 void* g_scratchPtr[STATIC_SCRATCH_MAX_DEVICES];
+// One per device: held while its address is looked up and for the length of every call that uses the array, so
+// that contexts on one GPU (which all share it) take turns.
+std::mutex g_scratchMutex[STATIC_SCRATCH_MAX_DEVICES];
 
 } // namespace
 
@@ -453,6 +456,7 @@ int resolve_static_scratch(x265gpu_ctx* ctx)
     const int dev = ctx->cfg.deviceId;
     if (dev < 0 || dev >= STATIC_SCRATCH_MAX_DEVICES)
         return X265GPU_OK;              // no static scratch on such a device: weight_cost_static reports it
+    std::lock_guard<std::mutex> scratchLock(g_scratchMutex[dev]);
     if (!g_scratchPtr[dev])
     {
         void* p = nullptr;
@@ -1354,6 +1358,9 @@ int x265gpu_weight_cost_static(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
         return X265GPU_ERR_ARG;
     if (!ctx->staticScratch)
         return fail(ctx, X265GPU_ERR_STATE, "weight_cost_static: no static scratch on this device");
+    // the call waits for its result before it returns, so holding the device's lock until then keeps calls of
+    // different contexts on one GPU out of each other's accumulator and plane
+    std::lock_guard<std::mutex> scratchLock(g_scratchMutex[ctx->cfg.deviceId]);
     const Geometry& g = ctx->g;
     const size_t planeBytes = (size_t)g.planeSize * ctx->bpp;
     if (wtPresent && STATIC_SCRATCH_PLANE + planeBytes > STATIC_SCRATCH_BYTES)

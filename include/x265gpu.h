@@ -221,8 +221,9 @@ typedef struct x265gpu_weight_job
     int32_t wtPresent, scale, log2Denom, offset;
 } x265gpu_weight_job;
 int x265gpu_weight_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_weight_job* jobs, uint32_t* costs);
-/* x265gpu_weight_cost for callers that cannot allocate device memory (code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
+/* x265gpu_weight_cost for callers that cannot allocate device memory (tight serving loops, harnesses that
+ * forbid hipMalloc).  It has no counterpart in the reference.  The call still waits for its result and
+ * copies it to `cost` in ordinary host memory, so it is not something a stream capture can record.  Same
  * arguments and result as x265gpu_weight_cost; the accumulator and the weighted copy of plane 0 live in a
  * fixed 8 MiB array inside the library's device image (one copy per GPU, held until the process ends)
  * instead of buffers the context allocates or grows, and the call itself performs no hipMalloc / hipFree.

@@ -83,6 +83,45 @@ def test_aq_frame_feeds_intra_costs():
     ref.close()
 
 
+def test_aq_frames_batches_of_shrinking_size_keep_the_earlier_factors():
+    """A batch of four pictures followed at once by a batch of one (another layout of the shared page-locked
+    arrays: HDR10 adds an array per picture): the factors of the first batch's last picture must reach its slot
+    untouched although nothing waited for their upload in between."""
+    import torch
+    from x265_amd import synth
+    W, H, depth, N = 416, 240, 8, 4
+    clip = synth.luma_clip(W, H, N, depth, seed=11)
+    chroma = [_picture(W, H, depth, 20 + i)[1:3] for i in range(N)]
+    param = orc.make_param(W, H)
+    ref = orc.Lookahead(depth, param, with_aq=True)
+    invs = []
+    for i in range(N):
+        _, _, inv, _, _ = orc.calc_adaptive_quant_frame(depth, clip[i], chroma[i][0], chroma[i][1], 2, 1.0)
+        invs.append(inv)
+        ref.add_frame(clip[i], inv)
+    dy = torch.from_numpy(np.stack(clip)).cuda()
+    du = torch.from_numpy(np.stack([c[0] for c in chroma])).cuda()
+    dv = torch.from_numpy(np.stack([c[1] for c in chroma])).cuda()
+    torch.cuda.synchronize()
+    ptrs = [(dy[i].data_ptr(), du[i].data_ptr(), dv[i].data_ptr()) for i in range(N)]
+    with api.Context(W, H, depth=depth, num_slots=N) as ctx:
+        ctx.set_mvcost(ref.table, ref.centre)
+        for rep in range(3):
+            ctx.lowres_init_device(list(range(N)), [p[0] for p in ptrs], [W] * N)
+            ctx.intra_estimate(list(range(N)))                 # keeps the side stream busy ahead of the installing copies
+            first = ctx.aq_frames_device(list(range(N)), ptrs, W, W // 2, 2, 1.0)
+            keep = ctx._aq_keep
+            second = ctx.aq_frames_device([0], ptrs[:1], W, W // 2, 2, 1.0, hdr10=bool(rep & 1), finish=False)
+            for i in range(N):
+                np.testing.assert_array_equal(first[i][2], invs[i])
+            for i in range(N):
+                _, _, (ce, ceaq, _) = ctx.get_costs(i, 0, 0)
+                assert ce == ref.frames[i].i64("costEst", 0, 0)
+                assert ceaq == ref.frames[i].i64("costEstAq", 0, 0), "picture %d, round %d" % (i, rep)
+            del keep, second
+    ref.close()
+
+
 def test_aq_frame_rejects_uncovered_modes():
     W, H = 64, 64
     y = np.zeros((H, W), np.uint8)

@@ -330,6 +330,23 @@ def test_search_launch_modes(monkeypatch, mode):
         ref.close()
 
 
+@pytest.mark.parametrize("after", [0, 2])
+def test_flow_search_wait_that_runs_out_is_run_again_per_diagonal(monkeypatch, after):
+    """The flow search's bounded wait: with the error word raised ahead of a launch (X265GPU_TEST_FLOW_FAULT, a test
+    hook) every wave of that launch that has to wait gives up and searches with made-up predictors.  The call that
+    next waits for the stream must notice, run the estimate calls made since the last check again with a launch per
+    anti-diagonal, and deliver the same results as ever; later batches take that mode by themselves."""
+    monkeypatch.setenv("X265GPU_SEARCH_MODE", "flow")
+    monkeypatch.setenv("X265GPU_TEST_FLOW_FAULT", str(after))
+    clip, ref, ctx, frames = _setup(448, 256, 6, 8, seed=23)
+    try:
+        _run_sequence(ref, ctx, frames)
+        assert b"run again" in ctx.L.x265gpu_last_error(ctx.h)
+    finally:
+        ctx.close()
+        ref.close()
+
+
 @pytest.mark.parametrize("depth,slices", [(8, 3), (10, 2), (8, 8)])
 def test_cooperative_slices(depth, slices):
     """--lookahead-slices: a singleCost outside batch mode runs each slice as its own bottom-up walk

@@ -91,6 +91,13 @@ class AqParams(C.Structure):
                 ("qpAdaptationRange", C.c_double), ("layers", C.c_void_p)]
 
 
+class AqPicture(C.Structure):
+    _fields_ = [("slot", C.c_int32), ("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p),
+                ("strideY", C.c_ssize_t), ("strideC", C.c_ssize_t), ("quantOffsets", C.c_void_p),
+                ("qpAqOffset", C.c_void_p), ("qpCuTreeOffset", C.c_void_p), ("invQscaleFactor", C.c_void_p),
+                ("wpSum", C.c_uint64 * 3), ("wpSsd", C.c_uint64 * 3)]
+
+
 class HevcAqLayer(C.Structure):
     _fields_ = [("aqPartWidth", C.c_int32), ("aqPartHeight", C.c_int32), ("numAQPartInWidth", C.c_int32),
                 ("numAQPartInHeight", C.c_int32), ("dActivity", C.c_void_p), ("dQpOffset", C.c_void_p),
@@ -471,6 +478,29 @@ class Context:
         if hevc_aq_parts:
             out += ([tuple(a) + (layers[k].dAvgActivity,) for k, a in enumerate(layer_arrays)],)
         return out
+
+    def aq_frames_device(self, slots, ptrs, stride_y, stride_c, aq_mode, strength, weightp=False, hdr10=False,
+                         finish=True):
+        """x265gpu_aq_frames[_begin] over device-resident 4:2:0 pictures: ptrs = [(y, u, v) device addresses].
+        -> list of (qpAqOffset, qpCuTreeOffset, invQscaleFactor, wp_sum, wp_ssd) per picture.  With finish=False the
+        arrays are still being written when this returns (x265gpu_aq_frames_finish or any reading call ends that)."""
+        g = self.cfg
+        blocks = ((g.sourceWidth + 15) >> 4) * ((g.sourceHeight + 15) >> 4)
+        n = len(slots)
+        pics = (AqPicture * n)()
+        arrays = []
+        for i in range(n):
+            qa, qc, inv = np.full(blocks, np.nan), np.full(blocks, np.nan), np.full(blocks, -1, np.int32)
+            arrays.append((qa, qc, inv))
+            pics[i].slot = slots[i]
+            pics[i].y, pics[i].u, pics[i].v = ptrs[i]
+            pics[i].strideY, pics[i].strideC = stride_y, stride_c
+            pics[i].qpAqOffset, pics[i].qpCuTreeOffset, pics[i].invQscaleFactor = _ptr(qa), _ptr(qc), _ptr(inv)
+        prm = AqParams(int(aq_mode), int(weightp), int(hdr10), 0, float(strength), 32, 0, None, None, None, 0, 0, 0.0, None)
+        fn = self.L.x265gpu_aq_frames if finish else self.L.x265gpu_aq_frames_begin
+        self._chk(fn(self.h, n, pics, MEM_DEVICE, C.byref(prm)))
+        self._aq_keep = (pics, arrays)        # the library's threads write into these until the batch is finished
+        return [arrays[i] + (np.array(pics[i].wpSum, np.uint64), np.array(pics[i].wpSsd, np.uint64)) for i in range(n)]
 
     def hist_stats(self, slot, y, u, v):
         """collectPictureStatistics of a 4:2:0 picture whose luma was given to lowres_init(slot, ...) ->

@@ -903,6 +903,10 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
                 }
                 __builtin_amdgcn_s_sleep(8);
             }
+            // a wait that was given up leaves the pending mark behind: the zero vector stands in for it (the host
+            // discards these results and runs the batch again)
+            if ((int)v == FLOW_PENDING)
+                v = 0;
             cx = (int)v;
             cy = (int)(v >> 32);
         }

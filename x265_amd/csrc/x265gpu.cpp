@@ -146,6 +146,8 @@ struct x265gpu_ctx
     char* aqDev = nullptr;              // the batched AQ pass's device arrays and their page-locked mirror, kept between
     char* aqHost = nullptr;             //   calls and grown when a larger batch comes
     size_t aqBufBytes = 0;
+    hipEvent_t aqInstalled = nullptr;   // the copies that install a batch's factors out of aqHost have finished
+    bool aqInstallInFlight = false;     // ... recorded and not yet waited for by the host
     std::vector<int32_t> intraDeferred;    // slots whose intra estimate ran ahead of their scale factors: AQ sums to redo
     bool aqInstalledOnMain = false;        // some of those factors were uploaded on the main stream (x265gpu_lowres_set_aq)
     int flowGridPad = 1;
@@ -154,6 +156,15 @@ struct x265gpu_ctx
     int* searchSync = nullptr;
     size_t searchSyncBytes = 0;
     int* searchErrHost = nullptr;     // pinned
+    // The estimate calls whose single-launch searches nobody has checked yet (the error word is read at the calls
+    // that wait for the stream).  Should a bounded wait ever run out, these are run again, in order, with a launch
+    // per anti-diagonal, and the context keeps to that mode from then on.
+    struct EstimateCall { std::vector<x265gpu_request> reqs; bool wantBatchOut; long long* deviceOut; };
+    std::vector<EstimateCall> unverified;
+    bool singleLaunchOff = false;
+    int searchRecoveries = 0;
+    int flowFaultAfter = -1;          // test hook (X265GPU_TEST_FLOW_FAULT): raise the error word ahead of that flow launch
+    int flowLaunches = 0;
 };
 
 // x265gpu_aq_frames_begin batches still on host threads: joined, uploaded, and the intra estimates that waited for
@@ -340,10 +351,49 @@ int fetch_search_error(x265gpu_ctx* ctx)
     return X265GPU_OK;
 }
 
-int check_search_error(x265gpu_ctx* ctx)
+} // namespace
+
+static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, bool wantBatchOut, long long* deviceOut);
+
+namespace {
+
+// Waits for the main stream and looks at the error word of the single-launch searches (flow and rows modes).  A wait
+// inside them that ran out (never seen; it would mean that workgroups were not started in index order, or that another
+// process held the GPU for a quarter of a second and more) left vectors behind that were searched with made-up
+// predictors.  Nothing is lost: the estimate calls made since the last check are run again with one launch per
+// anti-diagonal, which needs no assumption about the order in which workgroups start, and so is every later search of
+// this context.  What those calls read (planes, scale factors, weighted planes) must still be in place, which holds
+// for every caller that checks - waits - before it reuses a slot.
+int verify_searches(x265gpu_ctx* ctx, bool* recovered = nullptr)
 {
-    if (ctx->searchErrHost && ctx->searchErrHost[0])
-        return fail(ctx, X265GPU_ERR_DEVICE, "search: a wait for the row below ran out; results are invalid");
+    if (recovered)
+        *recovered = false;
+    int rc = fetch_search_error(ctx);
+    if (rc)
+        return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (!ctx->searchErrHost || !ctx->searchErrHost[0])
+    {
+        ctx->unverified.clear();
+        return X265GPU_OK;
+    }
+    ctx->searchErrHost[0] = 0;
+    HIPCHK(hipMemsetAsync(ctx->searchSync + SEARCH_SYNC_ERROR, 0, sizeof(int), ctx->stream));
+    ctx->singleLaunchOff = true;
+    ctx->searchRecoveries++;
+    ctx->err = "search: a wait inside the single-launch search ran out; the calls were run again with one launch per "
+               "anti-diagonal, the mode this context keeps from now on";
+    std::vector<x265gpu_ctx::EstimateCall> calls;
+    calls.swap(ctx->unverified);
+    for (const x265gpu_ctx::EstimateCall& c : calls)
+    {
+        rc = run_estimate(ctx, (int32_t)c.reqs.size(), c.reqs.data(), c.wantBatchOut, c.deviceOut);
+        if (rc)
+            return rc;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (recovered)
+        *recovered = true;
     return X265GPU_OK;
 }
 
@@ -596,6 +646,8 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
             ctx->searchFlow = !e || !strcmp(e, "flow");
             const char* pad = getenv("X265GPU_FLOW_PAD");
             ctx->flowGridPad = pad ? atoi(pad) : 1;
+            const char* fault = getenv("X265GPU_TEST_FLOW_FAULT");
+            ctx->flowFaultAfter = fault ? atoi(fault) : -1;
             if (ctx->searchFlow)
             {
                 for (int lv = 0; lv < 2 && rc == X265GPU_OK; lv++)
@@ -633,6 +685,7 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
             const char* e = getenv("X265GPU_INTRA_STREAM");
             if (hipEventCreateWithFlags(&ctx->intraFork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&ctx->intraDone, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->aqInstalled, hipEventDisableTiming) != hipSuccess ||
                 hipEventRecord(ctx->intraDone, ctx->stream) != hipSuccess)
             {
                 rc = X265GPU_ERR_DEVICE;
@@ -705,10 +758,11 @@ void x265gpu_close(x265gpu_ctx* ctx)
     if (ctx->puBuf) (void)hipFree(ctx->puBuf);
     if (ctx->mcstfBuf) (void)hipFree(ctx->mcstfBuf);
     if (ctx->seaBuf) (void)hipFree(ctx->seaBuf);
+    if (ctx->intraStream) (void)hipStreamSynchronize(ctx->intraStream);
     if (ctx->aqDev) (void)hipFree(ctx->aqDev);
     if (ctx->cutreeBuf) (void)hipFree(ctx->cutreeBuf);
     if (ctx->aqHost) (void)hipHostFree(ctx->aqHost);
-    if (ctx->intraStream) (void)hipStreamSynchronize(ctx->intraStream);
+    if (ctx->aqInstalled) (void)hipEventDestroy(ctx->aqInstalled);
     if (ctx->finishHost) (void)hipHostFree(ctx->finishHost);
     if (ctx->intraJobBuf) (void)hipFree(ctx->intraJobBuf);
     if (ctx->intraJobHost) (void)hipHostFree(ctx->intraJobHost);
@@ -776,11 +830,7 @@ int x265gpu_sync(x265gpu_ctx* ctx)
     FINISH_AQ(ctx);
     if (!ctx)
         return X265GPU_ERR_ARG;
-    int rc = fetch_search_error(ctx);
-    if (rc)
-        return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return check_search_error(ctx);
+    return verify_searches(ctx);
 }
 
 int x265gpu_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd)
@@ -815,6 +865,8 @@ int x265gpu_lowres_init_batch(x265gpu_ctx* ctx, int32_t n, const int32_t* slots,
     for (int i = 0; i < n; i++)
         if (!slot_ok(ctx, slots[i]) || !lumas[i] || strides[i] < g.srcWidth)
             return fail(ctx, X265GPU_ERR_ARG, "lowres_init: bad slot, plane or stride");
+    // cuTree passes queued so far hold the addresses of what this call rewrites: they run first
+    { const int rcTree = cutree_flush(ctx); if (rcTree) return rcTree; }
 
     std::vector<LowresJob> jobs(n);
     const size_t frameBytes = (size_t)g.srcWidth * g.srcHeight * ctx->bpp;
@@ -912,6 +964,8 @@ int x265gpu_lowres_set_aq(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQsca
     int rc = aq_finish_pending(ctx);
     if (rc)
         return rc;
+    // cuTree passes queued so far hold the addresses of what this call rewrites: they run first
+    { const int rcTree = cutree_flush(ctx); if (rcTree) return rcTree; }
     return set_aq_staged(ctx, slot, invQscaleFactor);
 }
 
@@ -925,6 +979,8 @@ int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots)
     for (int i = 0; i < n; i++)
         if (!slot_ok(ctx, slots[i]))
             return fail(ctx, X265GPU_ERR_ARG, "intra_estimate: bad slot");
+    // cuTree passes queued so far hold the addresses of what this call rewrites: they run first
+    { const int rcTree = cutree_flush(ctx); if (rcTree) return rcTree; }
     // Scale factors that host threads are still computing (x265gpu_aq_frames_begin) only enter the AQ-weighted sums:
     // the estimate itself starts now, so that what reads its per-block costs (weight analysis, cost passes) finds
     // them, and the sums are redone when the factors are installed (aq_finish_pending), ahead of whatever reads those.
@@ -979,7 +1035,7 @@ int x265gpu_intra_estimate(x265gpu_ctx* ctx, int32_t n, const int32_t* slots)
 }
 
 static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, bool wantBatchOut,
-                        long long* deviceOut = nullptr)
+                        long long* deviceOut)
 {
     if (!ctx || n < 0 || (n && !reqs))
         return X265GPU_ERR_ARG;
@@ -1147,7 +1203,15 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
             return rc;
     }
 
-    if (!sj.empty() && ctx->searchRows)
+    const bool singleLaunch = !sj.empty() && !ctx->singleLaunchOff;
+    if (singleLaunch && (ctx->searchRows || ctx->searchFlow))
+    {
+        // kept until a call that waits has seen the error word clear (verify_searches)
+        if (ctx->unverified.size() >= 256)
+            ctx->unverified.erase(ctx->unverified.begin());
+        ctx->unverified.push_back({ std::vector<x265gpu_request>(reqs, reqs + n), wantBatchOut, deviceOut });
+    }
+    if (singleLaunch && ctx->searchRows)
     {
         rc = ensure_search_sync(ctx, (int)sj.size());
         if (rc)
@@ -1161,12 +1225,14 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
                                   sj[0].method, ctx->costCentre, ctx->maxMvd, ctx->searchSync, &launches));
         pt.stop(launches);
     }
-    else if (!sj.empty() && ctx->searchFlow && slicesMax == 1 && ctx->flowChunkCount[0] <= 65535 &&
+    else if (singleLaunch && ctx->searchFlow && slicesMax == 1 && ctx->flowChunkCount[0] <= 65535 &&
              (sj4.empty() || ctx->flowChunkCount[1] <= 65535))
     {
         rc = ensure_search_sync(ctx, 1);
         if (rc)
             return rc;
+        if (ctx->flowFaultAfter >= 0 && ctx->flowLaunches++ == ctx->flowFaultAfter)
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(ctx->searchSync + SEARCH_SYNC_ERROR), 1, 1, ctx->stream));
         PhaseTimer pt(ctx, X265GPU_PHASE_SEARCH);
         int launches = 0;
         if (!sj4.empty())
@@ -1210,7 +1276,7 @@ static int run_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs
 int x265gpu_estimate(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs)
 {
     DeviceScope deviceScope(ctx, false);
-    return run_estimate(ctx, n, reqs, false);
+    return run_estimate(ctx, n, reqs, false, nullptr);
 }
 
 int x265gpu_estimate_sums_device(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* reqs, int64_t* deviceSums)
@@ -1227,18 +1293,22 @@ int x265gpu_estimate_costs(x265gpu_ctx* ctx, int32_t n, const x265gpu_request* r
     DeviceScope deviceScope(ctx, false);
     if (!out && n)
         return X265GPU_ERR_ARG;
-    int rc = run_estimate(ctx, n, reqs, true);
+    int rc = run_estimate(ctx, n, reqs, true, nullptr);
     if (rc || !n)
         return rc;
     HIPCHK(hipMemcpyAsync(ctx->batchSumsHost, ctx->batchSums, (size_t)n * 3 * sizeof(long long),
                           hipMemcpyDeviceToHost, ctx->stream));
-    rc = fetch_search_error(ctx);
+    bool recovered = false;
+    rc = verify_searches(ctx, &recovered);
     if (rc)
         return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    rc = check_search_error(ctx);
-    if (rc)
-        return rc;
+    if (recovered)
+    {
+        // the batch was run again: its totals once more
+        HIPCHK(hipMemcpyAsync(ctx->batchSumsHost, ctx->batchSums, (size_t)n * 3 * sizeof(long long),
+                              hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     for (int i = 0; i < n; i++)
     {
         if (reqs[i].bSearchOnly)
@@ -2588,12 +2658,22 @@ int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pic
         if (frc)
             return frc;
     }
+    // cuTree passes queued so far hold the addresses of what this call rewrites: they run first
+    { const int rcTree = cutree_flush(ctx); if (rcTree) return rcTree; }
     const bool hdr = params->bHDR10Opt && mapped;
     const size_t arrayBytes = align256(sizeof(uint32_t) * (size_t)blocks);
     const size_t perPic = (hdr ? 2 : 1) * arrayBytes + AQ_WP_BYTES;
     // after the pictures' arrays: the job structs, then the pointer pairs of the scatter that installs the factors
     const size_t jobsAt = perPic * n, ptrsAt = jobsAt + align256(sizeof(AqJob) * (size_t)n);
     const size_t total = ptrsAt + align256(2 * sizeof(void*) * (size_t)n);
+    // The previous batch's factors may still be on their way out of the page-locked arrays (the installing copies
+    // are queued behind an intra estimate on the side stream and nobody waits for them on the host): the arrays
+    // are not written again before those copies have finished.
+    if (ctx->aqInstallInFlight)
+    {
+        HIPCHK(hipEventSynchronize(ctx->aqInstalled));
+        ctx->aqInstallInFlight = false;
+    }
     if (total > ctx->aqBufBytes)
     {
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2766,8 +2846,12 @@ static int aq_finish_pending(x265gpu_ctx* ctx)
             if (e == hipSuccess)
                 e = launch_scatter_i32(up, (const int32_t* const*)(b->dev + b->ptrsAt),
                                        (int32_t* const*)(b->dev + b->ptrsAt) + count, (int)ctx->g.cuCount, count);
+            if (e == hipSuccess)
+                e = hipEventRecord(ctx->aqInstalled, up);
             if (e != hipSuccess)
                 rc = X265GPU_ERR_DEVICE;
+            else
+                ctx->aqInstallInFlight = true;
         }
         delete b->next;
         delete b;
@@ -2825,7 +2909,8 @@ int x265gpu_aq_frames_finish(x265gpu_ctx* ctx)
     DeviceScope deviceScope(ctx);
     if (!ctx)
         return X265GPU_ERR_ARG;
-    return aq_finish_pending(ctx);
+    FINISH_AQ(ctx);
+    return X265GPU_OK;
 }
 
 int x265gpu_aq_frames(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int32_t memKind, const x265gpu_aq_params* params)

@@ -20,9 +20,11 @@ constexpr int REPS = 256;
 #define R8(body) body body body body body body body body
 #define R64(body) R8(R8(body))
 
-enum Kind { K_SAD_U8, K_PK_ADD_I16, K_MIN_I32, K_ADD_U32, K_ALIGNBYTE, K_MOV_DPP, K_S_ADD, K_S_CSELECT, K_MIX, K_COUNT };
+enum Kind { K_SAD_U8, K_PK_ADD_I16, K_MIN_I32, K_ADD_U32, K_ALIGNBYTE, K_MOV_DPP, K_S_ADD, K_S_CSELECT, K_MIX, K_QSAD, K_MQSAD,
+            K_PERMLANE32_SWAP, K_MFMA_I8, K_COUNT };
 static const char* kindName[K_COUNT] = { "v_sad_u8", "v_pk_add_i16", "v_min_i32", "v_add_u32", "v_alignbyte_b32",
-                                          "v_mov_b32_dpp", "s_add_u32", "s_cmp+s_cselect", "valu+salu interleaved" };
+                                          "v_mov_b32_dpp", "s_add_u32", "s_cmp+s_cselect", "valu+salu interleaved",
+                                          "v_qsad_pk_u16_u8", "v_mqsad_pk_u16_u8", "v_permlane32_swap_b32", "v_mfma_i32_16x16x32_i8" };
 
 template <int KIND>
 __global__ void __launch_bounds__(1024) issue_kernel(unsigned long long* out, unsigned seed)
@@ -30,6 +32,10 @@ __global__ void __launch_bounds__(1024) issue_kernel(unsigned long long* out, un
     unsigned a0 = threadIdx.x * 3u + seed, a1 = a0 ^ 0x55u, a2 = a0 + 7u, a3 = a0 * 5u, a4 = a0 + 11u, a5 = a0 ^ 0xaau, a6 = a0 + 13u,
              a7 = a0 * 9u;
     unsigned s0 = seed, s1 = seed + 1, s2 = seed + 2, s3 = seed + 3;
+    // 64-bit operands of the four-offset byte SADs (a sliding 4-byte pattern against an 8-byte window, four 16-bit sums)
+    unsigned long long q0 = a0 * 0x100000001ull, q1 = a1 * 0x100000003ull, q2 = a2 * 0x100000005ull, q3 = a3 * 0x100000007ull;
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    v4i_t m0 = { 0, 0, 0, 0 }, m1 = m0, m2 = m0, m3 = m0;
     __syncthreads();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -69,6 +75,22 @@ __global__ void __launch_bounds__(1024) issue_kernel(unsigned long long* out, un
             { R8(asm volatile("s_cmp_lt_u32 %0, %4\n s_cselect_b32 %0, %1, %0\n s_cmp_lt_u32 %1, %4\n s_cselect_b32 %1, %2, %1\n"
                             "s_cmp_lt_u32 %2, %4\n s_cselect_b32 %2, %3, %2\n s_cmp_lt_u32 %3, %4\n s_cselect_b32 %3, %0, %3\n"
                             : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "s"(seed) : "scc");) }
+        else if (KIND == K_QSAD)
+            { R8(asm volatile("v_qsad_pk_u16_u8 %0, %0, %4, %0\n v_qsad_pk_u16_u8 %1, %1, %4, %1\n v_qsad_pk_u16_u8 %2, %2, %4, %2\n v_qsad_pk_u16_u8 %3, %3, %4, %3\n"
+                            "v_qsad_pk_u16_u8 %0, %0, %4, %0\n v_qsad_pk_u16_u8 %1, %1, %4, %1\n v_qsad_pk_u16_u8 %2, %2, %4, %2\n v_qsad_pk_u16_u8 %3, %3, %4, %3\n"
+                            : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(seed));) }
+        else if (KIND == K_MQSAD)
+            { R8(asm volatile("v_mqsad_pk_u16_u8 %0, %0, %4, %0\n v_mqsad_pk_u16_u8 %1, %1, %4, %1\n v_mqsad_pk_u16_u8 %2, %2, %4, %2\n v_mqsad_pk_u16_u8 %3, %3, %4, %3\n"
+                            "v_mqsad_pk_u16_u8 %0, %0, %4, %0\n v_mqsad_pk_u16_u8 %1, %1, %4, %1\n v_mqsad_pk_u16_u8 %2, %2, %4, %2\n v_mqsad_pk_u16_u8 %3, %3, %4, %3\n"
+                            : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(seed));) }
+        else if (KIND == K_PERMLANE32_SWAP)
+            { R8(asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                            "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+        else if (KIND == K_MFMA_I8)
+            { R8(asm volatile("v_mfma_i32_16x16x32_i8 %0, %4, %5, %0\n v_mfma_i32_16x16x32_i8 %1, %4, %5, %1\n v_mfma_i32_16x16x32_i8 %2, %4, %5, %2\n v_mfma_i32_16x16x32_i8 %3, %4, %5, %3\n"
+                            "v_mfma_i32_16x16x32_i8 %0, %4, %5, %0\n v_mfma_i32_16x16x32_i8 %1, %4, %5, %1\n v_mfma_i32_16x16x32_i8 %2, %4, %5, %2\n v_mfma_i32_16x16x32_i8 %3, %4, %5, %3\n"
+                            : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3) : "v"(q0), "v"(q1));) }
         else
             { R8(asm volatile("v_sad_u8 %0, %0, %8, %0\n s_add_u32 %9, %9, %11\n v_pk_add_i16 %1, %1, %8\n s_add_u32 %10, %10, %11\n"
                             "v_min_i32 %2, %2, %8\n s_add_u32 %9, %9, %11\n v_add_u32 %3, %3, %8\n s_add_u32 %10, %10, %11\n"
@@ -76,7 +98,8 @@ __global__ void __launch_bounds__(1024) issue_kernel(unsigned long long* out, un
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-    const unsigned sink = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + s0 + s1 + s2 + s3;
+    const unsigned sink = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + s0 + s1 + s2 + s3 + (unsigned)(q0 + q1 + q2 + q3) +
+                          (unsigned)(m0[0] + m1[1] + m2[2] + m3[3]);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if ((threadIdx.x & 63) == 0)
     {
@@ -141,6 +164,10 @@ int main()
             case K_MOV_DPP: rc = run<K_MOV_DPP>(w, dOut, hOut, cus, ticks, real); break;
             case K_S_ADD: rc = run<K_S_ADD>(w, dOut, hOut, cus, ticks, real); break;
             case K_S_CSELECT: rc = run<K_S_CSELECT>(w, dOut, hOut, cus, ticks, real); break;
+            case K_QSAD: rc = run<K_QSAD>(w, dOut, hOut, cus, ticks, real); break;
+            case K_MQSAD: rc = run<K_MQSAD>(w, dOut, hOut, cus, ticks, real); break;
+            case K_PERMLANE32_SWAP: rc = run<K_PERMLANE32_SWAP>(w, dOut, hOut, cus, ticks, real); break;
+            case K_MFMA_I8: rc = run<K_MFMA_I8>(w, dOut, hOut, cus, ticks, real); break;
             default: rc = run<K_MIX>(w, dOut, hOut, cus, ticks, real); break;
             }
             if (rc)

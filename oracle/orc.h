@@ -58,6 +58,10 @@ void orc_sad_x3(int w, int h, const pixel* fenc, const pixel* r0, const pixel* r
 void orc_sad_x4(int w, int h, const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2,
                 const pixel* r3, intptr_t rstride, int32_t* res);
 int  orc_satd(int w, int h, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+/* executed block compares per phase (orc_pixel.c): [phase][SAD, SATD, intra predictions] in 8x8 units; phases:
+ * 0 intra estimate, 1 motion search, 2 cost decision, 3 weight analysis, 4 anything else */
+extern long long orc_op_counters[5][3];
+extern int orc_op_phase;
 int  orc_sa8d(int size, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
 void orc_pixelavg_pp(int w, int h, pixel* dst, intptr_t ds, const pixel* s0, intptr_t ss0,
                      const pixel* s1, intptr_t ss1);

@@ -8,9 +8,16 @@
 int orc_depth(void) { return ORC_DEPTH; }
 
 /* sum of absolute differences: source/common/pixel.cpp:40-55 */
+/* Executed block compares, for the benchmark's algorithmic-operation count: [phase][0] SADs and [phase][1] SATDs
+ * in units of 64 pixels (an 8x8 block compare), [phase][2] 8x8 intra predictions.  The caller names the phase
+ * (orc_op_phase: 0 intra estimate, 1 motion search, 2 cost decision, 3 weight analysis, 4 anything else). */
+long long orc_op_counters[5][3];
+int orc_op_phase = 4;
+
 int orc_sad(int w, int h, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
 {
     int acc = 0;
+    orc_op_counters[orc_op_phase][0] += (w * h + 63) >> 6;
     for (int y = 0; y < h; y++, a += sa, b += sb)
         for (int x = 0; x < w; x++)
             acc += abs((int)a[x] - (int)b[x]);
@@ -69,6 +76,7 @@ static int had4x4_abs(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
 int orc_satd(int w, int h, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
 {
     int acc = 0;
+    orc_op_counters[orc_op_phase][1] += (w * h + 63) >> 6;
     if (w & 7)
     {
         for (int y = 0; y < h; y += 4)

@@ -35,14 +35,20 @@ def test_static_scratch_matches_allocating_entry_point(depth):
         assert len(set(want_big)) > 1 and min(want_big) > 0
         # first call: the larger picture; second call: the smaller one, whose plane covers only the start of
         # what the first left in the shared array
-        import torch
-        free_before = torch.cuda.mem_get_info()[0]
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")        # the runtime the library under test already runs on
+
+        def free_bytes():
+            free, total = C.c_size_t(), C.c_size_t()
+            assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+            return free.value
+        free_before = free_bytes()
         for w, wb, ws in zip(WEIGHTS, want_big, want_small):
             assert big.weight_cost_static(1, 0, *w) == wb, w
             assert small.weight_cost_static(1, 0, *w) == ws, w
         # "allocates nothing": the device's free memory is what it was (hipMemGetInfo; the allocating entry point
         # grows the context's buffers on its first weighted call, which was made above)
-        assert torch.cuda.mem_get_info()[0] == free_before
+        assert free_bytes() == free_before
         # and the other way round, ending on an unweighted call (accumulator only)
         for w, wb, ws in zip(reversed(WEIGHTS), reversed(want_big), reversed(want_small)):
             assert small.weight_cost_static(1, 0, *w) == ws, w

@@ -17,6 +17,11 @@ Two workloads per run, both through the C++ host layer (x265_amd/host) over the 
            (batches per decision), fed picture by picture and drained as Encoder::encode does; frames/s and
            milliseconds per slicetypeDecide call are what ONE encoder instance sees.
 
+The timed region is repeated (--reps, default 3): every repetition is exactly --steps steps between two fences;
+`value` and `ms_per_step` are the median repetition's, `repetitions` lists them all.  `host_cpu` says what the host
+spent beside the GPU (process CPU seconds per step, cores kept busy per GPU).  `other_configs` carries a few steps
+each of the other sizes the metric is quoted on (4K 10-bit, 4K 10-bit --hme, 8K 10-bit).
+
 Source pictures (Y, U, V) are resident in HBM before the timed region.  With --gpus N the parent starts N rank
 processes (one per GPU, torch.distributed over RCCL); every rank runs its own segment (weak scaling) and the
 per-request cost scalars of all ranks are gathered inside the timed step.  Under torchrun (WORLD_SIZE set) the
@@ -39,6 +44,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 SIMDS = 1024            # 256 compute units x 4
 ISSUE_BENCH = os.path.join(ROOT, "benchmarks", "micro", "issue_bench")
+# Algorithmic integer operations of one 8x8 block compare, as lane operations: a SAD is 64 absolute differences
+# accumulated, four (8-bit) or two (16-bit) per packed lane operation; a SATD is 64 subtractions and four 4x4
+# Hadamards of 64 additions / subtractions, 16 absolute values and 15 additions each (~450); an 8x8 intra prediction
+# is taken as 150 (64 samples of a two-tap interpolation with rounding, on average over DC / planar / angular).
+OPS_SAD = {1: 16, 2: 32}
+OPS_SATD = 450
+OPS_INTRA_PRED = 150
 
 
 def batch_requests(nframes, bframes):
@@ -128,10 +140,12 @@ def _oracle_frames(width, height, depth, bframes, clip, chroma, hme):
     return look
 
 
-def cpu_segment_seconds(width, height, depth, bframes, frames, seed, hme=False):
-    """The segment workload on the oracle, one core: seconds for `frames` frames."""
+def cpu_segment_seconds(width, height, depth, bframes, frames, seed, hme=False, counters=None):
+    """The segment workload on the oracle, one core: seconds for `frames` frames.  `counters` (a dict) receives the
+    block compares the oracle executed, per phase: the exact operation count of this clip's segment."""
     from oracle import orc
     clip, chroma = make_clip(width, height, frames, depth, seed)
+    orc.op_counters(depth, reset=True)
     t0 = time.perf_counter()
     look = _oracle_frames(width, height, depth, bframes, clip, chroma, hme)
     b1, b2 = batch_requests(frames, bframes)
@@ -142,6 +156,8 @@ def cpu_segment_seconds(width, height, depth, bframes, frames, seed, hme=False):
     look.cu_tree(orc.CuTreeParam(30, 1, 1, 0, 20, 0, 0.6), frames - 1, False)
     dt = time.perf_counter() - t0
     look.close()
+    if counters is not None:
+        counters.update(orc.op_counters(depth))
     return dt
 
 
@@ -173,7 +189,9 @@ def cpu_baselines(args):
     W, H, D = args.width, args.height, args.depth
     n = args.cpu_frames
     out = {}
-    dt = cpu_segment_seconds(W, H, D, args.bframes, n, 1234, args.hme)
+    counters = {}
+    dt = cpu_segment_seconds(W, H, D, args.bframes, n, 1234, args.hme, counters)
+    out["_op_counters"] = {"frames": n, "phases": counters}
     out["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
                            "sample": "segment workload, %d frames of %dx%d %d-bit, %.1f s on one core" % (n, W, H, D, dt)}
     dt = cpu_steady_seconds(W, H, D, n, 1234, args.hme)
@@ -266,8 +284,13 @@ def pmc_traffic_per_launch(c):
 
 # ---------------------------------------------------------------- launcher
 
-def launch_ranks(args, argv):
-    """--gpus N outside torchrun: N fresh rank processes; nothing in this process touches the GPU."""
+def launch_ranks(args, argv, script=None, timeout=None):
+    """--gpus N outside torchrun: N fresh rank processes; nothing in this process touches the GPU.  Rank 0's
+    standard output is passed on.  A rank that fails, or the whole set not finishing within `timeout` seconds,
+    ends every remaining rank and the exit status is non-zero: a stuck rank must not hold the caller to its own
+    limit."""
+    script = script or os.path.abspath(__file__)
+    timeout = args.rank_timeout if timeout is None else timeout
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -275,200 +298,164 @@ def launch_ranks(args, argv):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = rc or p.wait()
-    sys.stdout.write(out.decode())
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + timeout
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            rc = next((c for c in codes if c), 0)
+            break
+        failed = next((c for c in codes if c), 0)
+        if failed or time.monotonic() > deadline:
+            rc = failed or 124
+            sys.stderr.write("bench.py: %s; ending the remaining ranks\n"
+                             % ("a rank exited with status %d" % failed if failed else "ranks still running after %d s" % timeout))
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
     return rc
 
 
-# ---------------------------------------------------------------- rank body
+# ---------------------------------------------------------------- one configuration on the GPU
 
-def standin_rank(args, rank, world):
-    """Test rehearsal of the N > 1 path on CPU: gloo, and the oracle in the device's place.  Not a measurement."""
-    import torch
-    import torch.distributed as dist
-    from x265_amd import sharding
-    dist.init_process_group(args.backend, rank=rank, world_size=world)
-    from oracle import orc
-    clip, _ = make_clip(args.width, args.height, args.frames, args.depth, 1234 + rank)
-    look = orc.Lookahead(args.depth, orc.make_param(args.width, args.height, bframes=args.bframes))
-    for f in clip:
-        look.add_frame(f)
-    b1, b2 = batch_requests(args.frames, args.bframes)
-    t0 = time.perf_counter()
-    rows = []
-    for (p0, p1, b) in b1 + b2:
-        look.frame_cost(p0, p1, b)
-        fr = look.frames[b]
-        rows.append((fr.i64("costEst", b - p0, p1 - b), fr.i64("costEstAq", b - p0, p1 - b), fr.i64("intraMbs", b - p0)))
-    parts = sharding.gather_costs(np.array(rows, np.int64).reshape(-1, 3))
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    look.close()
-    dist.barrier()
-    dist.destroy_process_group()
-    return {"metric": "lookahead frames/sec", "value": args.frames * world / float(t.item()), "unit": "frames/s",
-            "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": 1000.0 * float(t.item()),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "CPU stand-in rehearsal of the multi-rank path (oracle + gloo); NOT a measurement",
-                       "gathered_requests": [int(p.shape[0]) for p in parts]}}
+class Workload:
+    """The segment workload of one configuration (size, depth, --hme) on this rank's GPU: source pictures resident in
+    HBM, `in_flight` lookahead instances (library context, host-layer window, stream and host thread each)."""
 
+    def __init__(self, cfg, rank, world, local_rank, distributed):
+        import ctypes as C
+        import torch
+        from x265_amd import api
+        self.C, self.torch, self.api = C, torch, api
+        self.cfg, self.rank, self.world, self.local_rank, self.distributed = cfg, rank, world, local_rank, distributed
+        W, H, D, F = cfg.width, cfg.height, cfg.depth, cfg.frames
+        self.bpp = 1 if D == 8 else 2
+        clip, chroma = cfg.clip if getattr(cfg, "clip", None) is not None else make_clip(W, H, F, D, 1234 + rank)
 
-def rank_main(args):
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    # Libraries under the process group print banners on stdout; keep fd 1 for the one JSON line.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-    if args.cpu_standin:
-        rec = standin_rank(args, rank, world)
-        sys.stdout.flush()
-        os.dup2(json_fd, 1)
-        os.close(json_fd)
-        if rank == 0:
-            print(json.dumps(rec), flush=True)
-        return
+        def to_dev(a):
+            return torch.from_numpy(a if D == 8 else a.view(np.int16)).cuda()
+        self.dev_y = to_dev(clip)
+        self.dev_u = to_dev(np.stack([c[0] for c in chroma]))
+        self.dev_v = to_dev(np.stack([c[1] for c in chroma]))
+        torch.cuda.synchronize()
+        yb, cb = W * H * self.bpp, (W // 2) * (H // 2) * self.bpp
+        self.y_ptrs = [self.dev_y.data_ptr() + i * yb for i in range(F)]
+        self.u_ptrs = [self.dev_u.data_ptr() + i * cb for i in range(F)]
+        self.v_ptrs = [self.dev_v.data_ptr() + i * cb for i in range(F)]
 
-    # Everything that starts another process (the issue-rate microbenchmark, the worker pool of the all-cores CPU
-    # baseline) runs before this process initialises the GPU.
-    rates = (issue_rates() if not args.no_micro else None) or recorded_issue_rates() if rank == 0 else None
-    cpu = cpu_baselines(args) if rank == 0 and world == 1 and args.cpu_frames > 0 else {}
+        hme_kw = dict(hme=True) if cfg.hme else {}
+        table, centre = api.bitcost_table(D)
+        self.Hlib = Hlib = api.load_host_library()
+        self.b1, self.b2 = b1, b2 = batch_requests(F, cfg.bframes)
+        a1 = np.ascontiguousarray(np.array(b1, np.int32).reshape(-1, 3))
+        a2 = np.ascontiguousarray(np.array(b2, np.int32).reshape(-1, 3))
+        self.n_search = sum(1 + (1 if p1 > b else 0) for (_, p1, b) in b1)
+        self.n_cost = len(b1) + len(b2)
+        vpn = C.c_void_p * F
+        frames_arr = (C.c_int32 * F)(*range(F))
+        ys, us, vs = vpn(*self.y_ptrs), vpn(*self.u_ptrs), vpn(*self.v_ptrs)
+        sy, sc = (C.c_ssize_t * F)(*[W] * F), (C.c_ssize_t * F)(*[W // 2] * F)
+        aqp = api.AqParams(2, 1, 0, 0, 1.0, 32, 0, None, None, None, 0, 0, 0.0, None)
+        keep = self._keep = (a1, a2, frames_arr, ys, us, vs, sy, sc, aqp)
 
-    import ctypes as C
-    import torch
-    distributed = world > 1 or args.force_dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the lookahead path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if distributed:
-        import torch.distributed as dist
-        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
-            os.environ.setdefault(k, v)       # --force-dist outside a launcher: a world of one
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        class Pipeline:
+            """One lookahead instance working on segments one after the other.  With --in-flight P, P of them take the
+            steps in turn from P host threads, each on a stream of its own: one segment's host phases (weight analysis,
+            AQ mapping, cuTree) then run beside another's searches."""
 
-    from x265_amd import api
+            def __init__(self, own_stream):
+                self.stream = torch.cuda.Stream() if own_stream else torch.cuda.current_stream()
+                self.ctx = api.Context(W, H, depth=D, bframes=cfg.bframes, num_slots=F, device=local_rank,
+                                       stream=self.stream.cuda_stream, **hme_kw)
+                self.ctx.set_mvcost(table, centre)
+                n_ = self.ctx.geom.cuCount
+                self.win = api.HostWindow(self.ctx, F, weightp=True)
+                self.offs = [(np.zeros(n_), np.zeros(n_)) for _ in range(F)]
+                self.invs = [np.zeros(n_, np.int32) for _ in range(F)]
+                for i in range(F):
+                    self.win.set_qp_offsets(i, *self.offs[i])
+                for k, t in enumerate(segment_slice_types(F, cfg.bframes)):
+                    self.win.set_slice_type(k, t)
+                self.iq = vpn(*[a.ctypes.data for a in self.invs])
 
-    W, H, D, F = args.width, args.height, args.depth, args.frames
-    bpp = 1 if D == 8 else 2
-    clip, chroma = make_clip(W, H, F, D, 1234 + rank)
+            def step(self):
+                win = self.win
+                win._chk(Hlib.xgh_pre_lookahead_aq(win.h, F, frames_arr, ys, us, vs, sy, sc, C.byref(aqp), self.iq, api.MEM_DEVICE))
+                Hlib.xgh_add_many(win.h, len(a1), a1.ctypes.data_as(C.c_void_p))
+                win.finish_batch()
+                Hlib.xgh_add_many(win.h, len(a2), a2.ctypes.data_as(C.c_void_p))
+                win.finish_batch()
+                win.cu_tree(F - 1, False, b_pyramid=True)
 
-    def to_dev(a):
-        return torch.from_numpy(a if D == 8 else a.view(np.int16)).cuda()
-    dev_y = to_dev(clip)
-    dev_u = to_dev(np.stack([c[0] for c in chroma]))
-    dev_v = to_dev(np.stack([c[1] for c in chroma]))
-    torch.cuda.synchronize()
-    yb, cb = W * H * bpp, (W // 2) * (H // 2) * bpp
-    y_ptrs = [dev_y.data_ptr() + i * yb for i in range(F)]
-    u_ptrs = [dev_u.data_ptr() + i * cb for i in range(F)]
-    v_ptrs = [dev_v.data_ptr() + i * cb for i in range(F)]
+            def close(self):
+                self.win.close()
+                self.ctx.close()
 
-    hme_kw = dict(hme=True) if args.hme else {}
-    table, centre = api.bitcost_table(D)
-    Hlib = api.load_host_library()
-    b1, b2 = batch_requests(F, args.bframes)
-    a1 = np.ascontiguousarray(np.array(b1, np.int32).reshape(-1, 3))
-    a2 = np.ascontiguousarray(np.array(b2, np.int32).reshape(-1, 3))
-    n_search = sum(1 + (1 if p1 > b else 0) for (_, p1, b) in b1)
-    n_cost = len(b1) + len(b2)
-    vpn = C.c_void_p * F
-    frames_arr = (C.c_int32 * F)(*range(F))
-    ys, us, vs = vpn(*y_ptrs), vpn(*u_ptrs), vpn(*v_ptrs)
-    sy, sc = (C.c_ssize_t * F)(*[W] * F), (C.c_ssize_t * F)(*[W // 2] * F)
-    aqp = api.AqParams(2, 1, 0, 0, 1.0, 32, 0, None, None, None, 0, 0, 0.0, None)
+        self.in_flight = max(1, cfg.in_flight)
+        self.pipes = [Pipeline(own_stream=self.in_flight > 1) for _ in range(self.in_flight)]
+        self.ctx = self.pipes[0].ctx
+        self.n = self.ctx.geom.cuCount
+        self.req_all = np.ascontiguousarray(np.concatenate([a1, a2]))
+        self.gather_lock = threading.Lock()
+        if distributed:
+            # per pipeline: the step's records in page-locked memory, their device copy, the gathered set
+            for pipe in self.pipes:
+                pipe.pinned = torch.zeros((self.n_cost, 3), dtype=torch.int64).pin_memory()
+                pipe.pin_np = pipe.pinned.numpy()
+                pipe.local = torch.zeros((self.n_cost, 3), dtype=torch.int64, device="cuda")
+                pipe.gathered = torch.zeros((world * self.n_cost, 3), dtype=torch.int64, device="cuda")
+                pipe.gathered_host = torch.zeros((world * self.n_cost, 3), dtype=torch.int64).pin_memory()
 
-    class Pipeline:
-        """One lookahead instance (library context, host-layer window) working on segments one after the other.  With
-        --in-flight P, P of them take the steps in turn from P host threads, each on a stream of its own: one
-        segment's host phases (weight analysis, AQ mapping, cuTree) then run beside another's searches."""
-
-        def __init__(self, own_stream):
-            self.stream = torch.cuda.Stream() if own_stream else torch.cuda.current_stream()
-            self.ctx = api.Context(W, H, depth=D, bframes=args.bframes, num_slots=F, device=local_rank,
-                                   stream=self.stream.cuda_stream, **hme_kw)
-            self.ctx.set_mvcost(table, centre)
-            n_ = self.ctx.geom.cuCount
-            self.win = api.HostWindow(self.ctx, F, weightp=True)
-            self.offs = [(np.zeros(n_), np.zeros(n_)) for _ in range(F)]
-            self.invs = [np.zeros(n_, np.int32) for _ in range(F)]
-            for i in range(F):
-                self.win.set_qp_offsets(i, *self.offs[i])
-            for k, t in enumerate(segment_slice_types(F, args.bframes)):
-                self.win.set_slice_type(k, t)
-            self.iq = vpn(*[a.ctypes.data for a in self.invs])
-
-        def step(self):
-            win = self.win
-            win._chk(Hlib.xgh_pre_lookahead_aq(win.h, F, frames_arr, ys, us, vs, sy, sc, C.byref(aqp), self.iq, api.MEM_DEVICE))
-            Hlib.xgh_add_many(win.h, len(a1), a1.ctypes.data_as(C.c_void_p))
-            win.finish_batch()
-            Hlib.xgh_add_many(win.h, len(a2), a2.ctypes.data_as(C.c_void_p))
-            win.finish_batch()
-            win.cu_tree(F - 1, False, b_pyramid=True)
-
-        def close(self):
-            self.win.close()
-            self.ctx.close()
-
-    in_flight = max(1, args.in_flight)
-    pipes = [Pipeline(own_stream=in_flight > 1) for _ in range(in_flight)]
-    ctx, win = pipes[0].ctx, pipes[0].win
-    n = ctx.geom.cuCount
-
-    req_all = np.ascontiguousarray(np.concatenate([a1, a2]))
-    if distributed:
-        # per pipeline: the step's records in page-locked memory, their device copy, the gathered set
-        for pipe in pipes:
-            pipe.pinned = torch.zeros((n_cost, 3), dtype=torch.int64).pin_memory()
-            pipe.pin_np = pipe.pinned.numpy()
-            pipe.local = torch.zeros((n_cost, 3), dtype=torch.int64, device="cuda")
-            pipe.gathered = torch.zeros((world * n_cost, 3), dtype=torch.int64, device="cuda")
-            pipe.gathered_host = torch.zeros((world * n_cost, 3), dtype=torch.int64).pin_memory()
-
-    def gather(pipe):
+    def gather(self, pipe):
         # this rank's per-request scalars (already on its host, where its own decisions read them) go to the
         # other ranks in one collective; rank 0 also brings the whole set back to its host
-        Hlib.xgh_collect_costs(pipe.win.h, len(req_all), req_all.ctypes.data_as(C.c_void_p), pipe.pin_np.ctypes.data_as(C.c_void_p))
+        import torch.distributed as dist
+        C = self.C
+        self.Hlib.xgh_collect_costs(pipe.win.h, len(self.req_all), self.req_all.ctypes.data_as(C.c_void_p),
+                                    pipe.pin_np.ctypes.data_as(C.c_void_p))
         pipe.local.copy_(pipe.pinned, non_blocking=True)
         dist.all_gather_into_tensor(pipe.gathered, pipe.local)
-        if rank == 0:
+        if self.rank == 0:
             pipe.gathered_host.copy_(pipe.gathered, non_blocking=True)
 
-    def segment_step(pipe=None):
-        pipe = pipe or pipes[0]
+    def segment_step(self, pipe=None):
+        pipe = pipe or self.pipes[0]
         pipe.step()
-        if distributed:
+        if self.distributed:
             # one collective at a time, in the same count on every rank
-            with gather_lock:
-                gather(pipe)
+            with self.gather_lock:
+                self.gather(pipe)
 
-    gather_lock = threading.Lock()
-
-    def run_steps(count):
+    def run_steps(self, count):
         """`count` segment steps: in turn on the pipelines, each pipeline driven by a host thread of its own."""
-        if in_flight == 1:
+        torch = self.torch
+        if self.in_flight == 1:
             for _ in range(count):
-                segment_step()
+                self.segment_step()
             return
         errs = []
 
         def work(k):
             try:
-                torch.cuda.set_device(local_rank)          # the current device is a per-thread setting
-                with torch.cuda.stream(pipes[k].stream):
-                    for _ in range(k, count, in_flight):
-                        segment_step(pipes[k])
+                torch.cuda.set_device(self.local_rank)          # the current device is a per-thread setting
+                with torch.cuda.stream(self.pipes[k].stream):
+                    for _ in range(k, count, self.in_flight):
+                        self.segment_step(self.pipes[k])
             except Exception as e:      # noqa: BLE001 - reported by the caller
                 errs.append(e)
-        th = [threading.Thread(target=work, args=(k,)) for k in range(in_flight)]
+        th = [threading.Thread(target=work, args=(k,)) for k in range(self.in_flight)]
         for t in th:
             t.start()
         for t in th:
@@ -476,58 +463,63 @@ def rank_main(args):
         if errs:
             raise errs[0]
 
-    def fence():
-        if distributed:
+    def fence(self):
+        if self.distributed:
+            import torch.distributed as dist
             dist.barrier()
-        torch.cuda.synchronize()
+        self.torch.cuda.synchronize()
 
-    run_steps(max(args.warmup, in_flight if args.warmup else 0))
-    fence()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = 1000.0 * dt / args.steps
-    fps = F * world * args.steps / dt
-
-    # one lookahead instance on its own (a segment's phases strictly one after the other), for comparison
-    single = None
-    if in_flight > 1:
-        ssteps = max(1, min(args.steps, 20))
-        fence()
+    def timed(self, steps):
+        """Exactly `steps` steps between two fences -> (seconds: the slowest rank's, host CPU seconds of this process)."""
+        self.fence()
+        c0 = time.process_time()
         t0 = time.perf_counter()
-        for _ in range(ssteps):
-            segment_step()
-        fence()
+        self.run_steps(steps)
+        self.fence()
+        dt = time.perf_counter() - t0
+        cpu = time.process_time() - c0
+        if self.distributed:
+            import torch.distributed as dist
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, cpu
+
+    def single_instance(self, steps):
+        """One lookahead instance on its own (a segment's phases strictly one after the other), for comparison."""
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.segment_step()
+        self.fence()
         sdt = time.perf_counter() - t0
-        single = {"ms_per_step": 1000.0 * sdt / ssteps, "frames_per_s_per_gpu": F * ssteps / sdt, "steps": ssteps}
+        return {"ms_per_step": 1000.0 * sdt / steps, "frames_per_s_per_gpu": self.cfg.frames * steps / sdt, "steps": steps}
 
-    # ---- per-phase kernel time with HIP events on the library's stream (separate, untimed pass) ----
-    ctx.profile_enable(True)
-    ctx.profile_read(reset=True)
-    prof_steps = 2
-    tp = time.perf_counter()
-    for _ in range(prof_steps):
-        segment_step()
-    torch.cuda.synchronize()
-    prof_wall_ms = 1000.0 * (time.perf_counter() - tp) / prof_steps
-    prof = ctx.profile_read(reset=True)
-    ctx.profile_enable(False)
+    def profile(self, prof_steps=2):
+        """Per-phase kernel time with HIP events on the library's stream: a separate, untimed pass of one instance."""
+        ctx = self.ctx
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        tp = time.perf_counter()
+        for _ in range(prof_steps):
+            self.segment_step()
+        self.torch.cuda.synchronize()
+        wall_ms = 1000.0 * (time.perf_counter() - tp) / prof_steps
+        prof = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+        return {k: (ms / prof_steps, launches / prof_steps) for k, (ms, launches) in prof.items()}, wall_ms
 
-    # ---- steady workload: the real decision loop, one encoder instance ----
-    steady = None
-    if rank == 0 and args.steady_steps > 0:
-        p = api.LookaheadParam(**dict(MEDIUM, bitDepth=D, bframes=args.bframes))
+    def steady(self, steady_steps):
+        """The real decision loop, one encoder instance: Lookahead::slicetypeDecide fed picture by picture."""
+        api, cfg = self.api, self.cfg
+        F, W = cfg.frames, cfg.width
+        p = api.LookaheadParam(**dict(MEDIUM, bitDepth=cfg.depth, bframes=cfg.bframes))
 
         def steady_step():
-            la = api.HostLookahead(ctx, p)
+            la = api.HostLookahead(self.ctx, p)
             out = 0
             for i in range(F):
-                la.add_device_picture(y_ptrs[i], u_ptrs[i], v_ptrs[i], W, W // 2)
+                la.add_device_picture(self.y_ptrs[i], self.u_ptrs[i], self.v_ptrs[i], W, W // 2)
                 out += la.get_decided() is not None
             la.flush()
             while la.get_decided() is not None:
@@ -537,27 +529,28 @@ def rank_main(args):
             assert out == F
             return calls
         steady_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        calls = 0
-        for _ in range(args.steady_steps):
+        self.torch.cuda.synchronize()
+        times, calls = [], 0
+        for _ in range(steady_steps):
+            t0 = time.perf_counter()
             calls += steady_step()
-        torch.cuda.synchronize()
-        sdt = time.perf_counter() - t0
-        steady = {"frames_per_s": F * args.steady_steps / sdt, "ms_per_slicetypeDecide": 1000.0 * sdt / calls,
-                  "slicetypeDecide_calls_per_segment": calls / args.steady_steps, "ms_per_segment": 1000.0 * sdt / args.steady_steps,
-                  "workload": "Lookahead::slicetypeDecide loop, preset medium (rc-lookahead 20, b-adapt 2, B-pyramid, weightp, AQ 2, "
-                              "cuTree), pool of 16 (batched requests per decision), %d-frame clip fed picture by picture" % F}
+            self.torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        sdt = sum(times)
+        med = sorted(times)[len(times) // 2]
+        return {"frames_per_s": F / med, "ms_per_slicetypeDecide": 1000.0 * med / (calls / steady_steps),
+                "slicetypeDecide_calls_per_segment": calls / steady_steps, "ms_per_segment": 1000.0 * med,
+                "ms_per_segment_all": [1000.0 * t for t in times], "frames_per_s_mean": F * steady_steps / sdt,
+                "workload": "Lookahead::slicetypeDecide loop, preset medium (rc-lookahead 20, b-adapt 2, B-pyramid, weightp, AQ 2, "
+                            "cuTree), pool of 16 (batched requests per decision), %d-frame clip fed picture by picture; the "
+                            "median of %d passes" % (F, steady_steps)}
 
-    g = ctx.geom
-    P = W * H
-
-    # Bytes the cost evaluation touches, counted from the vectors this step produced (frame k sits in slot k): a P
-    # request reads no pixels (vector costs, intra costs and AQ factors of each block); a B request reads the encode
-    # block, the two co-located blocks and, per list, the one half-pel plane block its vector points into, or the two
-    # blocks a quarter-pel vector averages (lowresMC, source/common/lowres.h:72-93).
-    def counted_cost_bytes():
-        cache = {}
+    def counted_cost_bytes(self):
+        """Bytes the cost evaluation touches, counted from the vectors this step produced (frame k sits in slot k): a P
+        request reads no pixels (vector costs, intra costs and AQ factors of each block); a B request reads the encode
+        block, the two co-located blocks and, per list, the one half-pel plane block its vector points into, or the
+        two blocks a quarter-pel vector averages (lowresMC, source/common/lowres.h:72-93)."""
+        cache, n, ctx, g = {}, self.n, self.ctx, self.ctx.geom
 
         def planes(slot, lst, dist):
             if (slot, lst, dist) not in cache:
@@ -565,23 +558,38 @@ def rank_main(args):
                 cache[(slot, lst, dist)] = int(n + np.count_nonzero((mv[:, 0] | mv[:, 1]) & 1))
             return cache[(slot, lst, dist)]
         total = 0
-        for p0, p1, b in list(b1) + list(b2):
+        for p0, p1, b in list(self.b1) + list(self.b2):
             total += 4 * g.heightInCU + 24                     # row sums and the request's totals
             if p1 > b:
                 blocks = 3 * n + planes(b, 0, b - p0) + planes(b, 1, p1 - b)
-                total += 64 * bpp * blocks + n * (8 + 8 + 4 + 4 + 4 + 2)
+                total += 64 * self.bpp * blocks + n * (8 + 8 + 4 + 4 + 4 + 2)
             else:
                 total += n * (4 + 4 + 4 + 2)
         return total
+
+    def close(self):
+        for pipe in self.pipes:
+            pipe.close()
+        self.pipes = []
+        self.dev_y = self.dev_u = self.dev_v = None
+        self.torch.cuda.empty_cache()
+
+
+def phase_report(wl, cfg, prof, rates, ops):
+    """(kernels, roofline): per-phase kernel times with their algorithmic rates, and the dominant kernel's roofline.
+    `ops`: executed block compares per phase from the oracle's run of the same segment, or None."""
+    W, H, D, F = cfg.width, cfg.height, cfg.depth, cfg.frames
+    bpp, n, g = wl.bpp, wl.n, wl.ctx.geom
+    P = W * H
+    n4 = g.widthInCU4 * g.heightInCU4 if cfg.hme else 0
     alg = {   # algorithmic bytes per step, per phase
         "lowres": F * 2 * P * bpp,
         "intra": F * ((P // 4) * bpp + 7 * n),
-        "search": n_search * (5 * (P // 4) * bpp + 12 * n),
-        "cost": counted_cost_bytes(),
+        "search": wl.n_search * (5 * (P // 4) * bpp + 12 * n),
+        "cost": wl.counted_cost_bytes(),
     }
     kernels = {}
-    for k, (ms, launches) in prof.items():
-        ms_step, l_step = ms / prof_steps, launches / prof_steps
+    for k, (ms_step, l_step) in prof.items():
         if ms_step <= 0:
             continue
         kernels[k] = {"ms_per_step": ms_step, "launches_per_step": l_step,
@@ -614,8 +622,10 @@ def rank_main(args):
     # rate says how much of the issue slots a kernel of this mix could still use.
     valu_peak = SIMDS * rates["clock_GHz"] / rates["valu_cycles_per_inst_per_simd_8_waves_fastest_kind"] if rates else None
     valu_peak_packed = SIMDS * rates["clock_GHz"] / rates["valu_cycles_per_inst_per_simd_8_waves"] if rates else None
+    search_waves = wl.n_search * (flow_waves_per_job(g.widthInCU, g.heightInCU) +
+                                  (flow_waves_per_job(g.widthInCU4, g.heightInCU4) if n4 else 0))
     for k, v in kernels.items():
-        c = pmc_kernel(args, names[k])
+        c = pmc_kernel(cfg, names[k])
         if not c or not valu_peak or not c.get("dispatches") or "SQ_INSTS_VALU" not in c:
             continue
         # launches of the phase's main kernel: the intra and cost phases count their small finalize kernel as well,
@@ -623,9 +633,12 @@ def rank_main(args):
         launches = v["launches_per_step"]
         if k in ("intra", "cost") or (k == "search" and mode == "flow"):
             launches /= 2
-        if k == "search" and mode == "flow" and args.hme:
+        if k == "search" and mode == "flow" and cfg.hme:
             launches = 1        # the two levels' kernels come back from pmc_kernel() summed per step
         insts = c["SQ_INSTS_VALU"] / c["dispatches"] * launches
+        if k == "search" and mode == "flow" and c.get("SQ_WAVES"):
+            # per wave rather than per dispatch: the counter pass may have run another segment length
+            insts = c["SQ_INSTS_VALU"] / c["SQ_WAVES"] * search_waves
         v["valu_G_insts_per_s"] = insts / (v["ms_per_step"] * 1e-3) / 1e9
         v["valu_frac"] = v["valu_G_insts_per_s"] / valu_peak
         v["valu_frac_at_sad_class_rate"] = v["valu_G_insts_per_s"] / valu_peak_packed
@@ -634,7 +647,27 @@ def rank_main(args):
             v["pmc_traffic_bytes_per_step"] = t * launches
             v["pmc_traffic_over_algorithmic"] = t * launches / alg[k]
 
-    pmc = pmc_kernel(args, kernel_name)
+    # The algorithmic form of the same fraction: the block compares the reference's algorithm executes on this very
+    # segment (counted by the oracle's run of it, cpu_baseline leg), as lane operations (OPS_* above), over 64 lanes x
+    # the instruction peak x the phase time.  It does not grow when a kernel issues more instructions for the same work.
+    if ops and valu_peak:
+        lane_ops = {
+            "intra": ops["intra"][1] * OPS_SATD + ops["intra"][2] * OPS_INTRA_PRED,
+            "search": ops["search"][0] * OPS_SAD[bpp] + ops["search"][1] * OPS_SATD,
+            "cost": ops["cost"][1] * OPS_SATD,
+        }
+        for k, total in lane_ops.items():
+            if k in kernels and total:
+                v = kernels[k]
+                v["algorithmic_lane_ops_per_step"] = total
+                v["algorithmic_frac"] = total / (64.0 * valu_peak * 1e9 * v["ms_per_step"] * 1e-3)
+                v["algorithmic_frac_at_sad_class_rate"] = total / (64.0 * valu_peak_packed * 1e9 * v["ms_per_step"] * 1e-3)
+        if "search" in kernels:
+            units = wl.n_search * (n + n4)
+            kernels["search"]["sads_per_block_search"] = ops["search"][0] / units
+            kernels["search"]["satds_per_block_search"] = ops["search"][1] / units
+
+    pmc = pmc_kernel(cfg, kernel_name)
     hbm = {"achieved": dom["algorithmic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["algorithmic_GBs"] / HBM_PEAK_GBS,
            "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": pmc_traffic_per_launch(pmc)}
     roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -644,24 +677,157 @@ def rank_main(args):
         # The block search is integer SAD / SATD work out of LDS: the resource it uses most is the SIMDs' vector issue,
         # not HBM.  Instructions per block search come from the counter passes of this configuration, cycles per
         # instruction and the clock from the microbenchmark.
-        per_wave = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"]
-        units = pmc["SQ_WAVES"] / pmc["dispatches"]                    # block searches per step (a wave each; with --hme both levels)
-        achieved = per_wave * units / (dom["ms_per_step"] * 1e-3) / 1e9
+        units = wl.n_search * (n + n4)           # block searches per step; the launch starts a few more waves than
+        waves = search_waves                     # that: chunks of a diagonal that are not full (they leave at once)
+        per_search = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"] * waves / units
+        achieved = per_search * units / (dom["ms_per_step"] * 1e-3) / 1e9
         roofline.update({"bound": "valu", "achieved": achieved, "peak": valu_peak, "unit": "G wave64-instructions/s",
                          "frac": achieved / valu_peak, "frac_at_sad_class_rate": achieved / valu_peak_packed,
-                         "peak_at_sad_class_rate": valu_peak_packed, "valu_insts_per_block_search": per_wave,
-                         "salu_insts_per_block_search": pmc.get("SQ_INSTS_SALU", 0) / pmc["SQ_WAVES"],
-                         "block_searches_per_step": units, "hbm": hbm,
+                         "peak_at_sad_class_rate": valu_peak_packed, "valu_insts_per_block_search": per_search,
+                         "salu_insts_per_block_search": pmc.get("SQ_INSTS_SALU", 0) / pmc["SQ_WAVES"] * waves / units,
+                         "block_searches_per_step": units, "idle_waves_per_step": max(0.0, waves - units), "hbm": hbm,
                          "note": "vector-issue roofline: measured instructions per 8x8 block search x block searches / phase time, "
                                  "against 1024 SIMDs x measured clock / measured cycles per wave64 instruction of the fastest kind "
                                  "(32-bit add); frac_at_sad_class_rate uses the measured rate of v_sad_u8 / v_pk_add_i16 / v_min_i32 / "
                                  "v_alignbyte_b32, which the search is mostly made of and which issue 1.8x more slowly, measured for an "
                                  "independent stream; the kernel's stream is dependent (SAD, DPP adds, DPP minima, lane read per step) and "
-                                 "by an occupancy test (8 -> 6 waves per SIMD costs 12 %) the phase is mostly at its issue limit"})
+                                 "by an occupancy test (8 -> 6 waves per SIMD costs 12 %) the phase is mostly at its issue limit; "
+                                 "algorithmic_frac counts the reference algorithm's executed SADs / SATDs instead of issued instructions"})
+        if "algorithmic_frac" in dom:
+            roofline["algorithmic_frac"] = dom["algorithmic_frac"]
+            roofline["algorithmic_frac_at_sad_class_rate"] = dom["algorithmic_frac_at_sad_class_rate"]
+            roofline["algorithmic_lane_ops_per_launch"] = dom["algorithmic_lane_ops_per_step"] / max(1.0, dom_launches)
     elif dominant == "search":
         roofline["note"] = ("no counter pass committed for this configuration (profiles/pmc_%s.json): the vector-issue "
                             "fraction is not reported; the HBM fraction is small by construction (integer search out of LDS)"
-                            % config_key(args))
+                            % config_key(cfg))
+    return kernels, roofline
+
+
+def flow_waves_per_job(W8, H8):
+    """Waves the single-launch search starts per job: four per chunk of an anti-diagonal t = x + 2y of the block grid
+    (the last chunk of a diagonal may hold fewer than four blocks; its other waves leave at once)."""
+    total = 0
+    for t in range((W8 - 1) + 2 * (H8 - 1) + 1):
+        ylo = max(0, (t - (W8 - 1) + 1) >> 1)
+        yhi = min(H8 - 1, t >> 1)
+        if yhi >= ylo:
+            total += 4 * ((yhi - ylo + 1 + 3) // 4)
+    return total
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+
+OTHER_CONFIGS = (   # the other sizes the metric is quoted on: (width, height, depth, hme, frames per step, steps)
+    (3840, 2160, 10, False, 60, 3),
+    (3840, 2160, 10, True, 60, 2),
+    (7680, 4320, 10, False, 16, 3),
+)
+
+
+def other_configs(args, rates, rank, world, local_rank):
+    """A bounded pass over the other configurations: a few steps each, frames/s, the search phase and its fractions."""
+    out, clips = [], {}
+    for (W, H, D, hme, F, steps) in OTHER_CONFIGS:
+        cfg = argparse.Namespace(**dict(vars(args), width=W, height=H, depth=D, hme=hme, frames=F))
+        key = (W, H, D, F)
+        if key not in clips:
+            clips.clear()                                   # one large clip in host memory at a time
+            clips[key] = make_clip(W, H, F, D, 1234 + rank)
+        cfg.clip = clips[key]
+        wl = Workload(cfg, rank, world, local_rank, False)
+        try:
+            wl.run_steps(wl.in_flight)
+            dt, _ = wl.timed(steps * wl.in_flight)
+            prof, _ = wl.profile(1)
+            kernels, roofline = phase_report(wl, cfg, prof, rates, None)
+            rec = {"workload": "%dx%d %d-bit%s, %d-frame segment per step" % (W, H, D, " --hme" if hme else "", F),
+                   "frames_per_s": F * steps * wl.in_flight / dt, "ms_per_step": 1000.0 * dt / (steps * wl.in_flight),
+                   "steps": steps * wl.in_flight}
+            for k in ("search", "cost", "intra", "lowres"):
+                if k in kernels:
+                    rec[k + "_ms"] = kernels[k]["ms_per_step"]
+            if "search" in kernels:
+                for k in ("valu_frac", "valu_frac_at_sad_class_rate", "pmc_traffic_over_algorithmic"):
+                    if k in kernels["search"]:
+                        rec["search_" + k] = kernels["search"][k]
+            out.append(rec)
+        finally:
+            wl.close()
+    return out
+
+
+# ---------------------------------------------------------------- rank body
+
+def rank_main(args):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # Libraries under the process group print banners on stdout; keep fd 1 for the one JSON line.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    # Host threads per lookahead instance for the library's double-precision AQ mapping: this rank's share of the host
+    # (at most 16 cores per GPU, the share of a GPU on the boxes this runs on) split over its instances, so that N
+    # ranks on one node do not start N x 2 x 16 mapping threads.
+    in_flight = max(1, args.in_flight)
+    share = max(1, min(16, len(os.sched_getaffinity(0)) // max(1, world)))
+    host_threads = os.environ.get("X265GPU_HOST_THREADS")
+    if host_threads is None:
+        host_threads = str(max(1, share // in_flight))
+        os.environ["X265GPU_HOST_THREADS"] = host_threads
+
+    # Everything that starts another process (the issue-rate microbenchmark, the worker pool of the all-cores CPU
+    # baseline) runs before this process initialises the GPU.
+    rates = (issue_rates() if not args.no_micro else None) or recorded_issue_rates() if rank == 0 else None
+    cpu = cpu_baselines(args) if rank == 0 and world == 1 and args.cpu_frames > 0 else {}
+    ops = cpu.pop("_op_counters", None)
+    if ops and ops["frames"] != args.frames:
+        ops = None                      # the oracle's counts describe another segment length
+
+    import torch
+    distributed = world > 1 or args.force_dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the lookahead path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)       # --force-dist outside a launcher: a world of one
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, D, F = args.width, args.height, args.depth, args.frames
+    wl = Workload(args, rank, world, local_rank, distributed)
+    wl.run_steps(max(args.warmup, in_flight if args.warmup else 0))
+    reps = [wl.timed(args.steps) for _ in range(max(1, args.reps))]
+    dts = [r[0] for r in reps]
+    dt = median(dts)
+    cpu_s = median([r[1] for r in reps])
+    ms_per_step = 1000.0 * dt / args.steps
+    fps = F * world * args.steps / dt
+    gathered_ok = None
+    if distributed and rank == 0:
+        # the gathered set of the last step: this rank's own records sit at its place in it
+        torch.cuda.synchronize()
+        pipe = wl.pipes[(args.steps - 1) % in_flight] if in_flight > 1 else wl.pipes[0]
+        mine = pipe.gathered_host.numpy()[rank * wl.n_cost:(rank + 1) * wl.n_cost]
+        gathered_ok = bool(np.array_equal(mine, pipe.pin_np)) and bool(np.any(pipe.pin_np))
+
+    single = wl.single_instance(max(1, min(args.steps, 20))) if in_flight > 1 else None
+    prof, prof_wall_ms = wl.profile(2)
+    steady = wl.steady(args.steady_steps) if rank == 0 and args.steady_steps > 0 else None
+    kernels, roofline = phase_report(wl, args, prof, rates, ops["phases"] if ops else None)
+    n = wl.n
+    n_search, n_cost = wl.n_search, wl.n_cost
+    wl.close()
+
+    others = None
+    if rank == 0 and world == 1 and not args.force_dist and not args.no_other_configs:
+        others = other_configs(args, rates, rank, world, local_rank)
 
     out = {
         "metric": "lookahead frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
@@ -676,16 +842,27 @@ def rank_main(args):
                    "blocks_per_frame": n, "bframes": args.bframes,
                    "segments_in_flight_per_gpu": in_flight,
                    "sharding": "one frame segment per rank, RCCL all_gather of the per-request cost scalars" if distributed else "single GPU"},
+        "repetitions": {"count": len(dts), "steps_each": args.steps, "ms_per_step": [1000.0 * t / args.steps for t in dts],
+                        "frames_per_s": [F * world * args.steps / t for t in dts],
+                        "ms_per_step_median": ms_per_step, "ms_per_step_min": 1000.0 * min(dts) / args.steps,
+                        "ms_per_step_max": 1000.0 * max(dts) / args.steps,
+                        "note": "value and ms_per_step are the median repetition; every repetition is exactly `steps` steps between two fences"},
+        "host_cpu": {"host_cpu_seconds_per_step": cpu_s / args.steps, "host_cores_needed_per_gpu": cpu_s / dt,
+                     "host_threads_per_instance": int(host_threads), "host_cores_visible": len(os.sched_getaffinity(0)),
+                     "note": "process CPU time of this rank over the timed region (every thread: the instances' host threads and the "
+                             "library's AQ mapping threads) / wall time = cores this rank keeps busy beside its GPU"},
         "roofline": roofline, "kernels": kernels, "machine": rates,
         "step_wall_ms_with_event_timers": prof_wall_ms,
     }
+    if gathered_ok is not None:
+        out["gathered_records_match_local"] = gathered_ok
     if single:
         out["single_instance"] = single
     if steady:
         out["steady_state"] = steady
+    if others is not None:
+        out["other_configs"] = others
     out.update(cpu)
-    for pipe in pipes:
-        pipe.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -701,6 +878,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=3, help="repetitions of the timed block of --steps steps; the median is reported")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
@@ -715,9 +893,8 @@ def main():
                     help="initialise the process group and run the gather even at world size 1 (rehearsal of the N>1 path)")
     ap.add_argument("--hme", action="store_true", help="--hme: quarter-res hex then half-res umh (x265's defaults, ranges 16 / 32)")
     ap.add_argument("--no-micro", action="store_true", help="skip the issue-rate microbenchmark (it runs as a child process)")
-    ap.add_argument("--backend", default="nccl", help="process-group backend of --cpu-standin (tests use gloo)")
-    ap.add_argument("--cpu-standin", action="store_true",
-                    help="TEST ONLY: rehearse the multi-rank path on CPU with the oracle in the device's place")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the bounded pass over 4K / 4K --hme / 8K")
+    ap.add_argument("--rank-timeout", type=int, default=900, help="--gpus N launcher: seconds after which remaining ranks are ended")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, sys.argv[1:]))

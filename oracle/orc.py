@@ -576,3 +576,17 @@ def mcstf_motion_search(cur, refs):
         for level in range(4):
             L.orc_mcstf_level(level, C.byref(cur.planes), C.byref(ref.planes), C.byref(m))
     return mvs, err, coarse
+
+
+OP_PHASES = ("intra", "search", "cost", "weights", "other")
+
+
+def op_counters(depth, reset=False):
+    """Executed block compares of this depth's library since load (or the last reset), per phase:
+    {phase: (SADs, SATDs, intra predictions)} in 8x8 units (orc_op_counters, orc_pixel.c)."""
+    arr = (C.c_longlong * 15).in_dll(lib(depth), "orc_op_counters")
+    out = {name: (int(arr[3 * i]), int(arr[3 * i + 1]), int(arr[3 * i + 2])) for i, name in enumerate(OP_PHASES)}
+    if reset:
+        for i in range(15):
+            arr[i] = 0
+    return out

@@ -230,6 +230,9 @@ void orc_intra_estimate(orc_tld* t, orc_lowres* fenc, const orc_param* p)
     const intptr_t ls = fenc->rp.stride;
     int costEst = 0, costEstAq = 0;
     (void)p;
+    const int phaseWas = orc_op_phase;
+    orc_op_phase = 0;
+    orc_op_counters[0][2] += 12LL * W * H;      /* DC, planar, six coarse angles, two passes of two */
 
     for (int cuY = 0; cuY < H; cuY++)
     {
@@ -297,6 +300,7 @@ void orc_intra_estimate(orc_tld* t, orc_lowres* fenc, const orc_param* p)
     }
     fenc->costEst[0][0] = costEst;
     fenc->costEstAq[0][0] = costEstAq;
+    orc_op_phase = phaseWas;
 }
 
 /* ---------------------------------------------------------------- AQ block energies */
@@ -730,6 +734,8 @@ uint32_t orc_weight_cost_luma(orc_tld* t, orc_lowres* fenc, orc_lowres* ref,
     }
     uint32_t cost = 0;
     int mb = 0;
+    const int phaseWas = orc_op_phase;
+    orc_op_phase = 3;
     for (int y = 0; y < fenc->lines; y += 8)
         for (int x = 0; x < fenc->width; x += 8, mb++)
         {
@@ -737,6 +743,7 @@ uint32_t orc_weight_cost_luma(orc_tld* t, orc_lowres* fenc, orc_lowres* ref,
             int satd = orc_satd(8, 8, src + off, stride, fenc->rp.plane[0] + off, stride);
             cost += imin(satd, fenc->intraCost[mb]);
         }
+    orc_op_phase = phaseWas;
     return cost;
 }
 
@@ -866,6 +873,7 @@ static void estimate_cu(orc_tld* t, const orc_param* p, orc_lowres** frames, int
     const int listDist[2] = { b - p0, p1 - b };
     int bcost = ORC_COST_MAX;
     int listused = 0;
+    orc_op_phase = 2;       /* the decision half; the searches below name themselves */
 
     orc_mv mvmin = { -cuX * 8 - 8, -cuY * 8 - 8 };
     orc_mv mvmax = { (W - cuX - 1) * 8 + 8, (H - cuY - 1) * 8 + 8 };
@@ -882,6 +890,7 @@ static void estimate_cu(orc_tld* t, const orc_param* p, orc_lowres** frames, int
             continue;
         }
 
+        orc_op_phase = 1;
         int numc = 0;
         orc_mv mvc[5], mvp = { 0, 0 };
         orc_mv* fencMV = hme ? &fenc->lowerResMvs[i][listDist[i]][cuXY] : &fenc->lowresMvs[i][listDist[i]][cuXY];
@@ -933,6 +942,7 @@ static void estimate_cu(orc_tld* t, const orc_param* p, orc_lowres** frames, int
             fencMV->y = 0;
         }
         if (*fencCost < bcost) { bcost = *fencCost; listused = i + 1; }
+        orc_op_phase = 2;
     }
     if (hme)
         return;

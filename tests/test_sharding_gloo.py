@@ -151,16 +151,22 @@ def test_two_rank_gather_matches_single_process(oracle_built):
         np.testing.assert_array_equal(np.array(parts[r], np.int64).reshape(-1, 3), _segment_costs(s, e))
 
 
-@pytest.mark.timeout(300)
-def test_bench_gpus_2_launches_two_ranks(oracle_built):
-    """`bench.py --gpus 2` outside torchrun starts two rank processes itself and rank 0 prints one JSON line with
-    n_gpus 2: the same launcher the GPU run uses, here with gloo and the oracle standing in for the device."""
-    import json
+def _launch(argv, gpus, timeout):
+    """bench.launch_ranks in a process of its own (it passes rank 0's output on to its standard output)."""
     import subprocess
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-standin", "--backend", "gloo",
-                          "--width", str(W), "--height", str(H), "--frames", "8", "--bframes", str(BFRAMES), "--steps", "1",
-                          "--warmup", "0", "--cpu-frames", "0"], capture_output=True, timeout=240,
-                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    code = ("import argparse, sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.launch_ranks(argparse.Namespace(gpus=%d, rank_timeout=%d), %r, script=%r))"
+            % (ROOT, gpus, timeout, argv, os.path.join(ROOT, "tests", "standin_rank.py")))
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=240,
+                          env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+
+
+@pytest.mark.timeout(300)
+def test_bench_launcher_starts_two_ranks(oracle_built):
+    """The launcher behind `bench.py --gpus 2` (outside torchrun) starts two rank processes itself and passes on
+    rank 0's one JSON line: here with gloo and the oracle standing in for the device (tests/standin_rank.py)."""
+    import json
+    out = _launch(["--width", str(W), "--height", str(H), "--frames", "8", "--bframes", str(BFRAMES)], 2, 200)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1
@@ -168,4 +174,16 @@ def test_bench_gpus_2_launches_two_ranks(oracle_built):
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     import bench
     b1, b2 = bench.batch_requests(8, BFRAMES)
-    assert rec["config"]["gathered_requests"] == [len(b1) + len(b2)] * 2
+    assert rec["gathered_requests"] == [len(b1) + len(b2)] * 2
+
+
+@pytest.mark.timeout(120)
+def test_bench_launcher_ends_a_stuck_rank():
+    """A rank that never finishes: after the launcher's time limit every remaining rank is ended and the exit status
+    is non-zero, instead of the caller waiting for its own limit."""
+    import time
+    t0 = time.monotonic()
+    out = _launch(["--hang-rank", "1", "--width", str(W), "--height", str(H), "--frames", "4"], 2, 5)
+    assert out.returncode != 0
+    assert time.monotonic() - t0 < 90
+    assert b"ending the remaining ranks" in out.stderr

@@ -472,12 +472,14 @@ class Workload:
     def timed(self, steps):
         """Exactly `steps` steps between two fences -> (seconds: the slowest rank's, host CPU seconds of this process)."""
         self.fence()
+        self.memo0 = self.ctx.aq_memo_stats()
         c0 = time.process_time()
         t0 = time.perf_counter()
         self.run_steps(steps)
         self.fence()
         dt = time.perf_counter() - t0
         cpu = time.process_time() - c0
+        self.memo1 = self.ctx.aq_memo_stats()
         if self.distributed:
             import torch.distributed as dist
             t = self.torch.tensor([dt], dtype=self.torch.float64, device="cuda")
@@ -817,6 +819,7 @@ def rank_main(args):
         mine = pipe.gathered_host.numpy()[rank * wl.n_cost:(rank + 1) * wl.n_cost]
         gathered_ok = bool(np.array_equal(mine, pipe.pin_np)) and bool(np.any(pipe.pin_np))
 
+    memo_lookups, memo_hits = wl.memo1[0] - wl.memo0[0], wl.memo1[1] - wl.memo0[1]
     single = wl.single_instance(max(1, min(args.steps, 20))) if in_flight > 1 else None
     prof, prof_wall_ms = wl.profile(2)
     steady = wl.steady(args.steady_steps) if rank == 0 and args.steady_steps > 0 else None
@@ -849,6 +852,7 @@ def rank_main(args):
                         "note": "value and ms_per_step are the median repetition; every repetition is exactly `steps` steps between two fences"},
         "host_cpu": {"host_cpu_seconds_per_step": cpu_s / args.steps, "host_cores_needed_per_gpu": cpu_s / dt,
                      "host_threads_per_instance": int(host_threads), "host_cores_visible": len(os.sched_getaffinity(0)),
+                     "aq_activity_memo_hit_rate": memo_hits / memo_lookups if memo_lookups else None,
                      "note": "process CPU time of this rank over the timed region (every thread: the instances' host threads and the "
                              "library's AQ mapping threads) / wall time = cores this rank keeps busy beside its GPU"},
         "roofline": roofline, "kernels": kernels, "machine": rates,

@@ -448,6 +448,10 @@ int x265gpu_aq_frames(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int
  * three arrays need the explicit call. */
 int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int32_t memKind, const x265gpu_aq_params* params);
 int x265gpu_aq_frames_finish(x265gpu_ctx* ctx);
+/* The auto-variance modes' block activity, pow(energy + 1, 0.1) in double (slicetype.cpp:541-578), is the host's
+ * libm result, looked up per integer energy once libm has computed it (same function, same bits; energies recur
+ * from picture to picture).  Process-wide counts since start: lookups, and those answered from the table. */
+void x265gpu_aq_memo_stats(uint64_t* lookups, uint64_t* hits);
 
 /* ---- cuTree: propagation of block costs along the lookahead's motion vectors ----
  *

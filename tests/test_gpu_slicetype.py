@@ -184,3 +184,17 @@ def test_4k_10bit_hme_decisions():
     hme = dict(hme=True, hme_methods=(orc.HEX, orc.UMH, orc.UMH), hme_range=(16, 32, 48))
     ctx_hme = dict(hme=True, hme_methods=(api.HEX_SEARCH, api.UMH_SEARCH, api.UMH_SEARCH), hme_range=(16, 32, 48))
     _compare(clip, chroma, depth, p, ctx_kw=ctx_hme, param_kw=hme)
+
+
+@pytest.mark.timeout(900)
+def test_4k_10bit_hme_rc_lookahead_40():
+    """3840x2160 10-bit, --hme, rc-lookahead 40, bframes 4 over 48 frames: the window depth of the 4K configuration as
+    it is quoted (slot count, request mix of the two batch loops, cuTree over 40 frames), not a short window."""
+    p = dict(api.LookaheadParam.MEDIUM, lookaheadDepth=40, bframes=4)
+    N, W, H, depth = 48, 3840, 2160, 10
+    clip = synth.luma_clip(W, H, N, depth, seed=43)
+    chroma = du.chroma_for(clip, depth, 44)
+    hme = dict(hme=True, hme_methods=(orc.HEX, orc.UMH, orc.UMH), hme_range=(16, 32, 48))
+    ctx_hme = dict(hme=True, hme_methods=(api.HEX_SEARCH, api.UMH_SEARCH, api.UMH_SEARCH), hme_range=(16, 32, 48))
+    types, cuts, trace = _compare(clip, chroma, depth, p, ctx_kw=ctx_hme, param_kw=hme)
+    assert len(types) == N and any(t == 5 for t in types)

@@ -22,7 +22,7 @@ EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_estimate_sums_device", "x265gpu_weight_cost", "x265gpu_weight_costs", "x265gpu_weight_cost_static", "x265gpu_weight_planes",
-    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_bipred_satd", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_aq_frames", "x265gpu_aq_frames_begin", "x265gpu_aq_frames_finish", "x265gpu_get_frame_costs", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_bipred_satd", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_aq_frames", "x265gpu_aq_frames_begin", "x265gpu_aq_frames_finish", "x265gpu_aq_memo_stats", "x265gpu_get_frame_costs", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
     "x265gpu_cutree_clear", "x265gpu_cutree_swap", "x265gpu_cutree_propagate", "x265gpu_cutree_get_propagate_cost",
     "x265gpu_cutree_finish", "x265gpu_hist_stats", "x265gpu_mcstf_motion_search",
     "x265gpu_profile_enable", "x265gpu_profile_read",
@@ -175,6 +175,8 @@ def load_library(path=None):
     L.x265gpu_hist_stats.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp]
     L.x265gpu_aq_frame.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp, vp, vp, vp, vp, vp, vp]
     L.x265gpu_aq_frames.argtypes = [vp, i32, vp, i32, vp]
+    L.x265gpu_aq_memo_stats.argtypes = [vp, vp]
+    L.x265gpu_aq_memo_stats.restype = None
     L.x265gpu_get_frame_costs.argtypes = [vp, i32, vp, vp, vp, vp]
     L.x265gpu_mcstf_motion_search.argtypes = [vp, i32, i32, vp, vp, vp, vp]
     L.x265gpu_interp_luma.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -501,6 +503,12 @@ class Context:
         self._chk(fn(self.h, n, pics, MEM_DEVICE, C.byref(prm)))
         self._aq_keep = (pics, arrays)        # the library's threads write into these until the batch is finished
         return [arrays[i] + (np.array(pics[i].wpSum, np.uint64), np.array(pics[i].wpSsd, np.uint64)) for i in range(n)]
+
+    def aq_memo_stats(self):
+        """(lookups, hits) of the library's per-energy activity table since the process started."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.L.x265gpu_aq_memo_stats(C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def hist_stats(self, slot, y, u, v):
         """collectPictureStatistics of a 4:2:0 picture whose luma was given to lowres_init(slot, ...) ->

@@ -10,8 +10,10 @@
 #include "kernels.h"
 #include "../../include/x265gpu.h"
 
+#include <atomic>
 #include <limits>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -47,7 +49,57 @@ double hdr10_shift(uint32_t lumaSum, uint32_t samples)
     return -6;
 }
 
+// A block's activity (energy * depthScale + 1)^0.1 exactly as the host's libm returns it: pow() computes it the first
+// time an energy is seen at a bit depth and the bits are kept.  Block energies are small integers (sixteenth- and
+// sixty-fourth-variances of 16x16 blocks) that recur within a picture and from picture to picture of a sequence:
+// after a few pictures nine lookups in ten are answered from the table.  One table per bit depth, shared by every
+// thread and context of the process: an entry is written once with the one value pow() can return for it (an
+// aligned 8-byte store), so a race between two threads only computes it twice.  Pages nobody touches cost nothing.
+constexpr uint32_t ACTIVITY_MEMO = 1u << 21;            // energies beyond (rare: the busiest 16x16 blocks) go to pow()
+std::atomic<std::atomic<uint64_t>*> activityMemo[3];     // depth 8, 10, 12
+std::atomic<uint64_t> activityLookups{0}, activityHits{0};
+
+inline double block_activity(uint32_t e, int depth, double depthScale, uint64_t& lookups, uint64_t& hits)
+{
+    const int d = depth == 8 ? 0 : depth == 10 ? 1 : depth == 12 ? 2 : -1;
+    lookups++;
+    if (d < 0 || e >= ACTIVITY_MEMO)
+        return pow(e * depthScale + 1, 0.1);
+    std::atomic<uint64_t>* tab = activityMemo[d].load(std::memory_order_acquire);
+    if (!tab)
+    {
+        std::atomic<uint64_t>* fresh = (std::atomic<uint64_t>*)calloc(ACTIVITY_MEMO, sizeof(std::atomic<uint64_t>));
+        if (!fresh)
+            return pow(e * depthScale + 1, 0.1);
+        if (activityMemo[d].compare_exchange_strong(tab, fresh, std::memory_order_acq_rel))
+            tab = fresh;
+        else
+            free(fresh);
+    }
+    const uint64_t bits = tab[e].load(std::memory_order_relaxed);
+    double a;
+    if (bits)                                   // no activity is +0.0: the result is at least 1
+    {
+        hits++;
+        memcpy(&a, &bits, sizeof(a));
+        return a;
+    }
+    a = pow(e * depthScale + 1, 0.1);
+    uint64_t out;
+    memcpy(&out, &a, sizeof(out));
+    tab[e].store(out, std::memory_order_relaxed);
+    return a;
+}
+
 } // namespace
+
+void aq_activity_memo_stats(uint64_t* lookups, uint64_t* hits)
+{
+    if (lookups)
+        *lookups = activityLookups.load();
+    if (hits)
+        *hits = activityHits.load();
+}
 
 // x265_exp2fix8 (source/common/common.cpp:96-103): 2^(-x/6) in 8.8 fixed point
 int aq_exp2fix8(double x)
@@ -88,6 +140,7 @@ void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy
         // first pass (:541-578): activity = (energy + 1)^0.1, kept in qpCuTreeOffset, and its first two moments
         const double depthScale = 1.f / (1 << (2 * (p.depth - 8)));
         double sum = 0, sumSq = 0;
+        uint64_t lookups = 0, hits = 0;
         for (int i = 0; i < blocks; i++)
         {
             // edge mode (:548-565): a block with edges is rated by its edge density, and marked when its mean gradient
@@ -98,11 +151,13 @@ void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy
                 e = edgeDensity[i];
                 inclined[i] = (avgAngle[i] >= 30 && avgAngle[i] <= 60) || (avgAngle[i] >= 120 && avgAngle[i] <= 150);
             }
-            const double a = pow(e * depthScale + 1, 0.1);
+            const double a = block_activity(e, p.depth, depthScale, lookups, hits);
             qpCuTreeOffset[i] = a;
             sum += a;
             sumSq += a * a;
         }
+        activityLookups.fetch_add(lookups, std::memory_order_relaxed);
+        activityHits.fetch_add(hits, std::memory_order_relaxed);
         sum /= p.blockCount;
         sumSq /= p.blockCount;
         strength = p.strength * sum;

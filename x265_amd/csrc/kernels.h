@@ -234,6 +234,8 @@ int aq_exp2fix8(double x);
 void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy, const uint32_t* lumaSum,
                       const float* quantOffsets, double* qpAqOffset, double* qpCuTreeOffset, int32_t* invQscale,
                       const uint32_t* edgeDensity = nullptr, const uint32_t* avgAngle = nullptr);
+// lookups of the per-energy activity table behind aq_frame_offsets, and how many it answered (process-wide, since start)
+void aq_activity_memo_stats(uint64_t* lookups, uint64_t* hits);
 void aq_finish_wp(int width, int height, unsigned long long sum[3], unsigned long long ssd[3]);
 // cuTreeFinish for qgSize > 8 (aq_host.cpp): propagate totals -> qpCuTreeOffset
 void cutree_finish_offsets(int blocks, const int32_t* intraCost, const int32_t* invQscale, const unsigned long long* totals,

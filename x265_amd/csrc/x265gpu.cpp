@@ -2904,6 +2904,11 @@ static int aq_finish_pending(x265gpu_ctx* ctx)
     return rc;
 }
 
+void x265gpu_aq_memo_stats(uint64_t* lookups, uint64_t* hits)
+{
+    aq_activity_memo_stats(lookups, hits);
+}
+
 int x265gpu_aq_frames_finish(x265gpu_ctx* ctx)
 {
     DeviceScope deviceScope(ctx);

@@ -448,6 +448,16 @@ int x265gpu_aq_frames(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int
  * three arrays need the explicit call. */
 int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int32_t memKind, const x265gpu_aq_params* params);
 int x265gpu_aq_frames_finish(x265gpu_ctx* ctx);
+/* --aq-motion: Lookahead::calcMotionAdaptiveQuantFrame (source/encoder/slicetype.cpp:3609-3663) for frame `slot`
+ * and its request (d0 = b - p0, d1 = p1 - b), which must have been estimated: the length of every block's vector
+ * in the lists its decision used is formed on the device from the resident lowresMvs / lowresCosts (no vector
+ * crosses to the host), the power of 0.1, the frame's mean and deviation and the offsets on the host (libm,
+ * sums in block order).  qpAqMotionOffset is written; qpAqOffset, qpCuTreeOffset and invQscaleFactor (cuCount
+ * entries each, the arrays of x265gpu_aq_frame) are added to where a block lies more than one deviation above the
+ * mean, and the slot's scale factors follow.  The walk over the mini-GOP (Lookahead::aqMotion, :3581-3607) is
+ * the caller's. */
+int x265gpu_aq_motion_frame(x265gpu_ctx* ctx, int32_t slot, int32_t d0, int32_t d1, double* qpAqOffset,
+                            double* qpCuTreeOffset, int32_t* invQscaleFactor, double* qpAqMotionOffset);
 /* The auto-variance modes' block activity, pow(energy + 1, 0.1) in double (slicetype.cpp:541-578), is the host's
  * libm result, looked up per integer energy once libm has computed it (same function, same bits; energies recur
  * from picture to picture).  Process-wide counts since start: lookups, and those answered from the table. */

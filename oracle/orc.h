@@ -205,6 +205,7 @@ typedef struct orc_lowres {
     uint16_t* propagateCost;
     double*  qpAqOffset;
     double*  qpCuTreeOffset;
+    double*  qpAqMotionOffset; /* --aq-motion (source/common/lowres.cpp:114-115), allocated on first use */
     int      sliceType;       /* X265_TYPE_* (source/x265.h) */
     /* what the slice-type decision keeps per frame (source/common/lowres.h:166-213) */
     int      sliceTypeReq;
@@ -292,6 +293,8 @@ typedef struct orc_la_param {
     int bEnableTemporalSubLayers; /* 0..2 */
     int maxNumReferences;
     int poolWorkers;              /* ThreadPool::m_numWorkers of the lookahead's pool, 0: no pool */
+    int bAQMotion;                /* --aq-motion */
+    int bHistBasedSceneCut;       /* --hist-scenecut: frames carry orc_hist_stats (orc_lowres_set_hist_stats) */
 } orc_la_param;
 typedef struct orc_la orc_la;
 orc_la* orc_la_create(const orc_param* p, const orc_la_param* lp, const orc_cutree_param* cp, orc_tld* tld);

@@ -44,7 +44,8 @@ class LaParam(C.Structure):
                 ("keyframeMax", C.c_int), ("bOpenGOP", C.c_int), ("bIntraRefresh", C.c_int), ("radl", C.c_int),
                 ("gopLookahead", C.c_int), ("cuTree", C.c_int), ("aqMode", C.c_int), ("vbvBufferSize", C.c_int),
                 ("vbvMaxBitrate", C.c_int), ("bCqp", C.c_int), ("bEnableTemporalSubLayers", C.c_int),
-                ("maxNumReferences", C.c_int), ("poolWorkers", C.c_int)]
+                ("maxNumReferences", C.c_int), ("poolWorkers", C.c_int), ("bAQMotion", C.c_int),
+                ("bHistBasedSceneCut", C.c_int)]
 
 
 class HistStats(C.Structure):
@@ -367,7 +368,8 @@ class SliceDecider:
         lp = LaParam(p["lookaheadDepth"], p["bFrameAdaptive"], p["bBPyramid"], p["scenecutThreshold"], p["scenecutBias"],
                      p["keyframeMin"], p["keyframeMax"], p["bOpenGOP"], p["bIntraRefresh"], p["radl"], p["gopLookahead"],
                      p["cuTree"], p["aqMode"] if p["bAdaptiveQuant"] else 0, p["vbvBufferSize"], p["vbvMaxBitrate"],
-                     p["bCqp"], p["bEnableTemporalSubLayers"], p["maxNumReferences"], p["poolWorkers"])
+                     p["bCqp"], p["bEnableTemporalSubLayers"], p["maxNumReferences"], p["poolWorkers"],
+                     p.get("bAQMotion", 0), p.get("bHistBasedSceneCut", 0))
         cp = CuTreeParam(p["fpsNum"], p["fpsDenom"], p["bBPyramid"], p["bEnableWeightedBiPred"], p["lookaheadDepth"],
                          p["vbvBufferSize"], p["qCompress"])
         assert look.param.bframes == p["bframes"] and look.param.bEnableWeightedPred == p["bEnableWeightedPred"]

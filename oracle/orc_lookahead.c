@@ -105,6 +105,7 @@ void orc_lowres_destroy(orc_lowres* lr)
     free(lr->propagateCost);
     free(lr->qpAqOffset);
     free(lr->qpCuTreeOffset);
+    free(lr->qpAqMotionOffset);
     free(lr->intraCost);
     free(lr->intraMode);
     free(lr->recalcRowSatds);

@@ -8,8 +8,9 @@
  *   Lookahead::scenecut / scenecutInternal                        :3186-3321
  *   Lookahead::slicetypePath / slicetypePathCost                  :3484-3579
  *   Lookahead::frameCostRecalculate                               :4068-4145
- * Not restated (the product's host layer refuses the same settings): zones, fades, analysis load, histogram
- * scene cuts, --aq-motion, --mcstf, more than two temporal sub-layers, qgSize 8, rc.hevcAq.
+ *   Lookahead::aqMotion / calcMotionAdaptiveQuantFrame            :3581-3663
+ * Not restated (the product's host layer refuses the same settings): zones, fades, analysis load,
+ * --mcstf, more than two temporal sub-layers, qgSize 8, rc.hevcAq.
  * Frames enter already pre-analysed (Lowres::init, AQ, intra estimate are per-frame functions of the
  * picture alone, so running them at addPicture instead of in PreLookaheadGroup changes nothing). */
 #include "orc.h"
@@ -88,6 +89,83 @@ static void cu_tree(orc_la* la, orc_lowres** frames, int numframes, int bIntra)
     orc_set_request_hook(NULL, NULL);
 }
 
+/* ---- :3609-3663.  The block vectors' lengths, raised to 0.1, normalised over the frame; blocks more than one
+ * deviation above the mean get the excess added to their offsets and the matching factor added to invQscaleFactor. */
+static void calc_motion_adaptive_quant_frame(orc_la* la, orc_lowres** frames, int p0, int p1, int b)
+{
+    orc_lowres* f = frames[b];
+    const int listDist[2] = { b - p0, p1 - b };
+    const int W = f->widthInCU, H = f->heightInCU;
+    (void)la;
+    if (!f->qpAqMotionOffset)
+        f->qpAqMotionOffset = (double*)calloc(f->cuCount, sizeof(double));
+    double qp_adj = 0, avg_adj = 0, avg_adj_pow2 = 0, sd;
+    for (int blocky = 0; blocky < H; blocky++)
+    {
+        int cuIndex = blocky * W;
+        for (int blockx = 0; blockx < W; blockx++, cuIndex++)
+        {
+            int lists_used = f->lowresCosts[b - p0][p1 - b][cuIndex] >> ORC_LOWRES_COST_SHIFT;
+            double displacement = 0;
+            for (int list = 0; list < 2; list++)
+                if ((lists_used >> list) & 1)
+                {
+                    const orc_mv* mvs = f->lowresMvs[list][listDist[list]];
+                    int32_t x = mvs[cuIndex].x, y = mvs[cuIndex].y;
+                    displacement += sqrt((double)(abs(x) * abs(x)) + (double)(abs(y) * abs(y)));
+                }
+            if (lists_used == 3)
+                displacement = displacement / 2;
+            qp_adj = pow(displacement, 0.1);
+            f->qpAqMotionOffset[cuIndex] = qp_adj;
+            avg_adj += qp_adj;
+            avg_adj_pow2 += qp_adj * qp_adj;
+        }
+    }
+    avg_adj /= f->cuCount;
+    avg_adj_pow2 /= f->cuCount;
+    sd = sqrt((avg_adj_pow2 - (avg_adj * avg_adj)));
+    if (sd > 0)
+        for (int cuIndex = 0; cuIndex < W * H; cuIndex++)
+        {
+            qp_adj = f->qpAqMotionOffset[cuIndex];
+            qp_adj = (qp_adj - avg_adj) / sd;
+            if (qp_adj > 1)
+            {
+                f->qpAqOffset[cuIndex] += qp_adj;
+                f->qpCuTreeOffset[cuIndex] += qp_adj;
+                f->invQscaleFactor[cuIndex] += orc_exp2fix8(qp_adj);
+            }
+        }
+}
+
+/* ---- :3581-3607 ---- */
+static void aq_motion(orc_la* la, orc_lowres** frames, int bIntra)
+{
+    if (bIntra)
+        return;
+    int curnonb = 0, lastnonb = 1;
+    while (frames[lastnonb]->sliceType != ORC_TYPE_P)
+        lastnonb++;
+    int bframes = lastnonb - 1;
+    if (la->lp.bBPyramid && bframes > 1)
+    {
+        int middle = (bframes + 1) / 2;
+        for (int i = 1; i < lastnonb; i++)
+        {
+            int p0 = i > middle ? middle : curnonb;
+            int p1 = i < middle ? middle : lastnonb;
+            if (i != middle)
+                calc_motion_adaptive_quant_frame(la, frames, p0, p1, i);
+        }
+        calc_motion_adaptive_quant_frame(la, frames, curnonb, lastnonb, middle);
+    }
+    else
+        for (int i = 1; i < lastnonb; i++)
+            calc_motion_adaptive_quant_frame(la, frames, curnonb, lastnonb, i);
+    calc_motion_adaptive_quant_frame(la, frames, curnonb, lastnonb, lastnonb);
+}
+
 /* ---- :4068-4145 (qgSize > 8, no hevcAq) ---- */
 int64_t orc_frame_cost_recalculate(orc_lowres** frames, int p0, int p1, int b)
 {
@@ -119,7 +197,7 @@ int64_t orc_frame_cost_recalculate(orc_lowres** frames, int p0, int p1, int b)
 static int64_t vbv_frame_cost(orc_la* la, orc_lowres** frames, int p0, int p1, int b)
 {
     int64_t cost = single_cost(la, frames, p0, p1, b, 0);
-    if (la->lp.aqMode)
+    if (la->lp.aqMode || la->lp.bAQMotion)
     {
         if (la->lp.cuTree)
             return orc_frame_cost_recalculate(frames, p0, p1, b);
@@ -561,6 +639,9 @@ static void slicetype_analyse(orc_la* la, orc_lowres** frames, int bKeyframe)
             frames[j]->sliceType = ORC_TYPE_P;
         resetStart = bKeyframe ? 1 : 2;
     }
+
+    if (lp->bAQMotion)
+        aq_motion(la, frames, bKeyframe);
 
     if (lp->cuTree)
         cu_tree(la, frames, imin(numFrames, lp->keyframeMax), bKeyframe);

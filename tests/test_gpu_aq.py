@@ -132,6 +132,63 @@ def test_aq_frames_batches_of_shrinking_size_keep_the_earlier_factors():
         hip.hipFree(p)
 
 
+def test_aq_motion_frame_against_its_formula():
+    """x265gpu_aq_motion_frame (calcMotionAdaptiveQuantFrame, slicetype.cpp:3609-3663) on a bidirectional request:
+    recomputed here from the vectors and list decisions the device holds, with the host's libm (math.pow / math.sqrt)
+    and sums in block order."""
+    import math
+    from x265_amd import synth
+    from x265_amd.lookahead import CostEstimateGroup, LowresState, PreLookaheadGroup
+    W, H, depth, N = 416, 240, 8, 3
+    clip = synth.luma_clip(W, H, N, depth, seed=3, scene_cut=False)
+    table, centre = api.bitcost_table(depth)
+    with api.Context(W, H, depth=depth, num_slots=N) as ctx:
+        ctx.set_mvcost(table, centre)
+        frames = [LowresState(i, i, ctx.D) for i in range(N)]
+        PreLookaheadGroup(ctx).process_tasks(frames, clip)
+        CostEstimateGroup(ctx, frames).single_cost(0, 2, 1)
+        n = ctx.geom.cuCount
+        rng = np.random.default_rng(4)
+        qa, qc = rng.normal(0, 1, n), rng.normal(0, 1, n)
+        inv = rng.integers(100, 400, n).astype(np.int32)
+        want_qa, want_qc, want_inv = qa.copy(), qc.copy(), inv.copy()
+        got_motion = ctx.aq_motion_frame(1, 1, 1, qa, qc, inv)
+        lc = ctx.get_costs(1, 1, 1)[0]
+        mv0, mv1 = ctx.get_mvs(1, 0, 1)[0], ctx.get_mvs(1, 1, 1)[0]
+        adj = np.zeros(n)
+        for i in range(n):
+            lists = int(lc[i]) >> 14
+            d = 0.0
+            if lists & 1:
+                d += math.sqrt(float(abs(int(mv0[i, 0])) ** 2) + float(abs(int(mv0[i, 1])) ** 2))
+            if lists & 2:
+                d += math.sqrt(float(abs(int(mv1[i, 0])) ** 2) + float(abs(int(mv1[i, 1])) ** 2))
+            if lists == 3:
+                d = d / 2
+            adj[i] = math.pow(d, 0.1)
+        avg = avg2 = 0.0
+        for v in adj.tolist():
+            avg += v
+            avg2 += v * v
+        avg /= n
+        avg2 /= n
+        sd = math.sqrt(avg2 - avg * avg)
+        assert sd > 0
+        raised = 0
+        for i in range(n):
+            q = (adj[i] - avg) / sd
+            if q > 1:
+                want_qa[i] += q
+                want_qc[i] += q
+                want_inv[i] += orc.lib(depth).orc_exp2fix8(orc.C.c_double(q))
+                raised += 1
+        assert 0 < raised < n
+        np.testing.assert_array_equal(got_motion, adj)
+        np.testing.assert_array_equal(qa, want_qa)
+        np.testing.assert_array_equal(qc, want_qc)
+        np.testing.assert_array_equal(inv, want_inv)
+
+
 def test_aq_frame_rejects_uncovered_modes():
     W, H = 64, 64
     y = np.zeros((H, W), np.uint8)

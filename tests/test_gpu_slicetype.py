@@ -120,6 +120,10 @@ CASES = [
     {"lookaheadDepth": 0, "bframes": 0, "bFrameAdaptive": 0, "bBPyramid": 0, "cuTree": 0},
     {"scenecutThreshold": 0},
     {"bEnableWeightedBiPred": 1, "fpsNum": 24000, "fpsDenom": 1001, "qCompress": 0.7},
+    {"bAQMotion": 1},                                         # --aq-motion, lazy order
+    {"bAQMotion": 1, "poolWorkers": 16},                      # ... with both batches (costs measured ahead must not go stale)
+    {"bAQMotion": 1, "poolWorkers": 16, "vbvBufferSize": 1000, "vbvMaxBitrate": 1000, "bBPyramid": 0},
+    {"bAQMotion": 1, "cuTree": 0},
 ]
 
 

@@ -22,7 +22,7 @@ EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_estimate_sums_device", "x265gpu_weight_cost", "x265gpu_weight_costs", "x265gpu_weight_cost_static", "x265gpu_weight_planes",
-    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_bipred_satd", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_aq_frames", "x265gpu_aq_frames_begin", "x265gpu_aq_frames_finish", "x265gpu_aq_memo_stats", "x265gpu_get_frame_costs", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_bipred_satd", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_aq_frames", "x265gpu_aq_frames_begin", "x265gpu_aq_frames_finish", "x265gpu_aq_memo_stats", "x265gpu_aq_motion_frame", "x265gpu_get_frame_costs", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
     "x265gpu_cutree_clear", "x265gpu_cutree_swap", "x265gpu_cutree_propagate", "x265gpu_cutree_get_propagate_cost",
     "x265gpu_cutree_finish", "x265gpu_hist_stats", "x265gpu_mcstf_motion_search",
     "x265gpu_profile_enable", "x265gpu_profile_read",
@@ -175,6 +175,7 @@ def load_library(path=None):
     L.x265gpu_hist_stats.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp]
     L.x265gpu_aq_frame.argtypes = [vp, i32, vp, ip, vp, vp, ip, i32, vp, vp, vp, vp, vp, vp, vp]
     L.x265gpu_aq_frames.argtypes = [vp, i32, vp, i32, vp]
+    L.x265gpu_aq_motion_frame.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     L.x265gpu_aq_memo_stats.argtypes = [vp, vp]
     L.x265gpu_aq_memo_stats.restype = None
     L.x265gpu_get_frame_costs.argtypes = [vp, i32, vp, vp, vp, vp]
@@ -504,6 +505,13 @@ class Context:
         self._aq_keep = (pics, arrays)        # the library's threads write into these until the batch is finished
         return [arrays[i] + (np.array(pics[i].wpSum, np.uint64), np.array(pics[i].wpSsd, np.uint64)) for i in range(n)]
 
+    def aq_motion_frame(self, slot, d0, d1, qp_aq, qp_cutree, inv_qscale):
+        """calcMotionAdaptiveQuantFrame for the estimated request (d0, d1) of `slot`: the three arrays are updated in
+        place (and the slot's factors with them); -> qpAqMotionOffset."""
+        out = np.zeros(self.geom.cuCount)
+        self._chk(self.L.x265gpu_aq_motion_frame(self.h, slot, d0, d1, _ptr(qp_aq), _ptr(qp_cutree), _ptr(inv_qscale), _ptr(out)))
+        return out
+
     def aq_memo_stats(self):
         """(lookups, hits) of the library's per-energy activity table since the process started."""
         a, b = C.c_uint64(), C.c_uint64()
@@ -620,13 +628,14 @@ class LookaheadParam(C.Structure):
                 ("maxNumReferences", C.c_int32), ("bEnableWeightedPred", C.c_int32), ("bEnableWeightedBiPred", C.c_int32),
                 ("fpsNum", C.c_int32), ("fpsDenom", C.c_int32), ("qCompress", C.c_double), ("bitDepth", C.c_int32),
                 ("poolWorkers", C.c_int32), ("bAdaptiveQuant", C.c_int32), ("aqMode", C.c_int32), ("aqStrength", C.c_double),
-                ("bPresearch", C.c_int32), ("lookaheadSlices", C.c_int32)]
+                ("bPresearch", C.c_int32), ("lookaheadSlices", C.c_int32), ("bAQMotion", C.c_int32)]
 
     MEDIUM = dict(bframes=4, lookaheadDepth=20, bFrameAdaptive=2, bBPyramid=1, scenecutThreshold=40, scenecutBias=0.05,
                   keyframeMin=25, keyframeMax=250, bOpenGOP=1, bIntraRefresh=0, radl=0, gopLookahead=0, cuTree=1,
                   bFrameBias=0, vbvBufferSize=0, vbvMaxBitrate=0, bCqp=0, bEnableTemporalSubLayers=0, maxNumReferences=3,
                   bEnableWeightedPred=1, bEnableWeightedBiPred=0, fpsNum=30, fpsDenom=1, qCompress=0.6, bitDepth=8,
-                  poolWorkers=0, bAdaptiveQuant=1, aqMode=2, aqStrength=1.0, bPresearch=1, lookaheadSlices=0)
+                  poolWorkers=0, bAdaptiveQuant=1, aqMode=2, aqStrength=1.0, bPresearch=1, lookaheadSlices=0,
+                  bAQMotion=0)
 
     def __init__(self, **kw):
         super().__init__()

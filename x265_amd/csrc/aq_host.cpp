@@ -198,6 +198,53 @@ void aq_frame_offsets(const AqFrameParams& p, int blocks, const uint32_t* energy
     }
 }
 
+// Lookahead::calcMotionAdaptiveQuantFrame from the displacements on (source/encoder/slicetype.cpp:3636-3662): the
+// power, the two running sums in block order, the deviation, and the update of the blocks more than one deviation
+// above the mean.  pow() of equal displacements (a panning picture has few distinct vectors) is looked up in a small
+// table of the values libm returned earlier in this call.
+int aq_motion_offsets(int blocks, const double* displacement, double* qpAqMotionOffset, double* qpAqOffset,
+                      double* qpCuTreeOffset, int32_t* invQscale)
+{
+    constexpr int SLOTS = 1024;
+    uint64_t keys[SLOTS];
+    double vals[SLOTS];
+    for (int i = 0; i < SLOTS; i++)
+        keys[i] = ~0ull;                 // no displacement has this bit pattern (a NaN)
+    double avg = 0, avgPow2 = 0;
+    for (int i = 0; i < blocks; i++)
+    {
+        uint64_t bits;
+        memcpy(&bits, &displacement[i], sizeof(bits));
+        const int at = (int)((bits * 0x9E3779B97F4A7C15ull) >> 54);
+        if (keys[at] != bits)
+        {
+            keys[at] = bits;
+            vals[at] = pow(displacement[i], 0.1);
+        }
+        const double q = vals[at];
+        qpAqMotionOffset[i] = q;
+        avg += q;
+        avgPow2 += q * q;
+    }
+    avg /= blocks;
+    avgPow2 /= blocks;
+    const double sd = sqrt((avgPow2 - (avg * avg)));
+    int changed = 0;
+    if (sd > 0)
+        for (int i = 0; i < blocks; i++)
+        {
+            const double q = (qpAqMotionOffset[i] - avg) / sd;
+            if (q > 1)
+            {
+                qpAqOffset[i] += q;
+                qpCuTreeOffset[i] += q;
+                invQscale[i] += aq_exp2fix8(q);
+                changed++;
+            }
+        }
+    return changed;
+}
+
 // LookaheadTLD::xPreanalyze for one layer (source/encoder/slicetype.cpp:358-428) from the device's quadrant
 // sums, then xPreanalyzeQp for it (:322-335).  Parts are visited in raster order and written through a running
 // pointer, as there; the mean divides by the layer's allocated part count.

@@ -412,4 +412,39 @@ hipError_t launch_aq_edge(hipStream_t s, int bpp, int depth, const AqEdgeJob& jo
     return hipGetLastError();
 }
 
+// ---- --aq-motion: the per-block displacement of Lookahead::calcMotionAdaptiveQuantFrame ----
+// (source/encoder/slicetype.cpp:3614-3635): the length of the block's vector in each list the request's decision
+// used (lowresCosts >> 14), halved when both were used.  One thread per 8x8 block over the arrays the estimate left
+// on the device; the square roots are IEEE double square roots as on the host, and what follows them (the power of
+// 0.1, the frame's mean and deviation, the offsets) is libm and ordered summation and stays on the host.
+__global__ void __launch_bounds__(256) aq_motion_kernel(const uint16_t* lowresCosts, const int32_t* mvs0, const int32_t* mvs1,
+                                                        int n, double* displacement)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const int lists = lowresCosts[i] >> LOWRES_COST_SHIFT;
+    double d = 0;
+    if (lists & 1)
+    {
+        const int x = abs(mvs0[2 * i]), y = abs(mvs0[2 * i + 1]);
+        d += __builtin_sqrt((double)(x * x) + (double)(y * y));
+    }
+    if (lists & 2)
+    {
+        const int x = abs(mvs1[2 * i]), y = abs(mvs1[2 * i + 1]);
+        d += __builtin_sqrt((double)(x * x) + (double)(y * y));
+    }
+    if (lists == 3)
+        d = d / 2;
+    displacement[i] = d;
+}
+
+hipError_t launch_aq_motion(hipStream_t s, const uint16_t* lowresCosts, const int32_t* mvs0, const int32_t* mvs1, int n,
+                            double* displacement)
+{
+    hipLaunchKernelGGL(aq_motion_kernel, dim3((n + 255) / 256), dim3(256), 0, s, lowresCosts, mvs0, mvs1, n, displacement);
+    return hipGetLastError();
+}
+
 } // namespace xg

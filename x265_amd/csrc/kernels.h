@@ -188,6 +188,12 @@ constexpr int AQ_WP_SHARDS = 64, AQ_WP_SHARD_STRIDE = 16;    // one 128-byte lin
 constexpr size_t AQ_WP_BYTES = (size_t)AQ_WP_SHARDS * AQ_WP_SHARD_STRIDE * sizeof(unsigned long long);
 hipError_t launch_aq_energy(hipStream_t s, int bpp, const AqJob& job);
 hipError_t launch_aq_energy_batch(hipStream_t s, int bpp, const AqJob* dJobs, int n, int visitWidth, int visitHeight);
+// --aq-motion: per-block vector length of a request's decision (aq_kernels.hip), then the host half (aq_host.cpp):
+// calcMotionAdaptiveQuantFrame from the displacements on; returns the number of blocks whose offsets changed
+hipError_t launch_aq_motion(hipStream_t s, const uint16_t* lowresCosts, const int32_t* mvs0, const int32_t* mvs1, int n,
+                            double* displacement);
+int aq_motion_offsets(int blocks, const double* displacement, double* qpAqMotionOffset, double* qpAqOffset,
+                      double* qpCuTreeOffset, int32_t* invQscale);
 hipError_t launch_scatter_i32(hipStream_t s, const int32_t* const* dSrc, int32_t* const* dDst, int count, int n);
 // xPreanalyze's quadrant sums: out holds 8 values per part (4 sums, 4 sums of squares), parts in raster order
 hipError_t launch_aq_quadrants(hipStream_t s, int bpp, const void* luma, long long stride, int width, int height, int partW,

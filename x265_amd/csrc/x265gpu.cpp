@@ -143,6 +143,8 @@ struct x265gpu_ctx
     size_t cutreeBufBytes = 0;
     char* finishHost = nullptr;         // page-locked landing area of cuTreeFinish's three per-block arrays
     size_t finishHostBytes = 0;
+    double* motionDev = nullptr;        // --aq-motion: per-block displacements (device, page-locked landing area)
+    double* motionHost = nullptr;
     char* aqDev = nullptr;              // the batched AQ pass's device arrays and their page-locked mirror, kept between
     char* aqHost = nullptr;             //   calls and grown when a larger batch comes
     size_t aqBufBytes = 0;
@@ -760,6 +762,8 @@ void x265gpu_close(x265gpu_ctx* ctx)
     if (ctx->seaBuf) (void)hipFree(ctx->seaBuf);
     if (ctx->intraStream) (void)hipStreamSynchronize(ctx->intraStream);
     if (ctx->aqDev) (void)hipFree(ctx->aqDev);
+    if (ctx->motionDev) (void)hipFree(ctx->motionDev);
+    if (ctx->motionHost) (void)hipHostFree(ctx->motionHost);
     if (ctx->cutreeBuf) (void)hipFree(ctx->cutreeBuf);
     if (ctx->aqHost) (void)hipHostFree(ctx->aqHost);
     if (ctx->aqInstalled) (void)hipEventDestroy(ctx->aqInstalled);
@@ -922,14 +926,15 @@ int x265gpu_lowres_init(x265gpu_ctx* ctx, int32_t slot, const void* luma, intptr
     return x265gpu_lowres_init_batch(ctx, 1, &slot, &luma, &stride, memKind, &poc);
 }
 
-static int set_aq_staged(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQscaleFactor, hipStream_t stream = nullptr)
+static int set_aq_staged(x265gpu_ctx* ctx, int32_t slot, const int32_t* invQscaleFactor, hipStream_t stream = nullptr,
+                         bool redoIntraSums = true)
 {
     if (!stream)
         stream = ctx->stream;
     Slot& s = ctx->slots[slot];
     // Factors that arrive after the picture's intra estimate: its AQ-weighted sums are redone (aq_finish_pending)
     // before anything reads them, behind this upload.
-    if (s.intraFresh)
+    if (s.intraFresh && redoIntraSums)
     {
         ctx->intraDeferred.push_back(slot);
         ctx->aqInstalledOnMain = true;
@@ -2902,6 +2907,33 @@ static int aq_finish_pending(x265gpu_ctx* ctx)
     ctx->intraDeferred.clear();
     join_intra(ctx);
     return rc;
+}
+
+int x265gpu_aq_motion_frame(x265gpu_ctx* ctx, int32_t slot, int32_t d0, int32_t d1, double* qpAqOffset,
+                            double* qpCuTreeOffset, int32_t* invQscaleFactor, double* qpAqMotionOffset)
+{
+    DeviceScope deviceScope(ctx);
+    FINISH_AQ(ctx);          // the arrays below are complete, and in the slot, before they are added to
+    if (!ctx || !slot_ok(ctx, slot) || d0 < 0 || d0 >= ctx->D || d1 < 0 || d1 >= ctx->D || !qpAqOffset || !qpCuTreeOffset ||
+        !invQscaleFactor || !qpAqMotionOffset)
+        return X265GPU_ERR_ARG;
+    const int n = ctx->g.cuCount, D = ctx->D;
+    if (!ctx->motionDev)
+    {
+        HIPCHK(hipMalloc((void**)&ctx->motionDev, sizeof(double) * (size_t)n));
+        HIPCHK(hipHostMalloc((void**)&ctx->motionHost, sizeof(double) * (size_t)n, hipHostMallocDefault));
+    }
+    Slot& sb = ctx->slots[slot];
+    HIPCHK(launch_aq_motion(ctx->stream, sb.lowresCosts + ((size_t)d0 * D + d1) * n, sb.mvs + ((size_t)(0 * D + d0) * n) * 2,
+                            sb.mvs + ((size_t)(1 * D + d1) * n) * 2, n, ctx->motionDev));
+    HIPCHK(hipMemcpyAsync(ctx->motionHost, ctx->motionDev, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (aq_motion_offsets(n, ctx->motionHost, qpAqMotionOffset, qpAqOffset, qpCuTreeOffset, invQscaleFactor) == 0)
+        return X265GPU_OK;
+    // The raised factors go to the slot for the cost passes and cuTree passes that follow.  The picture's intra
+    // estimate keeps the sums it formed with the factors of its time, as in x265, where lowresIntraEstimate has
+    // long run when aqMotion changes invQscaleFactor.
+    return set_aq_staged(ctx, slot, invQscaleFactor, nullptr, false);
 }
 
 void x265gpu_aq_memo_stats(uint64_t* lookups, uint64_t* hits)

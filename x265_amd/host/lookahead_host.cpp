@@ -727,7 +727,7 @@ int CuTree::cuTree(Lowres* const* frames, int numframes, bool bIntra)
 // requests are issued, and in which order, decides which motion searches run inside a bidirectional request
 // (the skip shortcut of estimateCUCost makes an L0 vector depend on that), so any other order gives other
 // vectors.  What differs from x265 is only where a request is computed: CostEstimateGroup sends it to the device.
-// Not covered (unsupported() says so): zones, fades, analysis load, histogram scene cuts, --aq-motion, --mcstf
+// Not covered (unsupported() says so): zones, fades, analysis load, histogram scene cuts, --mcstf
 // batches, more than two temporal sub-layers, qgSize 8 and rc.hevcAq in frameCostRecalculate.
 
 // x265_exp2fix8 (source/common/common.cpp:96-103) over x265_exp2_lut (source/common/constants.cpp:552-558),
@@ -826,6 +826,54 @@ void Lookahead::cuTree(Lowres** frames, int numframes, bool bIntra)
     note(CuTree(m_ctx, cp).cuTree(frames, numframes, bIntra));
 }
 
+// :3581-3607: the frames of the first mini-GOP, in the order and with the references the trellis costed them
+void Lookahead::aqMotion(Lowres** frames, bool bIntra)
+{
+    if (bIntra)
+        return;
+    ScopeTimer timer(m_seconds[T_CUTREE]);
+    int curnonb = 0, lastnonb = 1;
+    while (frames[lastnonb]->sliceType != TYPE_P)
+        lastnonb++;
+    const int bframes = lastnonb - 1;
+    note(resolveIntraTotals(m_ctx, frames, lastnonb + 1));          // the frames' offset arrays are complete
+    if (m_param.bBPyramid && bframes > 1)
+    {
+        const int middle = (bframes + 1) / 2;
+        for (int i = 1; i < lastnonb; i++)
+        {
+            const int p0 = i > middle ? middle : curnonb;
+            const int p1 = i < middle ? middle : lastnonb;
+            if (i != middle)
+                calcMotionAdaptiveQuantFrame(frames, p0, p1, i);
+        }
+        calcMotionAdaptiveQuantFrame(frames, curnonb, lastnonb, middle);
+    }
+    else
+        for (int i = 1; i < lastnonb; i++)
+            calcMotionAdaptiveQuantFrame(frames, curnonb, lastnonb, i);
+    calcMotionAdaptiveQuantFrame(frames, curnonb, lastnonb, lastnonb);
+}
+
+// :3609-3663: the vectors stay on the device (x265gpu_aq_motion_frame); what comes back is one double per block
+void Lookahead::calcMotionAdaptiveQuantFrame(Lowres** frames, int p0, int p1, int b)
+{
+    Lowres& f = *frames[b];
+    if (!f.qpAqOffset || !f.qpCuTreeOffset || !f.invQscaleFactor)
+    {
+        note(X265GPU_ERR_STATE);
+        return;
+    }
+    if (f.qpAqMotionOffset.empty())
+        f.qpAqMotionOffset.assign((size_t)m_geom.cuCount, 0.0);
+    // costs measured ahead of x265's order used the factors as they were: a request that comes now is measured anew
+    for (int i = 0; i < MAX_D; i++)
+        for (int j = 0; j < MAX_D; j++)
+            f.preCost[i][j].valid = false;
+    note(x265gpu_aq_motion_frame(m_ctx, f.slot, b - p0, p1 - b, f.qpAqOffset, f.qpCuTreeOffset, f.invQscaleFactor,
+                                 f.qpAqMotionOffset.data()));
+}
+
 // addPicture + checkLookaheadQueue (:1299-1342); no pool to wake here
 void Lookahead::addPicture(Lowres& frame, int sliceType)
 {
@@ -899,7 +947,7 @@ int64_t Lookahead::frameCostRecalculate(Lowres* const* frames, int p0, int p1, i
 int64_t Lookahead::vbvFrameCost(Lowres** frames, int p0, int p1, int b)   // :2830-2844
 {
     const int64_t c = cost(frames, p0, p1, b);
-    if (!(m_param.bAdaptiveQuant && m_param.aq.aqMode))
+    if (!((m_param.bAdaptiveQuant && m_param.aq.aqMode) || m_param.bAQMotion))
         return c;
     return m_param.cuTree ? frameCostRecalculate(frames, p0, p1, b) : frames[b]->costEstAq[b - p0][p1 - b];
 }
@@ -1323,6 +1371,9 @@ void Lookahead::slicetypeAnalyse(Lowres** frames, bool bKeyframe)
             frames[j]->sliceType = TYPE_P;
         resetStart = bKeyframe ? 1 : 2;
     }
+
+    if (P.bAQMotion)
+        aqMotion(frames, bKeyframe);
 
     if (P.cuTree)
         cuTree(frames, std::min(numFrames, P.keyframeMax), bKeyframe);
@@ -1836,6 +1887,9 @@ xgh_lookahead* xgh_lookahead_create(x265gpu_ctx* ctx, const xgh_lookahead_param*
     q.aq.bWeightedPred = q.bEnableWeightedPred || q.bEnableWeightedBiPred;
     q.bPresearch = p->bPresearch != 0;
     q.lookaheadSlices = p->lookaheadSlices;
+    q.bAQMotion = p->bAQMotion != 0;
+    if (q.bAQMotion)
+        q.bAdaptiveQuant = true;              // Lookahead::m_bAdaptiveQuant (slicetype.cpp:1080-1084)
     xgh_lookahead* h = new xgh_lookahead;
     h->ctx = ctx;
     h->la = new Lookahead(ctx, q);

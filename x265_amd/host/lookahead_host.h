@@ -84,6 +84,7 @@ struct Lowres
     double* qpAqOffset = nullptr;     // caller-owned, one entry per 8x8 lowres block (16x16 source block)
     double* qpCuTreeOffset = nullptr;
     int32_t* invQscaleFactor = nullptr;   // caller-owned, same shape; filled by the AQ form of processTasks
+    std::vector<double> qpAqMotionOffset; // --aq-motion (lowres.cpp:114-115), sized on first use
 
     // what the slice-type decision keeps per frame (source/common/lowres.h:166-213)
     int sliceTypeReq = TYPE_AUTO;
@@ -247,6 +248,7 @@ struct LookaheadParam
     int poolWorkers = 0;                          // ThreadPool::m_numWorkers of the lookahead's pool; 0: no pool, so
                                                   // requests are issued one by one in the order the decision needs them;
                                                   // > 0 with trellis B-adapt: the two batches of slicetypeAnalyse
+    bool bAQMotion = false;                       // --aq-motion: offsets raised where a block moves unlike the rest of its frame
     bool bAdaptiveQuant = true;                   // Lookahead::m_bAdaptiveQuant: pre-analysis runs calcAdaptiveQuantFrame
     x265gpu_aq_params aq;                         // its parameters (aqMode, strength, qgSize >= 16, ...)
     LookaheadParam();
@@ -287,6 +289,8 @@ private:
     void placeBref(Lowres** list, int start, int end, int num, int& brefs);
     void compCostBref(Lowres** frames, int start, int end, int num);
     void cuTree(Lowres** frames, int numframes, bool bIntra);
+    void aqMotion(Lowres** frames, bool bIntra);
+    void calcMotionAdaptiveQuantFrame(Lowres** frames, int p0, int p1, int b);
     int64_t cost(Lowres** frames, int p0, int p1, int b, bool bIntraPenalty = false);
     void note(int rc) { if (rc != X265GPU_OK && m_status == X265GPU_OK) m_status = rc; }
 
@@ -362,6 +366,7 @@ typedef struct xgh_lookahead_param
     int32_t bitDepth, poolWorkers, bAdaptiveQuant, aqMode;
     double  aqStrength;
     int32_t bPresearch, lookaheadSlices;
+    int32_t bAQMotion;
 } xgh_lookahead_param;
 typedef struct xgh_decided
 {

@@ -103,6 +103,7 @@ typedef struct x265gpu_geometry
     int64_t padOffset;            /* pixels from buffer start to pixel (0,0) */
     int32_t numCoopSlices;        /* Lookahead::m_numCoopSlices (1: whole frames) */
     int32_t numRowsPerSlice;      /* Lookahead::m_numRowsPerSlice; the last slice also takes the remainder rows */
+    int32_t sourceWidth, sourceHeight;   /* the picture size the context was opened with */
 } x265gpu_geometry;
 
 /* One cost-estimation request = one CostEstimateGroup::estimateFrameCost body

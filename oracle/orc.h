@@ -206,6 +206,8 @@ typedef struct orc_lowres {
     double*  qpAqOffset;
     double*  qpCuTreeOffset;
     double*  qpAqMotionOffset; /* --aq-motion (source/common/lowres.cpp:114-115), allocated on first use */
+    struct orc_hist_stats* hist; /* --hist-scenecut: collectPictureStatistics' results (orc_lowres_set_hist_stats) */
+    int      bHistScenecutAnalyzed;
     int      sliceType;       /* X265_TYPE_* (source/x265.h) */
     /* what the slice-type decision keeps per frame (source/common/lowres.h:166-213) */
     int      sliceTypeReq;
@@ -317,6 +319,7 @@ typedef struct orc_hist_stats {
     uint8_t  pad[5];
     uint16_t picAvgVariance, picAvgVarianceCb, picAvgVarianceCr, pad2;
 } orc_hist_stats;
+void orc_lowres_set_hist_stats(orc_lowres* lr, const orc_hist_stats* st);   /* keeps a copy */
 void orc_collect_picture_statistics(const pixel* lowresPlane0, intptr_t lowresStride, const pixel* y, intptr_t sy,
                                     const pixel* u, const pixel* v, intptr_t sc, int w, int h, orc_hist_stats* out);
 

@@ -526,6 +526,11 @@ def calc_adaptive_quant_frame(depth, y, u, v, aq_mode, strength, weightp=False, 
     return out
 
 
+def set_hist_stats(lowres, st):
+    """Hands a frame its collectPictureStatistics results for the --hist-scenecut decision (the oracle keeps a copy)."""
+    lowres.L.orc_lowres_set_hist_stats(C.c_void_p(lowres.h), C.byref(st))
+
+
 def collect_picture_statistics(lowres, y, u, v):
     """collectPictureStatistics for the frame behind `lowres` (an initialised Lowres) -> HistStats."""
     L = lowres.L

@@ -106,6 +106,7 @@ void orc_lowres_destroy(orc_lowres* lr)
     free(lr->qpAqOffset);
     free(lr->qpCuTreeOffset);
     free(lr->qpAqMotionOffset);
+    free(lr->hist);
     free(lr->intraCost);
     free(lr->intraMode);
     free(lr->recalcRowSatds);

@@ -9,6 +9,7 @@
  *   Lookahead::slicetypePath / slicetypePathCost                  :3484-3579
  *   Lookahead::frameCostRecalculate                               :4068-4145
  *   Lookahead::aqMotion / calcMotionAdaptiveQuantFrame            :3581-3663
+ *   Lookahead::histBasedScenecut / detectHistBasedSceneChange     :3323-3482
  * Not restated (the product's host layer refuses the same settings): zones, fades, analysis load,
  * --mcstf, more than two temporal sub-layers, qgSize 8, rc.hevcAq.
  * Frames enter already pre-analysed (Lowres::init, AQ, intra estimate are per-frame functions of the
@@ -42,6 +43,10 @@ struct orc_la
     orc_lowres* outq[QCAP];
     int outHead, outCount;
     int batchOpen;                     /* a CostEstimateGroup in batch mode is collecting requests */
+    /* --hist-scenecut (:1143-1174): running averages of the histogram differences per segment and plane */
+    uint32_t accHistDiffRunningAvg[3][4][4];
+    int resetRunningAvg;
+    uint32_t segmentCountThreshold;
     int32_t* trace;
     int ntrace, captrace;
 };
@@ -164,6 +169,95 @@ static void aq_motion(orc_la* la, orc_lowres** frames, int bIntra)
         for (int i = 1; i < lastnonb; i++)
             calc_motion_adaptive_quant_frame(la, frames, curnonb, lastnonb, i);
     calc_motion_adaptive_quant_frame(la, frames, curnonb, lastnonb, lastnonb);
+}
+
+void orc_lowres_set_hist_stats(orc_lowres* lr, const orc_hist_stats* st)
+{
+    if (!lr->hist)
+        lr->hist = (orc_hist_stats*)malloc(sizeof(orc_hist_stats));
+    *lr->hist = *st;
+    lr->bHistScenecutAnalyzed = 0;      /* collectPictureStatistics ends with this (:1833) */
+}
+
+/* ---- :3323-3454.  The segment size the thresholds are scaled by grows as the loops go: the remainder of the last
+ * column / row is added to the running width / height and never taken off again (kept as the reference has it). */
+static int detect_hist_based_scene_change(orc_la* la, orc_lowres** frames, int p0, int p1, int p2)
+{
+    const orc_hist_stats* prev = frames[p0]->hist;
+    const orc_hist_stats* cur = frames[p1]->hist;
+    const orc_hist_stats* fut = frames[p2]->hist;
+    frames[p1]->bHistScenecutAnalyzed = 1;
+
+    uint32_t abruptChangeCount = 0, sceneChangeCount = 0;
+    const uint32_t widthFullRes = (uint32_t)la->p.sourceWidth, heightFullRes = (uint32_t)la->p.sourceHeight;
+    uint32_t segmentWidth = widthFullRes / 4, segmentHeight = heightFullRes / 4;
+    const int64_t var[3][2] = { { cur->picAvgVariance, prev->picAvgVariance }, { cur->picAvgVarianceCb, prev->picAvgVarianceCb },
+                                { cur->picAvgVarianceCr, prev->picAvgVarianceCr } };
+
+    for (uint32_t sw = 0; sw < 4; sw++)
+        for (uint32_t sh = 0; sh < 4; sh++)
+        {
+            int isAbruptChange = 0, isSceneChange = 0;
+            segmentWidth += (sw == 3) ? widthFullRes - 4 * segmentWidth : 0;
+            segmentHeight += (sh == 3) ? heightFullRes - 4 * segmentHeight : 0;
+            const uint32_t num64 = (segmentWidth * segmentHeight) >> 12;       /* NUM64x64INPIC */
+            uint32_t thresh[3];
+            thresh[0] = (llabs(var[0][0] - var[0][1]) > 390 && (var[0][0] > 1500 || var[0][1] > 1500)) ? 3500 * num64 : 2250 * num64;
+            for (int c = 1; c < 3; c++)
+                thresh[c] = (llabs(var[c][0] - var[c][1]) > 10 && (var[c][0] > 20 || var[c][1] > 20)) ? 3500 / 4 * num64
+                                                                                                     : 2250 / 4 * num64;
+            uint32_t accHistDiff[3] = { 0, 0, 0 };
+            for (int bin = 0; bin < 256; bin++)
+                for (int c = 0; c < 3; c++)
+                    accHistDiff[c] += (uint32_t)abs((int32_t)cur->picHistogram[sw][sh][c][bin] - (int32_t)prev->picHistogram[sw][sh][c][bin]);
+            if (la->resetRunningAvg)
+                for (int c = 0; c < 3; c++)
+                    la->accHistDiffRunningAvg[c][sw][sh] = accHistDiff[c];
+            for (int c = 0; c < 3; c++)
+            {
+                const uint32_t err = (uint32_t)abs((int32_t)la->accHistDiffRunningAvg[c][sw][sh] - (int32_t)accHistDiff[c]);
+                if (err > thresh[c] && accHistDiff[c] >= err)
+                    isAbruptChange = 1;
+            }
+            if (isAbruptChange)
+            {
+                const int16_t f = (int16_t)fut->averageIntensityPerSegment[sw][sh][0];
+                const int16_t c = (int16_t)cur->averageIntensityPerSegment[sw][sh][0];
+                const int16_t q = (int16_t)prev->averageIntensityPerSegment[sw][sh][0];
+                const uint8_t futurePast = (uint8_t)abs(f - q), futurePresent = (uint8_t)abs(f - c), presentPast = (uint8_t)abs(c - q);
+                if (futurePresent >= 1.5 * futurePast && presentPast >= 1.5 * futurePast)
+                    ;                                   /* a flash */
+                else if (futurePresent < 4 && presentPast < 4)
+                    ;                                   /* a fade */
+                else if (abs(futurePresent - presentPast) < 4 && futurePresent + presentPast >= futurePast)
+                    ;                                   /* an intensity change */
+                else
+                    isSceneChange = 1;
+            }
+            else
+                la->accHistDiffRunningAvg[0][sw][sh] = (3 * la->accHistDiffRunningAvg[0][sw][sh] + accHistDiff[0]) / 4;
+            abruptChangeCount += isAbruptChange;
+            sceneChangeCount += isSceneChange;
+        }
+    la->resetRunningAvg = abruptChangeCount >= la->segmentCountThreshold;
+    return sceneChangeCount >= la->segmentCountThreshold;
+}
+
+/* ---- :3456-3482 ---- */
+static int hist_based_scenecut(orc_la* la, orc_lowres** frames, int p0, int p1, int numFrames)
+{
+    if (la->p.bframes)
+    {
+        int maxp1 = imin(p0 + 1 + la->p.bframes, numFrames);
+        for (int cp1 = p0; cp1 < maxp1; cp1++)
+        {
+            if (frames[cp1 + 1]->bHistScenecutAnalyzed)
+                continue;
+            if (frames[cp1 + 2] != NULL && detect_hist_based_scene_change(la, frames, cp1, cp1 + 1, cp1 + 2))
+                frames[cp1 + 1]->bScenecut = 1;
+        }
+    }
+    return frames[p1]->bScenecut;
 }
 
 /* ---- :4068-4145 (qgSize > 8, no hevcAq) ---- */
@@ -515,7 +609,8 @@ static void slicetype_analyse(orc_la* la, orc_lowres** frames, int bKeyframe)
 
     int numBFrames = 0;
     int numAnalyzed = numFrames;
-    int isScenecut = scenecut(la, frames, 0, 1, 1, origNumFrames);
+    int isScenecut = lp->bHistBasedSceneCut ? hist_based_scenecut(la, frames, 0, 1, origNumFrames)
+                                            : scenecut(la, frames, 0, 1, 1, origNumFrames);
 
     if (lp->scenecutThreshold && isScenecut)
     {
@@ -721,7 +816,7 @@ static void slicetype_decide(orc_la* la)
     maxSearch = j;
 
     if (la->lastNonB && ((lp->bFrameAdaptive && la->p.bframes) || lp->cuTree || lp->scenecutThreshold ||
-                         (lp->lookaheadDepth && lp->vbvBufferSize)))
+                         lp->bHistBasedSceneCut || (lp->lookaheadDepth && lp->vbvBufferSize)))
         slicetype_analyse(la, frames, 0);
 
     int bframes, brefs;
@@ -866,6 +961,8 @@ orc_la* orc_la_create(const orc_param* p, const orc_la_param* lp, const orc_cutr
     la->batchMotionSearch = lp->poolWorkers > 0 && lp->bFrameAdaptive == 2;
     la->batchFrameCosts = la->batchMotionSearch;
     la->blocks8x8 = tld->ncu;
+    la->resetRunningAvg = 1;
+    la->segmentCountThreshold = (uint32_t)(((float)((4 * 4) * 50) / 100) + 0.5);
     return la;
 }
 

@@ -56,7 +56,9 @@ def oracle_lookahead(clip, chroma, depth, p, **param_kw):
             s, d = lr.wp()
             s[:], d[:] = wsum, wssd
         else:
-            look.add_frame(y, np.full(look_ncu(param), 256, np.int32))
+            lr = look.add_frame(y, np.full(look_ncu(param), 256, np.int32))
+        if p.get("bHistBasedSceneCut"):
+            orc.set_hist_stats(lr, orc.collect_picture_statistics(lr, y, chroma[i][0], chroma[i][1]))
     return look, orc.SliceDecider(look, p)
 
 

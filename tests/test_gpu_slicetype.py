@@ -139,6 +139,32 @@ def test_decisions_and_request_order(kw):
     assert len(trace) >= N - 1
 
 
+@pytest.mark.parametrize("kw", [{}, {"poolWorkers": 16, "bframes": 3}, {"bFrameAdaptive": 0, "bBPyramid": 0, "cuTree": 0}],
+                         ids=["lazy", "pool16-bframes3", "no-badapt"])
+def test_histogram_scene_cut_decisions(kw):
+    """--hist-scenecut: collectPictureStatistics on the device (x265gpu_hist_stats) feeding histBasedScenecut /
+    detectHistBasedSceneChange (slicetype.cpp:3323-3482) in the host layer, against the oracle's statistics and its
+    restatement of the same decision.  A darker scene with other chroma follows a brighter one; a one-picture flash
+    and a slow brightening inside the scenes exercise the flash / fade / intensity-change branches."""
+    p = dict(api.LookaheadParam.MEDIUM, bHistBasedSceneCut=1, **kw)
+    N, W, H, depth = 30, 640, 368, 8
+    a = synth.luma_clip(W, H, N, depth, seed=61, scene_cut=False)
+    clip = np.empty_like(a)
+    chroma = du.chroma_for(a, depth, 62)
+    for i in range(N):
+        f = a[i].astype(np.int32)
+        if i >= 14:
+            f = f[::-1, ::-1] // 2 + 10                       # the second scene: mirrored, darker, flatter
+            chroma[i] = (np.clip(chroma[i][0].astype(np.int32) + 50, 0, 255).astype(np.uint8), chroma[i][1][::-1].copy())
+        if i == 6:
+            f = f + 90                                         # a flash
+        if 20 <= i < 26:
+            f = f + 3 * (i - 19)                               # a slow brightening
+        clip[i] = np.clip(f, 0, 255).astype(np.uint8)
+    types, cuts, trace = _compare(clip, chroma, depth, p)
+    assert cuts[14] == 1 and types[14] in (1, 2)
+
+
 def test_fades_weighted_prediction_in_decision_order():
     """A fade makes weightsAnalyse pick weights inside the requests the decision logic issues."""
     p = dict(api.LookaheadParam.MEDIUM)

@@ -60,7 +60,7 @@ class Geometry(C.Structure):
         ("width", C.c_int32), ("lines", C.c_int32), ("stride", C.c_int32), ("marginX", C.c_int32),
         ("marginY", C.c_int32), ("widthInCU", C.c_int32), ("heightInCU", C.c_int32), ("cuCount", C.c_int32),
         ("widthInCU4", C.c_int32), ("heightInCU4", C.c_int32), ("planeSize", C.c_int64), ("padOffset", C.c_int64),
-        ("numCoopSlices", C.c_int32), ("numRowsPerSlice", C.c_int32),
+        ("numCoopSlices", C.c_int32), ("numRowsPerSlice", C.c_int32), ("sourceWidth", C.c_int32), ("sourceHeight", C.c_int32),
     ]
 
 
@@ -628,14 +628,15 @@ class LookaheadParam(C.Structure):
                 ("maxNumReferences", C.c_int32), ("bEnableWeightedPred", C.c_int32), ("bEnableWeightedBiPred", C.c_int32),
                 ("fpsNum", C.c_int32), ("fpsDenom", C.c_int32), ("qCompress", C.c_double), ("bitDepth", C.c_int32),
                 ("poolWorkers", C.c_int32), ("bAdaptiveQuant", C.c_int32), ("aqMode", C.c_int32), ("aqStrength", C.c_double),
-                ("bPresearch", C.c_int32), ("lookaheadSlices", C.c_int32), ("bAQMotion", C.c_int32)]
+                ("bPresearch", C.c_int32), ("lookaheadSlices", C.c_int32), ("bAQMotion", C.c_int32),
+                ("bHistBasedSceneCut", C.c_int32)]
 
     MEDIUM = dict(bframes=4, lookaheadDepth=20, bFrameAdaptive=2, bBPyramid=1, scenecutThreshold=40, scenecutBias=0.05,
                   keyframeMin=25, keyframeMax=250, bOpenGOP=1, bIntraRefresh=0, radl=0, gopLookahead=0, cuTree=1,
                   bFrameBias=0, vbvBufferSize=0, vbvMaxBitrate=0, bCqp=0, bEnableTemporalSubLayers=0, maxNumReferences=3,
                   bEnableWeightedPred=1, bEnableWeightedBiPred=0, fpsNum=30, fpsDenom=1, qCompress=0.6, bitDepth=8,
                   poolWorkers=0, bAdaptiveQuant=1, aqMode=2, aqStrength=1.0, bPresearch=1, lookaheadSlices=0,
-                  bAQMotion=0)
+                  bAQMotion=0, bHistBasedSceneCut=0)
 
     def __init__(self, **kw):
         super().__init__()

@@ -803,6 +803,8 @@ int x265gpu_get_geometry(const x265gpu_ctx* ctx, x265gpu_geometry* o)
     o->padOffset = g.padOffset;
     o->numCoopSlices = ctx->numCoopSlices;
     o->numRowsPerSlice = ctx->numRowsPerSlice;
+    o->sourceWidth = ctx->cfg.sourceWidth;
+    o->sourceHeight = ctx->cfg.sourceHeight;
     return X265GPU_OK;
 }
 

@@ -727,7 +727,7 @@ int CuTree::cuTree(Lowres* const* frames, int numframes, bool bIntra)
 // requests are issued, and in which order, decides which motion searches run inside a bidirectional request
 // (the skip shortcut of estimateCUCost makes an L0 vector depend on that), so any other order gives other
 // vectors.  What differs from x265 is only where a request is computed: CostEstimateGroup sends it to the device.
-// Not covered (unsupported() says so): zones, fades, analysis load, histogram scene cuts, --mcstf
+// Not covered (unsupported() says so): zones, fades, analysis load, --mcstf
 // batches, more than two temporal sub-layers, qgSize 8 and rc.hevcAq in frameCostRecalculate.
 
 // x265_exp2fix8 (source/common/common.cpp:96-103) over x265_exp2_lut (source/common/constants.cpp:552-558),
@@ -824,6 +824,91 @@ void Lookahead::cuTree(Lowres** frames, int numframes, bool bIntra)
     cp.bitDepth = m_param.bitDepth;
     cp.trace = &m_trace;
     note(CuTree(m_ctx, cp).cuTree(frames, numframes, bIntra));
+}
+
+// :3323-3454.  Histogram differences of the 4x4 segments between the previous and the current picture against their
+// running averages; an abrupt change is a scene change unless the segment means say flash, fade or intensity change.
+// The segment size that scales the thresholds grows as the loops go (the last column's / row's remainder is added to
+// the running width / height and never taken off again): kept, in the reference's unsigned arithmetic.
+bool Lookahead::detectHistBasedSceneChange(Lowres** frames, int p0, int p1, int p2)
+{
+    const x265gpu_hist_stats_t& prev = *frames[p0]->hist;
+    const x265gpu_hist_stats_t& cur = *frames[p1]->hist;
+    const x265gpu_hist_stats_t& fut = *frames[p2]->hist;
+    frames[p1]->bHistScenecutAnalyzed = true;
+
+    uint32_t abruptChangeCount = 0, sceneChangeCount = 0;
+    const uint32_t widthFullRes = (uint32_t)m_geom.sourceWidth, heightFullRes = (uint32_t)m_geom.sourceHeight;
+    uint32_t segmentWidth = widthFullRes / 4, segmentHeight = heightFullRes / 4;
+    const int64_t var[3][2] = { { cur.picAvgVariance, prev.picAvgVariance }, { cur.picAvgVarianceCb, prev.picAvgVarianceCb },
+                                { cur.picAvgVarianceCr, prev.picAvgVarianceCr } };
+    for (uint32_t sw = 0; sw < 4; sw++)
+        for (uint32_t sh = 0; sh < 4; sh++)
+        {
+            bool isAbruptChange = false, isSceneChange = false;
+            segmentWidth += (sw == 3) ? widthFullRes - 4 * segmentWidth : 0;
+            segmentHeight += (sh == 3) ? heightFullRes - 4 * segmentHeight : 0;
+            const uint32_t num64 = (segmentWidth * segmentHeight) >> 12;      // NUM64x64INPIC (slicetype.h:64)
+            uint32_t thresh[3];
+            // PICTURE_DIFF_VARIANCE_TH 390, PICTURE_VARIANCE_TH 1500, HIGH / LOW_VAR_SCENE_CHANGE_TH 3500 / 2250; chroma:
+            // 10, 20 and the same two divided by 4 (slicetype.h:50-58)
+            thresh[0] = (std::llabs(var[0][0] - var[0][1]) > 390 && (var[0][0] > 1500 || var[0][1] > 1500)) ? 3500 * num64 : 2250 * num64;
+            for (int c = 1; c < 3; c++)
+                thresh[c] = (std::llabs(var[c][0] - var[c][1]) > 10 && (var[c][0] > 20 || var[c][1] > 20)) ? 3500 / 4 * num64
+                                                                                                          : 2250 / 4 * num64;
+            uint32_t accHistDiff[3] = { 0, 0, 0 };
+            for (int bin = 0; bin < 256; bin++)
+                for (int c = 0; c < 3; c++)
+                    accHistDiff[c] += (uint32_t)std::abs((int32_t)cur.picHistogram[sw][sh][c][bin] - (int32_t)prev.picHistogram[sw][sh][c][bin]);
+            if (m_resetRunningAvg)
+                for (int c = 0; c < 3; c++)
+                    m_accHistDiffRunningAvg[c][sw][sh] = accHistDiff[c];
+            for (int c = 0; c < 3; c++)
+            {
+                const uint32_t err = (uint32_t)std::abs((int32_t)m_accHistDiffRunningAvg[c][sw][sh] - (int32_t)accHistDiff[c]);
+                if (err > thresh[c] && accHistDiff[c] >= err)
+                    isAbruptChange = true;
+            }
+            if (isAbruptChange)
+            {
+                const int16_t f = (int16_t)fut.averageIntensityPerSegment[sw][sh][0];
+                const int16_t c = (int16_t)cur.averageIntensityPerSegment[sw][sh][0];
+                const int16_t q = (int16_t)prev.averageIntensityPerSegment[sw][sh][0];
+                const uint8_t futurePast = (uint8_t)std::abs(f - q), futurePresent = (uint8_t)std::abs(f - c);
+                const uint8_t presentPast = (uint8_t)std::abs(c - q);
+                if (futurePresent >= 1.5 * futurePast && presentPast >= 1.5 * futurePast)
+                    ;                                       // FLASH_TH: a flash
+                else if (futurePresent < 4 && presentPast < 4)
+                    ;                                       // FADE_TH: a fade
+                else if (std::abs(futurePresent - presentPast) < 4 && futurePresent + presentPast >= futurePast)
+                    ;                                       // INTENSITY_CHANGE_TH
+                else
+                    isSceneChange = true;
+            }
+            else   // only the luma average follows the picture (:3430)
+                m_accHistDiffRunningAvg[0][sw][sh] = (3 * m_accHistDiffRunningAvg[0][sw][sh] + accHistDiff[0]) / 4;
+            abruptChangeCount += isAbruptChange;
+            sceneChangeCount += isSceneChange;
+        }
+    m_resetRunningAvg = abruptChangeCount >= m_segmentCountThreshold;
+    return sceneChangeCount >= m_segmentCountThreshold;
+}
+
+// :3456-3482
+bool Lookahead::histBasedScenecut(Lowres** frames, int p0, int p1, int numFrames)
+{
+    if (m_param.bframes)
+    {
+        const int maxp1 = std::min(p0 + 1 + m_param.bframes, numFrames);
+        for (int cp1 = p0; cp1 < maxp1; cp1++)
+        {
+            if (frames[cp1 + 1]->bHistScenecutAnalyzed)
+                continue;
+            if (frames[cp1 + 2] != nullptr && detectHistBasedSceneChange(frames, cp1, cp1 + 1, cp1 + 2))
+                frames[cp1 + 1]->bScenecut = true;
+        }
+    }
+    return frames[p1]->bScenecut;
 }
 
 // :3581-3607: the frames of the first mini-GOP, in the order and with the references the trellis costed them
@@ -1253,7 +1338,8 @@ void Lookahead::slicetypeAnalyse(Lowres** frames, bool bKeyframe)
     note(resolveIntraTotals(m_ctx, frames, numFrames + 1));
 
     int numBFrames = 0, numAnalyzed = numFrames, resetStart;
-    const bool isScenecut = scenecut(frames, 0, 1, true, origNumFrames);
+    const bool isScenecut = P.bHistBasedSceneCut ? histBasedScenecut(frames, 0, 1, origNumFrames)
+                                                 : scenecut(frames, 0, 1, true, origNumFrames);
     if (P.scenecutThreshold && isScenecut)
     {
         frames[1]->sliceType = TYPE_I;
@@ -1515,11 +1601,21 @@ void Lookahead::slicetypeDecide()
             }
             note(group.processTasks((int)pre.size(), pre.data(), lumas.data(), strides.data(), nullptr));
         }
+        if (P.bHistBasedSceneCut)
+            for (size_t i = 0; i < pre.size(); i++)
+            {
+                // collectPictureStatistics (:1809-1834, the task's second step at :1852-1853) on the device
+                if (!pre[i]->hist)
+                    pre[i]->hist = std::make_shared<x265gpu_hist_stats_t>();
+                note(x265gpu_hist_stats(m_ctx, pre[i]->slot, pics[i].y, pics[i].strideY, pics[i].u, pics[i].v, pics[i].strideC,
+                                        pics[i].memKind, pre[i]->hist.get()));
+                pre[i]->bHistScenecutAnalyzed = false;
+            }
         for (Lowres* f : pre)
             f->lowresInit = true;
     }
 
-    if (m_lastNonB && ((P.bFrameAdaptive && P.bframes) || P.cuTree || P.scenecutThreshold ||
+    if (m_lastNonB && ((P.bFrameAdaptive && P.bframes) || P.cuTree || P.scenecutThreshold || P.bHistBasedSceneCut ||
                        (P.lookaheadDepth && P.vbvBufferSize)))
         slicetypeAnalyse(frames, false);
 
@@ -1888,6 +1984,7 @@ xgh_lookahead* xgh_lookahead_create(x265gpu_ctx* ctx, const xgh_lookahead_param*
     q.bPresearch = p->bPresearch != 0;
     q.lookaheadSlices = p->lookaheadSlices;
     q.bAQMotion = p->bAQMotion != 0;
+    q.bHistBasedSceneCut = p->bHistBasedSceneCut != 0;
     if (q.bAQMotion)
         q.bAdaptiveQuant = true;              // Lookahead::m_bAdaptiveQuant (slicetype.cpp:1080-1084)
     xgh_lookahead* h = new xgh_lookahead;

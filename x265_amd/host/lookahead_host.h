@@ -25,6 +25,7 @@
 
 #include <stdint.h>
 #include <deque>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -85,6 +86,8 @@ struct Lowres
     double* qpCuTreeOffset = nullptr;
     int32_t* invQscaleFactor = nullptr;   // caller-owned, same shape; filled by the AQ form of processTasks
     std::vector<double> qpAqMotionOffset; // --aq-motion (lowres.cpp:114-115), sized on first use
+    std::shared_ptr<x265gpu_hist_stats_t> hist;   // --hist-scenecut: collectPictureStatistics' results (lowres.h:245-253)
+    bool bHistScenecutAnalyzed = false;
 
     // what the slice-type decision keeps per frame (source/common/lowres.h:166-213)
     int sliceTypeReq = TYPE_AUTO;
@@ -248,6 +251,7 @@ struct LookaheadParam
     int poolWorkers = 0;                          // ThreadPool::m_numWorkers of the lookahead's pool; 0: no pool, so
                                                   // requests are issued one by one in the order the decision needs them;
                                                   // > 0 with trellis B-adapt: the two batches of slicetypeAnalyse
+    bool bHistBasedSceneCut = false;              // --hist-scenecut: scene cuts from histogram differences of the 4x4 segments
     bool bAQMotion = false;                       // --aq-motion: offsets raised where a block moves unlike the rest of its frame
     bool bAdaptiveQuant = true;                   // Lookahead::m_bAdaptiveQuant: pre-analysis runs calcAdaptiveQuantFrame
     x265gpu_aq_params aq;                         // its parameters (aqMode, strength, qgSize >= 16, ...)
@@ -290,6 +294,8 @@ private:
     void compCostBref(Lowres** frames, int start, int end, int num);
     void cuTree(Lowres** frames, int numframes, bool bIntra);
     void aqMotion(Lowres** frames, bool bIntra);
+    bool histBasedScenecut(Lowres** frames, int p0, int p1, int numFrames);
+    bool detectHistBasedSceneChange(Lowres** frames, int p0, int p1, int p2);
     void calcMotionAdaptiveQuantFrame(Lowres** frames, int p0, int p1, int b);
     int64_t cost(Lowres** frames, int p0, int p1, int b, bool bIntraPenalty = false);
     void note(int rc) { if (rc != X265GPU_OK && m_status == X265GPU_OK) m_status = rc; }
@@ -302,6 +308,10 @@ private:
     int m_lastKeyframe;
     bool m_isSceneTransition = false, m_extendGopBoundary = false;
     bool m_bBatchMotionSearch, m_bBatchFrameCosts;
+    // --hist-scenecut (slicetype.cpp:1143-1174): running averages of the histogram differences, [plane][segment]
+    uint32_t m_accHistDiffRunningAvg[3][4][4] = {};
+    bool m_resetRunningAvg = true;
+    uint32_t m_segmentCountThreshold = (uint32_t)(((float)((4 * 4) * 50) / 100) + 0.5);
     bool m_filled = false;
     size_t m_fullQueueSize;
     int m_inputCount = 0;
@@ -366,7 +376,7 @@ typedef struct xgh_lookahead_param
     int32_t bitDepth, poolWorkers, bAdaptiveQuant, aqMode;
     double  aqStrength;
     int32_t bPresearch, lookaheadSlices;
-    int32_t bAQMotion;
+    int32_t bAQMotion, bHistBasedSceneCut;
 } xgh_lookahead_param;
 typedef struct xgh_decided
 {

@@ -62,10 +62,12 @@ typedef struct x265gpu_ctx x265gpu_ctx;
  * source/common/param.cpp:197-260,310-315). */
 typedef struct x265gpu_config
 {
-    int32_t sourceWidth;          /* param->sourceWidth / sourceHeight, at least 16.  Sizes of the form 16k+1 are */
-    int32_t sourceHeight;         /* X265GPU_ERR_UNSUPPORTED: padded to the minimum CU size they gain a row or column  */
-                                  /* of 8x8 lowres blocks (Lowres::create sizes its arrays from the padded picture,   */
-                                  /* lowres.cpp:84-103) that this library, which sizes from the source, does not hold */
+    int32_t sourceWidth;          /* the size of the planes the caller hands over, at least 16.  An odd size (x265 takes */
+    int32_t sourceHeight;         /* one for 4:0:0 / 4:4:4 input only, param.cpp:1791-1794) is treated as x265 does: the */
+                                  /* lookahead's geometry is that of the picture padded to the minimum CU size of 8      */
+                                  /* (Encoder::configure, encoder.cpp:4470-4474, 4689-4693; Lowres::create sizes from    */
+                                  /* that, lowres.cpp:84-103), its samples beyond the source repeat the last column /   */
+                                  /* row (picyuv.cpp:572-583); the 4:2:0 entry points (AQ, histogram) then refuse        */
     int32_t internalBitDepth;     /* 8, 10 or 12 */
     int32_t maxCUSize;            /* CTU size; margins are maxCUSize+32 / maxCUSize+16 */
     int32_t bframes;              /* sizes the [bframes+2] result arrays */

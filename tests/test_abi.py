@@ -59,11 +59,6 @@ def test_open_rejects_bad_arguments(lib):
     cfg.bframes = 17
     assert lib.x265gpu_open(C.byref(cfg), C.byref(h)) == -1          # beyond X265_BFRAME_MAX
     cfg.bframes = 4
-    for w, hgt in ((320, 193), (321, 192), (33, 64)):
-        # 1 more than a multiple of 16: padding the picture to the minimum CU size adds a row or column of lowres
-        # blocks that the library's arrays, sized from the source size, do not have
-        cfg.sourceWidth, cfg.sourceHeight = w, hgt
-        assert lib.x265gpu_open(C.byref(cfg), C.byref(h)) == -5
     assert not h.value
 
 

@@ -82,6 +82,48 @@ def test_lowres_planes_and_intra(depth, size):
         ref.close()
 
 
+@pytest.mark.parametrize("size", [(321, 193), (337, 192), (320, 209), (33, 65)])
+@pytest.mark.parametrize("hme", [False, True])
+def test_odd_picture_sizes_are_padded_to_the_minimum_cu_size(size, hme):
+    """A picture one sample wider (taller) than a multiple of 16 gains a column (row) of 8x8 lowres blocks when x265
+    pads it to the minimum CU size of 8 (Encoder::configure; PicYuv repeats the last column / row into the padding).
+    The library gets the raw planes and the raw size; the oracle the picture x265's lookahead would see: padded, with
+    the edge samples repeated.  Planes, intra estimate and searches must agree."""
+    W, H = size
+    if hme and (W < 64 or H < 64):
+        pytest.skip("quarter-res level needs a larger picture")
+    PW, PH = (W + 7) // 8 * 8, (H + 7) // 8 * 8
+    N, depth = 3, 8
+    raw = synth.luma_clip(W, H, N, depth, seed=71)
+    padded = np.pad(raw, ((0, 0), (0, PH - H), (0, PW - W)), mode="edge")
+    kw = dict(hme=True) if hme else {}
+    ref = orc.Lookahead(depth, orc.make_param(PW, PH, **kw))
+    for f in padded:
+        ref.add_frame(f)
+    ctx = api.Context(W, H, depth=depth, num_slots=N, **kw)
+    try:
+        assert (ctx.geom.widthInCU, ctx.geom.heightInCU) == ((PW // 2 + 7) >> 3, (PH // 2 + 7) >> 3)
+        ctx.set_mvcost(ref.table, ref.centre)
+        frames = [LowresState(i, i, ctx.D) for i in range(N)]
+        PreLookaheadGroup(ctx).process_tasks(frames, raw)
+        for i in range(N):
+            for p in range(8 if hme else 4):
+                want = ref.frames[i].buffer(p) if p < 4 else ref.frames[i].lower_buffer(p - 4)
+                np.testing.assert_array_equal(ctx.get_plane(i, p), want, err_msg="frame %d plane %d" % (i, p))
+            cost, mode = ctx.get_intra(i)
+            np.testing.assert_array_equal(cost, ref.frames[i].intra_cost())
+            np.testing.assert_array_equal(mode, ref.frames[i].intra_mode())
+        est = CostEstimateGroup(ctx, frames)
+        for (p0, p1, b) in [(0, 1, 1), (0, 2, 1), (1, 2, 2)]:
+            assert est.single_cost(p0, p1, b) == ref.frame_cost(p0, p1, b), (p0, p1, b)
+            _check_request(ref, ctx, frames, p0, p1, b)
+        with pytest.raises(api.X265GpuError):
+            ctx.aq_energy(raw[0], raw[0][::2, ::2], raw[0][::2, ::2])       # 4:2:0 has no odd sizes
+    finally:
+        ctx.close()
+        ref.close()
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_scale_factors_after_the_intra_estimate(depth):
     """The intra estimate's per-block costs do not depend on AQ; its AQ-weighted row and frame sums do.  Factors

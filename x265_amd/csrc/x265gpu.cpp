@@ -152,6 +152,7 @@ struct x265gpu_ctx
     bool aqInstallInFlight = false;     // ... recorded and not yet waited for by the host
     std::vector<int32_t> intraDeferred;    // slots whose intra estimate ran ahead of their scale factors: AQ sums to redo
     bool aqInstalledOnMain = false;        // some of those factors were uploaded on the main stream (x265gpu_lowres_set_aq)
+    bool oddSize = false;             // luma-only picture of odd width or height: the 4:2:0 entry points (AQ, histogram) refuse
     int flowGridPad = 1;
     uint32_t* flowChunks[2] = { nullptr, nullptr };   // chunk tables of the half-res and the quarter-res block grid
     int flowChunkCount[2] = { 0, 0 };
@@ -227,11 +228,15 @@ struct DeviceScope
 };
 
 // Lowres::create, source/common/lowres.cpp:84-103 and :171-177, :211-213
-void compute_geometry(const x265gpu_config& cfg, Geometry& g)
+// `cfg` carries the picture size as the lookahead sees it in x265: Encoder::configure has padded param->sourceWidth /
+// sourceHeight to the minimum CU size by then (source/encoder/encoder.cpp:4470-4474, 4689-4693), and PicYuv holds the
+// source with its last column / row repeated into that padding (source/common/picyuv.cpp:572-583).  rawWidth /
+// rawHeight are what the caller's planes really hold; reads beyond them repeat the edge sample.
+void compute_geometry(const x265gpu_config& cfg, int rawWidth, int rawHeight, Geometry& g)
 {
     memset(&g, 0, sizeof(g));
-    g.srcWidth = cfg.sourceWidth;
-    g.srcHeight = cfg.sourceHeight;
+    g.srcWidth = rawWidth;
+    g.srcHeight = rawHeight;
     g.marginX = cfg.maxCUSize + 32;
     g.marginY = cfg.maxCUSize + 16;
     int width = cfg.sourceWidth / 2, lines = cfg.sourceHeight / 2;
@@ -533,17 +538,6 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
         (cfg->internalBitDepth != 8 && cfg->internalBitDepth != 10 && cfg->internalBitDepth != 12) ||
         (cfg->maxCUSize != 16 && cfg->maxCUSize != 32 && cfg->maxCUSize != 64))
         return X265GPU_ERR_ARG;
-    {
-        // x265 sizes the per-block arrays of Lowres from the picture padded to the minimum CU size (lowres.cpp:84-103)
-        // and runs its loops over the source size (slicetype.cpp:1061-1064); this library sizes both from the source
-        // size.  The few sizes where padding to a multiple of 8 adds a row or column of 8x8 lowres blocks (17, 33, ...)
-        // would make the 16x16-unit loops of the cuTree and AQ host code step past those arrays.
-        auto blocks = [](int v) { return ((v / 2) + 7) >> 3; };
-        auto pad8 = [](int v) { return (v + 7) & ~7; };
-        if (blocks(pad8(cfg->sourceWidth)) != blocks(cfg->sourceWidth) ||
-            blocks(pad8(cfg->sourceHeight)) != blocks(cfg->sourceHeight))
-            return X265GPU_ERR_UNSUPPORTED;
-    }
     auto methodOk = [](int m) { return m == X265GPU_DIA_SEARCH || m == X265GPU_HEX_SEARCH || m == X265GPU_UMH_SEARCH; };
     if (!methodOk(cfg->searchMethod))
         return X265GPU_ERR_UNSUPPORTED;
@@ -575,7 +569,19 @@ int x265gpu_open(const x265gpu_config* cfg, x265gpu_ctx** out)
     ctx->cfg = *cfg;
     ctx->bpp = cfg->internalBitDepth > 8 ? 2 : 1;
     ctx->D = cfg->bframes + 2;
-    compute_geometry(*cfg, ctx->g);
+    {
+        // An odd picture size (x265 takes one for 4:0:0 and 4:4:4 input only, source/common/param.cpp:1791-1794) is what
+        // the caller's luma planes hold; the lookahead's geometry is that of the picture Encoder::configure padded to
+        // the minimum CU size, 8 unless the caller says otherwise: a width of 16k+1 gains a column of 8x8 lowres blocks.
+        x265gpu_config padded = *cfg;
+        const int unit = 8;
+        if (cfg->sourceWidth & 1)
+            padded.sourceWidth = (cfg->sourceWidth + unit - 1) / unit * unit;
+        if (cfg->sourceHeight & 1)
+            padded.sourceHeight = (cfg->sourceHeight + unit - 1) / unit * unit;
+        compute_geometry(padded, cfg->sourceWidth, cfg->sourceHeight, ctx->g);
+        ctx->oddSize = ((cfg->sourceWidth | cfg->sourceHeight) & 1) != 0;
+    }
     // cooperative slices: Lookahead::Lookahead, source/encoder/slicetype.cpp:1122-1133
     ctx->numRowsPerSlice = ctx->g.H;
     ctx->numCoopSlices = 1;
@@ -2344,6 +2350,8 @@ int x265gpu_aq_energy(x265gpu_ctx* ctx, const void* y, intptr_t strideY, const v
     DeviceScope deviceScope(ctx);
     if (!ctx || !y || !u || !v || !energy || !wpSum || !wpSsd)
         return X265GPU_ERR_ARG;
+    if (ctx->oddSize)
+        return fail(ctx, X265GPU_ERR_UNSUPPORTED, "aq_energy: 4:2:0 pictures have even sizes (the context was opened with an odd one)");
     unsigned long long wp[6];
     YuvOnDevice pic;
     int rc = stage_aq_picture(ctx, "aq_energy", y, strideY, u, v, strideC, memKind, pic);
@@ -2446,6 +2454,8 @@ int x265gpu_aq_frame(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t str
     FINISH_AQ(ctx);
     if (!ctx || !params || !y || !u || !v || !wpSum || !wpSsd)
         return X265GPU_ERR_ARG;
+    if (ctx->oddSize)
+        return fail(ctx, X265GPU_ERR_UNSUPPORTED, "aq_frame: 4:2:0 pictures have even sizes (the context was opened with an odd one)");
     if (params->aqMode < 0 || params->aqMode > 4)
         return fail(ctx, X265GPU_ERR_ARG, "aq_frame: aqMode must be 0..4");
     if (params->qgSize != 0 && params->qgSize != 8 && params->qgSize != 16 && params->qgSize != 32 && params->qgSize != 64)
@@ -2629,6 +2639,8 @@ int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pic
         return X265GPU_ERR_ARG;
     if (!n)
         return X265GPU_OK;
+    if (ctx->oddSize)
+        return fail(ctx, X265GPU_ERR_UNSUPPORTED, "aq_frames: 4:2:0 pictures have even sizes (the context was opened with an odd one)");
     const int w = ctx->cfg.sourceWidth, h = ctx->cfg.sourceHeight;
     const bool offsets = !params->bSkipOffsets && params->aqMode != 0;
     const bool mapped = offsets && params->aqStrength != 0;
@@ -3012,6 +3024,8 @@ int x265gpu_hist_stats(x265gpu_ctx* ctx, int32_t slot, const void* y, intptr_t s
     DeviceScope deviceScope(ctx);
     if (!ctx || !slot_ok(ctx, slot) || !y || !u || !v || !out)
         return X265GPU_ERR_ARG;
+    if (ctx->oddSize)
+        return fail(ctx, X265GPU_ERR_UNSUPPORTED, "hist_stats: 4:2:0 pictures have even sizes (the context was opened with an odd one)");
     const int w = ctx->cfg.sourceWidth, h = ctx->cfg.sourceHeight;
     if (w < 64 || h < 64 || strideY < w || strideC < (w >> 1))
         return fail(ctx, X265GPU_ERR_ARG, "hist_stats: picture smaller than 64x64 or bad stride");

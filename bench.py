@@ -527,10 +527,14 @@ class Workload:
             while la.get_decided() is not None:
                 out += 1
             calls = la.decide_calls()
+            for k, v in la.seconds().items():
+                phases[k] = phases.get(k, 0.0) + v
             la.close()
             assert out == F
             return calls
+        phases = {}
         steady_step()
+        phases.clear()
         self.torch.cuda.synchronize()
         times, calls = [], 0
         for _ in range(steady_steps):
@@ -543,6 +547,7 @@ class Workload:
         return {"frames_per_s": F / med, "ms_per_slicetypeDecide": 1000.0 * med / (calls / steady_steps),
                 "slicetypeDecide_calls_per_segment": calls / steady_steps, "ms_per_segment": 1000.0 * med,
                 "ms_per_segment_all": [1000.0 * t for t in times], "frames_per_s_mean": F * steady_steps / sdt,
+                "ms_per_slicetypeDecide_by_phase": {k: 1000.0 * v / calls for k, v in phases.items()},
                 "workload": "Lookahead::slicetypeDecide loop, preset medium (rc-lookahead 20, b-adapt 2, B-pyramid, weightp, AQ 2, "
                             "cuTree), pool of 16 (batched requests per decision), %d-frame clip fed picture by picture; the "
                             "median of %d passes" % (F, steady_steps)}

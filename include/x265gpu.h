@@ -293,7 +293,7 @@ typedef struct x265gpu_pu_job
     int32_t mvminX, mvminY, mvmaxX, mvmaxY;   /* full-pel bounds (mvmin / mvmax) */
     int32_t numCandidates;                /* extra quarter-pel candidates mvc[], at most 12 */
     int32_t mvc[24];                      /* x, y pairs */
-    int32_t flags;                        /* X265GPU_PU_VERT_RESTRICTION or 0 */
+    int32_t flags;                        /* X265GPU_PU_VERT_RESTRICTION or 0, | X265GPU_PU_COST_TABLE(k) */
 } x265gpu_pu_job;
 
 /* motionEstimate's m_vertRestriction argument (the reference picture is the current picture, search.cpp:367): the
@@ -301,6 +301,11 @@ typedef struct x265gpu_pu_job
  * point requires, clipping has already done that; the restriction that matters is the one Search::setSearchRange
  * applies to mvmax (search.cpp:4975-4982), which is the caller's. */
 #define X265GPU_PU_VERT_RESTRICTION 1
+/* Which of the resident MV-cost tables prices the job's vectors (x265gpu_me_set_mvcost_tables): with delta QP on, a
+ * CU's searches run under its own QP's lambda (Analysis::setLambdaFromQP before every puMotionEstimation call,
+ * source/encoder/analysis.cpp:188, 243, 259, 274).  Table 0 when left out. */
+#define X265GPU_PU_COST_TABLE(k) ((int32_t)(k) << 8)
+#define X265GPU_PU_MAX_COST_TABLES 128
 
 typedef struct x265gpu_pu_result
 {
@@ -312,6 +317,9 @@ typedef struct x265gpu_pu_result
 /* BitCost table for the full-resolution searches (its lambda follows the slice QP,
  * unlike the lookahead's): same meaning as x265gpu_set_mvcost. */
 int x265gpu_me_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd);
+/* Several such tables at once, one per QP the picture's CUs use (BitCost keeps one per QP, bitcost.cpp:31-60);
+ * jobs choose theirs with X265GPU_PU_COST_TABLE.  Replaces whatever was set before. */
+int x265gpu_me_set_mvcost_tables(x265gpu_ctx* ctx, int32_t numTables, const uint16_t* const* centres, int32_t maxMvd);
 
 /* searchMethod: X265GPU_DIA_SEARCH, _HEX_, _UMH_, _STAR_, _SEA_ or _FULL_SEARCH (param->searchMethod);
  * merange: param->searchRange; subpelRefine: param->subpelRefine (0..7, workload table

@@ -17,7 +17,10 @@ def _padded(clip, W, H, ctu):
 
 
 def _run(W, H, depth, rows, method=api.STAR_SEARCH, merange=57, subpel=3, amp=False, rect=True, min_cu=8, ctu=64,
-         num_refs=1, lam=4.0, lookahead=True, seed=3, median=False, second_picture=False, num_l1=0):
+         num_refs=1, lam=4.0, lookahead=True, seed=3, median=False, second_picture=False, num_l1=0, cu_qp=None, area_qp=False,
+         temporal=False):
+    """cu_qp: (lowest, highest) QP, drawn per CU of every depth; area_qp: the area searches get QPs of their own;
+    temporal: a temporal candidate for about half the PUs and lists."""
     nframes = num_refs + 1 + max(int(second_picture), num_l1)
     clip = synth.luma_clip(W, H, nframes, depth, seed=seed, scene_cut=False)
     pads, mx, my = _padded(clip, W, H, ctu)
@@ -51,6 +54,23 @@ def _run(W, H, depth, rows, method=api.STAR_SEARCH, merange=57, subpel=3, amp=Fa
             med[:, :, 0] = rng.integers(0, 2, (cols * nrows, num_refs + num_l1))
             med[:, :, 1:] = rng.integers(-24, 25, (cols * nrows, num_refs + num_l1, 2))
         tme = api.ThreadedME(ctx, search=method, merange=merange, subpel=subpel, amp=amp, rect=rect, min_cu=min_cu, lam=lam)
+        rng = np.random.default_rng(seed + 100)
+        qps = areas = lam_by_qp = cands = None
+        if cu_qp:
+            # a lambda per QP that doubles every six QPs, as x265's does; the QPs of neighbouring CUs differ
+            lam_by_qp = np.round(2.0 ** ((np.arange(70) - 12) / 6.0), 4)
+            qps = rng.integers(cu_qp[0], cu_qp[1] + 1, (cols * nrows, tme.cus_per_ctu())).astype(np.int8)
+            if area_qp:
+                areas = rng.integers(cu_qp[0], cu_qp[1] + 1, (cols * nrows, 5)).astype(np.int8)
+            tme.set_cu_qp(qps, lam_by_qp, areas)
+        if temporal:
+            cands = np.zeros((cols * nrows, api.MAX_NUM_PUS_PER_CTU, 2), api.TME_TEMPORAL)
+            shape = cands.shape
+            cands["valid"] = rng.integers(0, 2, shape)
+            cands["mv"] = rng.integers(-40, 41, shape + (2,))
+            cands["colPoc"] = rng.integers(cur - 2, cur + 3, shape)
+            cands["colRefPoc"] = cands["colPoc"] - rng.integers(1, 4, shape) * rng.choice([-1, 1], shape)
+            tme.set_temporal(cands)
         try:
             got = tme.new_table()
             refs = [(f, f, True, None, lowres[r]) for r, f in enumerate(ref_frames)]
@@ -60,6 +80,8 @@ def _run(W, H, depth, rows, method=api.STAR_SEARCH, merange=57, subpel=3, amp=Fa
             got2 = None
             if second_picture:
                 # the next P picture predicted from this one: its reference is a P slice with a table of its own
+                tme.set_cu_qp(None, None)
+                tme.set_temporal(None)
                 got2 = tme.new_table()
                 tme.estimate_rows(cur + 1, cur + 1, [(cur, cur, False, got, None)], rows[0], rows[1], got2)
         finally:
@@ -68,11 +90,18 @@ def _run(W, H, depth, rows, method=api.STAR_SEARCH, merange=57, subpel=3, amp=Fa
     if method == api.SEA_SEARCH:
         for m in mes:
             m.build_integral()
+    qp_sets = None
+    if cu_qp:
+        qp_sets = {}
+        for qp in range(cu_qp[0], cu_qp[1] + 1):
+            t, c = orc.bitcost_table(depth, float(lam_by_qp[qp]))
+            qp_sets[qp] = ([orc.FullResME(depth, t, c, pads[cur], pads[f], mx, my) for f in ref_frames + l1_frames], (t, c),
+                           float(lam_by_qp[qp]))
     ser = SerialTME(mes, ref_frames + l1_frames, cur, W, H, bitsizes, (table, centre), lam, method=method, merange=merange,
                     subpel=subpel, amp=amp, rect=rect, ctu=ctu, min_cu=min_cu, lowres_mvs=lowres, median_mv=med,
-                    num_l0=num_refs)
+                    num_l0=num_refs, cu_qp=qps, area_qp=areas, qp_sets=qp_sets, temporal=cands)
     want = ser.run_rows(rows[0], rows[1])
-    for m in mes:
+    for m in mes + [m for s in (qp_sets or {}).values() for m in s[0]]:
         m.close()
     lo, hi = rows[0] * cols, rows[1] * cols
     for name in ME_FIELDS:
@@ -167,3 +196,23 @@ def test_generator_rejects_what_it_does_not_cover():
                 tme.estimate_rows(1, 1, [(0, 0, True, None, None)], 3, 5, out)
         finally:
             tme.close()
+
+
+def test_per_cu_qp_searches_under_each_cus_lambda():
+    """Delta QP on: every CU of every depth has a QP of its own (six of them in the picture), the area searches take
+    the CTU's and the quadrants'; P and B pictures, with AMP; then area QPs that no CU has (pps->maxCuDQPDepth 0)."""
+    got, _ = _run(704, 400, 8, (0, 7), cu_qp=(24, 29), amp=True, seed=11)
+    plain, _ = _run(704, 400, 8, (0, 7), amp=True, seed=11, lam=float(np.round(2.0 ** ((26 - 12) / 6.0), 4)))
+    assert (got["cost"] != plain["cost"]).mean() > 0.3          # the QPs matter to the result
+    _run(704, 400, 10, (2, 5), cu_qp=(30, 35), num_l1=1, num_refs=2, seed=12)
+    _run(704, 400, 8, (0, 7), cu_qp=(20, 23), area_qp=True, seed=13, ctu=32)
+
+
+def test_temporal_candidate_joins_the_predictors():
+    """sps->bTemporalMVPEnabled: the co-located vector, scaled by the POC distances, fills the second AMVP slot when the
+    spatial neighbours leave one free, and joins the motion candidates; P and B pictures, also together with per-CU QPs."""
+    got, _ = _run(704, 400, 8, (0, 7), temporal=True, seed=14)
+    plain, _ = _run(704, 400, 8, (0, 7), seed=14)
+    assert (got["mvp"] != plain["mvp"]).any(axis=(2, 3)).mean() > 0.01   # of all table positions, most of them unused
+    _run(704, 400, 8, (1, 4), temporal=True, num_l1=1, num_refs=2, seed=15, amp=True)
+    _run(704, 400, 10, (0, 3), temporal=True, cu_qp=(26, 28), seed=16, ctu=32, second_picture=True)

@@ -58,11 +58,16 @@ def scale_mv_by_poc_dist(mv, cur_poc, cur_ref_poc, col_poc, col_ref_poc):
 class SerialTME:
     def __init__(self, me_per_ref, ref_pocs, poc, pic_w, pic_h, bitsizes, cost_table, lam, method=3, merange=57,
                  subpel=3, amp=False, rect=True, ctu=64, min_cu=8, bframes=4, lowres_mvs=None, ref_is_intra=None,
-                 ref_tables=None, median_mv=None, ref_lag_pixels=None, num_l0=None):
+                 ref_tables=None, median_mv=None, ref_lag_pixels=None, num_l0=None, cu_qp=None, area_qp=None,
+                 qp_sets=None, temporal=None):
         """me_per_ref: one oracle FullResME (source PU in the current picture, searches in that reference) per
         reference, list 0's first (num_l0 of them; all of them for a P slice), then list 1's; bitsizes / cost_table:
-        (array, centre) pairs; lowres_mvs[r]: (blocks, 2) or None."""
+        (array, centre) pairs; lowres_mvs[r]: (blocks, 2) or None.
+        Delta QP: cu_qp[addr] = the QPs of the CTU's CUs (depth 0, then depth 1 in raster order, ...), area_qp[addr] =
+        the five QPs of the area searches (default: the depth-0 and depth-1 CUs'), qp_sets[qp] = (me_per_ref,
+        cost_table, lam) under that QP's lambda.  temporal: (CTUs, positions, 2) records of the temporal candidate."""
         self.me, self.ref_pocs, self.poc = me_per_ref, list(ref_pocs), poc
+        self.cu_qp, self.area_qp, self.qp_sets, self.temporal = cu_qp, area_qp, qp_sets, temporal
         self.num_l0 = len(self.ref_pocs) if num_l0 is None else num_l0
         self.is_p = self.num_l0 == len(self.ref_pocs)
         self.list_pocs = [self.ref_pocs[:self.num_l0], self.ref_pocs[self.num_l0:]]
@@ -121,8 +126,20 @@ class SerialTME:
         mx = (mx[0], max(min(mx[1], self.ref_lag), mn[1]))
         return mn, mx
 
-    def get_pmv(self, neighbours, pic_list, ref_idx):
-        """CUData::getPMV, temporal candidate unavailable (cudata.cpp:1845-1905, 1980-1983), with getDirectPMV /
+    def set_lambda_from_qp(self, qp):
+        """Search::setLambdaFromQP (search.cpp:214-224): the MV-cost table and the fixed-point lambda of that QP"""
+        self.me, (self.ct, self.ct0), lam = self.qp_sets[int(qp)]
+        self.lambda_fix8 = int(np.floor(256.0 * lam))
+
+    def cu_index(self, rel_x, rel_y, cu_size):
+        at, size = 0, self.ctu
+        while size > cu_size:
+            at += (self.ctu // size) ** 2
+            size //= 2
+        return at + (rel_y // cu_size) * (self.ctu // cu_size) + rel_x // cu_size
+
+    def get_pmv(self, neighbours, pic_list, ref_idx, temporal=None):
+        """CUData::getPMV (cudata.cpp:1845-1905, 1959-1983), with getDirectPMV /
         getIndirectPMV (:2110-2156): the asked list of the neighbour first, then the other one;
         neighbours[dir] = ((mv of list 0, mv of list 1), (refIdx of list 0, refIdx of list 1)) or None"""
         cur_ref_poc = self.list_pocs[pic_list][ref_idx]
@@ -162,6 +179,11 @@ class SerialTME:
                 mvc.append(indirect[d])
         if len(amvp) == 2 and amvp[0] == amvp[1]:
             amvp.pop()
+        if temporal is not None and temporal["valid"] and len(amvp) < 2:
+            t = scale_mv_by_poc_dist((int(temporal["mv"][0]), int(temporal["mv"][1])), self.poc, cur_ref_poc,
+                                     int(temporal["colPoc"]), int(temporal["colRefPoc"]))
+            amvp.append(t)
+            mvc.append(t)
         while len(amvp) < 2:
             amvp.append((0, 0))
         return amvp, mvc
@@ -216,7 +238,8 @@ class SerialTME:
                                                (int(e["ref"][0]), int(e["ref"][1]))))
                         else:
                             neighbours.append(None)
-                    cand, mvc = self.get_pmv(neighbours, pic_list, ref_idx)
+                    cand, mvc = self.get_pmv(neighbours, pic_list, ref_idx,
+                                             None if self.temporal is None else self.temporal[addr][pos][pic_list])
                     if mvc:
                         amvp = cand
                         if amvp[0] != amvp[1]:              # Search::selectMVP (search.cpp:2347-2383)
@@ -336,6 +359,8 @@ class SerialTME:
             for sub in range(4):
                 self.compute_mv_for_pus(addr, ctu_x, ctu_y, rel_x + (sub & 1) * hs, rel_y + (sub >> 1) * hs, hs)
         area_id = 0 if cu_size == ctu else (rel_x >= ctu // 2) + 2 * (rel_y >= ctu // 2) + 1
+        if self.cu_qp is not None:
+            self.set_lambda_from_qp(self.cu_qp[addr][self.cu_index(rel_x, rel_y, cu_size)])
         for w, h, part, is_amp in PU_LOOKUP:
             if w > cu_size or h > cu_size or (w != cu_size and h != cu_size):
                 continue
@@ -363,10 +388,16 @@ class SerialTME:
         ctu_x, ctu_y = (addr % self.cols) * ctu, (addr // self.cols) * ctu
         n = len(self.ref_pocs)
         self.area_best = [[(0, 0)] * n for _ in range(5)]
+        area_qp = None
+        if self.cu_qp is not None:
+            area_qp = self.area_qp[addr] if self.area_qp is not None else self.cu_qp[addr][:5]
+            self.set_lambda_from_qp(area_qp[0])
         self.pu_motion_estimation(addr, (ctu_x, ctu_y, ctu), SIZE_2Nx2N, 0, 0, 0, True)
         if ctu != self.min_cu:
             for sub in range(4):
                 hs = ctu // 2
+                if area_qp is not None:
+                    self.set_lambda_from_qp(area_qp[sub + 1])
                 self.pu_motion_estimation(addr, (ctu_x + (sub & 1) * hs, ctu_y + (sub >> 1) * hs, hs), SIZE_2Nx2N,
                                           sub + 1, 0, 0, True)
         if self.median_mv is not None:

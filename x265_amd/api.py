@@ -22,7 +22,7 @@ EXPORTS = (
     "x265gpu_open", "x265gpu_close", "x265gpu_get_geometry", "x265gpu_last_error", "x265gpu_sync",
     "x265gpu_set_mvcost", "x265gpu_lowres_init", "x265gpu_lowres_init_batch", "x265gpu_lowres_set_aq",
     "x265gpu_intra_estimate", "x265gpu_estimate", "x265gpu_estimate_costs", "x265gpu_estimate_sums_device", "x265gpu_weight_cost", "x265gpu_weight_costs", "x265gpu_weight_cost_static", "x265gpu_weight_planes",
-    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_bipred_satd", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_aq_frames", "x265gpu_aq_frames_begin", "x265gpu_aq_frames_finish", "x265gpu_aq_memo_stats", "x265gpu_aq_motion_frame", "x265gpu_get_frame_costs", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
+    "x265gpu_get_plane", "x265gpu_get_intra", "x265gpu_get_mvs", "x265gpu_get_hme_mvs", "x265gpu_get_costs", "x265gpu_me_set_mvcost", "x265gpu_me_set_mvcost_tables", "x265gpu_pu_motion_estimate", "x265gpu_get_full_plane", "x265gpu_block_compare", "x265gpu_bipred_satd", "x265gpu_aq_energy", "x265gpu_aq_frame", "x265gpu_aq_frames", "x265gpu_aq_frames_begin", "x265gpu_aq_frames_finish", "x265gpu_aq_memo_stats", "x265gpu_aq_motion_frame", "x265gpu_get_frame_costs", "x265gpu_cutree_finish_qg8", "x265gpu_cutree_finish_hevc", "x265gpu_host_alloc", "x265gpu_host_free", "x265gpu_interp_luma",
     "x265gpu_cutree_clear", "x265gpu_cutree_swap", "x265gpu_cutree_propagate", "x265gpu_cutree_get_propagate_cost",
     "x265gpu_cutree_finish", "x265gpu_hist_stats", "x265gpu_mcstf_motion_search",
     "x265gpu_profile_enable", "x265gpu_profile_read",
@@ -158,6 +158,7 @@ def load_library(path=None):
     L.x265gpu_get_hme_mvs.argtypes = [vp, i32, i32, i32, vp, vp]
     L.x265gpu_get_costs.argtypes = [vp, i32, i32, i32, vp, vp, C.POINTER(FrameCost)]
     L.x265gpu_me_set_mvcost.argtypes = [vp, vp, i32]
+    L.x265gpu_me_set_mvcost_tables.argtypes = [vp, i32, vp, i32]
     L.x265gpu_pu_motion_estimate.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
     L.x265gpu_get_full_plane.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.x265gpu_block_compare.argtypes = [vp, i32, i32, i32, vp, vp]
@@ -379,14 +380,22 @@ class Context:
         max_mvd = min(centre, len(t) - 1 - centre)
         self._chk(self.L.x265gpu_me_set_mvcost(self.h, C.c_void_p(t.ctypes.data + 2 * centre), max_mvd))
 
+    def me_set_mvcost_tables(self, tables, centre):
+        """Several MV-cost tables (one per QP in use); jobs name theirs by index."""
+        ts = [np.ascontiguousarray(t, np.uint16) for t in tables]
+        max_mvd = min(min(centre, len(t) - 1 - centre) for t in ts)
+        ptrs = (C.c_void_p * len(ts))(*[t.ctypes.data + 2 * centre for t in ts])
+        self._chk(self.L.x265gpu_me_set_mvcost_tables(self.h, len(ts), ptrs, max_mvd))
+
     def pu_motion_estimate(self, slot_fenc, slot_ref, method, merange, subpel, jobs, vert_restriction=False):
-        """jobs: iterable of (x, y, w, h, (mvpx, mvpy), (minx, miny), (maxx, maxy), [(cx, cy), ...]);
+        """jobs: iterable of (x, y, w, h, (mvpx, mvpy), (minx, miny), (maxx, maxy), [(cx, cy), ...][, cost table]);
         returns [((mvx, mvy), cost), ...] in job order."""
         jobs = list(jobs)
         arr = (PuJob * len(jobs))()
-        for k, (x, y, w, h, mvp, mvmin, mvmax, mvc) in enumerate(jobs):
+        for k, job in enumerate(jobs):
+            x, y, w, h, mvp, mvmin, mvmax, mvc = job[:8]
             j = arr[k]
-            j.flags = 1 if vert_restriction else 0
+            j.flags = (1 if vert_restriction else 0) | ((job[8] if len(job) > 8 else 0) << 8)
             j.x, j.y, j.w, j.h = x, y, w, h
             j.mvpX, j.mvpY = mvp
             j.mvminX, j.mvminY = mvmin
@@ -615,6 +624,7 @@ HOST_EXPORTS = (
     "xgh_lookahead_intra_mbs", "xgh_lookahead_slot", "xgh_lookahead_qp_offsets", "xgh_lookahead_inv_qscale",
     "xgh_lookahead_planned_satd", "xgh_lookahead_recalc_row_satds", "xgh_lookahead_decide_calls", "xgh_lookahead_presearch_hits", "xgh_lookahead_precost_hits", "xgh_lookahead_seconds",
     "xgh_tme_create", "xgh_tme_destroy", "xgh_tme_unsupported", "xgh_tme_estimate_rows", "xgh_tme_estimate_rows_b", "xgh_tme_seconds", "xgh_tme_counts",
+    "xgh_tme_set_cu_qp", "xgh_tme_cus_per_ctu", "xgh_tme_set_temporal",
 )
 
 
@@ -731,6 +741,10 @@ def load_host_library():
     H.xgh_tme_estimate_rows_b.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, vp, vp]
     H.xgh_tme_counts.argtypes = [vp, C.POINTER(i64 * 6)]
     H.xgh_tme_counts.restype = None
+    H.xgh_tme_set_cu_qp.argtypes = [vp, vp, vp, vp, i32]
+    H.xgh_tme_cus_per_ctu.argtypes = [vp]
+    H.xgh_tme_set_temporal.argtypes = [vp, vp]
+    H.xgh_tme_set_temporal.restype = None
     _libs[HOST_LIB_PATH] = H
     return H
 
@@ -979,6 +993,8 @@ MAX_NUM_PUS_PER_CTU = 593
 # MEData (source/encoder/threadedme.h:122-130)
 ME_DATA = np.dtype([("mv", np.int32, (2, 2)), ("mvp", np.int32, (2, 2)), ("mvCost", np.uint32, 2),
                     ("ref", np.int32, 2), ("bits", np.int32), ("cost", np.uint32)])
+# TmeTemporal (x265_amd/host/threaded_me_host.h): the temporal AMVP candidate of one PU and list
+TME_TEMPORAL = np.dtype([("valid", np.int32), ("mv", np.int32, 2), ("colPoc", np.int32), ("colRefPoc", np.int32)])
 
 
 class TmeParam(C.Structure):
@@ -1009,6 +1025,7 @@ class ThreadedME:
         p.refLagPixels = ctx.cfg.sourceHeight if ref_lag_pixels is None else ref_lag_pixels
         p.lambda_ = lam
         self.param = p
+        self._qp = self._temporal = None
         self.h = self.H.xgh_tme_create(ctx.h, C.byref(p))
         if not self.h:
             raise X265GpuError("xgh_tme_create failed")
@@ -1032,6 +1049,40 @@ class ThreadedME:
         s = (C.c_double * 3)()
         self.H.xgh_tme_seconds(self.h, C.byref(s))
         return dict(zip(("host", "device", "total"), list(s)))
+
+    def cus_per_ctu(self):
+        return self.H.xgh_tme_cus_per_ctu(self.h)
+
+    def set_cu_qp(self, qp, lambda_by_qp, area_qp=None):
+        """qp: (CTUs of the picture, cus_per_ctu()) QPs, depth 0 first, raster order inside a depth, or None to go back
+        to the one lambda; area_qp: (CTUs, 5) QPs of the area searches or None (the depth-0 and depth-1 CUs');
+        lambda_by_qp: lambda per QP (x265_lambda_tab)."""
+        if qp is None:
+            self._qp = None
+            rc = self.H.xgh_tme_set_cu_qp(self.h, None, None, None, 0)
+        else:
+            c = self.counts()
+            qp = np.ascontiguousarray(qp, np.int8)
+            assert qp.shape == (c["cols"] * c["rows"], self.cus_per_ctu())
+            lam = np.ascontiguousarray(lambda_by_qp, np.float64)
+            if area_qp is not None:
+                area_qp = np.ascontiguousarray(area_qp, np.int8)
+                assert area_qp.shape == (c["cols"] * c["rows"], 5)
+            self._qp = (qp, area_qp, lam)
+            rc = self.H.xgh_tme_set_cu_qp(self.h, qp.ctypes.data, None if area_qp is None else area_qp.ctypes.data,
+                                          lam.ctypes.data, len(lam))
+        if rc:
+            raise X265GpuError("xgh_tme_set_cu_qp failed with status %d" % rc)
+
+    def set_temporal(self, candidates):
+        """candidates: (CTUs of the picture, MAX_NUM_PUS_PER_CTU, 2) TME_TEMPORAL records (one per result-table position
+        and list), or None: no temporal candidate"""
+        if candidates is not None:
+            c = self.counts()
+            assert candidates.dtype == TME_TEMPORAL and candidates.flags.c_contiguous
+            assert candidates.shape == (c["cols"] * c["rows"], MAX_NUM_PUS_PER_CTU, 2)
+        self._temporal = candidates
+        self.H.xgh_tme_set_temporal(self.h, None if candidates is None else candidates.ctypes.data)
 
     def new_table(self):
         c = self.counts()

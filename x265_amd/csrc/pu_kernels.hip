@@ -1218,8 +1218,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XG_PU_
     c.maxy = job.maxy;
     c.mvpx = job.mvpx;
     c.mvpy = job.mvpy;
-    c.cx = as_global<uint16_t>(costTab) - job.mvpx;
-    c.cy = as_global<uint16_t>(costTab) - job.mvpy;
+    // the job's own MV-cost table (one per QP in use, 2 * maxMvd + 2 entries apart)
+    const XG_GLOBAL uint16_t* table = as_global<uint16_t>(costTab) + (size_t)((unsigned)job.flags >> 8) * (2 * (size_t)maxMvd + 2);
+    c.cx = table - job.mvpx;
+    c.cy = table - job.mvpy;
     c.lo = -maxMvd;
     c.hi = maxMvd;
     c.depth = f.depth;

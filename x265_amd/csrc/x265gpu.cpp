@@ -104,6 +104,7 @@ struct x265gpu_ctx
     uint16_t* meCostBuf = nullptr;    // BitCost table of the full-resolution searches
     uint16_t* meCostCentre = nullptr;
     int meMaxMvd = 0;
+    int meCostTables = 0;             // tables resident (one per QP in use), 2 * meMaxMvd + 2 entries apart
     char* puBuf = nullptr;            // device staging: jobs, then results
     size_t puBufSize = 0;
     uint32_t* seaBuf = nullptr;       // successive elimination: 12 block-sum planes of one reference + one scratch plane
@@ -1635,24 +1636,36 @@ int ensure_pu_buf(x265gpu_ctx* ctx, size_t bytes)
 }
 } // namespace
 
-int x265gpu_me_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd)
+int x265gpu_me_set_mvcost_tables(x265gpu_ctx* ctx, int32_t numTables, const uint16_t* const* centres, int32_t maxMvd)
 {
     DeviceScope deviceScope(ctx);
-    if (!ctx || !centre || maxMvd < 1024)
+    if (!ctx || !centres || numTables < 1 || numTables > X265GPU_PU_MAX_COST_TABLES || maxMvd < 1024)
         return X265GPU_ERR_ARG;
+    for (int k = 0; k < numTables; k++)
+        if (!centres[k])
+            return X265GPU_ERR_ARG;
     if (ctx->meCostBuf)
     {
         HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipFree(ctx->meCostBuf));
         ctx->meCostBuf = nullptr;
     }
-    const size_t count = 2 * (size_t)maxMvd + 1;
-    HIPCHK(hipMalloc((void**)&ctx->meCostBuf, count * sizeof(uint16_t)));
-    HIPCHK(hipMemcpyAsync(ctx->meCostBuf, centre - maxMvd, count * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    // the tables behind each other, each 2 * maxMvd + 2 entries apart (an even count keeps them dword aligned)
+    const size_t count = 2 * (size_t)maxMvd + 1, stride = count + 1;
+    HIPCHK(hipMalloc((void**)&ctx->meCostBuf, numTables * stride * sizeof(uint16_t)));
+    for (int k = 0; k < numTables; k++)
+        HIPCHK(hipMemcpyAsync(ctx->meCostBuf + k * stride, centres[k] - maxMvd, count * sizeof(uint16_t), hipMemcpyHostToDevice,
+                              ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->meCostCentre = ctx->meCostBuf + maxMvd;
     ctx->meMaxMvd = maxMvd;
+    ctx->meCostTables = numTables;
     return X265GPU_OK;
+}
+
+int x265gpu_me_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd)
+{
+    return x265gpu_me_set_mvcost_tables(ctx, 1, &centre, maxMvd);
 }
 
 int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotRef, int32_t searchMethod, int32_t merange,
@@ -1702,7 +1715,7 @@ int x265gpu_pu_motion_estimate(x265gpu_ctx* ctx, int32_t slotFenc, int32_t slotR
         // the PU inside the picture, shapes the tiling handles, vectors that stay inside the padded plane
         if (j.w < 4 || j.h < 4 || j.w > 64 || j.h > 64 || (j.w & 3) || (j.h & 3) || j.x < 0 || j.y < 0 ||
             j.x + j.w > ctx->fullW || j.y + j.h > ctx->fullH || j.numCandidates < 0 || j.numCandidates > 12 ||
-            j.mvminX > j.mvmaxX || j.mvminY > j.mvmaxY || (j.flags & ~X265GPU_PU_VERT_RESTRICTION) ||
+            j.mvminX > j.mvmaxX || j.mvminY > j.mvmaxY || (j.flags & 0xfe) || ((unsigned)j.flags >> 8) >= (unsigned)ctx->meCostTables ||
             j.x + j.mvminX < -ctx->fullMarginX + 8 || j.x + j.w + j.mvmaxX > ctx->fullW + ctx->fullMarginX - 16 ||
             j.y + j.mvminY < -ctx->fullMarginY + 8 || j.y + j.h + j.mvmaxY > ctx->fullH + ctx->fullMarginY - 8)
         {

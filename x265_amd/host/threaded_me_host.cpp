@@ -96,9 +96,10 @@ bool getIndirectPMV(const SliceRefs& s, MV& out, const Neighbour& nb, int picLis
     return false;
 }
 
-// CUData::getPMV without a temporal candidate (source/common/cudata.cpp:1845-1905, 1980-1983): the two AMVP
-// candidates and the wider list of motion candidates; returns the size of that list
-int getPMV(const SliceRefs& s, const Neighbour* nb, int picList, int refIdx, MV amvpCand[2], MV* pmv)
+// CUData::getPMV (source/common/cudata.cpp:1845-1905, 1959-1983): the two AMVP candidates and the wider list of
+// motion candidates; returns the size of that list.  `temporal`: neighbours[MD_COLLOCATED] for this list, or NULL
+int getPMV(const SliceRefs& s, const Neighbour* nb, int picList, int refIdx, MV amvpCand[2], MV* pmv,
+           const TmeTemporal* temporal)
 {
     MV direct[MD_ABOVE_LEFT + 1], indirect[MD_ABOVE_LEFT + 1];
     bool validDirect[MD_ABOVE_LEFT + 1], validIndirect[MD_ABOVE_LEFT + 1];
@@ -142,6 +143,9 @@ int getPMV(const SliceRefs& s, const Neighbour* nb, int picList, int refIdx, MV 
     }
     if (num == 2)
         num -= amvpCand[0] == amvpCand[1];
+    if (temporal && temporal->valid && num < 2)
+        pmv[numMvc++] = amvpCand[num++] =
+            scaleMvByPOCDist(temporal->mv, s.poc, s.refPOC[picList][refIdx], temporal->colPoc, temporal->colRefPoc);
     while (num < 2)
         amvpCand[num].x = amvpCand[num].y = 0, num++;
     return numMvc;
@@ -177,8 +181,9 @@ inline int getTUBits(int idx, int numIdx) { return idx + (idx < numIdx - 1); }  
 }  // namespace
 
 ThreadedME::ThreadedME(x265gpu_ctx* ctx, const TmeParam& p)
-    : m_ctx(ctx), m_p(p), m_unsupported(NULL), m_numCuInWidth(0), m_numCuInHeight(0), m_numLevels(0), m_lambdaFix8(0),
-      m_searches(0), m_deviceCalls(0), m_jobs(NULL), m_results(NULL), m_jobCap(0), m_pool(NULL)
+    : m_ctx(ctx), m_p(p), m_unsupported(NULL), m_numCuInWidth(0), m_numCuInHeight(0), m_numLevels(0), m_cuQp(NULL), m_areaQp(NULL),
+      m_temporal(NULL), m_setsOnDevice(0), m_searches(0), m_deviceCalls(0), m_jobs(NULL), m_results(NULL), m_jobCap(0),
+      m_pool(NULL)
 {
     m_seconds[0] = m_seconds[1] = m_seconds[2] = 0;
     const int ctu = p.maxCUSize, mn = p.minCUSize;
@@ -198,20 +203,80 @@ ThreadedME::ThreadedME(x265gpu_ctx* ctx, const TmeParam& p)
     m_numCuInHeight = (p.picHeight + ctu - 1) / ctu;
     // BitCost::s_bitsizes and the lambda-scaled table of BitCost::setQP (source/encoder/bitcost.cpp:31-101)
     m_bitsizes.resize(4 * BC_MAX_MV + 1);
-    m_costTable.resize(4 * BC_MAX_MV + 1);
     float* bs = m_bitsizes.data() + 2 * BC_MAX_MV;
-    uint16_t* ct = m_costTable.data() + 2 * BC_MAX_MV;
     const float twoOverLn2 = 2.0f / logf(2.0f);
     bs[0] = 0.718f;
     for (int i = 1; i <= 2 * BC_MAX_MV; i++)
         bs[i] = bs[-i] = logf((float)(i + 1)) * twoOverLn2 + 1.718f;
+    addCostSet(p.lambda);
+    buildTasks();
+}
+
+// the lambda-scaled table of BitCost::setQP (source/encoder/bitcost.cpp:31-60) and RDCost::setLambda's fixed-point lambda
+// (source/encoder/rdcost.h:88-92) for one more lambda
+void ThreadedME::addCostSet(double lambda)
+{
+    m_costSets.emplace_back();
+    CostSet& cs = m_costSets.back();
+    cs.table.resize(4 * BC_MAX_MV + 1);
+    const float* bs = m_bitsizes.data() + 2 * BC_MAX_MV;
+    uint16_t* ct = cs.table.data() + 2 * BC_MAX_MV;
     for (int i = 0; i <= 2 * BC_MAX_MV; i++)
     {
-        const double scaled = bs[i] * p.lambda + 0.5f;
+        const double scaled = bs[i] * lambda + 0.5f;
         ct[i] = ct[-i] = (uint16_t)(scaled < 32767.0 ? scaled : 32767.0);
     }
-    m_lambdaFix8 = (uint64_t)floor(256.0 * p.lambda);       // RDCost::setLambda (source/encoder/rdcost.h:88-92)
-    buildTasks();
+    cs.lambdaFix8 = (uint64_t)floor(256.0 * lambda);
+}
+
+int ThreadedME::setCuQp(const int8_t* qp, const int8_t* areaQp, const double* lambdaByQp, int numQp)
+{
+    if (qp && (!lambdaByQp || numQp < 1 || numQp > 128))
+        return X265GPU_ERR_ARG;
+    m_cuQp = qp;
+    m_areaQp = qp ? areaQp : NULL;
+    if (qp)
+    {
+        m_lambdaByQp.assign(lambdaByQp, lambdaByQp + numQp);
+        if (m_setOfQp.size() != (size_t)numQp)
+        {
+            // another table of lambdas: start over with the sets (set 0, TmeParam's lambda, stays)
+            m_costSets.resize(1);
+            m_setsOnDevice = 0;
+            m_setOfQp.assign((size_t)numQp, -1);
+        }
+    }
+    return X265GPU_OK;
+}
+
+int ThreadedME::cusPerCtu() const
+{
+    int n = 0;
+    for (int size = m_p.maxCUSize; size >= m_p.minCUSize; size >>= 1)
+        n += (m_p.maxCUSize / size) * (m_p.maxCUSize / size);
+    return n;
+}
+
+int ThreadedME::cuIndex(const PuTask& t) const
+{
+    int at = 0;
+    for (int size = m_p.maxCUSize; size > t.cuSize; size >>= 1)
+        at += (m_p.maxCUSize / size) * (m_p.maxCUSize / size);
+    return at + (t.cuY / t.cuSize) * (m_p.maxCUSize / t.cuSize) + t.cuX / t.cuSize;
+}
+
+int ThreadedME::costSetOfQp(int qp)
+{
+    if (qp < 0 || (size_t)qp >= m_setOfQp.size() || !(m_lambdaByQp[qp] > 0))
+        return -1;
+    if (m_setOfQp[qp] < 0)
+    {
+        if (m_costSets.size() >= (size_t)X265GPU_PU_MAX_COST_TABLES)
+            return -1;
+        addCostSet(m_lambdaByQp[qp]);
+        m_setOfQp[qp] = (int)m_costSets.size() - 1;
+    }
+    return m_setOfQp[qp];
 }
 
 // ThreadedME::initPuStartIdx (source/encoder/threadedme.cpp:84-106), then the call order of
@@ -314,9 +379,9 @@ uint32_t ThreadedME::bitcost(MV mv, MV mvp) const
     return (uint32_t)(bs[mv.x - mvp.x] + bs[mv.y - mvp.y] + 0.5f);
 }
 
-uint32_t ThreadedME::mvcost(MV mv, MV mvp) const
+uint32_t ThreadedME::mvcost(MV mv, MV mvp, int set) const
 {
-    const uint16_t* ct = m_costTable.data() + 2 * BC_MAX_MV;
+    const uint16_t* ct = m_costSets[set].table.data() + 2 * BC_MAX_MV;
     return (uint16_t)(ct[mv.x - mvp.x] + ct[mv.y - mvp.y]);
 }
 
@@ -460,6 +525,7 @@ struct Item
     int ctuAddr, ctuLocal, task, puIdx;
     int x, y, w, h;              // PU in the picture
     int cuPelX, cuPelY;
+    int set;                     // its CU's lambda: cost set and MV-cost table on the device
 };
 
 // what one reference's pass leaves for the closing bookkeeping
@@ -488,6 +554,7 @@ inline x265gpu_pu_job makeJob(const Item& it, MV mvp, MV mvmin, MV mvmax, int nu
 {
     x265gpu_pu_job j;
     memset(&j, 0, sizeof(j));
+    j.flags = X265GPU_PU_COST_TABLE(it.set);
     j.x = it.x;
     j.y = it.y;
     j.w = it.w;
@@ -541,10 +608,31 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
     const int ctu = m_p.maxCUSize;
     const int numCtus = (rowEnd - rowBegin) * m_numCuInWidth, firstCtu = rowBegin * m_numCuInWidth;
     const int lowresBlocksInRow = ((m_p.picWidth / 2) + 7) >> 3;       // Lowres::maxBlocksInRow
-    int rc = x265gpu_me_set_mvcost(m_ctx, m_costTable.data() + 2 * BC_MAX_MV, 2 * BC_MAX_MV);
-    if (rc)
-        return rc;
-    m_deviceCalls++;
+    // the lambdas of these rows' CUs: one cost set (MV-cost table, fixed-point lambda) each; their tables go to the
+    // device together whenever a new one has appeared
+    const int perCtuQp = cusPerCtu();
+    if (m_cuQp)
+        for (int c = 0; c < numCtus; c++)
+            for (int k = 0; k < perCtuQp; k++)
+                if (costSetOfQp(m_cuQp[(size_t)(firstCtu + c) * perCtuQp + k]) < 0)
+                    return X265GPU_ERR_ARG;
+    if (m_areaQp)
+        for (int k = firstCtu * 5; k < (firstCtu + numCtus) * 5; k++)
+            if (costSetOfQp(m_areaQp[k]) < 0)
+                return X265GPU_ERR_ARG;
+    int rc = X265GPU_OK;
+    if (m_setsOnDevice != m_costSets.size())
+    {
+        std::vector<const uint16_t*> centres;
+        for (const CostSet& cs : m_costSets)
+            centres.push_back(cs.table.data() + 2 * BC_MAX_MV);
+        rc = x265gpu_me_set_mvcost_tables(m_ctx, (int32_t)centres.size(), centres.data(), 2 * BC_MAX_MV);
+        if (rc)
+            return rc;
+        m_setsOnDevice = m_costSets.size();
+        m_deviceCalls++;
+    }
+    auto setOf = [&](int ctuAddr, int cu) { return m_cuQp ? m_setOfQp[m_cuQp[(size_t)ctuAddr * perCtuQp + cu]] : 0; };
 
     for (int c = 0; c < numCtus; c++)
         for (int k = 0; k < MAX_NUM_PUS_PER_CTU; k++)
@@ -587,6 +675,7 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
             for (int a = 0; a < numAreas; a++)
             {
                 Item it;
+                it.set = m_areaQp ? m_setOfQp[m_areaQp[(size_t)addr * 5 + a]] : setOf(addr, a);
                 it.w = it.h = a ? ctu / 2 : ctu;
                 it.x = ctuX + (a ? ((a - 1) & 1) * (ctu / 2) : 0);
                 it.y = ctuY + (a ? ((a - 1) >> 1) * (ctu / 2) : 0);
@@ -660,7 +749,8 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
                 const int c = (int)(i / perCtu), ti = parts[i % perCtu].first, k = parts[i % perCtu].second;
                 const int addr = firstCtu + c, ctuX = (addr % m_numCuInWidth) * ctu, ctuY = (addr / m_numCuInWidth) * ctu;
                 const PuTask& t = m_tasks[ti];
-                items[i] = Item{ addr, c, ti, k, ctuX + t.pu[k].x, ctuY + t.pu[k].y, t.pu[k].w, t.pu[k].h, ctuX + t.cuX, ctuY + t.cuY };
+                items[i] = Item{ addr, c, ti, k, ctuX + t.pu[k].x, ctuY + t.pu[k].y, t.pu[k].w, t.pu[k].h, ctuX + t.cuX, ctuY + t.cuY,
+                                 setOf(addr, cuIndex(t)) };
             }
         });
         if (raw.size() < numItems * numRefs)
@@ -700,7 +790,10 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
                         }
                     }
                     MV cand[2];
-                    ps.numMvc = getPMV(slice, nb, list, refIdx, cand, ps.mvc);
+                    const TmeTemporal* temporal =
+                        m_temporal ? &m_temporal[((size_t)it.ctuAddr * MAX_NUM_PUS_PER_CTU + t.finalIdx + it.puIdx * t.puOffset) * 2 + list]
+                                   : NULL;
+                    ps.numMvc = getPMV(slice, nb, list, refIdx, cand, ps.mvc, temporal);
                     if (ps.numMvc > 0)
                     {
                         ps.amvp[0] = cand[0];
@@ -903,15 +996,15 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
                         const RefRaw& rr = raw[i * numRefs + r];
                         uint32_t bits = listSelBits[list] + MVP_IDX_BITS + (uint32_t)getTUBits(refIdx, slice.numRefIdx[list]);
                         bits += bitcost(rr.outmv, rr.meMvp);
-                        const uint32_t mvCost = mvcost(rr.outmv, rr.meMvp);
-                        uint32_t cost = ((uint32_t)rr.satdCost - mvCost) + getCost(bits);
+                        const uint32_t mvCost = mvcost(rr.outmv, rr.meMvp, it.set);
+                        uint32_t cost = ((uint32_t)rr.satdCost - mvCost) + getCost(bits, it.set);
                         if (rr.bLowresMVP)
                         {
                             // Search::updateMVP (search.cpp:4961-4967)
                             const int diffBits = (int)bitcost(rr.outmv, rr.mvp) - (int)bitcost(rr.outmv, rr.mvpLowres);
                             const uint32_t origBits = bits;
                             bits = origBits + diffBits;
-                            cost = (cost - getCost(origBits)) + getCost(bits);
+                            cost = (cost - getCost(origBits, it.set)) + getCost(bits, it.set);
                         }
                         // Search::checkBestMVP (search.cpp:4947-4958)
                         int mvpIdx = rr.mvpIdx;
@@ -921,7 +1014,7 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
                             mvpIdx = !mvpIdx;
                             const uint32_t origBits = bits;
                             bits = origBits + diffBits;
-                            cost = (cost - getCost(origBits)) + getCost(bits);
+                            cost = (cost - getCost(origBits, it.set)) + getCost(bits, it.set);
                         }
                         if (cost < best[list].cost)
                         {
@@ -1029,13 +1122,13 @@ int ThreadedME::estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL
                     {
                         const size_t k = (size_t)biOf[i];
                         bidirBits = (int)(best[0].bits + best[1].bits + listSelBits[2] - (listSelBits[0] + listSelBits[1]));
-                        bidirCost = (uint32_t)biAll[k * 2] + getCost((uint32_t)bidirBits);
+                        bidirCost = (uint32_t)biAll[k * 2] + getCost((uint32_t)bidirBits, it.set);
                         if (biReqs[k].tryZero)
                         {
                             const MV zero = { 0, 0 };
                             const uint32_t bits0 = best[0].bits - bitcost(best[0].mv, best[0].mvp) + bitcost(zero, best[0].mvp);
                             const uint32_t bits1 = best[1].bits - bitcost(best[1].mv, best[1].mvp) + bitcost(zero, best[1].mvp);
-                            const uint32_t cost = (uint32_t)biAll[k * 2 + 1] + getCost(bits0) + getCost(bits1);
+                            const uint32_t cost = (uint32_t)biAll[k * 2 + 1] + getCost(bits0, it.set) + getCost(bits1, it.set);
                             if (cost < bidirCost)
                             {
                                 bidirMv[0] = bidirMv[1] = zero;
@@ -1111,6 +1204,19 @@ int xgh_tme_estimate_rows_b(xgh_tme* t, int32_t slotFenc, int32_t poc, int32_t n
     if (!t)
         return X265GPU_ERR_ARG;
     return t->me.estimateRowsB(slotFenc, poc, numRefsL0, numRefsL1, refs, rowBegin, rowEnd, medianMv, out);
+}
+
+int xgh_tme_set_cu_qp(xgh_tme* t, const int8_t* qp, const int8_t* areaQp, const double* lambdaByQp, int32_t numQp)
+{
+    return t ? t->me.setCuQp(qp, areaQp, lambdaByQp, numQp) : X265GPU_ERR_ARG;
+}
+
+int xgh_tme_cus_per_ctu(const xgh_tme* t) { return t ? t->me.cusPerCtu() : 0; }
+
+void xgh_tme_set_temporal(xgh_tme* t, const xgh_tme_temporal* candidates)
+{
+    if (t)
+        t->me.setTemporalCandidates(candidates);
 }
 
 void xgh_tme_seconds(const xgh_tme* t, double seconds[3])

@@ -14,11 +14,13 @@
 // Covered: P and B slices (any number of references per list; in a B slice the bidirectional candidate of
 // search.cpp:415-511 through x265gpu_bipred_satd, and the list-selection bits that depend on what the
 // partition's first part chose), every shape of g_puLookup (source/encoder/threadedme.h:67-92) under
-// bEnableAMP / bEnableRectInter, one slice QP for the picture (no per-CU delta QP), one slice, no
-// frame-parallel lag window beyond refLagPixels.  The temporal candidate
+// bEnableAMP / bEnableRectInter, one slice, no frame-parallel lag window beyond refLagPixels.  With delta QP on,
+// every CU searches under its own QP's lambda (Analysis::setLambdaFromQP, analysis.cpp:188, 243, 259, 274): the
+// per-CU QPs are an input (setCuQp; x265 derives them from rate-control state in calculateQpforCuSize), the
+// MV-cost tables of the QPs in use live on the device side by side.  The temporal candidate
 // (neighbours[MD_COLLOCATED]) and CUData::getMedianColMV read the reference picture's coded CUs, which
-// only the encoder has: the median vector is an optional input, the temporal candidate is taken as
-// unavailable (--no-temporal-mvp).
+// only the encoder has: both are optional inputs (setTemporalCandidates, medianMv); without them the temporal
+// candidate is unavailable (--no-temporal-mvp).
 #ifndef X265GPU_THREADED_ME_HOST_H
 #define X265GPU_THREADED_ME_HOST_H
 
@@ -80,6 +82,16 @@ struct TmeRef
                                  //   distance was never searched (the 0x7FFF sentinel of search.cpp:2331)
 };
 
+// neighbours[MD_COLLOCATED] of one PU and list as CUData::getNeighbourMV leaves it (source/common/cudata.cpp:1987-2080):
+// whether a co-located vector exists (refIdx != -1), the vector, and the two POCs CUData::getPMV scales it by
+// (the co-located picture's own POC and the POC that vector refers to, cudata.cpp:1959-1977)
+struct TmeTemporal
+{
+    int32_t valid;
+    MV      mv;
+    int32_t colPoc, colRefPoc;
+};
+
 // One prediction-unit search call of Analysis::computeMVForPUs: a CU and one g_puLookup entry.
 struct PuTask
 {
@@ -113,6 +125,19 @@ public:
     int estimateRowsB(int slotFenc, int poc, int numRefsL0, int numRefsL1, const TmeRef* refs, int rowBegin, int rowEnd,
                       const int32_t* medianMv, MEData* out);
 
+    // Per-CU QPs of the picture for the calls that follow (NULL: the one lambda of TmeParam again).  qp holds, per
+    // CTU of the picture, cusPerCtu() entries: the CUs of depth 0, then those of depth 1 in raster order, and so on
+    // down to minCUSize - what Analysis::computeMVForPUs would pass to setLambdaFromQP for that CU (a CU deeper than
+    // pps->maxCuDQPDepth inherits its parent's, analysis.cpp:183-190).  The area searches take areaQp's five QPs per
+    // CTU (the CTU, then its quadrants: analysis.cpp:259, 274 compute them whatever maxCuDQPDepth is), or, with
+    // areaQp NULL, those of the CTU's depth-0 and depth-1 CUs.  lambdaByQp: x265_lambda_tab
+    // (source/common/constants.cpp), numQp entries, copied.  The QP arrays stay the caller's and must outlive the calls.
+    int setCuQp(const int8_t* qp, const int8_t* areaQp, const double* lambdaByQp, int numQp);
+    int cusPerCtu() const;
+    // The temporal AMVP candidates of the picture (sps->bTemporalMVPEnabled), or NULL: per CTU of the picture
+    // MAX_NUM_PUS_PER_CTU table positions x 2 lists, indexed like the result table.
+    void setTemporalCandidates(const TmeTemporal* t) { m_temporal = t; }
+
     const std::vector<PuTask>& tasks() const { return m_tasks; }
     int numLevels() const { return m_numLevels; }
     int numCuInWidth() const { return m_numCuInWidth; }
@@ -124,10 +149,13 @@ public:
 
 private:
     void buildTasks();
+    void addCostSet(double lambda);
     void visit(int cuX, int cuY, int cuSize, std::vector<int>& writer);
     uint32_t bitcost(MV mv, MV mvp) const;
-    uint32_t mvcost(MV mv, MV mvp) const;
-    uint32_t getCost(uint32_t bits) const { return (uint32_t)(((uint64_t)bits * m_lambdaFix8 + 128) >> 8); }
+    uint32_t mvcost(MV mv, MV mvp, int set) const;
+    uint32_t getCost(uint32_t bits, int set) const { return (uint32_t)(((uint64_t)bits * m_costSets[set].lambdaFix8 + 128) >> 8); }
+    int costSetOfQp(int qp);                         // builds the QP's table on first use; -1: no such QP
+    int cuIndex(const PuTask& t) const;
     void clipMv(int cuPelX, int cuPelY, MV& mv) const;
     void setSearchRange(int cuPelX, int cuPelY, MV mvp, int merange, MV& mvmin, MV& mvmax) const;
 
@@ -139,8 +167,16 @@ private:
     std::vector<PuTask> m_tasks;                    // call order of computeMVForPUs
     int m_numLevels;
     std::vector<float> m_bitsizes;                  // BitCost::s_bitsizes, centred
-    std::vector<uint16_t> m_costTable;              // BitCost::m_cost, centred
-    uint64_t m_lambdaFix8;                          // RDCost::m_lambda
+    // BitCost::m_cost (centred) and RDCost::m_lambda per lambda in use: set 0 is TmeParam::lambda, the others the
+    // QPs that setCuQp's array has named so far; a job's set is also its MV-cost table's index on the device
+    struct CostSet { std::vector<uint16_t> table; uint64_t lambdaFix8; };
+    std::vector<CostSet> m_costSets;
+    std::vector<int> m_setOfQp;
+    std::vector<double> m_lambdaByQp;
+    const int8_t* m_cuQp;
+    const int8_t* m_areaQp;
+    const TmeTemporal* m_temporal;
+    size_t m_setsOnDevice;
     int64_t m_searches, m_deviceCalls;
     double m_seconds[3];
     class Pool;
@@ -157,6 +193,7 @@ extern "C" {
 typedef x265gpu_host::MEData xgh_me_data;
 typedef x265gpu_host::TmeParam xgh_tme_param;
 typedef x265gpu_host::TmeRef xgh_tme_ref;
+typedef x265gpu_host::TmeTemporal xgh_tme_temporal;
 typedef struct xgh_tme xgh_tme;
 
 xgh_tme* xgh_tme_create(x265gpu_ctx* ctx, const xgh_tme_param* p);
@@ -168,6 +205,11 @@ int xgh_tme_estimate_rows(xgh_tme* t, int32_t slotFenc, int32_t poc, int32_t num
 int xgh_tme_estimate_rows_b(xgh_tme* t, int32_t slotFenc, int32_t poc, int32_t numRefsL0, int32_t numRefsL1,
                             const xgh_tme_ref* refs, int32_t rowBegin, int32_t rowEnd, const int32_t* medianMv,
                             xgh_me_data* out);
+// per-CU QPs / temporal candidates of the picture for the calls that follow (see ThreadedME::setCuQp,
+// setTemporalCandidates); NULL switches them off again
+int xgh_tme_set_cu_qp(xgh_tme* t, const int8_t* qp, const int8_t* areaQp, const double* lambdaByQp, int32_t numQp);
+int xgh_tme_cus_per_ctu(const xgh_tme* t);
+void xgh_tme_set_temporal(xgh_tme* t, const xgh_tme_temporal* candidates);
 // seconds so far: {host logic, inside device calls (upload + kernels + download), whole estimateRows calls}
 void xgh_tme_seconds(const xgh_tme* t, double seconds[3]);
 // counts: {tasks per CTU, dependency levels, CTUs per row, CTU rows, searches so far, device calls so far}

@@ -68,11 +68,24 @@ struct BlockCtx
     XG_LDS uint32_t* win;          // full-pel window, WIN rows of LdsT<P>::WIN_S dwords
     XG_LDS uint32_t* sub;          // sub-pel window, 4 planes x SUB_ROWS rows of LdsT<P>::SUB_S dwords
     XG_LDS uint32_t* tab;          // MV-cost windows, 2 axes x TAB_N entries of 16 bits
+#ifdef XG_STAMP
+    unsigned long long st[8];
+#endif
     int relX, relY;                // block origin relative to the window's first pixel
     int subRelX, subRelY;          // the same for the sub-pel window
     int tabLoX, tabLoY;            // MVD of entry 0 of each axis' staged table window
     int tabBiasX, tabBiasY;        // quarter-pel component + bias = index into the 2 x TAB_N table entries
 };
+
+#ifdef XG_STAMP
+// timing build: every block of a flow launch's first job leaves the constant 100 MHz clock at the ends of its stages
+// (benchmarks/chain_probe.py reads them back and walks the critical path of the dependency chain)
+constexpr int XG_STAMP_BLOCKS = 1 << 16;
+__device__ unsigned long long xg_stamps[XG_STAMP_BLOCKS * 8];
+#define STAMP(c, i) (c).st[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define STAMP(c, i)
+#endif
 
 constexpr int WIN = 32;            // full-pel window side, pixels
 constexpr int WIN_PAD = 12;        // pixels between the window's edge and the centre block
@@ -756,7 +769,9 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
         // row lies inside mvmin.y..mvmax.y.
         const int gi = c.g & 3;
         const unsigned qyr = (unsigned)c.yr * 4u;
+        STAMP(c, 4);
         stage_subpel<P>(c, bqx, bqy);
+        STAMP(c, 5);
         {
             const int qx = bqx + 2 * nib(SQ1_X, gi), qy = bqy + 2 * nib(SQ1_Y, gi);
             const int cost = eval_sub<P, EV_SAD>(c, qx, qy, ((bqx | bqy) & 1) != 0);     // half-pel steps keep the parity
@@ -840,6 +855,8 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
 #endif
     c.relX = c.relY = c.subRelX = c.subRelY = NOT_STAGED;
     c.tabLoX = c.tabLoY = c.tabBiasX = c.tabBiasY = 0;
+    STAMP(c, 0);
+    STAMP(c, 7);
     // search bounds that stay inside the extended frame (slicetype.cpp:4417-4420)
     c.minx = -cuX * 8 - 8;
     c.miny = -cuY * 8 - 8;
@@ -909,6 +926,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
                 v = 0;
             cx = (int)v;
             cy = (int)(v >> 32);
+            STAMP(c, 1);
         }
         else if (MODE == MODE_ROWS)
         {
@@ -982,6 +1000,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         win_store<P>(c, ws);
         tab_store<P>(c, ts);
         lds_handover();
+        STAMP(c, 2);
         if (t0need && t0staged)
             t0 = (int)((const XG_LDS uint16_t*)c.tab)[(c.r & 1) * TAB_N + t0d - (c.r ? c.tabLoY : c.tabLoX)];
 #pragma unroll
@@ -1035,6 +1054,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     }
 
     int mx, my;
+    STAMP(c, 3);
     int fencCost = motion_estimate_lowres<P, METHOD>(c, mvpx, mvpy, job.merange, zeroSad, zeroSatd, mvpSad, mv0cost, mx, my);
     // bidir skip shortcut (slicetype.cpp:4485-4489)
     if (skipCost < 64 && skipCost < fencCost && job.bBidir)
@@ -1050,6 +1070,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         if (lane == 0)
             __hip_atomic_store(rowCount, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    STAMP(c, 6);
     if (lane == 0)
     {
         if (MODE != MODE_DIAG)
@@ -1065,7 +1086,18 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     }
     rightX = mx;
     rightY = my;
+#ifdef XG_STAMP
+    if (MODE == MODE_FLOW && blockIdx.x == 0 && cuXY < XG_STAMP_BLOCKS && lane < 8)
+        xg_stamps[cuXY * 8 + lane] = c.st[lane];
+#endif
 }
+
+#ifdef XG_STAMP
+extern "C" int x265gpu_debug_read_stamps(void* out, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(xg_stamps), bytes < sizeof(xg_stamps) ? bytes : sizeof(xg_stamps));
+}
+#endif
 
 // Block rows [first, last] of cooperative slice `slice` (slicetype.cpp:4265-4266); one slice: the frame.
 __device__ __forceinline__ void slice_rows(const SearchJob& job, int H, int slice, int& first, int& last)

@@ -15,7 +15,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$KEY
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--cpu-frames 0 --no-micro --steady-steps 0 --in-flight 1 $*"
+ARGS="--cpu-frames 0 --no-micro --no-other-configs --steady-steps 0 --in-flight 1 --reps 1 $*"
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 5 --warmup 2 $ARGS > $OUT/bench_traced.json 2> $OUT/trace.log || { echo "kernel trace failed"; tail -5 $OUT/trace.log; exit 1; }
 find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 echo "trace ok"

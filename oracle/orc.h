@@ -208,6 +208,8 @@ typedef struct orc_lowres {
     double*  qpAqMotionOffset; /* --aq-motion (source/common/lowres.cpp:114-115), allocated on first use */
     struct orc_hist_stats* hist; /* --hist-scenecut: collectPictureStatistics' results (orc_lowres_set_hist_stats) */
     int      bHistScenecutAnalyzed;
+    double   frameVariance;      /* calcAdaptiveQuantFrame's tail (slicetype.cpp:688-703), read by the fade detection */
+    int      bIsFadeEnd;
     int      sliceType;       /* X265_TYPE_* (source/x265.h) */
     /* what the slice-type decision keeps per frame (source/common/lowres.h:166-213) */
     int      sliceTypeReq;
@@ -297,6 +299,7 @@ typedef struct orc_la_param {
     int poolWorkers;              /* ThreadPool::m_numWorkers of the lookahead's pool, 0: no pool */
     int bAQMotion;                /* --aq-motion */
     int bHistBasedSceneCut;       /* --hist-scenecut: frames carry orc_hist_stats (orc_lowres_set_hist_stats) */
+    int bEnableFades;             /* --fades: frames carry frameVariance (orc_lowres_set_frame_variance) */
 } orc_la_param;
 typedef struct orc_la orc_la;
 orc_la* orc_la_create(const orc_param* p, const orc_la_param* lp, const orc_cutree_param* cp, orc_tld* tld);
@@ -320,6 +323,8 @@ typedef struct orc_hist_stats {
     uint16_t picAvgVariance, picAvgVarianceCb, picAvgVarianceCr, pad2;
 } orc_hist_stats;
 void orc_lowres_set_hist_stats(orc_lowres* lr, const orc_hist_stats* st);   /* keeps a copy */
+void orc_lowres_set_frame_variance(orc_lowres* lr, double v);
+int  orc_lowres_is_fade_end(const orc_lowres* lr);
 void orc_collect_picture_statistics(const pixel* lowresPlane0, intptr_t lowresStride, const pixel* y, intptr_t sy,
                                     const pixel* u, const pixel* v, intptr_t sc, int w, int h, orc_hist_stats* out);
 

@@ -45,7 +45,7 @@ class LaParam(C.Structure):
                 ("gopLookahead", C.c_int), ("cuTree", C.c_int), ("aqMode", C.c_int), ("vbvBufferSize", C.c_int),
                 ("vbvMaxBitrate", C.c_int), ("bCqp", C.c_int), ("bEnableTemporalSubLayers", C.c_int),
                 ("maxNumReferences", C.c_int), ("poolWorkers", C.c_int), ("bAQMotion", C.c_int),
-                ("bHistBasedSceneCut", C.c_int)]
+                ("bHistBasedSceneCut", C.c_int), ("bEnableFades", C.c_int)]
 
 
 class HistStats(C.Structure):
@@ -369,7 +369,7 @@ class SliceDecider:
                      p["keyframeMin"], p["keyframeMax"], p["bOpenGOP"], p["bIntraRefresh"], p["radl"], p["gopLookahead"],
                      p["cuTree"], p["aqMode"] if p["bAdaptiveQuant"] else 0, p["vbvBufferSize"], p["vbvMaxBitrate"],
                      p["bCqp"], p["bEnableTemporalSubLayers"], p["maxNumReferences"], p["poolWorkers"],
-                     p.get("bAQMotion", 0), p.get("bHistBasedSceneCut", 0))
+                     p.get("bAQMotion", 0), p.get("bHistBasedSceneCut", 0), p.get("bEnableFades", 0))
         cp = CuTreeParam(p["fpsNum"], p["fpsDenom"], p["bBPyramid"], p["bEnableWeightedBiPred"], p["lookaheadDepth"],
                          p["vbvBufferSize"], p["qCompress"])
         assert look.param.bframes == p["bframes"] and look.param.bEnableWeightedPred == p["bEnableWeightedPred"]
@@ -524,6 +524,16 @@ def calc_adaptive_quant_frame(depth, y, u, v, aq_mode, strength, weightp=False, 
     if block_variance:
         out += (var, float(fvar[0]))
     return out
+
+
+def set_frame_variance(lowres, v):
+    """Lowres::frameVariance, read by the fade detection of slicetypeDecide (--fades)."""
+    lowres.L.orc_lowres_set_frame_variance.argtypes = [C.c_void_p, C.c_double]
+    lowres.L.orc_lowres_set_frame_variance(C.c_void_p(lowres.h), float(v))
+
+
+def is_fade_end(lowres):
+    return bool(lowres.L.orc_lowres_is_fade_end(C.c_void_p(lowres.h)))
 
 
 def set_hist_stats(lowres, st):

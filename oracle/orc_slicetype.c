@@ -10,7 +10,8 @@
  *   Lookahead::frameCostRecalculate                               :4068-4145
  *   Lookahead::aqMotion / calcMotionAdaptiveQuantFrame            :3581-3663
  *   Lookahead::histBasedScenecut / detectHistBasedSceneChange     :3323-3482
- * Not restated (the product's host layer refuses the same settings): zones, fades, analysis load,
+ *   the fade detection of slicetypeDecide (--fades)               :2042-2088, 2153-2155
+ * Not restated (the product's host layer refuses the same settings): zones, analysis load,
  * --mcstf, more than two temporal sub-layers, qgSize 8, rc.hevcAq.
  * Frames enter already pre-analysed (Lowres::init, AQ, intra estimate are per-frame functions of the
  * picture alone, so running them at addPicture instead of in PreLookaheadGroup changes nothing). */
@@ -47,6 +48,10 @@ struct orc_la
     uint32_t accHistDiffRunningAvg[3][4][4];
     int resetRunningAvg;
     uint32_t segmentCountThreshold;
+    /* --fades (:2042-2088, slicetype.h:196-200) */
+    double frameVariance[ORC_BFRAME_MAX + 4];
+    int isFadeIn, fadeStart;
+    uint64_t fadeCount;
     int32_t* trace;
     int ntrace, captrace;
 };
@@ -169,6 +174,59 @@ static void aq_motion(orc_la* la, orc_lowres** frames, int bIntra)
         for (int i = 1; i < lastnonb; i++)
             calc_motion_adaptive_quant_frame(la, frames, curnonb, lastnonb, i);
     calc_motion_adaptive_quant_frame(la, frames, curnonb, lastnonb, lastnonb);
+}
+
+void orc_lowres_set_frame_variance(orc_lowres* lr, double v) { lr->frameVariance = v; }
+int orc_lowres_is_fade_end(const orc_lowres* lr) { return lr->bIsFadeEnd; }
+
+/* ---- :2042-2088: a run of pictures whose variance does not fall is a fade-in; the picture that ends a run of at
+ * least a second is marked, and the fix-ups below make it a keyframe.  Kept to the letter, including the ring
+ * index over POC modulo the array length. ---- */
+static void detect_fades(orc_la* la, orc_lowres** list)
+{
+    int j, endIndex = 0, length = ORC_BFRAME_MAX + 4;
+    for (j = 0; j < length; j++)
+        la->frameVariance[j] = -1;
+    for (j = 0; list[j] != NULL; j++)
+        la->frameVariance[list[j]->frameNum % length] = list[j]->frameVariance;
+    for (int k = list[0]->frameNum % length; k <= list[j - 1]->frameNum % length; k++)
+    {
+        if (la->frameVariance[k] == -1)
+            break;
+        if ((k > 0 && la->frameVariance[k] >= la->frameVariance[k - 1]) ||
+            (k == 0 && la->frameVariance[k] >= la->frameVariance[length - 1]))
+        {
+            la->isFadeIn = 1;
+            if (la->fadeCount == 0 && la->fadeStart == -1)
+            {
+                for (int temp = list[0]->frameNum; temp <= list[j - 1]->frameNum; temp++)
+                    if (k == temp % length)
+                    {
+                        la->fadeStart = temp ? temp - 1 : 0;
+                        break;
+                    }
+            }
+            la->fadeCount = list[endIndex]->frameNum > la->fadeStart ? list[endIndex]->frameNum - la->fadeStart : 0;
+            endIndex++;
+        }
+        else
+        {
+            if (la->isFadeIn && la->fadeCount >= (uint64_t)(la->cp.fpsNum / la->cp.fpsDenom))
+            {
+                for (int temp = 0; list[temp] != NULL; temp++)
+                    if (list[temp]->frameNum == la->fadeStart + (int)la->fadeCount)
+                    {
+                        list[temp]->bIsFadeEnd = 1;
+                        break;
+                    }
+            }
+            la->isFadeIn = 0;
+            la->fadeCount = 0;
+            la->fadeStart = -1;
+        }
+        if (k == length - 1)
+            k = -1;
+    }
 }
 
 void orc_lowres_set_hist_stats(orc_lowres* lr, const orc_hist_stats* st)
@@ -815,6 +873,9 @@ static void slicetype_decide(orc_la* la)
         frames[j + 1] = la->inq[j];
     maxSearch = j;
 
+    if (lp->bEnableFades)
+        detect_fades(la, list);
+
     if (la->lastNonB && ((lp->bFrameAdaptive && la->p.bframes) || lp->cuTree || lp->scenecutThreshold ||
                          lp->bHistBasedSceneCut || (lp->lookaheadDepth && lp->vbvBufferSize)))
         slicetype_analyse(la, frames, 0);
@@ -842,6 +903,8 @@ static void slicetype_decide(orc_la* la)
             if (warn)
                 frm->sliceType = lp->bOpenGOP && la->lastKeyframe >= 0 ? ORC_TYPE_I : ORC_TYPE_IDR;
         }
+        if (frm->bIsFadeEnd)           /* :2153-2155 */
+            frm->sliceType = lp->bOpenGOP && la->lastKeyframe >= 0 ? ORC_TYPE_I : ORC_TYPE_IDR;
         if (frm->sliceType == ORC_TYPE_I && frm->frameNum - la->lastKeyframe >= lp->keyframeMin)
         {
             if (lp->bOpenGOP)
@@ -962,6 +1025,7 @@ orc_la* orc_la_create(const orc_param* p, const orc_la_param* lp, const orc_cutr
     la->batchFrameCosts = la->batchMotionSearch;
     la->blocks8x8 = tld->ncu;
     la->resetRunningAvg = 1;
+    la->fadeStart = -1;            /* :1067-1069 */
     la->segmentCountThreshold = (uint32_t)(((float)((4 * 4) * 50) / 100) + 0.5);
     return la;
 }

@@ -47,10 +47,14 @@ def oracle_lookahead(clip, chroma, depth, p, **param_kw):
     look = orc.Lookahead(depth, param, with_aq=True)
     for i, y in enumerate(clip):
         if aq_on:
-            qa, qc, inv, wsum, wssd = orc.calc_adaptive_quant_frame(
+            res = orc.calc_adaptive_quant_frame(
                 depth, y, chroma[i][0], chroma[i][1], p["aqMode"], p["aqStrength"],
-                weightp=bool(p["bEnableWeightedPred"] or p["bEnableWeightedBiPred"]))[:5]
+                weightp=bool(p["bEnableWeightedPred"] or p["bEnableWeightedBiPred"]),
+                block_variance=bool(p.get("bEnableFades")))
+            qa, qc, inv, wsum, wssd = res[:5]
             lr = look.add_frame(y, inv)
+            if p.get("bEnableFades"):
+                orc.set_frame_variance(lr, res[-1])
             lr.qp_aq_offset()[:] = qa
             lr.qp_cutree_offset()[:] = qc
             s, d = lr.wp()

@@ -37,6 +37,7 @@ def _compare(clip, chroma, depth, p, forced=None, ctx_kw=None, param_kw=None):
             have = (d.sliceType, d.bScenecut, d.bKeyframe, d.bLastMiniGopBFrame, d.leadingBframes)
             want = tuple(int(fr.i64(k)) for k in ("sliceType", "bScenecut", "bKeyframe", "bLastMiniGopBFrame", "leadingBframes"))
             assert have == want, "frame %d: %s, oracle %s" % (d.frame, have, want)
+            assert bool(d.bIsFadeEnd) == orc.is_fade_end(fr), "fade end of frame %d" % d.frame
         # the requests, in issue order
         t_want, t_got = dec.trace(), la.trace()
         assert t_got.shape == t_want.shape, "host issued %d requests, oracle %d" % (len(t_got), len(t_want))
@@ -92,6 +93,7 @@ def _compare(clip, chroma, depth, p, forced=None, ctx_kw=None, param_kw=None):
             assert la.presearch_hits() > 0           # single requests did find searches that ran ahead with a batch
         if not p.get("bPresearch", 1):
             assert la.presearch_hits() == 0
+        _compare.fade_ends = [d.frame for d in got if d.bIsFadeEnd]
         return [d.sliceType for d in sorted(got, key=lambda d: d.frame)], [d.bScenecut for d in sorted(got, key=lambda d: d.frame)], t_want
     finally:
         la.close()
@@ -228,3 +230,25 @@ def test_4k_10bit_hme_rc_lookahead_40():
     ctx_hme = dict(hme=True, hme_methods=(api.HEX_SEARCH, api.UMH_SEARCH, api.UMH_SEARCH), hme_range=(16, 32, 48))
     types, cuts, trace = _compare(clip, chroma, depth, p, ctx_kw=ctx_hme, param_kw=hme)
     assert len(types) == N and any(t == 5 for t in types)
+
+
+@pytest.mark.parametrize("kw", [{}, {"poolWorkers": 16, "bOpenGOP": 0}], ids=["lazy", "pool16-closed-gop"])
+def test_fade_in_ends_on_a_keyframe(kw):
+    """--fades: the picture variances of calcAdaptiveQuantFrame's tail come from the device; a fade-in of a second or
+    more (here 16 pictures at 10 fps with rising contrast) ends on a picture that the fix-ups make a
+    keyframe (slicetype.cpp:2042-2088, 2153-2155)."""
+    p = dict(api.LookaheadParam.MEDIUM, bEnableFades=1, fpsNum=10, scenecutThreshold=0, **kw)
+    N, W, H, depth = 40, 256, 160, 8
+    base = synth.luma_clip(W, H, N, depth, seed=21, scene_cut=False).astype(np.float64)
+    gain = np.ones(N)
+    gain[:4] = np.linspace(0.3, 0.2, 4)
+    gain[4:20] = np.linspace(0.2, 1.0, 16)
+    gain[20:] = np.linspace(1.0, 0.4, N - 20)              # and a fade-out afterwards, which ends the run
+    clip = 0.8 * base.mean(axis=0, keepdims=True) + 0.2 * base      # one scene that moves a little
+    mean = clip.mean(axis=(1, 2), keepdims=True)
+    clip = np.clip(mean + (clip - mean) * gain[:, None, None] * 2.0, 0, 255).astype(np.uint8)
+    types, _, _ = _compare(clip, du.chroma_for(clip, depth, 22), depth, p)
+    ends = _compare.fade_ends
+    assert ends == [20], ends
+    for f in ends:
+        assert types[f] in (1, 2)

@@ -639,14 +639,15 @@ class LookaheadParam(C.Structure):
                 ("fpsNum", C.c_int32), ("fpsDenom", C.c_int32), ("qCompress", C.c_double), ("bitDepth", C.c_int32),
                 ("poolWorkers", C.c_int32), ("bAdaptiveQuant", C.c_int32), ("aqMode", C.c_int32), ("aqStrength", C.c_double),
                 ("bPresearch", C.c_int32), ("lookaheadSlices", C.c_int32), ("bAQMotion", C.c_int32),
-                ("bHistBasedSceneCut", C.c_int32)]
+                ("bHistBasedSceneCut", C.c_int32), ("bEnableFades", C.c_int32), ("qgSize", C.c_int32),
+                ("bHevcAq", C.c_int32), ("qpAdaptationRange", C.c_double)]
 
     MEDIUM = dict(bframes=4, lookaheadDepth=20, bFrameAdaptive=2, bBPyramid=1, scenecutThreshold=40, scenecutBias=0.05,
                   keyframeMin=25, keyframeMax=250, bOpenGOP=1, bIntraRefresh=0, radl=0, gopLookahead=0, cuTree=1,
                   bFrameBias=0, vbvBufferSize=0, vbvMaxBitrate=0, bCqp=0, bEnableTemporalSubLayers=0, maxNumReferences=3,
                   bEnableWeightedPred=1, bEnableWeightedBiPred=0, fpsNum=30, fpsDenom=1, qCompress=0.6, bitDepth=8,
                   poolWorkers=0, bAdaptiveQuant=1, aqMode=2, aqStrength=1.0, bPresearch=1, lookaheadSlices=0,
-                  bAQMotion=0, bHistBasedSceneCut=0)
+                  bAQMotion=0, bHistBasedSceneCut=0, bEnableFades=0, qgSize=32, bHevcAq=0, qpAdaptationRange=1.0)
 
     def __init__(self, **kw):
         super().__init__()
@@ -658,7 +659,7 @@ class LookaheadParam(C.Structure):
 
 class Decided(C.Structure):
     _fields_ = [("frame", C.c_int32), ("sliceType", C.c_int32), ("bScenecut", C.c_int32), ("bKeyframe", C.c_int32),
-                ("bLastMiniGopBFrame", C.c_int32), ("leadingBframes", C.c_int32)]
+                ("bLastMiniGopBFrame", C.c_int32), ("leadingBframes", C.c_int32), ("bIsFadeEnd", C.c_int32)]
 
 
 def load_host_library():

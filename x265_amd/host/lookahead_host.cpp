@@ -36,6 +36,7 @@ void Lowres::reset()
     }
     bLastMiniGopBFrame = false;
     bKeyframe = false;
+    bIsFadeEnd = false;               // lowres.cpp:348
     leadingBframes = 0;
     indB = 0;
     if (!plannedType.empty())
@@ -249,6 +250,40 @@ int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const Picture*
     rc = x265gpu_intra_estimate(m_ctx, n, slots.data());
     if (rc != X265GPU_OK)
         return rc;
+    if (aq.bBlockVariance || aq.qgSize == 8 || aq.bHevcAq)
+    {
+        // forms of calcAdaptiveQuantFrame with per-picture outputs beyond the three arrays (the variance tail of
+        // --fades / --dynamic-refine, invQscaleFactor8x8 of qgSize 8, the layers of rc.hevcAq): one call per picture
+        x265gpu_geometry g;
+        x265gpu_get_geometry(m_ctx, &g);
+        for (int i = 0; i < n; i++)
+        {
+            Lowres& fr = *frames[i];
+            x265gpu_aq_params q = aq;
+            const size_t blocks = (size_t)g.cuCount * (aq.qgSize == 8 ? 4 : 1);
+            if (aq.bBlockVariance)
+            {
+                fr.blockVariance.assign(blocks, 0);
+                q.blockVariance = fr.blockVariance.data();
+                q.frameVariance = &fr.frameVariance;
+            }
+            if (aq.qgSize == 8)
+            {
+                fr.invQscaleFactor8x8.assign((size_t)g.cuCount, 0);
+                q.invQscaleFactor8x8 = fr.invQscaleFactor8x8.data();
+            }
+            uint64_t wpSum[3], wpSsd[3];
+            rc = x265gpu_aq_frame(m_ctx, fr.slot, pics[i].y, pics[i].strideY, pics[i].u, pics[i].v, pics[i].strideC,
+                                  pics[i].memKind, &q, ap[i].quantOffsets, fr.qpAqOffset, fr.qpCuTreeOffset,
+                                  fr.invQscaleFactor, wpSum, wpSsd);
+            if (rc != X265GPU_OK)
+                return rc;
+            fr.wp_sum = wpSum[0];
+            fr.wp_ssd = wpSsd[0];
+            fr.intraTotalsPending = true;
+        }
+        return X265GPU_OK;
+    }
     // pictures of one batch live in one kind of memory.  The sums that weightsAnalyse reads are back when this
     // returns; the offsets are still being mapped on the library's host threads and are finished from inside the
     // next estimate call, after its searches have been queued: resolveIntraTotals() then reads the frames' intra totals.
@@ -727,7 +762,7 @@ int CuTree::cuTree(Lowres* const* frames, int numframes, bool bIntra)
 // requests are issued, and in which order, decides which motion searches run inside a bidirectional request
 // (the skip shortcut of estimateCUCost makes an L0 vector depend on that), so any other order gives other
 // vectors.  What differs from x265 is only where a request is computed: CostEstimateGroup sends it to the device.
-// Not covered (unsupported() says so): zones, fades, analysis load, --mcstf
+// Not covered (unsupported() says so): zones, analysis load, --mcstf
 // batches, more than two temporal sub-layers, qgSize 8 and rc.hevcAq in frameCostRecalculate.
 
 // x265_exp2fix8 (source/common/common.cpp:96-103) over x265_exp2_lut (source/common/constants.cpp:552-558),
@@ -1554,6 +1589,54 @@ void Lookahead::compCostBref(Lowres** frames, int start, int end, int num)      
 }
 
 // :1982-2751 without zones, fades, analysis load, MCSTF and the temporal-layer GOP tables
+// :2042-2088.  A run of pictures whose variance does not fall is a fade-in; the picture that ends a run of at least
+// a second is marked, and the fix-ups of the mini-GOP make it a keyframe.  The ring index over POC modulo the array
+// length, its wrap inside the loop and the use of list[endIndex] are the reference's.
+void Lookahead::detectFades(Lowres** list)
+{
+    const int length = X265GPU_BFRAME_MAX + 4;
+    int j, endIndex = 0;
+    for (j = 0; j < length; j++)
+        m_frameVariance[j] = -1;
+    for (j = 0; list[j] != nullptr; j++)
+        m_frameVariance[list[j]->frameNum % length] = list[j]->frameVariance;
+    const int first = list[0]->frameNum, last = list[j - 1]->frameNum;
+    for (int k = first % length; k <= last % length; k++)
+    {
+        if (m_frameVariance[k] == -1)
+            break;
+        const double before = k > 0 ? m_frameVariance[k - 1] : m_frameVariance[length - 1];
+        if (m_frameVariance[k] >= before)
+        {
+            m_isFadeIn = true;
+            if (m_fadeCount == 0 && m_fadeStart == -1)
+                for (int poc = first; poc <= last; poc++)
+                    if (k == poc % length)
+                    {
+                        m_fadeStart = poc ? poc - 1 : 0;
+                        break;
+                    }
+            m_fadeCount = list[endIndex]->frameNum > m_fadeStart ? list[endIndex]->frameNum - m_fadeStart : 0;
+            endIndex++;
+        }
+        else
+        {
+            if (m_isFadeIn && m_fadeCount >= (uint64_t)(m_param.fpsNum / m_param.fpsDenom))
+                for (int t = 0; list[t] != nullptr; t++)
+                    if (list[t]->frameNum == m_fadeStart + (int)m_fadeCount)
+                    {
+                        list[t]->bIsFadeEnd = true;
+                        break;
+                    }
+            m_isFadeIn = false;
+            m_fadeCount = 0;
+            m_fadeStart = -1;
+        }
+        if (k == length - 1)
+            k = -1;
+    }
+}
+
 void Lookahead::slicetypeDecide()
 {
     const LookaheadParam& P = m_param;
@@ -1615,6 +1698,9 @@ void Lookahead::slicetypeDecide()
             f->lowresInit = true;
     }
 
+    if (P.bEnableFades)
+        detectFades(list);
+
     if (m_lastNonB && ((P.bFrameAdaptive && P.bframes) || P.cuTree || P.scenecutThreshold || P.bHistBasedSceneCut ||
                        (P.lookaheadDepth && P.vbvBufferSize)))
         slicetypeAnalyse(frames, false);
@@ -1647,6 +1733,8 @@ void Lookahead::slicetypeDecide()
             if (!compatible)
                 frm.sliceType = keyType;
         }
+        if (frm.bIsFadeEnd)                        // :2153-2155
+            frm.sliceType = P.bOpenGOP && m_lastKeyframe >= 0 ? TYPE_I : TYPE_IDR;
         if (frm.sliceType == TYPE_I && sinceKey >= P.keyframeMin)
         {
             if (P.bOpenGOP)
@@ -1985,6 +2073,8 @@ xgh_lookahead* xgh_lookahead_create(x265gpu_ctx* ctx, const xgh_lookahead_param*
     q.lookaheadSlices = p->lookaheadSlices;
     q.bAQMotion = p->bAQMotion != 0;
     q.bHistBasedSceneCut = p->bHistBasedSceneCut != 0;
+    q.bEnableFades = p->bEnableFades != 0;
+    q.aq.bBlockVariance = q.bEnableFades;     // param->bDynamicRefine || param->bEnableFades (slicetype.cpp:688)
     if (q.bAQMotion)
         q.bAdaptiveQuant = true;              // Lookahead::m_bAdaptiveQuant (slicetype.cpp:1080-1084)
     xgh_lookahead* h = new xgh_lookahead;
@@ -2052,6 +2142,7 @@ int xgh_lookahead_get_decided(xgh_lookahead* h, xgh_decided* out)
     out->bKeyframe = f->bKeyframe;
     out->bLastMiniGopBFrame = f->bLastMiniGopBFrame;
     out->leadingBframes = f->leadingBframes;
+    out->bIsFadeEnd = f->bIsFadeEnd;
     return 1;
 }
 

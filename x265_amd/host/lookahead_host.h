@@ -88,6 +88,10 @@ struct Lowres
     std::vector<double> qpAqMotionOffset; // --aq-motion (lowres.cpp:114-115), sized on first use
     std::shared_ptr<x265gpu_hist_stats_t> hist;   // --hist-scenecut: collectPictureStatistics' results (lowres.h:245-253)
     bool bHistScenecutAnalyzed = false;
+    double frameVariance = 0;             // --fades: calcAdaptiveQuantFrame's tail (slicetype.cpp:688-703)
+    bool bIsFadeEnd = false;
+    std::vector<uint32_t> blockVariance;  // its per-block output, sized on first use
+    std::vector<int32_t> invQscaleFactor8x8;      // qgSize 8 (lowres.cpp:99-100)
 
     // what the slice-type decision keeps per frame (source/common/lowres.h:166-213)
     int sliceTypeReq = TYPE_AUTO;
@@ -253,6 +257,7 @@ struct LookaheadParam
                                                   // > 0 with trellis B-adapt: the two batches of slicetypeAnalyse
     bool bHistBasedSceneCut = false;              // --hist-scenecut: scene cuts from histogram differences of the 4x4 segments
     bool bAQMotion = false;                       // --aq-motion: offsets raised where a block moves unlike the rest of its frame
+    bool bEnableFades = false;                    // --fades: the picture that ends a fade-in of a second or more becomes a keyframe
     bool bAdaptiveQuant = true;                   // Lookahead::m_bAdaptiveQuant: pre-analysis runs calcAdaptiveQuantFrame
     x265gpu_aq_params aq;                         // its parameters (aqMode, strength, qgSize >= 16, ...)
     LookaheadParam();
@@ -312,6 +317,12 @@ private:
     uint32_t m_accHistDiffRunningAvg[3][4][4] = {};
     bool m_resetRunningAvg = true;
     uint32_t m_segmentCountThreshold = (uint32_t)(((float)((4 * 4) * 50) / 100) + 0.5);
+    // --fades (slicetype.cpp:1067-1069, slicetype.h:196-200)
+    double m_frameVariance[X265GPU_BFRAME_MAX + 4];
+    bool m_isFadeIn = false;
+    uint64_t m_fadeCount = 0;
+    int m_fadeStart = -1;
+    void detectFades(Lowres** list);
     bool m_filled = false;
     size_t m_fullQueueSize;
     int m_inputCount = 0;
@@ -377,11 +388,15 @@ typedef struct xgh_lookahead_param
     double  aqStrength;
     int32_t bPresearch, lookaheadSlices;
     int32_t bAQMotion, bHistBasedSceneCut;
+    int32_t bEnableFades;
+    int32_t qgSize, bHevcAq;      /* rc.qgSize (0 = 32), rc.hevcAq */
+    double  qpAdaptationRange;    /* rc.qpAdaptationRange */
 } xgh_lookahead_param;
 typedef struct xgh_decided
 {
     int32_t frame;                /* index in order of xgh_lookahead_add_picture */
     int32_t sliceType, bScenecut, bKeyframe, bLastMiniGopBFrame, leadingBframes;
+    int32_t bIsFadeEnd;
 } xgh_decided;
 xgh_lookahead* xgh_lookahead_create(x265gpu_ctx* ctx, const xgh_lookahead_param* p);
 void xgh_lookahead_destroy(xgh_lookahead* la);

@@ -208,6 +208,9 @@ typedef struct orc_lowres {
     double*  qpAqMotionOffset; /* --aq-motion (source/common/lowres.cpp:114-115), allocated on first use */
     struct orc_hist_stats* hist; /* --hist-scenecut: collectPictureStatistics' results (orc_lowres_set_hist_stats) */
     int      bHistScenecutAnalyzed;
+    int      qg8;                /* rc.qgSize == 8: invQscaleFactor holds Lowres::invQscaleFactor8x8 (what the estimates,
+                                  * the intra estimate and cuTree read then: slicetype.cpp:798, 3791, 4532) and the two
+                                  * offset arrays hold (2 widthInCU) x (2 heightInCU) doubles (lowres.cpp:92-95) */
     double   frameVariance;      /* calcAdaptiveQuantFrame's tail (slicetype.cpp:688-703), read by the fade detection */
     int      bIsFadeEnd;
     int      sliceType;       /* X265_TYPE_* (source/x265.h) */

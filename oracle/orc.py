@@ -192,14 +192,14 @@ def ptr(a):
 
 def make_param(width, height, bframes=4, hme=False, weightp=False, ctu=64, search=HEX,
                hme_methods=(HEX, UMH, UMH), hme_range=(16, 32, 48), bframe_bias=0, mcstf=False,
-               lookahead_slices=0, max_slices=1):
+               lookahead_slices=0, max_slices=1, qg_size=32):
     p = Param()
     p.sourceWidth, p.sourceHeight, p.maxCUSize, p.bframes = width, height, ctu, bframes
     p.bEnableHME = int(hme)
     for k in range(3):
         p.hmeSearchMethod[k] = hme_methods[k]
         p.hmeRange[k] = hme_range[k]
-    p.qgSize = 32
+    p.qgSize = qg_size
     p.bFrameBias = bframe_bias
     p.bEnableWeightedPred = int(weightp)
     p.maxSlices = max_slices
@@ -306,10 +306,10 @@ class Lowres:
         return self._view("propagateCost", 0, 0, self.ncu(), np.uint16)
 
     def qp_aq_offset(self):
-        return self._view("qpAqOffset", 0, 0, self.ncu(), np.float64)
+        return self._view("qpAqOffset", 0, 0, self.ncu() * (4 if self.i64("qg8") else 1), np.float64)
 
     def qp_cutree_offset(self):
-        return self._view("qpCuTreeOffset", 0, 0, self.ncu(), np.float64)
+        return self._view("qpCuTreeOffset", 0, 0, self.ncu() * (4 if self.i64("qg8") else 1), np.float64)
 
     def set_slice_type(self, t):
         self.L.orc_lowres_set_slice_type(self.h, int(t))

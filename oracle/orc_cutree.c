@@ -42,8 +42,23 @@ static void clip_add(uint16_t* s, int x)
 }
 
 /* source/encoder/slicetype.cpp:4016-4064 (the qgSize > 8, non-hevcAq branch) */
+void orc_cutree_finish_qg8(int W, int H, const int32_t* intraCost, const int32_t* invQscale8x8,
+                           const uint16_t* propagateCost, int fpsFactor, double weightdelta, double strength,
+                           const double* qpAqOffset, double* qpCuTreeOffset);
+
 void orc_cutree_finish(const orc_cutree_param* cp, orc_lowres* frame, double averageDuration, int ref0Distance)
 {
+    if (frame->qg8)
+    {
+        int fpsFactor8 = (int)(clip_duration(averageDuration) / clip_duration((double)cp->fpsDenom / cp->fpsNum) * 256);
+        double wd = 0.0;
+        if (ref0Distance && frame->weightedCostDelta[ref0Distance - 1] > 0)
+            wd = 1.0 - frame->weightedCostDelta[ref0Distance - 1];
+        orc_cutree_finish_qg8(frame->widthInCU, frame->heightInCU, frame->intraCost, frame->invQscaleFactor,
+                              frame->propagateCost, fpsFactor8, wd, 5.0 * (1.0 - cp->qCompress), frame->qpAqOffset,
+                              frame->qpCuTreeOffset);
+        return;
+    }
     int fpsFactor = (int)(clip_duration(averageDuration) / clip_duration((double)cp->fpsDenom / cp->fpsNum) * 256);
     double strength = 5.0 * (1.0 - cp->qCompress);      /* m_cuTreeStrength, :1075 */
     double weightdelta = 0.0;
@@ -237,7 +252,7 @@ void orc_cutree(orc_tld* t, const orc_param* p, const orc_cutree_param* cp, orc_
         if (bIntra)
         {
             memset(frames[0]->propagateCost, 0, cuCount * sizeof(uint16_t));
-            memcpy(frames[0]->qpCuTreeOffset, frames[0]->qpAqOffset, cuCount * sizeof(double));
+            memcpy(frames[0]->qpCuTreeOffset, frames[0]->qpAqOffset, cuCount * (frames[0]->qg8 ? 4 : 1) * sizeof(double));
             free(scratch);
             return;
         }

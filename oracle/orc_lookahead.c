@@ -62,8 +62,9 @@ orc_lowres* orc_lowres_create(const orc_param* p, int withAq)
     {
         lr->invQscaleFactor = (int*)calloc(lr->cuCount, sizeof(int));
         lr->propagateCost = (uint16_t*)calloc(lr->cuCount, sizeof(uint16_t));
-        lr->qpAqOffset = (double*)calloc(lr->cuCount, sizeof(double));
-        lr->qpCuTreeOffset = (double*)calloc(lr->cuCount, sizeof(double));
+        lr->qg8 = p->qgSize == 8;
+        lr->qpAqOffset = (double*)calloc((size_t)lr->cuCount * (lr->qg8 ? 4 : 1), sizeof(double));
+        lr->qpCuTreeOffset = (double*)calloc((size_t)lr->cuCount * (lr->qg8 ? 4 : 1), sizeof(double));
     }
     lr->intraCost = (int32_t*)malloc(sizeof(int32_t) * lr->cuCount);
     lr->intraMode = (uint8_t*)malloc(lr->cuCount);
@@ -1163,6 +1164,7 @@ int64_t orc_lowres_i64(orc_lowres* lr, const char* f, int i, int j)
     if (!strcmp(f, "bLastMiniGopBFrame")) return lr->bLastMiniGopBFrame;
     if (!strcmp(f, "leadingBframes")) return lr->leadingBframes;
     if (!strcmp(f, "indB")) return lr->indB;
+    if (!strcmp(f, "qg8")) return lr->qg8;
     if (!strcmp(f, "weightedCostDelta")) return (int64_t)lr->weightedCostDelta[i];
     return -1;
 }

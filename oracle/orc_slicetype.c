@@ -318,7 +318,7 @@ static int hist_based_scenecut(orc_la* la, orc_lowres** frames, int p0, int p1, 
     return frames[p1]->bScenecut;
 }
 
-/* ---- :4068-4145 (qgSize > 8, no hevcAq) ---- */
+/* ---- :4068-4145 (no hevcAq) ---- */
 int64_t orc_frame_cost_recalculate(orc_lowres** frames, int p0, int p1, int b)
 {
     orc_lowres* f = frames[b];
@@ -336,7 +336,13 @@ int64_t orc_frame_cost_recalculate(orc_lowres** frames, int p0, int p1, int b)
         {
             int cuxy = cux + cuy * W;
             int cuCost = f->lowresCosts[b - p0][p1 - b][cuxy] & ORC_LOWRES_COST_MASK;
-            cuCost = (cuCost * orc_exp2fix8(qp_offset[cuxy]) + 128) >> 8;
+            double qp_adj;
+            if (f->qg8)
+                qp_adj = (qp_offset[cux * 2 + cuy * W * 4] + qp_offset[cux * 2 + cuy * W * 4 + 1] +
+                          qp_offset[cux * 2 + cuy * W * 4 + 2 * W] + qp_offset[cux * 2 + cuy * W * 4 + 2 * W + 1]) / 4;
+            else
+                qp_adj = qp_offset[cuxy];
+            cuCost = (cuCost * orc_exp2fix8(qp_adj) + 128) >> 8;
             f->recalcRowSatds[cuy] += cuCost;
             if ((cuy > 0 && cuy < H - 1 && cux > 0 && cux < W - 1) || W <= 2 || H <= 2)
                 score += cuCost;

@@ -41,18 +41,20 @@ def chroma_for(clip, depth, seed):
 def oracle_lookahead(clip, chroma, depth, p, **param_kw):
     """-> (orc.Lookahead with every frame pre-analysed, orc.SliceDecider).  p: api.LookaheadParam.MEDIUM-style dict."""
     h, w = clip.shape[1:]
-    param = orc.make_param(w, h, bframes=p["bframes"], weightp=bool(p["bEnableWeightedPred"]),
-                           bframe_bias=p["bFrameBias"], **param_kw)
     aq_on = bool(p["bAdaptiveQuant"])
+    qg = p.get("qgSize", 32) if aq_on else 32
+    param = orc.make_param(w, h, bframes=p["bframes"], weightp=bool(p["bEnableWeightedPred"]),
+                           bframe_bias=p["bFrameBias"], qg_size=qg, **param_kw)
     look = orc.Lookahead(depth, param, with_aq=True)
     for i, y in enumerate(clip):
         if aq_on:
             res = orc.calc_adaptive_quant_frame(
                 depth, y, chroma[i][0], chroma[i][1], p["aqMode"], p["aqStrength"],
                 weightp=bool(p["bEnableWeightedPred"] or p["bEnableWeightedBiPred"]),
-                block_variance=bool(p.get("bEnableFades")))
+                block_variance=bool(p.get("bEnableFades")), qg_size=qg)
             qa, qc, inv, wsum, wssd = res[:5]
-            lr = look.add_frame(y, inv)
+            # with qgSize 8 the estimates read invQscaleFactor8x8; the offset arrays are per 8x8 source block
+            lr = look.add_frame(y, res[5] if qg == 8 else inv)
             if p.get("bEnableFades"):
                 orc.set_frame_variance(lr, res[-1])
             lr.qp_aq_offset()[:] = qa

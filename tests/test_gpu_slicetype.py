@@ -126,6 +126,10 @@ CASES = [
     {"bAQMotion": 1, "poolWorkers": 16},                      # ... with both batches (costs measured ahead must not go stale)
     {"bAQMotion": 1, "poolWorkers": 16, "vbvBufferSize": 1000, "vbvMaxBitrate": 1000, "bBPyramid": 0},
     {"bAQMotion": 1, "cuTree": 0},
+    {"qgSize": 8},                                            # --qg-size 8: invQscaleFactor8x8, offsets per 8x8 source block
+    {"qgSize": 8, "poolWorkers": 16, "vbvBufferSize": 1000, "vbvMaxBitrate": 1000},   # ... and frameCostRecalculate's mean of four
+    {"qgSize": 8, "bFrameAdaptive": 1, "bEnableWeightedPred": 0},
+    {"qgSize": 16, "bEnableFades": 1},
 ]
 
 

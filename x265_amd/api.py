@@ -942,7 +942,7 @@ class HostLookahead:
         return self.H.xgh_lookahead_slot(self.h, frame)
 
     def qp_offsets(self, frame, cutree=False):
-        n = self.ctx.geom.cuCount
+        n = self.ctx.geom.cuCount * (4 if self.param.bAdaptiveQuant and self.param.qgSize == 8 else 1)
         return np.ctypeslib.as_array(self.H.xgh_lookahead_qp_offsets(self.h, frame, int(cutree)), shape=(n,)).copy()
 
     def inv_qscale(self, frame):

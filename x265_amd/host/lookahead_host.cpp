@@ -642,8 +642,12 @@ void CuTree::cuTreeFinish(Lowres& frame, double averageDuration, int ref0Distanc
     double weightdelta = 0.0;
     if (ref0Distance && frame.weightedCostDelta[ref0Distance - 1] > 0)
         weightdelta = 1.0 - frame.weightedCostDelta[ref0Distance - 1];
-    note(x265gpu_cutree_finish(m_ctx, frame.slot, fpsFactor, weightdelta, m_cuTreeStrength, frame.qpAqOffset,
-                               frame.qpCuTreeOffset));
+    if (m_p.qgSize == 8)
+        note(x265gpu_cutree_finish_qg8(m_ctx, frame.slot, fpsFactor, weightdelta, m_cuTreeStrength, frame.qpAqOffset,
+                                       frame.qpCuTreeOffset));
+    else
+        note(x265gpu_cutree_finish(m_ctx, frame.slot, fpsFactor, weightdelta, m_cuTreeStrength, frame.qpAqOffset,
+                                   frame.qpCuTreeOffset));
 }
 
 void CuTree::estimateCUPropagate(Lowres* const* frames, double averageDuration, int p0, int p1, int b, int referenced)
@@ -684,7 +688,7 @@ int CuTree::cuTree(Lowres* const* frames, int numframes, bool bIntra)
             note(x265gpu_cutree_clear(m_ctx, frames[0]->slot));
             x265gpu_geometry g;
             x265gpu_get_geometry(m_ctx, &g);
-            memcpy(frames[0]->qpCuTreeOffset, frames[0]->qpAqOffset, sizeof(double) * g.cuCount);
+            memcpy(frames[0]->qpCuTreeOffset, frames[0]->qpAqOffset, sizeof(double) * g.cuCount * (m_p.qgSize == 8 ? 4 : 1));
             return m_status;
         }
         note(x265gpu_cutree_swap(m_ctx, frames[lastnonb]->slot, frames[0]->slot));
@@ -763,7 +767,7 @@ int CuTree::cuTree(Lowres* const* frames, int numframes, bool bIntra)
 // (the skip shortcut of estimateCUCost makes an L0 vector depend on that), so any other order gives other
 // vectors.  What differs from x265 is only where a request is computed: CostEstimateGroup sends it to the device.
 // Not covered (unsupported() says so): zones, analysis load, --mcstf
-// batches, more than two temporal sub-layers, qgSize 8 and rc.hevcAq in frameCostRecalculate.
+// batches, more than two temporal sub-layers, rc.hevcAq, --aq-motion together with qgSize 8.
 
 // x265_exp2fix8 (source/common/common.cpp:96-103) over x265_exp2_lut (source/common/constants.cpp:552-558),
 // whose entries are round(256 * (2^(i/64) - 1)); inside x265 this is the function itself
@@ -818,7 +822,10 @@ int Lookahead::unsupported() const
 {
     const LookaheadParam& p = m_param;
     if (p.bEnableTemporalSubLayers > 2 || p.bframes > X265GPU_BFRAME_MAX || p.lookaheadDepth > LOOKAHEAD_MAX ||
-        (p.bAdaptiveQuant && (p.aq.qgSize == 8 || p.aq.bHevcAq)) || p.keyframeMin < 1 ||
+        (p.bAdaptiveQuant && p.aq.bHevcAq) || p.keyframeMin < 1 ||
+        // calcMotionAdaptiveQuantFrame indexes the qgSize 8 offset arrays by lowres block (:3648-3658) and changes
+        // invQscaleFactor, which no estimate reads then: the device form would install those as the slot's factors
+        (p.bAQMotion && p.aq.qgSize == 8) ||
         (p.cuTree && !p.lookaheadDepth))          // Encoder::configure turns cuTree off without a lookahead (encoder.cpp:4103)
         return X265GPU_ERR_UNSUPPORTED;
     return X265GPU_OK;
@@ -857,6 +864,7 @@ void Lookahead::cuTree(Lowres** frames, int numframes, bool bIntra)
     cp.qCompress = m_param.qCompress;
     cp.bEnableWeightedPred = m_param.bEnableWeightedPred;
     cp.bitDepth = m_param.bitDepth;
+    cp.qgSize = m_param.bAdaptiveQuant ? m_param.aq.qgSize : 32;
     cp.trace = &m_trace;
     note(CuTree(m_ctx, cp).cuTree(frames, numframes, bIntra));
 }
@@ -1049,6 +1057,7 @@ int64_t Lookahead::frameCostRecalculate(Lowres* const* frames, int p0, int p1, i
         return -1;
     }
     f.recalcRowSatds.assign(H, 0);
+    const bool qg8 = m_param.bAdaptiveQuant && m_param.aq.qgSize == 8;
     int64_t score = 0;
     const bool tiny = W <= 2 || H <= 2;
     for (int y = H - 1; y >= 0; y--)
@@ -1056,7 +1065,16 @@ int64_t Lookahead::frameCostRecalculate(Lowres* const* frames, int p0, int p1, i
         {
             const int i = x + y * W;
             int c = costs[i] & 0x3FFF;                                  // LOWRES_COST_MASK
-            c = (c * exp2fix8(f.qpCuTreeOffset[i]) + 128) >> 8;
+            double qpAdj;
+            if (qg8)
+            {
+                // the four 8x8 source blocks under the lowres block, rows of maxBlocksInRowFullRes = 2 W entries
+                const double* q = f.qpCuTreeOffset + x * 2 + y * W * 4;
+                qpAdj = (q[0] + q[1] + q[2 * W] + q[2 * W + 1]) / 4;
+            }
+            else
+                qpAdj = f.qpCuTreeOffset[i];
+            c = (c * exp2fix8(qpAdj) + 128) >> 8;
             f.recalcRowSatds[y] += c;
             if (tiny || (y > 0 && y < H - 1 && x > 0 && x < W - 1))
                 score += c;
@@ -2032,6 +2050,7 @@ struct xgh_lookahead
     Lookahead* la;
     std::deque<LaFrame> frames;           // stable addresses: frames are only appended
     int cuCount;
+    bool qg8;
 };
 
 xgh_lookahead* xgh_lookahead_create(x265gpu_ctx* ctx, const xgh_lookahead_param* p)
@@ -2075,6 +2094,9 @@ xgh_lookahead* xgh_lookahead_create(x265gpu_ctx* ctx, const xgh_lookahead_param*
     q.bHistBasedSceneCut = p->bHistBasedSceneCut != 0;
     q.bEnableFades = p->bEnableFades != 0;
     q.aq.bBlockVariance = q.bEnableFades;     // param->bDynamicRefine || param->bEnableFades (slicetype.cpp:688)
+    q.aq.qgSize = p->qgSize ? p->qgSize : 32;
+    q.aq.bHevcAq = p->bHevcAq;
+    q.aq.qpAdaptationRange = p->qpAdaptationRange;
     if (q.bAQMotion)
         q.bAdaptiveQuant = true;              // Lookahead::m_bAdaptiveQuant (slicetype.cpp:1080-1084)
     xgh_lookahead* h = new xgh_lookahead;
@@ -2088,6 +2110,7 @@ xgh_lookahead* xgh_lookahead_create(x265gpu_ctx* ctx, const xgh_lookahead_param*
     x265gpu_geometry g;
     x265gpu_get_geometry(ctx, &g);
     h->cuCount = g.cuCount;
+    h->qg8 = q.bAdaptiveQuant && q.aq.qgSize == 8;
     return h;
 }
 
@@ -2108,9 +2131,11 @@ int xgh_lookahead_add_picture(xgh_lookahead* h, const void* y, const void* u, co
     const int idx = (int)h->frames.size();
     h->frames.emplace_back();
     LaFrame& f = h->frames.back();
-    f.qpAq.assign(h->cuCount, 0.0);
-    f.qpCuTree.assign(h->cuCount, 0.0);
-    f.invQ.assign(h->cuCount, 0);
+    // Lowres::create: cuCountFullRes entries with qgSize 8, zeroed (lowres.cpp:92-116)
+    const size_t offsets = (size_t)h->cuCount * (h->qg8 ? 4 : 1);
+    f.qpAq.assign(offsets, 0.0);
+    f.qpCuTree.assign(offsets, 0.0);
+    f.invQ.assign(offsets, 0);
     f.lowres.slot = idx;
     f.lowres.frameNum = idx;
     f.lowres.qpAqOffset = f.qpAq.data();
@@ -2186,7 +2211,8 @@ const double* xgh_lookahead_qp_offsets(const xgh_lookahead* h, int32_t frame, in
 const int32_t* xgh_lookahead_inv_qscale(const xgh_lookahead* h, int32_t frame)
 {
     lookahead_resolve(h);
-    return h->frames[frame].invQ.data();
+    // what the estimates read: invQscaleFactor8x8 with qgSize 8
+    return h->qg8 ? h->frames[frame].lowres.invQscaleFactor8x8.data() : h->frames[frame].invQ.data();
 }
 const int64_t* xgh_lookahead_planned_satd(const xgh_lookahead* h, int32_t frame, const int32_t** types, int32_t* indB)
 {

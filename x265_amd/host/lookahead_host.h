@@ -82,7 +82,8 @@ struct Lowres
     uint64_t wp_sum = 0, wp_ssd = 0;  // plane 0, as calcAdaptiveQuantFrame leaves them (slicetype.cpp:663-686)
     bool weighted[MAX_D];             // weightedRef[d].isWeighted
     double weightedCostDelta[MAX_D];
-    double* qpAqOffset = nullptr;     // caller-owned, one entry per 8x8 lowres block (16x16 source block)
+    double* qpAqOffset = nullptr;     // caller-owned, one entry per 8x8 lowres block (16x16 source block); with qgSize 8
+                                      // four times as many, one per 8x8 source block (lowres.cpp:92-95)
     double* qpCuTreeOffset = nullptr;
     int32_t* invQscaleFactor = nullptr;   // caller-owned, same shape; filled by the AQ form of processTasks
     std::vector<double> qpAqMotionOffset; // --aq-motion (lowres.cpp:114-115), sized on first use
@@ -201,6 +202,7 @@ struct CuTreeParam
     double qCompress = 0.6;
     bool bEnableWeightedPred = false;             // cuTree's own requests analyse weights like any other
     int bitDepth = 8;
+    int qgSize = 32;                              // rc.qgSize: 8 selects the qgSize 8 loop of cuTreeFinish (:4030-4049)
     std::vector<RequestTrace>* trace = nullptr;
 };
 
@@ -259,7 +261,7 @@ struct LookaheadParam
     bool bAQMotion = false;                       // --aq-motion: offsets raised where a block moves unlike the rest of its frame
     bool bEnableFades = false;                    // --fades: the picture that ends a fade-in of a second or more becomes a keyframe
     bool bAdaptiveQuant = true;                   // Lookahead::m_bAdaptiveQuant: pre-analysis runs calcAdaptiveQuantFrame
-    x265gpu_aq_params aq;                         // its parameters (aqMode, strength, qgSize >= 16, ...)
+    x265gpu_aq_params aq;                         // its parameters (aqMode, strength, qgSize, ...)
     LookaheadParam();
 };
 

@@ -211,6 +211,12 @@ typedef struct orc_lowres {
     int      qg8;                /* rc.qgSize == 8: invQscaleFactor holds Lowres::invQscaleFactor8x8 (what the estimates,
                                   * the intra estimate and cuTree read then: slicetype.cpp:798, 3791, 4532) and the two
                                   * offset arrays hold (2 widthInCU) x (2 heightInCU) doubles (lowres.cpp:92-95) */
+    /* rc.hevcAq: the PicQPAdaptationLayers of the enabled depths (source/common/lowres.cpp:128-155), the one of
+     * minAQDepth last; set with orc_lowres_set_hevc_layer from what xPreanalyze (orc_hevc_aq_layer) produced */
+    int      numAqLayers;
+    struct { int partW, partH, numW, numH; double* dQpOffset; double* dCuTreeOffset; } aqLayer[4];
+    double*  cuTreeOffset8x8;    /* qgSize 8: PicQPAdaptationLayer::dCuTreeOffset8x8 of that last layer */
+    int      sourceWidth, sourceHeight;
     double   frameVariance;      /* calcAdaptiveQuantFrame's tail (slicetype.cpp:688-703), read by the fade detection */
     int      bIsFadeEnd;
     int      sliceType;       /* X265_TYPE_* (source/x265.h) */
@@ -327,6 +333,9 @@ typedef struct orc_hist_stats {
 } orc_hist_stats;
 void orc_lowres_set_hist_stats(orc_lowres* lr, const orc_hist_stats* st);   /* keeps a copy */
 void orc_lowres_set_frame_variance(orc_lowres* lr, double v);
+void orc_lowres_set_hevc_layer(orc_lowres* lr, int k, int partW, int partH, int numW, int numH, const double* dQpOffset,
+                               const double* dCuTreeOffset);      /* layers in increasing depth, k = 0.. */
+double* orc_lowres_hevc_layer(orc_lowres* lr, int k, int which /* 0 dQpOffset, 1 dCuTreeOffset */, int* count);
 int  orc_lowres_is_fade_end(const orc_lowres* lr);
 void orc_collect_picture_statistics(const pixel* lowresPlane0, intptr_t lowresStride, const pixel* y, intptr_t sy,
                                     const pixel* u, const pixel* v, intptr_t sc, int w, int h, orc_hist_stats* out);

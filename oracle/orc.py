@@ -536,6 +536,26 @@ def is_fade_end(lowres):
     return bool(lowres.L.orc_lowres_is_fade_end(C.c_void_p(lowres.h)))
 
 
+def set_hevc_layer(lowres, k, part, num_w, num_h, qp_offset, cutree_offset):
+    """rc.hevcAq: hands a frame layer k (increasing depth, the one of minAQDepth last) as xPreanalyze left it."""
+    L = lowres.L
+    L.orc_lowres_set_hevc_layer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    qp = np.ascontiguousarray(qp_offset, np.float64)
+    tree = np.ascontiguousarray(cutree_offset, np.float64)
+    assert qp.size == num_w * num_h == tree.size
+    L.orc_lowres_set_hevc_layer(C.c_void_p(lowres.h), k, part, part, num_w, num_h, ptr(qp), ptr(tree))
+
+
+def hevc_layer(lowres, k, which):
+    """-> layer k's dQpOffset (which 0) or dCuTreeOffset (1) as the oracle holds it now"""
+    L = lowres.L
+    L.orc_lowres_hevc_layer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.orc_lowres_hevc_layer.restype = C.POINTER(C.c_double)
+    n = C.c_int()
+    p = L.orc_lowres_hevc_layer(C.c_void_p(lowres.h), k, which, C.byref(n))
+    return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+
 def set_hist_stats(lowres, st):
     """Hands a frame its collectPictureStatistics results for the --hist-scenecut decision (the oracle keeps a copy)."""
     lowres.L.orc_lowres_set_hist_stats(C.c_void_p(lowres.h), C.byref(st))

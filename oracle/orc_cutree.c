@@ -46,8 +46,58 @@ void orc_cutree_finish_qg8(int W, int H, const int32_t* intraCost, const int32_t
                            const uint16_t* propagateCost, int fpsFactor, double weightdelta, double strength,
                            const double* qpAqOffset, double* qpCuTreeOffset);
 
+void orc_lowres_set_hevc_layer(orc_lowres* lr, int k, int partW, int partH, int numW, int numH, const double* dQpOffset,
+                               const double* dCuTreeOffset)
+{
+    size_t n = (size_t)numW * numH;
+    lr->aqLayer[k].partW = partW;
+    lr->aqLayer[k].partH = partH;
+    lr->aqLayer[k].numW = numW;
+    lr->aqLayer[k].numH = numH;
+    free(lr->aqLayer[k].dQpOffset);
+    free(lr->aqLayer[k].dCuTreeOffset);
+    lr->aqLayer[k].dQpOffset = (double*)malloc(n * sizeof(double));
+    lr->aqLayer[k].dCuTreeOffset = (double*)malloc(n * sizeof(double));
+    memcpy(lr->aqLayer[k].dQpOffset, dQpOffset, n * sizeof(double));
+    memcpy(lr->aqLayer[k].dCuTreeOffset, dCuTreeOffset, n * sizeof(double));
+    if (k + 1 > lr->numAqLayers)
+        lr->numAqLayers = k + 1;
+    if (lr->qg8 && !lr->cuTreeOffset8x8)
+        lr->cuTreeOffset8x8 = (double*)calloc((size_t)lr->cuCount * 4, sizeof(double));   /* PicQPAdaptationLayer::create */
+}
+
+double* orc_lowres_hevc_layer(orc_lowres* lr, int k, int which, int* count)
+{
+    *count = lr->aqLayer[k].numW * lr->aqLayer[k].numH;
+    return which ? lr->aqLayer[k].dCuTreeOffset : lr->aqLayer[k].dQpOffset;
+}
+
+/* Lookahead::computeCUTreeQpOffset (source/encoder/slicetype.cpp:3876-4014) over the frame's layers */
+static void compute_cutree_qp_offset(const orc_cutree_param* cp, orc_lowres* frame, double averageDuration, int ref0Distance)
+{
+    int fpsFactor = (int)(clip_duration(averageDuration) / clip_duration((double)cp->fpsDenom / cp->fpsNum) * 256);
+    double weightdelta = 0.0;
+    if (ref0Distance && frame->weightedCostDelta[ref0Distance - 1] > 0)
+        weightdelta = 1.0 - frame->weightedCostDelta[ref0Distance - 1];
+    double strength = 6.0 * (1.0 - cp->qCompress);       /* m_cuTreeStrength with rc.hevcAq, :1075 */
+    const int W = frame->widthInCU, H = frame->heightInCU;
+    if (frame->qg8)
+        orc_cutree_ratio8x8(W, H, frame->intraCost, frame->invQscaleFactor, frame->propagateCost, fpsFactor, weightdelta,
+                            frame->cuTreeOffset8x8);
+    for (int k = 0; k < frame->numAqLayers; k++)
+        orc_cutree_hevc_layer(frame->qg8, frame->qg8 ? 2 * W : W, frame->sourceWidth, frame->sourceHeight,
+                              frame->aqLayer[k].partW, frame->aqLayer[k].partH, frame->aqLayer[k].numW, frame->aqLayer[k].numH,
+                              frame->intraCost, frame->invQscaleFactor, frame->propagateCost, fpsFactor, weightdelta, strength,
+                              frame->cuTreeOffset8x8, frame->aqLayer[k].dQpOffset, frame->aqLayer[k].dCuTreeOffset);
+}
+
 void orc_cutree_finish(const orc_cutree_param* cp, orc_lowres* frame, double averageDuration, int ref0Distance)
 {
+    if (frame->numAqLayers)
+    {
+        compute_cutree_qp_offset(cp, frame, averageDuration, ref0Distance);
+        return;
+    }
     if (frame->qg8)
     {
         int fpsFactor8 = (int)(clip_duration(averageDuration) / clip_duration((double)cp->fpsDenom / cp->fpsNum) * 256);

@@ -63,6 +63,8 @@ orc_lowres* orc_lowres_create(const orc_param* p, int withAq)
         lr->invQscaleFactor = (int*)calloc(lr->cuCount, sizeof(int));
         lr->propagateCost = (uint16_t*)calloc(lr->cuCount, sizeof(uint16_t));
         lr->qg8 = p->qgSize == 8;
+        lr->sourceWidth = p->sourceWidth;
+        lr->sourceHeight = p->sourceHeight;
         lr->qpAqOffset = (double*)calloc((size_t)lr->cuCount * (lr->qg8 ? 4 : 1), sizeof(double));
         lr->qpCuTreeOffset = (double*)calloc((size_t)lr->cuCount * (lr->qg8 ? 4 : 1), sizeof(double));
     }
@@ -104,6 +106,12 @@ void orc_lowres_destroy(orc_lowres* lr)
     free(lr->lowerResBuffer[0]);
     free(lr->invQscaleFactor);
     free(lr->propagateCost);
+    for (int k = 0; k < lr->numAqLayers; k++)
+    {
+        free(lr->aqLayer[k].dQpOffset);
+        free(lr->aqLayer[k].dCuTreeOffset);
+    }
+    free(lr->cuTreeOffset8x8);
     free(lr->qpAqOffset);
     free(lr->qpCuTreeOffset);
     free(lr->qpAqMotionOffset);

@@ -12,7 +12,8 @@
  *   Lookahead::histBasedScenecut / detectHistBasedSceneChange     :3323-3482
  *   the fade detection of slicetypeDecide (--fades)               :2042-2088, 2153-2155
  * Not restated (the product's host layer refuses the same settings): zones, analysis load,
- * --mcstf, more than two temporal sub-layers, qgSize 8, rc.hevcAq.
+ * --mcstf, more than two temporal sub-layers.  qgSize 8 and rc.hevcAq act through the frames (orc_lowres::qg8,
+ * aqLayer[]) in cuTreeFinish and frameCostRecalculate.
  * Frames enter already pre-analysed (Lowres::init, AQ, intra estimate are per-frame functions of the
  * picture alone, so running them at addPicture instead of in PreLookaheadGroup changes nothing). */
 #include "orc.h"
@@ -328,7 +329,8 @@ int64_t orc_frame_cost_recalculate(orc_lowres** frames, int p0, int p1, int b)
     const int W = f->widthInCU, H = f->heightInCU;
     if (!f->recalcRowSatds)
         f->recalcRowSatds = (int32_t*)malloc(sizeof(int32_t) * H);
-    const double* qp_offset = f->qpCuTreeOffset;
+    /* rc.hevcAq: the offsets of the layer of minAQDepth stand in for qpCuTreeOffset (:4078-4112) */
+    const double* qp_offset = f->numAqLayers ? f->aqLayer[f->numAqLayers - 1].dCuTreeOffset : f->qpCuTreeOffset;
     for (int cuy = H - 1; cuy >= 0; cuy--)
     {
         f->recalcRowSatds[cuy] = 0;

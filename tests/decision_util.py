@@ -47,7 +47,9 @@ def oracle_lookahead(clip, chroma, depth, p, **param_kw):
                            bframe_bias=p["bFrameBias"], qg_size=qg, **param_kw)
     look = orc.Lookahead(depth, param, with_aq=True)
     for i, y in enumerate(clip):
-        if aq_on:
+        if aq_on and p.get("bHevcAq"):
+            hevc_frame(look, depth, y, chroma[i], p, qg)
+        elif aq_on:
             res = orc.calc_adaptive_quant_frame(
                 depth, y, chroma[i][0], chroma[i][1], p["aqMode"], p["aqStrength"],
                 weightp=bool(p["bEnableWeightedPred"] or p["bEnableWeightedBiPred"]),
@@ -66,6 +68,47 @@ def oracle_lookahead(clip, chroma, depth, p, **param_kw):
         if p.get("bHistBasedSceneCut"):
             orc.set_hist_stats(lr, orc.collect_picture_statistics(lr, y, chroma[i][0], chroma[i][1]))
     return look, orc.SliceDecider(look, p)
+
+
+def hevc_parts(w, h, qg):
+    """The layers Lowres::create makes for a 64x64 CTU (source/common/lowres.h:120-142, lowres.cpp:128-155):
+    (part size, parts in width, parts in height) of the enabled depths; the depth-3 layer has the doubled lowres grid."""
+    w8, h8 = ((w // 2) + 7) >> 3, ((h // 2) + 7) >> 3
+    out = []
+    for d in {64: (0, 2), 32: (0, 1, 2), 16: (0, 1, 2), 8: (0, 1, 2, 3)}[qg]:
+        s = 64 >> d
+        out.append((s, 2 * w8, 2 * h8) if d == 3 else (s, (w + s - 1) // s, (h + s - 1) // s))
+    return out
+
+
+def hevc_frame(look, depth, y, uv, p, qg):
+    """rc.hevcAq pre-analysis of one frame on the oracle side: xPreanalyze per layer (orc_hevc_aq_layer), the scale
+    factors from the finest layer's offsets in visiting order (slicetype.cpp:441-447), the qgSize 8 means (:647-660),
+    and the wp sums of the closing energy round."""
+    L = look.L
+    h, w = y.shape
+    w8, h8 = ((w // 2) + 7) >> 3, ((h // 2) + 7) >> 3
+    layers = []
+    for (s, nw, nh) in hevc_parts(w, h, qg):
+        act, qp, tree = (np.zeros(nw * nh) for _ in range(3))
+        L.orc_hevc_aq_layer(orc.ptr(y), y.strides[0] // y.itemsize, w, h, s, s, nw, nh, float(p["qpAdaptationRange"]),
+                            orc.ptr(act), orc.ptr(qp), orc.ptr(tree))
+        layers.append((s, nw, nh, qp, tree))
+    blk = 8 if qg == 8 else 16
+    visited = ((w + blk - 1) // blk) * ((h + blk - 1) // blk)
+    inv = np.zeros(w8 * h8 * (4 if qg == 8 else 1), np.int32)
+    inv[:visited] = [L.orc_exp2fix8(float(q)) for q in layers[-1][3][:visited]]
+    if qg == 8:
+        grid = inv.reshape(2 * h8, 2 * w8)
+        inv = ((grid[0::2, 0::2] + grid[0::2, 1::2] + grid[1::2, 0::2] + grid[1::2, 1::2]) // 4).reshape(-1).astype(np.int32)
+    lr = look.add_frame(y, np.ascontiguousarray(inv))
+    for k, (s, nw, nh, qp, tree) in enumerate(layers):
+        orc.set_hevc_layer(lr, k, s, nw, nh, qp, tree)
+    ref = orc.calc_adaptive_quant_frame(depth, y, uv[0], uv[1], p["aqMode"], p["aqStrength"],
+                                        weightp=bool(p["bEnableWeightedPred"] or p["bEnableWeightedBiPred"]), qg_size=qg)
+    s_, d_ = lr.wp()
+    s_[:], d_[:] = ref[3], ref[4]
+    return lr
 
 
 def look_ncu(param):

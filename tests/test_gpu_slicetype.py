@@ -54,6 +54,15 @@ def _compare(clip, chroma, depth, p, forced=None, ctx_kw=None, param_kw=None):
                     np.testing.assert_array_equal(la.qp_offsets(i, True), fr.qp_cutree_offset(), err_msg="qpCuTreeOffset %d" % i)
             if p["cuTree"]:
                 np.testing.assert_array_equal(ctx.cutree_get_propagate_cost(i), fr.propagate_cost(), err_msg="propagateCost %d" % i)
+            if p["bAdaptiveQuant"] and p.get("bHevcAq"):
+                for which in (0, 1):
+                    have = la.aq_layers(i, which)
+                    assert len(have) == len(du.hevc_parts(W, H, p["qgSize"]))
+                    for k, a in enumerate(have):
+                        np.testing.assert_array_equal(a, orc.hevc_layer(fr, k, which), err_msg="layer %d of frame %d (%d)" % (k, i, which))
+        if p["bAdaptiveQuant"] and p.get("bHevcAq") and p["cuTree"]:
+            # computeCUTreeQpOffset did run: some frame's tree offsets left its AQ offsets
+            assert any((la.aq_layers(i, 1)[-1] != la.aq_layers(i, 0)[-1]).any() for i in range(N))
         seen_mv = set()
         for (p0, p1, b, do0, do1, _batch) in t_want.tolist():
             d0, d1 = b - p0, p1 - b
@@ -130,6 +139,10 @@ CASES = [
     {"qgSize": 8, "poolWorkers": 16, "vbvBufferSize": 1000, "vbvMaxBitrate": 1000},   # ... and frameCostRecalculate's mean of four
     {"qgSize": 8, "bFrameAdaptive": 1, "bEnableWeightedPred": 0},
     {"qgSize": 16, "bEnableFades": 1},
+    {"bHevcAq": 1, "qpAdaptationRange": 1.5},                 # --hevc-aq: layers of offsets, computeCUTreeQpOffset
+    {"bHevcAq": 1, "qgSize": 8, "poolWorkers": 16, "vbvBufferSize": 1000, "vbvMaxBitrate": 1000},
+    {"bHevcAq": 1, "qgSize": 16, "vbvBufferSize": 1000, "vbvMaxBitrate": 1000, "bBPyramid": 0},
+    {"bHevcAq": 1, "qgSize": 64, "bFrameAdaptive": 1},
 ]
 
 

@@ -624,7 +624,7 @@ HOST_EXPORTS = (
     "xgh_lookahead_intra_mbs", "xgh_lookahead_slot", "xgh_lookahead_qp_offsets", "xgh_lookahead_inv_qscale",
     "xgh_lookahead_planned_satd", "xgh_lookahead_recalc_row_satds", "xgh_lookahead_decide_calls", "xgh_lookahead_presearch_hits", "xgh_lookahead_precost_hits", "xgh_lookahead_seconds",
     "xgh_tme_create", "xgh_tme_destroy", "xgh_tme_unsupported", "xgh_tme_estimate_rows", "xgh_tme_estimate_rows_b", "xgh_tme_seconds", "xgh_tme_counts",
-    "xgh_tme_set_cu_qp", "xgh_tme_cus_per_ctu", "xgh_tme_set_temporal",
+    "xgh_tme_set_cu_qp", "xgh_tme_cus_per_ctu", "xgh_tme_set_temporal", "xgh_lookahead_aq_layer",
 )
 
 
@@ -640,14 +640,15 @@ class LookaheadParam(C.Structure):
                 ("poolWorkers", C.c_int32), ("bAdaptiveQuant", C.c_int32), ("aqMode", C.c_int32), ("aqStrength", C.c_double),
                 ("bPresearch", C.c_int32), ("lookaheadSlices", C.c_int32), ("bAQMotion", C.c_int32),
                 ("bHistBasedSceneCut", C.c_int32), ("bEnableFades", C.c_int32), ("qgSize", C.c_int32),
-                ("bHevcAq", C.c_int32), ("qpAdaptationRange", C.c_double)]
+                ("bHevcAq", C.c_int32), ("qpAdaptationRange", C.c_double), ("maxCUSize", C.c_int32)]
 
     MEDIUM = dict(bframes=4, lookaheadDepth=20, bFrameAdaptive=2, bBPyramid=1, scenecutThreshold=40, scenecutBias=0.05,
                   keyframeMin=25, keyframeMax=250, bOpenGOP=1, bIntraRefresh=0, radl=0, gopLookahead=0, cuTree=1,
                   bFrameBias=0, vbvBufferSize=0, vbvMaxBitrate=0, bCqp=0, bEnableTemporalSubLayers=0, maxNumReferences=3,
                   bEnableWeightedPred=1, bEnableWeightedBiPred=0, fpsNum=30, fpsDenom=1, qCompress=0.6, bitDepth=8,
                   poolWorkers=0, bAdaptiveQuant=1, aqMode=2, aqStrength=1.0, bPresearch=1, lookaheadSlices=0,
-                  bAQMotion=0, bHistBasedSceneCut=0, bEnableFades=0, qgSize=32, bHevcAq=0, qpAdaptationRange=1.0)
+                  bAQMotion=0, bHistBasedSceneCut=0, bEnableFades=0, qgSize=32, bHevcAq=0, qpAdaptationRange=1.0,
+                  maxCUSize=64)
 
     def __init__(self, **kw):
         super().__init__()
@@ -722,6 +723,7 @@ def load_host_library():
     H.xgh_lookahead_qp_offsets.restype = C.POINTER(C.c_double)
     H.xgh_lookahead_inv_qscale.argtypes = [vp, i32]
     H.xgh_lookahead_inv_qscale.restype = C.POINTER(i32)
+    H.xgh_lookahead_aq_layer.argtypes = [vp, i32, i32, i32, C.POINTER(C.POINTER(C.c_double)), C.POINTER(i32)]
     H.xgh_lookahead_planned_satd.argtypes = [vp, i32, C.POINTER(C.POINTER(i32)), C.POINTER(i32)]
     H.xgh_lookahead_planned_satd.restype = C.POINTER(i64)
     H.xgh_lookahead_recalc_row_satds.argtypes = [vp, i32]
@@ -944,6 +946,16 @@ class HostLookahead:
     def qp_offsets(self, frame, cutree=False):
         n = self.ctx.geom.cuCount * (4 if self.param.bAdaptiveQuant and self.param.qgSize == 8 else 1)
         return np.ctypeslib.as_array(self.H.xgh_lookahead_qp_offsets(self.h, frame, int(cutree)), shape=(n,)).copy()
+
+    def aq_layers(self, frame, which):
+        """rc.hevcAq: the frame's layers' dQpOffset (which 0) or dCuTreeOffset (1), the layer of minAQDepth last"""
+        out = []
+        p, n = C.POINTER(C.c_double)(), C.c_int32()
+        count = self.H.xgh_lookahead_aq_layer(self.h, frame, 0, which, C.byref(p), C.byref(n))
+        for k in range(count):
+            self.H.xgh_lookahead_aq_layer(self.h, frame, k, which, C.byref(p), C.byref(n))
+            out.append(np.ctypeslib.as_array(p, shape=(n.value,)).copy())
+        return out
 
     def inv_qscale(self, frame):
         n = self.ctx.geom.cuCount

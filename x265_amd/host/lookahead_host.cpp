@@ -172,6 +172,68 @@ int LookaheadTLD::weightsAnalyse(int n, Lowres* const* fencs, Lowres* const* ref
     return X265GPU_OK;
 }
 
+// aqLayerDepth (source/common/lowres.h:120-139) as one bit per enabled depth, by CTU size (64, 32, 16) and
+// log2(maxCUSize) - log2(qgSize); minAQSize (:142) is the depth whose layer has the doubled lowres grid
+static const unsigned char kAqDepthMask[3][4] = { { 0x5, 0x7, 0x7, 0xf }, { 0x3, 0x3, 0x7, 0x0 }, { 0x1, 0x3, 0x0, 0x0 } };
+static const int kMinAqSize[3] = { 3, 2, 1 };
+
+void Lowres::createAqLayers(const x265gpu_geometry& g, int maxCUSize, int qgSize)
+{
+    aqLayers.clear();
+    int log2Ctu = 0, log2Qg = 0;
+    while ((1 << log2Ctu) < maxCUSize)
+        log2Ctu++;
+    while ((1 << log2Qg) < qgSize)
+        log2Qg++;
+    const int ctuSizeIdx = 6 - log2Ctu, aqDepth = log2Ctu - log2Qg;
+    if (ctuSizeIdx < 0 || ctuSizeIdx > 2 || aqDepth < 0 || aqDepth > 3)
+        return;
+    for (int d = 0; d < 4; d++)
+    {
+        if (!(kAqDepthMask[ctuSizeIdx][aqDepth] >> d & 1))
+            continue;
+        AqLayer l;
+        l.partWidth = l.partHeight = maxCUSize >> d;
+        if (kMinAqSize[ctuSizeIdx] == d)
+        {
+            l.numPartInWidth = g.widthInCU * 2;
+            l.numPartInHeight = g.heightInCU * 2;
+        }
+        else
+        {
+            l.numPartInWidth = (g.sourceWidth + l.partWidth - 1) / l.partWidth;
+            l.numPartInHeight = (g.sourceHeight + l.partHeight - 1) / l.partHeight;
+        }
+        const size_t n = (size_t)l.numPartInWidth * l.numPartInHeight;
+        l.dActivity.assign(n, 0.0);
+        l.dQpOffset.assign(n, 0.0);
+        l.dCuTreeOffset.assign(n, 0.0);
+        l.dAvgActivity = 0;
+        aqLayers.push_back(std::move(l));
+    }
+    if (qgSize == 8)
+        dCuTreeOffset8x8.assign((size_t)g.cuCount * 4, 0.0);
+}
+
+// the frame's layers as the library's call takes them
+static std::vector<x265gpu_hevc_aq_layer> layerDescriptors(Lowres& fr)
+{
+    std::vector<x265gpu_hevc_aq_layer> d(fr.aqLayers.size());
+    for (size_t k = 0; k < d.size(); k++)
+    {
+        Lowres::AqLayer& l = fr.aqLayers[k];
+        d[k].aqPartWidth = l.partWidth;
+        d[k].aqPartHeight = l.partHeight;
+        d[k].numAQPartInWidth = l.numPartInWidth;
+        d[k].numAQPartInHeight = l.numPartInHeight;
+        d[k].dActivity = l.dActivity.data();
+        d[k].dQpOffset = l.dQpOffset.data();
+        d[k].dCuTreeOffset = l.dCuTreeOffset.data();
+        d[k].dAvgActivity = l.dAvgActivity;
+    }
+    return d;
+}
+
 // ---- PreLookaheadGroup ----
 int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const void* const* lumas, const intptr_t* strides,
                                     const int32_t* const* invQscale)
@@ -272,12 +334,23 @@ int PreLookaheadGroup::processTasks(int n, Lowres* const* frames, const Picture*
                 fr.invQscaleFactor8x8.assign((size_t)g.cuCount, 0);
                 q.invQscaleFactor8x8 = fr.invQscaleFactor8x8.data();
             }
+            std::vector<x265gpu_hevc_aq_layer> layers;
+            if (aq.bHevcAq)
+            {
+                if (fr.aqLayers.empty())
+                    return X265GPU_ERR_ARG;             // the caller creates them (Lowres::createAqLayers)
+                layers = layerDescriptors(fr);
+                q.numLayers = (int32_t)layers.size();
+                q.layers = layers.data();
+            }
             uint64_t wpSum[3], wpSsd[3];
             rc = x265gpu_aq_frame(m_ctx, fr.slot, pics[i].y, pics[i].strideY, pics[i].u, pics[i].v, pics[i].strideC,
                                   pics[i].memKind, &q, ap[i].quantOffsets, fr.qpAqOffset, fr.qpCuTreeOffset,
                                   fr.invQscaleFactor, wpSum, wpSsd);
             if (rc != X265GPU_OK)
                 return rc;
+            for (size_t k = 0; k < layers.size(); k++)
+                fr.aqLayers[k].dAvgActivity = layers[k].dAvgActivity;
             fr.wp_sum = wpSum[0];
             fr.wp_ssd = wpSsd[0];
             fr.intraTotalsPending = true;
@@ -633,7 +706,7 @@ static double clipDuration(double f) { return f < 0.01 ? 0.01 : (f > 1.0 ? 1.0 :
 CuTree::CuTree(x265gpu_ctx* ctx, const CuTreeParam& p) : m_ctx(ctx), m_p(p)
 {
     m_frameDuration = (double)p.fpsDenom / p.fpsNum;
-    m_cuTreeStrength = 5.0 * (1.0 - p.qCompress);
+    m_cuTreeStrength = (p.bHevcAq ? 6.0 : 5.0) * (1.0 - p.qCompress);
 }
 
 void CuTree::cuTreeFinish(Lowres& frame, double averageDuration, int ref0Distance)
@@ -642,7 +715,16 @@ void CuTree::cuTreeFinish(Lowres& frame, double averageDuration, int ref0Distanc
     double weightdelta = 0.0;
     if (ref0Distance && frame.weightedCostDelta[ref0Distance - 1] > 0)
         weightdelta = 1.0 - frame.weightedCostDelta[ref0Distance - 1];
-    if (m_p.qgSize == 8)
+    if (m_p.bHevcAq)
+    {
+        // computeCUTreeQpOffset (:3876-4014): every layer's dCuTreeOffset from its dQpOffset
+        std::vector<x265gpu_hevc_aq_layer> layers = layerDescriptors(frame);
+        note(layers.empty() ? X265GPU_ERR_ARG
+                            : x265gpu_cutree_finish_hevc(m_ctx, frame.slot, fpsFactor, weightdelta, m_cuTreeStrength, m_p.qgSize,
+                                                         (int32_t)layers.size(), layers.data(),
+                                                         m_p.qgSize == 8 ? frame.dCuTreeOffset8x8.data() : nullptr));
+    }
+    else if (m_p.qgSize == 8)
         note(x265gpu_cutree_finish_qg8(m_ctx, frame.slot, fpsFactor, weightdelta, m_cuTreeStrength, frame.qpAqOffset,
                                        frame.qpCuTreeOffset));
     else
@@ -822,7 +904,7 @@ int Lookahead::unsupported() const
 {
     const LookaheadParam& p = m_param;
     if (p.bEnableTemporalSubLayers > 2 || p.bframes > X265GPU_BFRAME_MAX || p.lookaheadDepth > LOOKAHEAD_MAX ||
-        (p.bAdaptiveQuant && p.aq.bHevcAq) || p.keyframeMin < 1 ||
+        (p.aq.bHevcAq && (p.bAQMotion || (p.maxCUSize != 64 && p.maxCUSize != 32 && p.maxCUSize != 16))) || p.keyframeMin < 1 ||
         // calcMotionAdaptiveQuantFrame indexes the qgSize 8 offset arrays by lowres block (:3648-3658) and changes
         // invQscaleFactor, which no estimate reads then: the device form would install those as the slot's factors
         (p.bAQMotion && p.aq.qgSize == 8) ||
@@ -865,6 +947,7 @@ void Lookahead::cuTree(Lowres** frames, int numframes, bool bIntra)
     cp.bEnableWeightedPred = m_param.bEnableWeightedPred;
     cp.bitDepth = m_param.bitDepth;
     cp.qgSize = m_param.bAdaptiveQuant ? m_param.aq.qgSize : 32;
+    cp.bHevcAq = m_param.bAdaptiveQuant && m_param.aq.bHevcAq;
     cp.trace = &m_trace;
     note(CuTree(m_ctx, cp).cuTree(frames, numframes, bIntra));
 }
@@ -1058,6 +1141,9 @@ int64_t Lookahead::frameCostRecalculate(Lowres* const* frames, int p0, int p1, i
     }
     f.recalcRowSatds.assign(H, 0);
     const bool qg8 = m_param.bAdaptiveQuant && m_param.aq.qgSize == 8;
+    // rc.hevcAq: the offsets of the layer of minAQDepth stand in for qpCuTreeOffset (:4078-4112)
+    const double* qpOffset = m_param.bAdaptiveQuant && m_param.aq.bHevcAq && !f.aqLayers.empty()
+                                 ? f.aqLayers.back().dCuTreeOffset.data() : f.qpCuTreeOffset;
     int64_t score = 0;
     const bool tiny = W <= 2 || H <= 2;
     for (int y = H - 1; y >= 0; y--)
@@ -1069,11 +1155,11 @@ int64_t Lookahead::frameCostRecalculate(Lowres* const* frames, int p0, int p1, i
             if (qg8)
             {
                 // the four 8x8 source blocks under the lowres block, rows of maxBlocksInRowFullRes = 2 W entries
-                const double* q = f.qpCuTreeOffset + x * 2 + y * W * 4;
+                const double* q = qpOffset + x * 2 + y * W * 4;
                 qpAdj = (q[0] + q[1] + q[2 * W] + q[2 * W + 1]) / 4;
             }
             else
-                qpAdj = f.qpCuTreeOffset[i];
+                qpAdj = qpOffset[i];
             c = (c * exp2fix8(qpAdj) + 128) >> 8;
             f.recalcRowSatds[y] += c;
             if (tiny || (y > 0 && y < H - 1 && x > 0 && x < W - 1))
@@ -1687,6 +1773,10 @@ void Lookahead::slicetypeDecide()
         std::vector<Picture> pics(pre.size());
         for (size_t i = 0; i < pre.size(); i++)
             pics[i] = pre[i]->pic;
+        if (P.bAdaptiveQuant && P.aq.bHevcAq)
+            for (Lowres* f : pre)
+                if (f->aqLayers.empty())
+                    f->createAqLayers(m_geom, P.maxCUSize, P.aq.qgSize);
         if (P.bAdaptiveQuant)
             note(group.processTasks((int)pre.size(), pre.data(), pics.data(), P.aq, nullptr));
         else
@@ -2097,6 +2187,9 @@ xgh_lookahead* xgh_lookahead_create(x265gpu_ctx* ctx, const xgh_lookahead_param*
     q.aq.qgSize = p->qgSize ? p->qgSize : 32;
     q.aq.bHevcAq = p->bHevcAq;
     q.aq.qpAdaptationRange = p->qpAdaptationRange;
+    q.maxCUSize = p->maxCUSize ? p->maxCUSize : 64;
+    if (q.aq.bHevcAq)
+        q.bAdaptiveQuant = true;              // Lookahead::m_bAdaptiveQuant (slicetype.cpp:1080-1084)
     if (q.bAQMotion)
         q.bAdaptiveQuant = true;              // Lookahead::m_bAdaptiveQuant (slicetype.cpp:1080-1084)
     xgh_lookahead* h = new xgh_lookahead;
@@ -2213,6 +2306,18 @@ const int32_t* xgh_lookahead_inv_qscale(const xgh_lookahead* h, int32_t frame)
     lookahead_resolve(h);
     // what the estimates read: invQscaleFactor8x8 with qgSize 8
     return h->qg8 ? h->frames[frame].lowres.invQscaleFactor8x8.data() : h->frames[frame].invQ.data();
+}
+int xgh_lookahead_aq_layer(const xgh_lookahead* h, int32_t frame, int32_t layer, int32_t which, const double** out, int32_t* n)
+{
+    lookahead_resolve(h);
+    const std::vector<Lowres::AqLayer>& l = h->frames[frame].lowres.aqLayers;
+    if (layer >= 0 && layer < (int)l.size())
+    {
+        const std::vector<double>& a = which ? l[layer].dCuTreeOffset : l[layer].dQpOffset;
+        *out = a.data();
+        *n = (int32_t)a.size();
+    }
+    return (int)l.size();
 }
 const int64_t* xgh_lookahead_planned_satd(const xgh_lookahead* h, int32_t frame, const int32_t** types, int32_t* indB)
 {

@@ -93,6 +93,17 @@ struct Lowres
     bool bIsFadeEnd = false;
     std::vector<uint32_t> blockVariance;  // its per-block output, sized on first use
     std::vector<int32_t> invQscaleFactor8x8;      // qgSize 8 (lowres.cpp:99-100)
+    // rc.hevcAq: the PicQPAdaptationLayers of the enabled depths (lowres.cpp:128-155), the one of minAQDepth last
+    struct AqLayer
+    {
+        int partWidth, partHeight, numPartInWidth, numPartInHeight;
+        std::vector<double> dActivity, dQpOffset, dCuTreeOffset;
+        double dAvgActivity;
+    };
+    std::vector<AqLayer> aqLayers;
+    std::vector<double> dCuTreeOffset8x8;         // of that last layer, qgSize 8
+    // Lowres::create's layer loop for a picture of the context's size
+    void createAqLayers(const x265gpu_geometry& g, int maxCUSize, int qgSize);
 
     // what the slice-type decision keeps per frame (source/common/lowres.h:166-213)
     int sliceTypeReq = TYPE_AUTO;
@@ -203,6 +214,7 @@ struct CuTreeParam
     bool bEnableWeightedPred = false;             // cuTree's own requests analyse weights like any other
     int bitDepth = 8;
     int qgSize = 32;                              // rc.qgSize: 8 selects the qgSize 8 loop of cuTreeFinish (:4030-4049)
+    bool bHevcAq = false;                         // rc.hevcAq: cuTreeFinish is computeCUTreeQpOffset over the frame's layers
     std::vector<RequestTrace>* trace = nullptr;
 };
 
@@ -259,6 +271,7 @@ struct LookaheadParam
                                                   // > 0 with trellis B-adapt: the two batches of slicetypeAnalyse
     bool bHistBasedSceneCut = false;              // --hist-scenecut: scene cuts from histogram differences of the 4x4 segments
     bool bAQMotion = false;                       // --aq-motion: offsets raised where a block moves unlike the rest of its frame
+    int maxCUSize = 64;                           // read for the layers of rc.hevcAq
     bool bEnableFades = false;                    // --fades: the picture that ends a fade-in of a second or more becomes a keyframe
     bool bAdaptiveQuant = true;                   // Lookahead::m_bAdaptiveQuant: pre-analysis runs calcAdaptiveQuantFrame
     x265gpu_aq_params aq;                         // its parameters (aqMode, strength, qgSize, ...)
@@ -393,6 +406,7 @@ typedef struct xgh_lookahead_param
     int32_t bEnableFades;
     int32_t qgSize, bHevcAq;      /* rc.qgSize (0 = 32), rc.hevcAq */
     double  qpAdaptationRange;    /* rc.qpAdaptationRange */
+    int32_t maxCUSize;            /* 0 = 64 */
 } xgh_lookahead_param;
 typedef struct xgh_decided
 {
@@ -415,6 +429,9 @@ int32_t xgh_lookahead_intra_mbs(const xgh_lookahead* la, int32_t frame, int32_t 
 int32_t xgh_lookahead_slot(const xgh_lookahead* la, int32_t frame);
 const double* xgh_lookahead_qp_offsets(const xgh_lookahead* la, int32_t frame, int32_t which /*0 aq, 1 cuTree*/);
 const int32_t* xgh_lookahead_inv_qscale(const xgh_lookahead* la, int32_t frame);
+/* rc.hevcAq: layer `layer` of the frame (0 .. count - 1, the one of minAQDepth last); which: 0 dQpOffset, 1 dCuTreeOffset;
+ * returns the layer count, *out / *n the array and its length */
+int xgh_lookahead_aq_layer(const xgh_lookahead* la, int32_t frame, int32_t layer, int32_t which, const double** out, int32_t* n);
 /* VBV lookahead results: counts of valid entries come back through n */
 const int64_t* xgh_lookahead_planned_satd(const xgh_lookahead* la, int32_t frame, const int32_t** types, int32_t* indB);
 const int32_t* xgh_lookahead_recalc_row_satds(const xgh_lookahead* la, int32_t frame);

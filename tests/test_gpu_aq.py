@@ -239,6 +239,24 @@ def test_aq_edge_mode(depth, size, qg):
     assert (plain[0] != want[0]).mean() > 0.2
 
 
+@pytest.mark.parametrize("qg", [8, 32])
+def test_aq_edge_mode_full_swing_12bit(qg):
+    """12-bit pictures with black-to-white steps: Sobel gradients of the blurred picture reach 16 * 4095, more than
+    16 bits hold; the pixels whose angle the host decides carry them whole."""
+    W, H, depth = 554, 140, 12
+    rng = np.random.default_rng(615366048)
+    y = rng.integers(0, 4096, (H, W)).astype(np.uint16)
+    blocks = np.repeat(np.repeat(rng.integers(0, 2, (H // 4 + 1, W // 4 + 1)), 4, axis=0), 4, axis=1)[:H, :W]
+    y[H // 2:] = (blocks[H // 2:] * 4095).astype(np.uint16)             # 4x4 checks of 0 / 4095: steep diagonals
+    u = rng.integers(0, 4096, (H // 2, W // 2)).astype(np.uint16)
+    v = rng.integers(1365, 2048, (H // 2, W // 2)).astype(np.uint16)
+    want = orc.calc_adaptive_quant_frame(depth, y, u, v, 4, 0.4, hdr10=True, qg_size=qg)
+    with api.Context(W, H, depth=depth, num_slots=1) as ctx:
+        got = ctx.aq_frame(y, u, v, 4, 0.4, hdr10=True, slot=0, qg_size=qg)
+    for k, (g, w_) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(g, w_, err_msg="output %d" % k)
+
+
 def test_aq_edge_mode_in_bands(monkeypatch):
     """The picture pass in bands of three tile rows (as a picture too large for one list of host-side angles runs)."""
     monkeypatch.setenv("X265GPU_AQ_EDGE_BAND_ROWS", "3")

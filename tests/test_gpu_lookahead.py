@@ -15,12 +15,18 @@ def _setup(width, height, nframes, depth, with_aq=False, seed=1234, bframes=4, c
     """`search` (search=, hme=, hme_methods=, hme_range=) goes to the oracle's param and the context alike."""
     if clip is None:
         clip = synth.luma_clip(width, height, nframes, depth, seed=seed)
-    param = orc.make_param(width, height, bframes=bframes, **search)
+    # an odd size reaches x265's lookahead padded to the minimum CU size with the edge samples repeated
+    # (Encoder::configure, PicYuv): that picture is what the oracle gets, the library gets the raw one
+    ow, oh, oclip = width, height, clip
+    if (width | height) & 1:
+        ow, oh = (width + 7) // 8 * 8, (height + 7) // 8 * 8
+        oclip = np.pad(np.asarray(clip), ((0, 0), (0, oh - height), (0, ow - width)), mode="edge")
+    param = orc.make_param(ow, oh, bframes=bframes, **search)
     ref = orc.Lookahead(depth, param, with_aq=with_aq)
     aq = None
     if with_aq:
         rng = np.random.default_rng(seed + 1)
-    for f in clip:
+    for f in oclip:
         q = None
         if with_aq:
             tmp = orc.Lowres(ref.L, depth, param)

@@ -384,8 +384,10 @@ __global__ void __launch_bounds__(256) aq_edge_kernel(AqEdgeJob job, int thresho
     if (listed)
     {
         const uint32_t at = atomicAdd(job.listCount, 1u);
-        job.list[2 * at] = (uint32_t)(by * job.blocksX + bx);
-        job.list[2 * at + 1] = ((uint32_t)gV & 0xffffu) | ((uint32_t)gH << 16);
+        // three words per record: a 12-bit picture's gradients reach 16 * 4095, beyond 16 bits
+        job.list[3 * at] = (uint32_t)(by * job.blocksX + bx);
+        job.list[3 * at + 1] = (uint32_t)gV;
+        job.list[3 * at + 2] = (uint32_t)gH;
     }
     __syncthreads();
     if (tid < 4 * 3)

@@ -221,7 +221,7 @@ struct AqEdgeJob
     uint32_t* edgeSsd;
     uint32_t* thetaSum;
     uint32_t* listCount;                     // one counter, zeroed per launch
-    uint32_t* list;                          // pairs { block index, gradientV | gradientH << 16 }, capacity = pixels of the launch
+    uint32_t* list;                          // triples { block index, gradientV, gradientH }, capacity = pixels of the launch
 };
 hipError_t launch_aq_edge(hipStream_t s, int bpp, int depth, const AqEdgeJob& job, int tileRows);
 int edge_theta(int gradientV, int gradientH);    // aq_host.cpp

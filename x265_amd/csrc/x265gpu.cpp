@@ -2397,7 +2397,7 @@ int aq_edge_pass(x265gpu_ctx* ctx, const YuvOnDevice& pic, int B, int w, int h, 
     bandRows = bandRows < 1 ? 1 : bandRows;
     const size_t arrayBytes = align256(sizeof(uint32_t) * (size_t)blocks);
     const size_t bandPixels = (size_t)bandRows * tileCols * 256;
-    const size_t total = 3 * arrayBytes + 256 + bandPixels * 2 * sizeof(uint32_t);
+    const size_t total = 3 * arrayBytes + 256 + bandPixels * 3 * sizeof(uint32_t);
     int rc = ensure_pu_buf(ctx, total);
     if (rc)
         return rc;
@@ -2429,14 +2429,11 @@ int aq_edge_pass(x265gpu_ctx* ctx, const YuvOnDevice& pic, int B, int w, int h, 
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (!count)
             continue;
-        records.resize(2 * (size_t)count);
-        HIPCHK(hipMemcpyAsync(records.data(), job.list, 2 * (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        records.resize(3 * (size_t)count);
+        HIPCHK(hipMemcpyAsync(records.data(), job.list, 3 * (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         for (uint32_t i = 0; i < count; i++)
-        {
-            const uint32_t g = records[2 * (size_t)i + 1];
-            extra[records[2 * (size_t)i]] += (uint32_t)edge_theta((int16_t)(g & 0xffff), (int16_t)(g >> 16));
-        }
+            extra[records[3 * (size_t)i]] += (uint32_t)edge_theta((int)records[3 * (size_t)i + 1], (int)records[3 * (size_t)i + 2]);
     }
     std::vector<uint32_t> sums(3 * (size_t)blocks);
     for (int k = 0; k < 3; k++)

@@ -460,7 +460,8 @@ int x265gpu_aq_frames(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int
 int x265gpu_aq_frames_begin(x265gpu_ctx* ctx, int32_t n, x265gpu_aq_picture* pics, int32_t memKind, const x265gpu_aq_params* params);
 int x265gpu_aq_frames_finish(x265gpu_ctx* ctx);
 /* --aq-motion: Lookahead::calcMotionAdaptiveQuantFrame (source/encoder/slicetype.cpp:3609-3663) for frame `slot`
- * and its request (d0 = b - p0, d1 = p1 - b), which must have been estimated: the length of every block's vector
+ * and its request (d0 = b - p0, d1 = p1 - b), which must have been estimated (x265 itself reads never-written arrays
+ * when it has not been; a caller that wants a first-use frame's outcome there skips the call): the length of every block's vector
  * in the lists its decision used is formed on the device from the resident lowresMvs / lowresCosts (no vector
  * crosses to the host), the power of 0.1, the frame's mean and deviation and the offsets on the host (libm,
  * sums in block order).  qpAqMotionOffset is written; qpAqOffset, qpCuTreeOffset and invQscaleFactor (cuCount

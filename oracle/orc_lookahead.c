@@ -75,7 +75,10 @@ orc_lowres* orc_lowres_create(const orc_param* p, int withAq)
         for (int j = 0; j < p->bframes + 2; j++)
         {
             lr->rowSatds[i][j] = (int32_t*)malloc(sizeof(int32_t) * lr->heightInCU);
-            lr->lowresCosts[i][j] = (uint16_t*)malloc(sizeof(uint16_t) * lr->cuCount);
+            /* zeroed: --aq-motion reads the list bits of requests nobody has estimated yet (slicetype.cpp:3624 with a
+             * B pyramid under fast or no B-adapt, before compCostBref); x265 then sees whatever Lowres::create's
+             * malloc returned, which for a frame in first use is zero pages: "no list used" */
+            lr->lowresCosts[i][j] = (uint16_t*)calloc(lr->cuCount, sizeof(uint16_t));
         }
         for (int l = 0; l < 2; l++)
         {

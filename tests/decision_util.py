@@ -48,7 +48,7 @@ def oracle_lookahead(clip, chroma, depth, p, **param_kw):
     look = orc.Lookahead(depth, param, with_aq=True)
     for i, y in enumerate(clip):
         if aq_on and p.get("bHevcAq"):
-            hevc_frame(look, depth, y, chroma[i], p, qg)
+            lr = hevc_frame(look, depth, y, chroma[i], p, qg)
         elif aq_on:
             res = orc.calc_adaptive_quant_frame(
                 depth, y, chroma[i][0], chroma[i][1], p["aqMode"], p["aqStrength"],
@@ -105,9 +105,12 @@ def hevc_frame(look, depth, y, uv, p, qg):
     for k, (s, nw, nh, qp, tree) in enumerate(layers):
         orc.set_hevc_layer(lr, k, s, nw, nh, qp, tree)
     ref = orc.calc_adaptive_quant_frame(depth, y, uv[0], uv[1], p["aqMode"], p["aqStrength"],
-                                        weightp=bool(p["bEnableWeightedPred"] or p["bEnableWeightedBiPred"]), qg_size=qg)
+                                        weightp=bool(p["bEnableWeightedPred"] or p["bEnableWeightedBiPred"]), qg_size=qg,
+                                        block_variance=bool(p.get("bEnableFades")))
     s_, d_ = lr.wp()
     s_[:], d_[:] = ref[3], ref[4]
+    if p.get("bEnableFades"):
+        orc.set_frame_variance(lr, ref[-1])
     return lr
 
 

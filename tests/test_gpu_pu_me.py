@@ -126,6 +126,32 @@ def test_pu_successive_elimination(depth, merange, subpel, seed):
     ref.close()
 
 
+@pytest.mark.parametrize("method", [orc.DIA, orc.HEX, orc.STAR])
+def test_pu_start_point_without_residual_returns_at_once(method):
+    """A start point with SAD 0 ends motionEstimate before the search (motion.cpp:1007-1011), and before the closing
+    zero-vector check: in flat pictures a PU whose horizontal range is one position wide (as the picture edge leaves
+    it for a PU in the padding) keeps its clipped predictor although (0,0) costs the same."""
+    W, H, depth, ctu = 416, 336, 8, 64
+    clip, pads, mx, my, fw, fh = _pictures(W, H, depth, ctu, 9)
+    clip = np.full_like(clip, 100)
+    pads = [np.full_like(p, 100) for p in pads]
+    table, centre = orc.bitcost_table(depth, 1.0)
+    ref = orc.FullResME(depth, table, centre, pads[1], pads[0], mx, my)
+    with api.Context(W, H, depth=depth, num_slots=2, ctu=ctu, keep_full_res=True) as ctx:
+        ctx.lowres_init(0, clip[0])
+        ctx.lowres_init(1, clip[1])
+        ctx.me_set_mvcost(table, centre)
+        jobs = [(432, 336, 16, 8, (7, 4), (-9, -7), (-9, 7), [(7, 4), (-36, 4), (12, 4)]),
+                (432, 336, 16, 16, (24, 0), (-9, -8), (-9, 7), []),
+                (432, 352, 16, 16, (-36, 4), (-9, -7), (-9, 7), [])]
+        got = ctx.pu_motion_estimate(1, 0, method, 8, 2, jobs)
+        for j, g in zip(jobs, got):
+            want = ref.estimate(j[0], j[1], j[2], j[3], j[4], j[5], j[6], method, 8, 2, j[7])
+            assert g == want, (j, g, want)
+        assert got[0][0] == (-36, 4) and got[1][0] == (-36, 0)
+    ref.close()
+
+
 def test_pu_motion_estimate_12bit():
     _run(12, orc.STAR, 57, 3, 64, seed=1212)
     _run(12, orc.UMH, 24, 5, 48, seed=1213)

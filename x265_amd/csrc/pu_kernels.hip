@@ -1285,7 +1285,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XG_PU_
     }
 
     int bqx, bqy, bcost;
-    if (c.bcost == 0)
+    // no residual at the start point: motionEstimate returns at once (motion.cpp:1007-1011), before the search, the
+    // sub-pel steps and the closing zero-vector check
+    const bool startIsExact = c.bcost == 0;
+    if (startIsExact)
     {
         bqx = c.bmx * 4;
         bqy = c.bmy * 4;
@@ -1371,7 +1374,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XG_PU_
     }
 
     // the fork's closing zero-vector check: the vector is replaced, the cost is not (motion.cpp:1762-1768)
-    if (bqx | bqy)
+    if ((bqx | bqy) && !startIsExact)
     {
         const int cost = subpel_cost<P>(c, 0, 0, true);
         if (cost <= bcost)

@@ -1077,6 +1077,14 @@ void Lookahead::calcMotionAdaptiveQuantFrame(Lowres** frames, int p0, int p1, in
     }
     if (f.qpAqMotionOffset.empty())
         f.qpAqMotionOffset.assign((size_t)m_geom.cuCount, 0.0);
+    if (f.costEst[b - p0][p1 - b] < 0)
+    {
+        // Nobody has estimated this request yet (a B pyramid under fast or no B-adapt gets here before compCostBref
+        // asks for it): x265 reads lowresCosts as Lowres::create's malloc left it, zero pages for a frame in first
+        // use.  No list used, no displacement, no deviation: the offsets stay as they are.
+        std::fill(f.qpAqMotionOffset.begin(), f.qpAqMotionOffset.end(), 0.0);
+        return;
+    }
     // costs measured ahead of x265's order used the factors as they were: a request that comes now is measured anew
     for (int i = 0; i < MAX_D; i++)
         for (int j = 0; j < MAX_D; j++)

@@ -100,7 +100,8 @@ def draw_pu(rng):
     return dict(depth=int(rng.choice([8, 10, 12])), method=int(rng.choice([orc.DIA, orc.HEX, orc.UMH, orc.STAR, orc.FULL, orc.SEA])),
                 merange=int(rng.choice([4, 8, 16, 24, 57])), subpel=int(rng.integers(0, 8)),
                 size=(int(rng.integers(20, 70)) * 8 + int(rng.integers(0, 4)) * 2, int(rng.integers(12, 40)) * 8 + int(rng.integers(0, 4)) * 2),
-                lam=float(rng.choice([0, 0, 2.5, 9.5, 40.0])), seed=int(rng.integers(1, 1 << 30)))
+                lam=float(rng.choice([0, 0, 2.5, 9.5, 40.0])), seed=int(rng.integers(1, 1 << 30)),
+                content=str(rng.choice(["synth", "synth", "flat", "half"])), narrow=bool(rng.integers(0, 2)))
 
 
 def pu_round(cfg):
@@ -108,7 +109,8 @@ def pu_round(cfg):
         TP.test_pu_successive_elimination(cfg["depth"], cfg["merange"], cfg["subpel"], cfg["seed"] % 100000)
         return
     merange = min(cfg["merange"], 6) if cfg["method"] == orc.FULL else cfg["merange"]
-    TP._run(cfg["depth"], cfg["method"], merange, cfg["subpel"], 24, cfg["seed"], size=cfg["size"], lam=cfg["lam"] or None)
+    TP._run(cfg["depth"], cfg["method"], merange, cfg["subpel"], 24, cfg["seed"], size=cfg["size"], lam=cfg["lam"] or None,
+            content=cfg["content"], narrow=cfg["narrow"])
 
 
 def draw_mcstf(rng):

@@ -21,7 +21,8 @@ def _pictures(W, H, depth, ctu, seed):
     return clip, pads, mx, my, fw, fh
 
 
-def _jobs(rng, fw, fh, mx, my, merange, count):
+def _jobs(rng, fw, fh, mx, my, merange, count, narrow=False):
+    """narrow: a third of the jobs get a range one to three positions wide in x or y (what a picture edge leaves)"""
     jobs = []
     while len(jobs) < count:
         w, h = PU_SHAPES[rng.integers(len(PU_SHAPES))]
@@ -33,16 +34,26 @@ def _jobs(rng, fw, fh, mx, my, merange, count):
         hi = (min((mvp[0] >> 2) + merange, fw - x - w + mx - 24), min((mvp[1] >> 2) + merange, fh - y - h + my - 24))
         if lo[0] > hi[0] or lo[1] > hi[1]:
             continue
+        if narrow and rng.integers(0, 3) == 0:
+            axis, width = int(rng.integers(0, 2)), int(rng.integers(0, 3))
+            at = int(rng.integers(lo[axis], hi[axis] + 1))
+            lo = tuple(at if k == axis else v for k, v in enumerate(lo))
+            hi = tuple(min(at + width, hi[axis]) if k == axis else v for k, v in enumerate(hi))
         nc = int(rng.integers(0, 4))
         mvc = [(int(rng.integers(-60, 61)), int(rng.integers(-60, 61))) for _ in range(nc)]
         jobs.append((x, y, w, h, mvp, lo, hi, mvc))
     return jobs
 
 
-def _run(depth, method, merange, subpel, count, seed, size=(416, 240), lam=None):
+def _run(depth, method, merange, subpel, count, seed, size=(416, 240), lam=None, content="synth", narrow=False):
+    """content: "synth", "flat" (both pictures one value: no residual anywhere) or "half" (the right half flat)"""
     W, H = size
     ctu = 64
     clip, pads, mx, my, fw, fh = _pictures(W, H, depth, ctu, seed)
+    if content != "synth":
+        clip = clip.copy()
+        clip[:, :, (0 if content == "flat" else W // 2):] = clip[0, H // 2, W // 2]
+        pads = [np.pad(f, ((my, my + fh - H), (mx, mx + fw - W)), mode="edge") for f in clip]
     table, centre = orc.bitcost_table(depth, lam)
     ref = orc.FullResME(depth, table, centre, pads[1], pads[0], mx, my)
     ctx = api.Context(W, H, depth=depth, num_slots=2, ctu=ctu, keep_full_res=True)
@@ -54,7 +65,7 @@ def _run(depth, method, merange, subpel, count, seed, size=(416, 240), lam=None)
             assert (ox, oy) == (mx, my)
             np.testing.assert_array_equal(plane, pads[k], err_msg="padded full-resolution plane %d" % k)
         ctx.me_set_mvcost(table, centre)
-        jobs = _jobs(np.random.default_rng(seed), fw, fh, mx, my, merange, count)
+        jobs = _jobs(np.random.default_rng(seed), fw, fh, mx, my, merange, count, narrow)
         got = ctx.pu_motion_estimate(1, 0, method, merange, subpel, jobs)
         for j, g in zip(jobs, got):
             want = ref.estimate(j[0], j[1], j[2], j[3], j[4], j[5], j[6], method, merange, subpel, j[7])

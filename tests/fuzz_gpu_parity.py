@@ -249,7 +249,7 @@ def draw_decide(rng):
         p["lookaheadDepth"] = max(p["lookaheadDepth"], p["bframes"] + 2)
     if "poolWorkers" in p:                     # the harness expects searches run ahead of single requests to be found
         p["bframes"], p["lookaheadDepth"] = max(p["bframes"], 3), max(p["lookaheadDepth"], 10)
-    return dict(p=p, n=int(rng.integers(12, 30)), size=(int(rng.integers(12, 24)) * 16, int(rng.integers(8, 14)) * 16),
+    return dict(p=p, n=int(rng.integers(12, 30)), size=(int(rng.integers(96, 192)) * 2, int(rng.integers(64, 112)) * 2),
                 depth=int(rng.choice([8, 8, 10])), seed=int(rng.integers(1, 1 << 30)))
 
 

@@ -249,6 +249,17 @@ def test_4k_10bit_hme_rc_lookahead_40():
     assert len(types) == N and any(t == 5 for t in types)
 
 
+@pytest.mark.parametrize("qg", [8, 32])
+def test_hevc_aq_layers_that_overhang_the_picture(qg):
+    """368x180: the finest layer's doubled lowres grid has a row of parts below the picture (and the coarser layers'
+    last rows are cut); computeCUTreeQpOffset divides 0 by 0 there, here as in the oracle."""
+    p = dict(api.LookaheadParam.MEDIUM, bHevcAq=1, qgSize=qg, qpAdaptationRange=3.0, aqMode=3, poolWorkers=16,
+             vbvBufferSize=1000, vbvMaxBitrate=1000)
+    N, W, H, depth = 21, 368, 180, 10
+    clip = du.two_scene_clip(W, H, N, depth, seed=9681)
+    _compare(clip, du.chroma_for(clip, depth, 681), depth, p)
+
+
 @pytest.mark.parametrize("kw", [{}, {"poolWorkers": 16, "bOpenGOP": 0}], ids=["lazy", "pool16-closed-gop"])
 def test_fade_in_ends_on_a_keyframe(kw):
     """--fades: the picture variances of calcAdaptiveQuantFrame's tail come from the device; a fade-in of a second or

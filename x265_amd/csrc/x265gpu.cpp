@@ -2236,10 +2236,9 @@ int x265gpu_cutree_finish_hevc(x265gpu_ctx* ctx, int32_t slot, int32_t fpsFactor
     {
         const x265gpu_hevc_aq_layer& l = layers[d];
         if (l.aqPartWidth < (qg8 ? 8 : 16) || l.aqPartHeight < (qg8 ? 8 : 16) || l.numAQPartInWidth < 1 || l.numAQPartInHeight < 1 ||
-            !l.dQpOffset || !l.dCuTreeOffset ||
-            // every part must cover at least one AQ block of the picture
-            (long long)(l.numAQPartInWidth - 1) * l.aqPartWidth >= ctx->cfg.sourceWidth ||
-            (long long)(l.numAQPartInHeight - 1) * l.aqPartHeight >= ctx->cfg.sourceHeight)
+            !l.dQpOffset || !l.dCuTreeOffset)
+            // (a part may lie wholly outside the picture: the doubled lowres grid of the finest layer has such rows
+            // and columns whenever the picture is not a multiple of 16, and the reference gives them 0 / 0)
             return fail(ctx, X265GPU_ERR_ARG, "cutree_finish_hevc: bad layer");
         partW[d] = l.aqPartWidth;
         partH[d] = l.aqPartHeight;

@@ -243,6 +243,9 @@ def draw_decide(rng):
             p["bEnableFades"], p["fpsNum"] = 1, int(rng.choice([5, 10]))
     if rng.integers(0, 5) == 0:
         p["bHistBasedSceneCut"] = 1
+    if "poolWorkers" not in p and rng.integers(0, 4) == 0:
+        p["lookaheadSlices"] = int(rng.integers(2, 5))         # single requests run in cooperative slices
+    p["lookaheadDepth"] = max(p["lookaheadDepth"], p["bframes"] + 1)      # x265_check_params (param.cpp:1811)
     if p.get("bEnableFades"):
         # the fade detection reads frameVariance of the first bframes + 2 queued frames, of which x265 has pre-analysed
         # only the first lookaheadDepth: beyond them it reads what Lowres::create left
@@ -250,7 +253,7 @@ def draw_decide(rng):
     if "poolWorkers" in p:                     # the harness expects searches run ahead of single requests to be found
         p["bframes"], p["lookaheadDepth"] = max(p["bframes"], 3), max(p["lookaheadDepth"], 10)
     return dict(p=p, n=int(rng.integers(12, 30)), size=(int(rng.integers(96, 192)) * 2, int(rng.integers(64, 112)) * 2),
-                depth=int(rng.choice([8, 8, 10])), seed=int(rng.integers(1, 1 << 30)))
+                depth=int(rng.choice([8, 8, 10, 12])), seed=int(rng.integers(1, 1 << 30)))
 
 
 def decide_round(cfg):
@@ -290,14 +293,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--skip", type=int, default=0, help="draw this many configurations without running them first")
+    ap.add_argument("--log", default=None, help="file that receives every round's configuration before it runs")
     ap.add_argument("--what", default="lookahead", choices=["lookahead", "pu", "mcstf", "aq", "decide", "tme"])
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
+    log = open(a.log, "w") if a.log else None
     drawer, runner = {"lookahead": (draw, one_round), "pu": (draw_pu, pu_round), "mcstf": (draw_mcstf, mcstf_round),
                       "aq": (draw_aq, aq_round), "decide": (draw_decide, decide_round), "tme": (draw_tme, tme_round)}[a.what]
     t0, rounds, refused = time.time(), 0, 0
+    for _ in range(a.skip):
+        drawer(rng)
     while time.time() - t0 < a.seconds:
         cfg = drawer(rng)
+        if log:
+            log.write(repr(cfg) + "\n")
+            log.flush()
         try:
             runner(cfg)
         except api.X265GpuError as e:

@@ -249,6 +249,14 @@ def test_4k_10bit_hme_rc_lookahead_40():
     assert len(types) == N and any(t == 5 for t in types)
 
 
+def test_driver_refuses_what_x265_refuses():
+    """rc-lookahead must exceed bframes (x265_check_params, param.cpp:1811): the decision reads frames[bframes + 1]."""
+    with api.Context(256, 160, num_slots=4) as ctx:
+        with pytest.raises(api.X265GpuError):
+            api.HostLookahead(ctx, api.LookaheadParam(bframes=6, lookaheadDepth=5))
+        api.HostLookahead(ctx, api.LookaheadParam(bframes=4, lookaheadDepth=5)).close()
+
+
 @pytest.mark.parametrize("qg", [8, 32])
 def test_hevc_aq_layers_that_overhang_the_picture(qg):
     """368x180: the finest layer's doubled lowres grid has a row of parts below the picture (and the coarser layers'

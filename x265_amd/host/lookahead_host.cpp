@@ -904,6 +904,7 @@ int Lookahead::unsupported() const
 {
     const LookaheadParam& p = m_param;
     if (p.bEnableTemporalSubLayers > 2 || p.bframes > X265GPU_BFRAME_MAX || p.lookaheadDepth > LOOKAHEAD_MAX ||
+        (p.bframes && p.bframes >= p.lookaheadDepth) ||   // x265_check_params (param.cpp:1811): the decision reads frames[bframes + 1]
         (p.aq.bHevcAq && (p.bAQMotion || (p.maxCUSize != 64 && p.maxCUSize != 32 && p.maxCUSize != 16))) || p.keyframeMin < 1 ||
         // calcMotionAdaptiveQuantFrame indexes the qgSize 8 offset arrays by lowres block (:3648-3658) and changes
         // invQscaleFactor, which no estimate reads then: the device form would install those as the slot's factors

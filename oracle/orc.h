@@ -223,6 +223,7 @@ typedef struct orc_lowres {
     /* what the slice-type decision keeps per frame (source/common/lowres.h:166-213) */
     int      sliceTypeReq;
     int      bScenecut, bKeyframe, bLastMiniGopBFrame, leadingBframes;
+    int      gopOffset, gopId, tempLayer;   /* Frame::m_gopOffset, m_gopId, m_tempLayer (source/common/frame.h:96, 167-168) */
     int      indB;
     int64_t  plannedSatd[ORC_LOOKAHEAD_MAX + 1];
     int      plannedType[ORC_LOOKAHEAD_MAX + 1];

@@ -175,6 +175,7 @@ void orc_lowres_init(orc_lowres* lr, const orc_param* p, const pixel* luma, intp
     lr->bLastMiniGopBFrame = 0;
     lr->bKeyframe = 0;
     lr->leadingBframes = 0;
+    lr->gopOffset = lr->gopId = lr->tempLayer = 0;
     lr->indB = 0;
     for (int i = 0; i <= ORC_LOOKAHEAD_MAX; i++)
         lr->plannedType[i] = ORC_TYPE_AUTO;
@@ -1174,6 +1175,9 @@ int64_t orc_lowres_i64(orc_lowres* lr, const char* f, int i, int j)
     if (!strcmp(f, "bKeyframe")) return lr->bKeyframe;
     if (!strcmp(f, "bLastMiniGopBFrame")) return lr->bLastMiniGopBFrame;
     if (!strcmp(f, "leadingBframes")) return lr->leadingBframes;
+    if (!strcmp(f, "gopOffset")) return lr->gopOffset;
+    if (!strcmp(f, "gopId")) return lr->gopId;
+    if (!strcmp(f, "tempLayer")) return lr->tempLayer;
     if (!strcmp(f, "indB")) return lr->indB;
     if (!strcmp(f, "qg8")) return lr->qg8;
     if (!strcmp(f, "weightedCostDelta")) return (int64_t)lr->weightedCostDelta[i];

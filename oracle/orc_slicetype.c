@@ -52,6 +52,7 @@ struct orc_la
     /* --fades (:2042-2088, slicetype.h:196-200) */
     double frameVariance[ORC_BFRAME_MAX + 4];
     int isFadeIn, fadeStart;
+    int gopId;                     /* --temporal-layers 3..5 (:1176-1192) */
     uint64_t fadeCount;
     int32_t* trace;
     int ntrace, captrace;
@@ -863,6 +864,218 @@ static void comp_cost_bref(orc_la* la, orc_lowres** frames, int start, int end, 
 
 static void out_push(orc_la* la, orc_lowres* f) { la->outq[(la->outHead + la->outCount++) % QCAP] = f; }
 
+/* ---- :2607-2716: the mini-GOP list[0..bframes] without the temporal-layer orders ---- */
+static void plain_mini_gop(orc_la* la, orc_lowres** frames, orc_lowres** list, int bframes, int* brefs, int* maxSearch)
+{
+    const orc_la_param* lp = &la->lp;
+    if (bframes)
+        list[bframes - 1]->bLastMiniGopBFrame = 1;
+    list[bframes]->leadingBframes = bframes;
+    la->lastNonB = list[bframes];
+
+    if (lp->bBPyramid && bframes > 1 && !*brefs)
+        place_bref(la, list, 0, bframes, bframes + 1, brefs);
+
+    if (!lp->bCqp)
+    {
+        int p0, p1, b;
+        if (!*maxSearch)
+            for (int i = 0; i <= bframes; i++)
+                frames[i + 1] = list[i];
+        p1 = b = bframes + 1;
+        p0 = IS_TYPE_I(frames[bframes + 1]->sliceType) ? b : 0;
+        single_cost(la, frames, p0, p1, b, 0);
+        if (lp->bEnableTemporalSubLayers > 1 && bframes)
+            comp_cost_bref(la, frames, 0, bframes, bframes + 1);
+        else if (bframes)
+        {
+            p0 = 0;
+            int isp0available = frames[bframes + 1]->sliceType == ORC_TYPE_IDR ? 0 : 1;
+            for (b = 1; b <= bframes; b++)
+            {
+                if (!isp0available)
+                    p0 = b;
+                if (frames[b]->sliceType == ORC_TYPE_B)
+                    for (p1 = b; frames[p1]->sliceType == ORC_TYPE_B; p1++)
+                        ;
+                else
+                    p1 = bframes + 1;
+                single_cost(la, frames, p0, p1, b, 0);
+                if (frames[b]->sliceType == ORC_TYPE_BREF)
+                {
+                    p0 = b;
+                    isp0available = 1;
+                }
+            }
+        }
+    }
+
+    /* dequeue the mini-GOP: non-B first, then B-refs, then the other B frames (:2672-2715) */
+    memmove(la->inq, la->inq + bframes + 1, sizeof(la->inq[0]) * (la->inCount - bframes - 1));
+    la->inCount -= bframes + 1;
+    *maxSearch -= bframes + 1;
+    out_push(la, list[bframes]);
+    if (*brefs)
+        for (int i = 0; i < bframes; i++)
+            if (list[i]->sliceType == ORC_TYPE_BREF)
+                out_push(la, list[i]);
+    for (int i = 0; i < bframes; i++)
+        if (list[i]->sliceType != ORC_TYPE_BREF)
+            out_push(la, list[i]);
+
+}
+
+/* x265_gop_ra / x265_gop_ra_length (source/x265.h:835-): coding order of the hierarchical mini-GOPs of 4, 8 and 16
+ * pictures, POC offset and temporal layer of each position */
+static const int8_t gop_ra_length[3] = { 4, 8, 16 };
+static const int8_t gop_ra_poc[3][16] = {
+    { 4, 2, 1, 3 },
+    { 8, 4, 2, 1, 3, 6, 5, 7 },
+    { 16, 8, 4, 2, 1, 3, 6, 5, 7, 12, 10, 9, 11, 14, 13, 15 },
+};
+static const int8_t gop_ra_layer[3][16] = {
+    { 0, 1, 2, 2 },
+    { 0, 1, 2, 3, 3, 2, 3, 3 },
+    { 0, 1, 2, 3, 4, 4, 3, 4, 4, 2, 3, 4, 4, 3, 4, 4 },
+};
+
+static void dequeue(orc_la* la, int count, int* maxSearch)
+{
+    memmove(la->inq, la->inq + count, sizeof(la->inq[0]) * (la->inCount - count));
+    la->inCount -= count;
+    *maxSearch -= count;
+}
+
+/* ---- :2304-2571 ---- */
+static void temporal_mini_gop(orc_la* la, orc_lowres** frames, orc_lowres** list, int bframes, int* brefs, int* maxSearch)
+{
+    const orc_la_param* lp = &la->lp;
+    if (bframes < la->p.bframes)
+    {
+        /* a partial mini-GOP: sub-GOPs of the lengths that fit, longest first, then a plain remainder */
+        int leftOver = bframes + 1;
+        int gopId = la->gopId - 1;
+        int gopLen = gopId >= 0 ? gop_ra_length[gopId] : 0;
+        int listReset = 0;
+        while (gopId >= 0 && leftOver > 3)
+        {
+            if (leftOver < gopLen)
+            {
+                gopId = gopId - 1;
+                gopLen = gopId >= 0 ? gop_ra_length[gopId] : 0;
+                continue;
+            }
+            int newbFrames = listReset + gopLen - 1;
+            if (!IS_TYPE_I(list[newbFrames]->sliceType))
+                list[newbFrames]->sliceType = ORC_TYPE_P;
+            if (newbFrames)
+                list[newbFrames - 1]->bLastMiniGopBFrame = 1;
+            list[newbFrames]->leadingBframes = newbFrames;
+            la->lastNonB = list[newbFrames];
+            if (lp->bBPyramid && newbFrames)
+                place_bref(la, list, listReset, newbFrames, newbFrames + 1, brefs);
+            if (!lp->bCqp)
+            {
+                /* (:2343-2347 needs maxSearch == 0, which cannot be while pictures of this list remain) */
+                int b = newbFrames + 1;
+                int p0 = IS_TYPE_I(frames[b]->sliceType) ? b : listReset;
+                single_cost(la, frames, p0, b, b, 0);
+                if (newbFrames)
+                    comp_cost_bref(la, frames, listReset, newbFrames, newbFrames + 1);
+            }
+            dequeue(la, gopLen, maxSearch);
+            list[newbFrames]->gopOffset = 0;
+            list[newbFrames]->gopId = gopId;
+            list[newbFrames]->tempLayer = gop_ra_layer[gopId][0];
+            out_push(la, list[newbFrames]);
+            for (int j = 1; j < gopLen; j++)
+            {
+                int offset = listReset + (gop_ra_poc[gopId][j] - 1);
+                list[offset]->gopOffset = j;
+                /* :2393 writes list[bframes]->m_gopId here, which leaves the B pictures' field unset (it is never
+                 * initialised); the id is stored where :2563 stores it for a full mini-GOP */
+                list[offset]->gopId = gopId;
+                list[offset]->tempLayer = gop_ra_layer[gopId][j];
+                out_push(la, list[offset]);
+            }
+            listReset += gopLen;
+            leftOver -= gopLen;
+            gopId -= 1;
+            gopLen = gopId >= 0 ? gop_ra_length[gopId] : 0;
+        }
+        if (leftOver > 0 && leftOver < 4)
+        {
+            int newbFrames = listReset + leftOver - 1;
+            if (!IS_TYPE_I(list[newbFrames]->sliceType))
+                list[newbFrames]->sliceType = ORC_TYPE_P;
+            if (newbFrames)
+                list[newbFrames - 1]->bLastMiniGopBFrame = 1;
+            list[newbFrames]->leadingBframes = newbFrames;
+            la->lastNonB = list[newbFrames];
+            if (lp->bBPyramid && (newbFrames - listReset) > 1)
+                place_bref(la, list, listReset, newbFrames, newbFrames + 1, brefs);
+            if (!lp->bCqp)
+            {
+                int b = newbFrames + 1;
+                int p0 = IS_TYPE_I(frames[b]->sliceType) ? b : listReset;
+                single_cost(la, frames, p0, b, b, 0);
+                if (newbFrames)
+                    comp_cost_bref(la, frames, listReset, newbFrames, newbFrames + 1);
+            }
+            dequeue(la, leftOver, maxSearch);
+            list[newbFrames]->gopOffset = 0;
+            list[newbFrames]->gopId = -1;
+            list[newbFrames]->tempLayer = 0;
+            out_push(la, list[newbFrames]);
+            if (*brefs)
+                for (int i = listReset; i < newbFrames; i++)
+                    if (list[i]->sliceType == ORC_TYPE_BREF)
+                    {
+                        list[i]->gopOffset = 0;
+                        list[i]->gopId = -1;
+                        list[i]->tempLayer = 0;
+                        out_push(la, list[i]);
+                    }
+            for (int i = listReset; i < newbFrames; i++)
+                if (list[i]->sliceType != ORC_TYPE_BREF)
+                {
+                    list[i]->gopOffset = 0;
+                    list[i]->gopId = -1;
+                    list[i]->tempLayer = 1;
+                    out_push(la, list[i]);
+                }
+        }
+        return;
+    }
+
+    /* the complete mini-GOP */
+    list[bframes - 1]->bLastMiniGopBFrame = 1;
+    list[bframes]->leadingBframes = bframes;
+    la->lastNonB = list[bframes];
+    if (lp->bBPyramid && !*brefs)
+        place_bref(la, list, 0, bframes, bframes + 1, brefs);
+    if (!lp->bCqp)
+    {
+        int b = bframes + 1;
+        int p0 = IS_TYPE_I(frames[b]->sliceType) ? b : 0;
+        single_cost(la, frames, p0, b, b, 0);
+        comp_cost_bref(la, frames, 0, bframes, bframes + 1);
+    }
+    dequeue(la, bframes + 1, maxSearch);
+    list[bframes]->gopOffset = 0;
+    list[bframes]->gopId = la->gopId;
+    list[bframes]->tempLayer = gop_ra_layer[la->gopId][0];
+    out_push(la, list[bframes]);
+    for (int j = 1; j <= bframes; j++)
+    {
+        int offset = gop_ra_poc[la->gopId][j] - 1;
+        list[offset]->gopOffset = j;
+        list[offset]->gopId = la->gopId;
+        list[offset]->tempLayer = gop_ra_layer[la->gopId][j];
+        out_push(la, list[offset]);
+    }
+}
+
 /* ---- :1982-2751 ---- */
 static void slicetype_decide(orc_la* la)
 {
@@ -953,60 +1166,10 @@ static void slicetype_decide(orc_la* la)
             break;
     }
 
-    if (bframes)
-        list[bframes - 1]->bLastMiniGopBFrame = 1;
-    list[bframes]->leadingBframes = bframes;
-    la->lastNonB = list[bframes];
-
-    if (lp->bBPyramid && bframes > 1 && !brefs)
-        place_bref(la, list, 0, bframes, bframes + 1, &brefs);
-
-    if (!lp->bCqp)
-    {
-        int p0, p1, b;
-        if (!maxSearch)
-            for (int i = 0; i <= bframes; i++)
-                frames[i + 1] = list[i];
-        p1 = b = bframes + 1;
-        p0 = IS_TYPE_I(frames[bframes + 1]->sliceType) ? b : 0;
-        single_cost(la, frames, p0, p1, b, 0);
-        if (lp->bEnableTemporalSubLayers > 1 && bframes)
-            comp_cost_bref(la, frames, 0, bframes, bframes + 1);
-        else if (bframes)
-        {
-            p0 = 0;
-            int isp0available = frames[bframes + 1]->sliceType == ORC_TYPE_IDR ? 0 : 1;
-            for (b = 1; b <= bframes; b++)
-            {
-                if (!isp0available)
-                    p0 = b;
-                if (frames[b]->sliceType == ORC_TYPE_B)
-                    for (p1 = b; frames[p1]->sliceType == ORC_TYPE_B; p1++)
-                        ;
-                else
-                    p1 = bframes + 1;
-                single_cost(la, frames, p0, p1, b, 0);
-                if (frames[b]->sliceType == ORC_TYPE_BREF)
-                {
-                    p0 = b;
-                    isp0available = 1;
-                }
-            }
-        }
-    }
-
-    /* dequeue the mini-GOP: non-B first, then B-refs, then the other B frames (:2672-2715) */
-    memmove(la->inq, la->inq + bframes + 1, sizeof(la->inq[0]) * (la->inCount - bframes - 1));
-    la->inCount -= bframes + 1;
-    maxSearch -= bframes + 1;
-    out_push(la, list[bframes]);
-    if (brefs)
-        for (int i = 0; i < bframes; i++)
-            if (list[i]->sliceType == ORC_TYPE_BREF)
-                out_push(la, list[i]);
-    for (int i = 0; i < bframes; i++)
-        if (list[i]->sliceType != ORC_TYPE_BREF)
-            out_push(la, list[i]);
+    if (lp->bEnableTemporalSubLayers > 2)
+        temporal_mini_gop(la, frames, list, bframes, &brefs, &maxSearch);
+    else
+        plain_mini_gop(la, frames, list, bframes, &brefs, &maxSearch);
 
     int isKeyFrameAnalyse = lp->cuTree || (lp->vbvBufferSize && lp->lookaheadDepth);
     if (isKeyFrameAnalyse && IS_TYPE_I(la->lastNonB->sliceType))
@@ -1034,6 +1197,7 @@ orc_la* orc_la_create(const orc_param* p, const orc_la_param* lp, const orc_cutr
     la->blocks8x8 = tld->ncu;
     la->resetRunningAvg = 1;
     la->fadeStart = -1;            /* :1067-1069 */
+    la->gopId = lp->bEnableTemporalSubLayers > 2 ? lp->bEnableTemporalSubLayers - 3 : 0;
     la->segmentCountThreshold = (uint32_t)(((float)((4 * 4) * 50) / 100) + 0.5);
     return la;
 }

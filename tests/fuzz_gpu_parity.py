@@ -252,6 +252,12 @@ def draw_decide(rng):
         p["lookaheadDepth"] = max(p["lookaheadDepth"], p["bframes"] + 2)
     if "poolWorkers" in p:                     # the harness expects searches run ahead of single requests to be found
         p["bframes"], p["lookaheadDepth"] = max(p["bframes"], 3), max(p["lookaheadDepth"], 10)
+    layers = int(rng.choice([0, 0, 0, 0, 2, 3, 4, 5]))
+    if layers:
+        p["bEnableTemporalSubLayers"] = layers
+    if layers > 2:                             # Encoder::configure's consequences (encoder.cpp:4322-4332)
+        p["bframes"], p["bFrameAdaptive"], p["bBPyramid"] = (4 << (layers - 3)) - 1, 0, int(rng.integers(0, 4) != 0)
+        p["lookaheadDepth"] = max(p["lookaheadDepth"], p["bframes"] + (2 if p.get("bEnableFades") else 1))
     return dict(p=p, n=int(rng.integers(12, 30)), size=(int(rng.integers(96, 192)) * 2, int(rng.integers(64, 112)) * 2),
                 depth=int(rng.choice([8, 8, 10, 12])), seed=int(rng.integers(1, 1 << 30)))
 

@@ -38,6 +38,9 @@ def _compare(clip, chroma, depth, p, forced=None, ctx_kw=None, param_kw=None):
             want = tuple(int(fr.i64(k)) for k in ("sliceType", "bScenecut", "bKeyframe", "bLastMiniGopBFrame", "leadingBframes"))
             assert have == want, "frame %d: %s, oracle %s" % (d.frame, have, want)
             assert bool(d.bIsFadeEnd) == orc.is_fade_end(fr), "fade end of frame %d" % d.frame
+            have = (d.gopOffset, d.gopId, d.tempLayer)
+            want = tuple(int(fr.i64(k)) for k in ("gopOffset", "gopId", "tempLayer"))
+            assert have == want, "frame %d: place in its mini-GOP %s, oracle %s" % (d.frame, have, want)
         # the requests, in issue order
         t_want, t_got = dec.trace(), la.trace()
         assert t_got.shape == t_want.shape, "host issued %d requests, oracle %d" % (len(t_got), len(t_want))
@@ -143,6 +146,13 @@ CASES = [
     {"bHevcAq": 1, "qgSize": 8, "poolWorkers": 16, "vbvBufferSize": 1000, "vbvMaxBitrate": 1000},
     {"bHevcAq": 1, "qgSize": 16, "vbvBufferSize": 1000, "vbvMaxBitrate": 1000, "bBPyramid": 0},
     {"bHevcAq": 1, "qgSize": 64, "bFrameAdaptive": 1},
+    # --temporal-layers 3..5: hierarchical mini-GOPs of 4 / 8 / 16 pictures; the scene cut and the end of the clip
+    # leave partial ones, which split into shorter orders and a plain remainder
+    {"bEnableTemporalSubLayers": 3, "bframes": 3, "bFrameAdaptive": 0},
+    {"bEnableTemporalSubLayers": 4, "bframes": 7, "bFrameAdaptive": 0, "poolWorkers": 16},
+    {"bEnableTemporalSubLayers": 4, "bframes": 7, "bFrameAdaptive": 0, "bBPyramid": 0, "vbvBufferSize": 1000, "vbvMaxBitrate": 1000},
+    {"bEnableTemporalSubLayers": 5, "bframes": 15, "bFrameAdaptive": 0},
+    {"bEnableTemporalSubLayers": 5, "bframes": 15, "bFrameAdaptive": 0, "bOpenGOP": 0, "keyframeMax": 13, "keyframeMin": 1},
 ]
 
 
@@ -255,6 +265,13 @@ def test_driver_refuses_what_x265_refuses():
         with pytest.raises(api.X265GpuError):
             api.HostLookahead(ctx, api.LookaheadParam(bframes=6, lookaheadDepth=5))
         api.HostLookahead(ctx, api.LookaheadParam(bframes=4, lookaheadDepth=5)).close()
+        # three to five temporal sub-layers fix the B-frame count and turn adaptive placement off
+        # (Encoder::configure, encoder.cpp:4303-4332); one layer and more than five do not reach the lookahead
+        for kw in (dict(bEnableTemporalSubLayers=4, bframes=4, bFrameAdaptive=0), dict(bEnableTemporalSubLayers=3, bframes=3, bFrameAdaptive=2),
+                   dict(bEnableTemporalSubLayers=1), dict(bEnableTemporalSubLayers=6, bframes=15, bFrameAdaptive=0)):
+            with pytest.raises(api.X265GpuError):
+                api.HostLookahead(ctx, api.LookaheadParam(**kw))
+        api.HostLookahead(ctx, api.LookaheadParam(bEnableTemporalSubLayers=3, bframes=3, bFrameAdaptive=0)).close()
 
 
 @pytest.mark.parametrize("qg", [8, 32])

@@ -348,7 +348,7 @@ class SerialTME:
                 o["mvp"][l] = best[l]["mvp"]
                 o["mvCost"][l] = best[l]["mvCost"]
                 o["cost"] = best[l]["cost"]
-                o["bits"] = best[l]["bits"]
+                o["bits"] = ((best[l]["bits"] + (1 << 31)) & U32) - (1 << 31)     # uint32_t bits (checkBestMVP may wrap it), read as int
                 o["ref"][l] = best[l]["ref"]
 
     # ---- Analysis::computeMVForPUs ----

@@ -660,7 +660,8 @@ class LookaheadParam(C.Structure):
 
 class Decided(C.Structure):
     _fields_ = [("frame", C.c_int32), ("sliceType", C.c_int32), ("bScenecut", C.c_int32), ("bKeyframe", C.c_int32),
-                ("bLastMiniGopBFrame", C.c_int32), ("leadingBframes", C.c_int32), ("bIsFadeEnd", C.c_int32)]
+                ("bLastMiniGopBFrame", C.c_int32), ("leadingBframes", C.c_int32), ("bIsFadeEnd", C.c_int32),
+                ("gopOffset", C.c_int32), ("gopId", C.c_int32), ("tempLayer", C.c_int32)]
 
 
 def load_host_library():

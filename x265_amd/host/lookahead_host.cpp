@@ -898,12 +898,18 @@ Lookahead::Lookahead(x265gpu_ctx* ctx, const LookaheadParam& param) : m_ctx(ctx)
     m_fullQueueSize = (size_t)(param.lookaheadDepth > 1 ? param.lookaheadDepth : 1);
     m_bBatchMotionSearch = param.poolWorkers > 0 && param.bFrameAdaptive == 2;   // :1091
     m_bBatchFrameCosts = m_bBatchMotionSearch;                             // :1100
+    m_gopId = param.bEnableTemporalSubLayers > 2 ? param.bEnableTemporalSubLayers - 3 : 0;   // :1176-1192
 }
 
 int Lookahead::unsupported() const
 {
     const LookaheadParam& p = m_param;
-    if (p.bEnableTemporalSubLayers > 2 || p.bframes > X265GPU_BFRAME_MAX || p.lookaheadDepth > LOOKAHEAD_MAX ||
+    // Encoder::configure (encoder.cpp:4303-4332) leaves 0, 2 or 3..5 layers, and with 3..5 a fixed B-frame count
+    // and no adaptive placement; the decision below relies on all three
+    const int layers = p.bEnableTemporalSubLayers;
+    const bool badLayers = layers < 0 || layers == 1 || layers > 5 ||
+                           (layers > 2 && (p.bFrameAdaptive || p.bframes != (4 << (layers - 3)) - 1));
+    if (badLayers || p.bframes > X265GPU_BFRAME_MAX || p.lookaheadDepth > LOOKAHEAD_MAX ||
         (p.bframes && p.bframes >= p.lookaheadDepth) ||   // x265_check_params (param.cpp:1811): the decision reads frames[bframes + 1]
         (p.aq.bHevcAq && (p.bAQMotion || (p.maxCUSize != 64 && p.maxCUSize != 32 && p.maxCUSize != 16))) || p.keyframeMin < 1 ||
         // calcMotionAdaptiveQuantFrame indexes the qgSize 8 offset arrays by lowres block (:3648-3658) and changes
@@ -1701,7 +1707,7 @@ void Lookahead::compCostBref(Lowres** frames, int start, int end, int num)      
     compCostBref(frames, avg + 1, end, end - avg);
 }
 
-// :1982-2751 without zones, fades, analysis load, MCSTF and the temporal-layer GOP tables
+// :1982-2751 without zones, analysis load and MCSTF
 // :2042-2088.  A run of pictures whose variance does not fall is a fade-in; the picture that ends a run of at least
 // a second is marked, and the fix-ups of the mini-GOP make it a keyframe.  The ring index over POC modulo the array
 // length, its wrap inside the loop and the use of list[endIndex] are the reference's.
@@ -1747,6 +1753,210 @@ void Lookahead::detectFades(Lowres** list)
         }
         if (k == length - 1)
             k = -1;
+    }
+}
+
+// The pictures that leave the window: off the input queue before they enter the output queue (:2672-2685)
+void Lookahead::dequeue(int count, int& maxSearch)
+{
+    m_inputQueue.erase(m_inputQueue.begin(), m_inputQueue.begin() + count);
+    maxSearch -= count;
+}
+
+// :2607-2716, the mini-GOP of list[0..bframes] without the temporal-layer orders
+void Lookahead::finishMiniGop(Lowres** frames, Lowres** list, int bframes, int& brefs, int& maxSearch)
+{
+    const LookaheadParam& P = m_param;
+    if (bframes)
+        list[bframes - 1]->bLastMiniGopBFrame = true;
+    list[bframes]->leadingBframes = bframes;
+    m_lastNonB = list[bframes];
+
+    if (P.bBPyramid && bframes > 1 && !brefs)
+        placeBref(list, 0, bframes, bframes + 1, brefs);
+
+    // the costs rate control will ask for, while the frames are still in the window (:2620-2670)
+    if (!P.bCqp)
+    {
+        if (!maxSearch)
+            for (int i = 0; i <= bframes; i++)
+                frames[i + 1] = list[i];
+        const int nonB = bframes + 1;
+        cost(frames, isTypeI(frames[nonB]->sliceType) ? nonB : 0, nonB, nonB);
+        if (P.bEnableTemporalSubLayers > 1 && bframes)
+            compCostBref(frames, 0, bframes, bframes + 1);
+        else
+        {
+            int p0 = 0;
+            bool p0Available = frames[nonB]->sliceType != TYPE_IDR;
+            for (int b = 1; b <= bframes; b++)
+            {
+                if (!p0Available)
+                    p0 = b;
+                int p1 = nonB;
+                if (frames[b]->sliceType == TYPE_B)
+                    for (p1 = b; frames[p1]->sliceType == TYPE_B; p1++)
+                        ;                                       // next non-B or B-ref
+                cost(frames, p0, p1, b);
+                if (frames[b]->sliceType == TYPE_BREF)
+                {
+                    p0 = b;
+                    p0Available = true;
+                }
+            }
+        }
+    }
+
+    // hand the mini-GOP over in coded order: the non-B frame, B-refs, then the plain B frames (:2672-2715)
+    dequeue(bframes + 1, maxSearch);
+    m_outputQueue.push_back(list[bframes]);
+    for (int pass = 0; pass < 2; pass++)
+        for (int i = 0; i < bframes; i++)
+            if ((list[i]->sliceType == TYPE_BREF) == (pass == 0) && (pass == 1 || brefs))
+                m_outputQueue.push_back(list[i]);
+}
+
+// x265_gop_ra (source/x265.h:835-): the coding order of a hierarchical mini-GOP of 4, 8 or 16 pictures as (POC offset,
+// temporal layer) pairs: the closing picture first, then of every interval its middle before its two halves, one
+// layer down per halving
+namespace {
+struct GopEntry { int pocOffset, layer; };
+const int kGopLength[3] = { 4, 8, 16 };
+
+void fillGopOrder(GopEntry* out, int& n, int lo, int hi, int layer)
+{
+    if (hi - lo < 2)
+        return;
+    const int mid = (lo + hi) / 2;
+    out[n++] = { mid, layer };
+    fillGopOrder(out, n, lo, mid, layer + 1);
+    fillGopOrder(out, n, mid, hi, layer + 1);
+}
+
+const GopEntry* gopOrder(int gopId)
+{
+    static GopEntry table[3][16];
+    static bool built = false;
+    if (!built)
+    {
+        for (int g = 0; g < 3; g++)
+        {
+            int n = 0;
+            table[g][n++] = { kGopLength[g], 0 };
+            fillGopOrder(table[g], n, 0, kGopLength[g], 1);
+        }
+        built = true;
+    }
+    return table[gopId];
+}
+}
+
+// The costs rate control will ask for of the sub-GOP list[first..nonB] (:2339-2359, 2424-2444, 2510-2528)
+void Lookahead::subGopCosts(Lowres** frames, int first, int nonB)
+{
+    if (m_param.bCqp)
+        return;
+    // (the reference's refill of frames[] for a lookahead without a window cannot run: the window holds at least the
+    // pictures still to hand over)
+    const int b = nonB + 1;
+    cost(frames, isTypeI(frames[b]->sliceType) ? b : first, b, b);
+    if (nonB)
+        compCostBref(frames, first, nonB, nonB + 1);
+}
+
+// :2304-2571.  A full mini-GOP leaves in the hierarchical order of its length; a shorter one (a keyframe or the end
+// of the stream cut it) is split into the longest orders that fit, and what is left over (under four pictures)
+// leaves as a plain mini-GOP.  The indices that stay relative to the whole list (leadingBframes, the count handed
+// to placeBref and compCostBref) are the reference's.
+void Lookahead::finishTemporalMiniGop(Lowres** frames, Lowres** list, int bframes, int& brefs, int& maxSearch)
+{
+    const LookaheadParam& P = m_param;
+    auto closeSubGop = [&](int first, int nonB)
+    {
+        Lowres& last = *list[nonB];
+        if (!isTypeI(last.sliceType))
+            last.sliceType = TYPE_P;
+        if (nonB)
+            list[nonB - 1]->bLastMiniGopBFrame = true;
+        last.leadingBframes = nonB;
+        m_lastNonB = &last;
+        (void)first;
+    };
+    auto hierarchical = [&](int first, int nonB, int gopId)
+    {
+        const GopEntry* order = gopOrder(gopId);
+        Lowres& last = *list[nonB];
+        last.gopOffset = 0;
+        last.gopId = gopId;
+        last.tempLayer = order[0].layer;
+        m_outputQueue.push_back(&last);
+        // the B pictures in coding order.  (The reference stores the mini-GOP's id into the list's last picture
+        // here, :2393, and leaves the B pictures' own field as it was; every picture carries its id here.)
+        for (int j = 1; j < kGopLength[gopId]; j++)
+        {
+            Lowres& f = *list[first + order[j].pocOffset - 1];
+            f.gopOffset = j;
+            f.gopId = gopId;
+            f.tempLayer = order[j].layer;
+            m_outputQueue.push_back(&f);
+        }
+    };
+
+    if (bframes == P.bframes)
+    {
+        list[bframes - 1]->bLastMiniGopBFrame = true;
+        list[bframes]->leadingBframes = bframes;
+        m_lastNonB = list[bframes];
+        if (P.bBPyramid && !brefs)
+            placeBref(list, 0, bframes, bframes + 1, brefs);
+        subGopCosts(frames, 0, bframes);
+        dequeue(bframes + 1, maxSearch);
+        hierarchical(0, bframes, m_gopId);
+        return;
+    }
+
+    int leftOver = bframes + 1, first = 0;
+    int gopId = m_gopId - 1;
+    while (gopId >= 0 && leftOver > 3)
+    {
+        const int gopLen = kGopLength[gopId];
+        if (leftOver < gopLen)
+        {
+            gopId--;
+            continue;
+        }
+        const int nonB = first + gopLen - 1;
+        closeSubGop(first, nonB);
+        if (P.bBPyramid && nonB)
+            placeBref(list, first, nonB, nonB + 1, brefs);
+        subGopCosts(frames, first, nonB);
+        dequeue(gopLen, maxSearch);
+        hierarchical(first, nonB, gopId);
+        first += gopLen;
+        leftOver -= gopLen;
+        gopId--;
+    }
+    if (leftOver > 0 && leftOver < 4)
+    {
+        const int nonB = first + leftOver - 1;
+        closeSubGop(first, nonB);
+        if (P.bBPyramid && nonB - first > 1)
+            placeBref(list, first, nonB, nonB + 1, brefs);
+        subGopCosts(frames, first, nonB);
+        dequeue(leftOver, maxSearch);
+        // the non-B picture, the B-refs (if the list holds any at all), then the plain B pictures, one layer up
+        for (int pass = 0; pass < 3; pass++)
+            for (int i = pass ? first : nonB; i < (pass ? nonB : nonB + 1); i++)
+            {
+                Lowres& f = *list[i];
+                const bool isBref = f.sliceType == TYPE_BREF;
+                if ((pass == 1 && !(brefs && isBref)) || (pass == 2 && isBref))
+                    continue;
+                f.gopOffset = 0;
+                f.gopId = -1;
+                f.tempLayer = pass == 2 ? 1 : 0;
+                m_outputQueue.push_back(&f);
+            }
     }
 }
 
@@ -1891,54 +2101,10 @@ void Lookahead::slicetypeDecide()
             break;
     }
 
-    if (bframes)
-        list[bframes - 1]->bLastMiniGopBFrame = true;
-    list[bframes]->leadingBframes = bframes;
-    m_lastNonB = list[bframes];
-
-    if (P.bBPyramid && bframes > 1 && !brefs)
-        placeBref(list, 0, bframes, bframes + 1, brefs);
-
-    // the costs rate control will ask for, while the frames are still in the window (:2620-2670)
-    if (!P.bCqp)
-    {
-        if (!maxSearch)
-            for (int i = 0; i <= bframes; i++)
-                frames[i + 1] = list[i];
-        const int nonB = bframes + 1;
-        cost(frames, isTypeI(frames[nonB]->sliceType) ? nonB : 0, nonB, nonB);
-        if (P.bEnableTemporalSubLayers > 1 && bframes)
-            compCostBref(frames, 0, bframes, bframes + 1);
-        else
-        {
-            int p0 = 0;
-            bool p0Available = frames[nonB]->sliceType != TYPE_IDR;
-            for (int b = 1; b <= bframes; b++)
-            {
-                if (!p0Available)
-                    p0 = b;
-                int p1 = nonB;
-                if (frames[b]->sliceType == TYPE_B)
-                    for (p1 = b; frames[p1]->sliceType == TYPE_B; p1++)
-                        ;                                       // next non-B or B-ref
-                cost(frames, p0, p1, b);
-                if (frames[b]->sliceType == TYPE_BREF)
-                {
-                    p0 = b;
-                    p0Available = true;
-                }
-            }
-        }
-    }
-
-    // hand the mini-GOP over in coded order: the non-B frame, B-refs, then the plain B frames (:2672-2715)
-    m_inputQueue.erase(m_inputQueue.begin(), m_inputQueue.begin() + bframes + 1);
-    maxSearch -= bframes + 1;
-    m_outputQueue.push_back(list[bframes]);
-    for (int pass = 0; pass < 2; pass++)
-        for (int i = 0; i < bframes; i++)
-            if ((list[i]->sliceType == TYPE_BREF) == (pass == 0) && (pass == 1 || brefs))
-                m_outputQueue.push_back(list[i]);
+    if (P.bEnableTemporalSubLayers > 2)
+        finishTemporalMiniGop(frames, list, bframes, brefs, maxSearch);
+    else
+        finishMiniGop(frames, list, bframes, brefs, maxSearch);
 
     // after a keyframe, run the analysis again from it so that cuTree / VBV planning start there (:2718-2747)
     if ((P.cuTree || (P.vbvBufferSize && P.lookaheadDepth)) && isTypeI(m_lastNonB->sliceType))
@@ -2270,6 +2436,9 @@ int xgh_lookahead_get_decided(xgh_lookahead* h, xgh_decided* out)
     out->bLastMiniGopBFrame = f->bLastMiniGopBFrame;
     out->leadingBframes = f->leadingBframes;
     out->bIsFadeEnd = f->bIsFadeEnd;
+    out->gopOffset = f->gopOffset;
+    out->gopId = f->gopId;
+    out->tempLayer = f->tempLayer;
     return 1;
 }
 

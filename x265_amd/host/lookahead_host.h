@@ -109,6 +109,9 @@ struct Lowres
     int sliceTypeReq = TYPE_AUTO;
     bool bScenecut = false, bKeyframe = false, bLastMiniGopBFrame = false;
     int leadingBframes = 0;
+    // --temporal-layers 3..5: the picture's place in its hierarchical mini-GOP (Frame::m_gopOffset, m_gopId,
+    // m_tempLayer; source/common/frame.h:96, 167-168)
+    int gopOffset = 0, gopId = 0, tempLayer = 0;
     int indB = 0;
     std::vector<int64_t> plannedSatd;     // [LOOKAHEAD_MAX + 1] once the VBV lookahead has run
     std::vector<int32_t> plannedType;
@@ -255,7 +258,8 @@ struct LookaheadParam
     int bFrameBias = 0;
     int vbvBufferSize = 0, vbvMaxBitrate = 0;
     bool bCqp = false;                            // rc.rateControlMode == X265_RC_CQP
-    int bEnableTemporalSubLayers = 0;             // 0..2
+    int bEnableTemporalSubLayers = 0;             // 0, 2, or 3..5 with bframes 3 / 7 / 15 and no B-adapt, as
+                                                  // Encoder::configure leaves them (encoder.cpp:4303-4332)
     int maxNumReferences = 3;
     bool bEnableWeightedPred = true;
     bool bEnableWeightedBiPred = false;
@@ -311,6 +315,10 @@ private:
     void vbvLookahead(Lowres** frames, int numFrames, bool keyframe);
     int64_t vbvFrameCost(Lowres** frames, int p0, int p1, int b);
     void placeBref(Lowres** list, int start, int end, int num, int& brefs);
+    void finishMiniGop(Lowres** frames, Lowres** list, int bframes, int& brefs, int& maxSearch);
+    void finishTemporalMiniGop(Lowres** frames, Lowres** list, int bframes, int& brefs, int& maxSearch);
+    void subGopCosts(Lowres** frames, int first, int nonB);
+    void dequeue(int count, int& maxSearch);
     void compCostBref(Lowres** frames, int start, int end, int num);
     void cuTree(Lowres** frames, int numframes, bool bIntra);
     void aqMotion(Lowres** frames, bool bIntra);
@@ -326,6 +334,7 @@ private:
     int m_8x8Blocks;
     Lowres* m_lastNonB = nullptr;
     int m_lastKeyframe;
+    int m_gopId = 0;                  // --temporal-layers 3..5: which of the 4 / 8 / 16 picture orders a full mini-GOP takes
     bool m_isSceneTransition = false, m_extendGopBoundary = false;
     bool m_bBatchMotionSearch, m_bBatchFrameCosts;
     // --hist-scenecut (slicetype.cpp:1143-1174): running averages of the histogram differences, [plane][segment]
@@ -413,6 +422,7 @@ typedef struct xgh_decided
     int32_t frame;                /* index in order of xgh_lookahead_add_picture */
     int32_t sliceType, bScenecut, bKeyframe, bLastMiniGopBFrame, leadingBframes;
     int32_t bIsFadeEnd;
+    int32_t gopOffset, gopId, tempLayer;
 } xgh_decided;
 xgh_lookahead* xgh_lookahead_create(x265gpu_ctx* ctx, const xgh_lookahead_param* p);
 void xgh_lookahead_destroy(xgh_lookahead* la);

@@ -312,8 +312,12 @@ def main():
         drawer(rng)
     while time.time() - t0 < a.seconds:
         cfg = drawer(rng)
+        # the single-launch search: one wait for the neighbour vectors, or as they come, in turn (by round, so that
+        # the draws stay what they are for a seed)
+        staged = ("0", "100000")[(a.skip + rounds + refused) & 1]
+        os.environ["X265GPU_FLOW_STAGED_JOBS"] = staged
         if log:
-            log.write(repr(cfg) + "\n")
+            log.write("staged_jobs=%s " % staged + repr(cfg) + "\n")
             log.flush()
         try:
             runner(cfg)

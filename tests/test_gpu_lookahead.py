@@ -301,6 +301,24 @@ def test_lowres_search_methods(depth, search):
         ref.close()
 
 
+@pytest.mark.parametrize("depth,kw", [(8, {}), (10, {}), (8, dict(search=orc.UMH)),
+                                      (8, dict(hme=True, hme_methods=(orc.HEX, orc.UMH, orc.UMH), hme_range=(16, 32, 48)))],
+                         ids=["hex8", "hex10", "umh8", "hme8"])
+@pytest.mark.parametrize("staged_jobs", ["0", "100000"], ids=["one-wait", "as-they-come"])
+def test_flow_search_both_ways_of_taking_neighbour_vectors(monkeypatch, staged_jobs, depth, kw):
+    """The single-launch search takes a block's neighbour vectors in one wait (launches of many searches) or as the
+    dependent chain produces them (launches of few, X265GPU_FLOW_STAGED_JOBS sets the limit): the same results
+    either way, whatever the launch size.  The clip has a scene cut, across which neighbouring vectors differ and
+    late ones are fetched and measured in a pass of their own."""
+    monkeypatch.setenv("X265GPU_FLOW_STAGED_JOBS", staged_jobs)
+    clip, ref, ctx, frames = _setup(400, 240, 8, depth, seed=4242, **kw)
+    try:
+        _run_sequence(ref, ctx, frames)
+    finally:
+        ctx.close()
+        ref.close()
+
+
 @pytest.mark.parametrize("depth,methods,ranges", [
     (8, (orc.HEX, orc.UMH, orc.UMH), (16, 32, 48)),        # x265's defaults for --hme
     (10, (orc.HEX, orc.UMH, orc.UMH), (16, 32, 48)),

@@ -30,6 +30,7 @@
 // natural alignment are replayed at 64 cycles).  Groups without a candidate
 // issue no loads, and the two MV-cost reads of a candidate ride on lanes 0 and
 // 1 of its group and are folded into the row reduction.
+#include <cstdlib>
 #include "device_common.h"
 #include "kernels.h"
 
@@ -814,7 +815,7 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
 constexpr int MODE_DIAG = 0, MODE_ROWS = 1, MODE_FLOW = 2;
 constexpr int FLOW_PENDING = 0x7FFF;          // no search produces this x: vectors stay within the padded picture
 constexpr int FLOW_POLL_LIMIT = 1 << 18;
-template <typename P, int METHOD, int MODE>
+template <typename P, int METHOD, int MODE, bool STAGED = false>
 __device__ __forceinline__ void search_block(const SearchJob& job, const Geometry& g, int level0, int cuX, int cuY,
                                              bool lastRow, int lane, const uint16_t* costTab, int maxMvd,
                                              XG_LDS uint32_t* lds, int& rightX, int& rightY,
@@ -893,17 +894,27 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         // reads (SATD); group 6 = (0,0) in the searched full-pel plane (SAD)
         const int off = (c.g == 0) ? 1 : (c.g == 1) ? W : (c.g == 2) ? W - 1 : W + 1;
         const bool mine = (c.g == 0) ? v0 : (c.g == 1) ? v1 : (c.g == 2) ? v2 : (c.g == 3) ? v3 : false;
+        // STAGED (MODE_FLOW launches of few searches, which are paid in the length of the dependent chain): the
+        // neighbour vectors are taken as they come.  The block below right finished three steps of the chain ago,
+        // the block below two, and the blocks to the right and below left are the two this block is handed out
+        // behind: they finish last.  Whatever hangs only on the vectors that are there at the first look (their
+        // candidate blocks, both zero blocks, the window around the first guess, the table window, their SATDs) is
+        // done at once; the others are then waited for in the order they come in, and one that equals a vector
+        // already measured (a smooth field's usual case) costs no memory round trip between its arrival and the
+        // search.  One that does not is fetched and measured in a pass of its own.  A launch with more searches
+        // than the chip holds waves is paid per instruction instead, and takes the vectors in one wait.
         int cx = 0, cy = 0;
-        if (MODE == MODE_FLOW)
+        long long flowV = FLOW_PENDING;
+        // wait for the vectors of the lanes that `want` one (the vector is its own ready flag)
+        auto flow_wait = [&](bool want, bool nearby)
         {
-            long long v = 0;
             int polls = 0;
             for (;;)
             {
-                if (mine)
-                    v = __hip_atomic_load((const XG_GLOBAL long long*)(mvs + 2 * (cuXY + off)), __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT);
-                if (!__builtin_amdgcn_ballot_w64(mine && (int)v == FLOW_PENDING))
+                if (want && (!STAGED || (int)flowV == FLOW_PENDING))
+                    flowV = __hip_atomic_load((const XG_GLOBAL long long*)(mvs + 2 * (cuXY + off)), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+                if (!__builtin_amdgcn_ballot_w64(want && (int)flowV == FLOW_PENDING))
                     break;
                 // never expected to run out (a block only waits for blocks handed out before it); rather than hang
                 // the device, stop waiting here and, through the error word, everywhere, and let the host call fail
@@ -918,15 +929,40 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
                         break;
                     }
                 }
-                __builtin_amdgcn_s_sleep(8);
+                // a vector one step of the chain away is looked for often; one further off, which is what a wave
+                // handed out far ahead of the wavefront waits for first, less and less often: every look is a
+                // request to the L2 channel that the wavefront's own hand-overs go through
+                if (!STAGED)
+                    __builtin_amdgcn_s_sleep(8);
+                else if (nearby)
+                    __builtin_amdgcn_s_sleep(2);
+                else if (polls < 16)
+                    __builtin_amdgcn_s_sleep(8);
+                else
+                    __builtin_amdgcn_s_sleep(32);
             }
             // a wait that was given up leaves the pending mark behind: the zero vector stands in for it (the host
             // discards these results and runs the batch again)
-            if ((int)v == FLOW_PENDING)
-                v = 0;
-            cx = (int)v;
-            cy = (int)(v >> 32);
-            STAMP(c, 1);
+            if (want && (int)flowV == FLOW_PENDING)
+                flowV = 0;
+        };
+        bool later = false;                     // this lane's vector was still pending at the first look
+        if (MODE == MODE_FLOW)
+        {
+            if (STAGED)
+            {
+                if (mine)
+                    flowV = __hip_atomic_load((const XG_GLOBAL long long*)(mvs + 2 * (cuXY + off)), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+                later = mine && (int)flowV == FLOW_PENDING;
+            }
+            else
+                flow_wait(mine, false);
+            if (mine && !later)
+            {
+                cx = (int)flowV;
+                cy = (int)(flowV >> 32);
+            }
         }
         else if (MODE == MODE_ROWS)
         {
@@ -954,33 +990,46 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
             cx = hx;
             cy = hy;
         }
+        // bit 8 G: group G's vector is still to come (wave-uniform)
+        const unsigned long long laterMask = STAGED ? __builtin_amdgcn_ballot_w64(later) : 0ull;
+#define AT_HAND(G) (!STAGED || !((laterMask >> (8 * G)) & 1))
         // A guess at where the search will start, so that its window can be in flight together
-        // with the candidate blocks: the first neighbour vector, treated the way the predictor
+        // with the candidate blocks: the first neighbour vector at hand, treated the way the predictor
         // will be.  The MV-cost windows are staged around MVD 0, where a search near its
         // predictor prices from.
         int sx = 0, sy = 0;
-        if (v0) { sx = group_value<0>(cx); sy = group_value<0>(cy); }
-        else if (v1) { sx = group_value<1>(cx); sy = group_value<1>(cy); }
+        if (v0 && AT_HAND(0)) { sx = group_value<0>(cx); sy = group_value<0>(cy); }
+        else if (v1 && AT_HAND(1)) { sx = group_value<1>(cx); sy = group_value<1>(cy); }
+        else if (STAGED && v3 && AT_HAND(3)) { sx = group_value<3>(cx); sy = group_value<3>(cy); }
         else if (v4) { sx = group_value<4>(cx); sy = group_value<4>(cy); }
         sx = (clampi(sx, c.minx * 4, c.maxx * 4) + 2) >> 2;
         sy = (clampi(sy, c.miny * 4, c.maxy * 4) + 2) >> 2;
 
-        const bool cand = mine || (c.g == 4 && v4);
+        const bool cand = (mine && !later) || (c.g == 4 && v4);
         // The kernel pays for every line a load touches (the vector L1 serves about one line per two cycles per
         // compute unit whether it hits or not), so nothing is fetched twice.  Neighbouring blocks mostly carry the
-        // same vector: a candidate equal to one of a lower group takes that group's SATD instead of reading the
-        // same eight rows again (it can never be picked, the first strictly smaller cost wins).  The zero block of
+        // same vector: a candidate equal to one of another group takes that group's figures instead of reading the
+        // same eight rows again (equal vectors have equal costs, so which of them the strict '<' chain below picks
+        // makes no difference to what it returns).  The zero block of
         // the searched plane is the zero block of the closing check whenever both are plane 0 of the same picture.
         // The table entry of mvcost(0,0) comes out of the table window staged below when it lies inside it.
+        // (both components fit 16 bits: vectors stay within the padded picture, in quarter pixels)
         int origin = c.g;
+        {
+            const int vec = (cx & 0xffff) | (int)((unsigned)cy << 16);
+            // branch-free, highest group first, so that the lowest group with the same vector is the one that stays
 #define SAME_AS(G, VALID)                                                                    \
-        if ((VALID) && cand && c.g > G && origin == c.g && cx == group_value<G>(cx) && cy == group_value<G>(cy)) \
-            origin = G;
-        SAME_AS(0, v0)
-        SAME_AS(1, v1)
-        SAME_AS(2, v2)
-        SAME_AS(3, v3)
+            {                                                                                \
+                const bool same = (VALID) & cand & (c.g > G) & (vec == group_value<G>(vec)); \
+                origin = same ? G : origin;                                                  \
+            }
+            SAME_AS(3, v3 && AT_HAND(3))
+            SAME_AS(2, v2 && AT_HAND(2))
+            SAME_AS(1, v1 && AT_HAND(1))
+            SAME_AS(0, v0 && AT_HAND(0))
 #undef SAME_AS
+        }
+#undef AT_HAND
         const bool dup = origin != c.g;
         const bool zeroShared = job.zeroRef == job.refOrigin && job.zeroStride == stride;     // wave-uniform
         Row<P> ref = cand_row<P>(c, cx, cy, (cand && !dup) || (c.g == 6 && !zeroShared));
@@ -989,20 +1038,25 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         // table entries of mvcost(0,0) should this group's vector become the predictor
         // (group 6 stands in for the zero predictor of a block without neighbours)
         int t0 = 0;
-        const int t0d = c.r == 0 ? -cx : -cy;                    // the MVD of the zero vector under this predictor
-        const bool t0need = (cand || c.g == 6) && c.r < 2 && !dup;
-        const bool t0staged = (unsigned)(t0d + 4 * (TAB_N / 8)) < (unsigned)TAB_N && maxMvd >= TAB_N;
-        if (t0need && !t0staged)
-            t0 = (int)c.costBase[(unsigned)(clampi(t0d, -maxMvd, maxMvd) + maxMvd)];
+        const bool tabCovers = maxMvd >= TAB_N;
+        {
+            const int t0d = c.r == 0 ? -cx : -cy;                // the MVD of the zero vector under this predictor
+            const bool t0staged = (unsigned)(t0d + 4 * (TAB_N / 8)) < (unsigned)TAB_N && tabCovers;
+            if ((cand || c.g == 6) && c.r < 2 && !dup && !t0staged)
+                t0 = (int)c.costBase[(unsigned)(clampi(t0d, -maxMvd, maxMvd) + maxMvd)];
+        }
         const WinStage<P> ws = win_load<P>(c, sx, sy);
         const TabStage ts = tab_load<P>(c, 0, 0);
         lds_handover();
         win_store<P>(c, ws);
         tab_store<P>(c, ts);
         lds_handover();
-        STAMP(c, 2);
-        if (t0need && t0staged)
-            t0 = (int)((const XG_LDS uint16_t*)c.tab)[(c.r & 1) * TAB_N + t0d - (c.r ? c.tabLoY : c.tabLoX)];
+        {
+            const int t0d = c.r == 0 ? -cx : -cy;
+            const bool t0staged = (unsigned)(t0d + 4 * (TAB_N / 8)) < (unsigned)TAB_N && tabCovers;
+            if ((cand || c.g == 6) && c.r < 2 && !dup && t0staged)
+                t0 = (int)((const XG_LDS uint16_t*)c.tab)[(c.r & 1) * TAB_N + t0d - (c.r ? c.tabLoY : c.tabLoX)];
+        }
 #pragma unroll
         for (int i = 0; i < PixT<P>::NW; i++)
             c.fr.w[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c.r, (int)c.fr.w[i]);
@@ -1018,12 +1072,88 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         }
 
         int cost = reduce_cost<P, EV_SATD>(c, ref, 0);
-        {
-            const int fromOrigin = __builtin_amdgcn_ds_bpermute(32 * origin, cost);
-            cost = dup ? fromOrigin : cost;
-        }
-        const int sad = sad8x8<P>(c.fr, ref);
+        int sad = sad8x8<P>(c.fr, ref);
         t0 += dpp<DPP_XOR1>(t0);
+        STAMP(c, 1);
+        STAMP(c, 2);
+        if (STAGED && laterMask)
+        {
+            // ---- the vectors that were still to come, in the order the chain produces them ----
+            // bit 8 G: group G holds figures it measured itself
+            unsigned long long measured = __builtin_amdgcn_ballot_w64(cand && !dup);
+            const int turn = c.g == 3 ? 0 : c.g == 1 ? 1 : 2;
+#pragma unroll 1
+            for (int k = 0; k < 3; k++)
+            {
+                const bool want = later && turn == k;
+                if (!__builtin_amdgcn_ballot_w64(want))
+                    continue;
+                flow_wait(want, k > 0);
+                STAMP(c, 2);
+                if (want)
+                {
+                    cx = (int)flowV;
+                    cy = (int)(flowV >> 32);
+                }
+                {
+                    // the lowest group that measured the same vector (a waiting group has measured nothing yet, so
+                    // it never finds itself); of the last turn's two, which may carry the same new vector, the
+                    // lower group fetches it
+                    const int vec = (cx & 0xffff) | (int)((unsigned)cy << 16);
+                    int found = c.g;
+#define SAME_AS(G)                                                                            \
+                    {                                                                         \
+                        const bool same = (((measured >> (8 * G)) & 1) != 0) & (vec == group_value<G>(vec)); \
+                        found = same ? G : found;                                             \
+                    }
+                    SAME_AS(4)
+                    SAME_AS(3)
+                    SAME_AS(2)
+                    SAME_AS(1)
+                    SAME_AS(0)
+#undef SAME_AS
+                    const bool g0waits = ((__builtin_amdgcn_ballot_w64(want) >> 0) & 1) != 0;
+                    const bool g0new = g0waits & (__builtin_amdgcn_readlane(found, 0) == 0);
+                    const bool asG0 = g0new & (c.g == 2) & (found == 2) & (vec == group_value<0>(vec));
+                    found = asG0 ? 0 : found;
+                    origin = want ? found : origin;
+                }
+                const bool fetch = want && origin == c.g;
+                const unsigned long long fetching = __builtin_amdgcn_ballot_w64(fetch);
+                if (fetching)
+                {
+                    // a vector that no group has measured yet: its block, and a pass for it
+                    const Row<P> ref2 = cand_row<P>(c, cx, cy, fetch);
+                    int t0b = 0;
+                    const int t0d = c.r == 0 ? -cx : -cy;
+                    const bool t0staged = (unsigned)(t0d + 4 * (TAB_N / 8)) < (unsigned)TAB_N && tabCovers;
+                    if (fetch && c.r < 2)
+                        t0b = t0staged ? (int)((const XG_LDS uint16_t*)c.tab)[(c.r & 1) * TAB_N + t0d - (c.r ? c.tabLoY : c.tabLoX)]
+                                       : (int)c.costBase[(unsigned)(clampi(t0d, -maxMvd, maxMvd) + maxMvd)];
+                    const int cost2 = reduce_cost<P, EV_SATD>(c, ref2, 0);
+                    const int sad2 = sad8x8<P>(c.fr, ref2);
+                    t0b += dpp<DPP_XOR1>(t0b);
+                    cost = fetch ? cost2 : cost;
+                    sad = fetch ? sad2 : sad;
+                    t0 = fetch ? t0b : t0;
+                    measured |= fetching;
+                }
+            }
+        }
+        {
+            // groups whose vector another group measured take that group's figures (without STAGED such a group is
+            // always the higher one, which the strict '<' below never picks: only its cost is looked at)
+            const bool copy = origin != c.g;
+            const int costO = __builtin_amdgcn_ds_bpermute(32 * origin, cost);
+            cost = copy ? costO : cost;
+            if (STAGED)
+            {
+                const int sadO = __builtin_amdgcn_ds_bpermute(32 * origin, sad);
+                const int t0O = __builtin_amdgcn_ds_bpermute(32 * origin, t0);
+                sad = copy ? sadO : sad;
+                t0 = copy ? t0O : t0;
+            }
+        }
         zeroSatd = group_value<5>(cost);
         zeroSad = group_value<6>(sad);
         int mvpcost = COST_MAX;
@@ -1251,7 +1381,7 @@ search_rows_kernel_wide(const SearchJob* jobs, int nJobs, Geometry g, int level0
 // job) fastest: a block only ever waits for blocks of lower chunks, i.e. of workgroups handed out before its own,
 // so the lowest unfinished workgroup can always run.  Should the hardware not hold to that, the bounded poll in
 // search_block ends the wait and the call fails.
-template <typename P, int METHOD>
+template <typename P, int METHOD, bool STAGED>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8)))
 search_flow_kernel(const SearchJob* jobs, int nJobs, Geometry g, int level0, const uint32_t* chunkTab, const uint16_t* costTab,
                    int maxMvd, int* sync)
@@ -1270,7 +1400,7 @@ search_flow_kernel(const SearchJob* jobs, int nJobs, Geometry g, int level0, con
         return;
     const int xq = t - 2 * yq;
     int rx = 0, ry = 0;
-    search_block<P, METHOD, MODE_FLOW>(job, g, level0, W - 1 - xq, H - 1 - yq, yq == 0, threadIdx.x & 63, costTab, maxMvd,
+    search_block<P, METHOD, MODE_FLOW, STAGED>(job, g, level0, W - 1 - xq, H - 1 - yq, yq == 0, threadIdx.x & 63, costTab, maxMvd,
                                        (XG_LDS uint32_t*)ldsBuf + wave * WaveLds<P>::TOTAL, rx, ry,
                                        (XG_GLOBAL int*)sync + SYNC_ERROR, 0);
 }
@@ -1297,19 +1427,28 @@ int search_flow_chunks(int W, int H, uint32_t* out)
     return n;
 }
 
-template <typename P>
+template <typename P, bool STAGED>
 static void launch_flow_method(int method, hipStream_t s, dim3 grid, const SearchJob* dJobs, int n, const Geometry& g,
                                int level0, const uint32_t* chunkTab, const uint16_t* costTab, int maxMvd, int* sync)
 {
     if (method == X265GPU_DIA)
-        hipLaunchKernelGGL((search_flow_kernel<P, X265GPU_DIA>), grid, dim3(256), 0, s, dJobs, n, g, level0, chunkTab, costTab,
-                           maxMvd, sync);
+        hipLaunchKernelGGL((search_flow_kernel<P, X265GPU_DIA, STAGED>), grid, dim3(256), 0, s, dJobs, n, g, level0, chunkTab,
+                           costTab, maxMvd, sync);
     else if (method == X265GPU_UMH)
-        hipLaunchKernelGGL((search_flow_kernel<P, X265GPU_UMH>), grid, dim3(256), 0, s, dJobs, n, g, level0, chunkTab, costTab,
-                           maxMvd, sync);
+        hipLaunchKernelGGL((search_flow_kernel<P, X265GPU_UMH, STAGED>), grid, dim3(256), 0, s, dJobs, n, g, level0, chunkTab,
+                           costTab, maxMvd, sync);
     else
-        hipLaunchKernelGGL((search_flow_kernel<P, X265GPU_HEX>), grid, dim3(256), 0, s, dJobs, n, g, level0, chunkTab, costTab,
-                           maxMvd, sync);
+        hipLaunchKernelGGL((search_flow_kernel<P, X265GPU_HEX, STAGED>), grid, dim3(256), 0, s, dJobs, n, g, level0, chunkTab,
+                           costTab, maxMvd, sync);
+}
+
+// Launches of up to this many searches take the neighbour vectors as they come (search_block's STAGED form): their
+// time is the length of the dependent chain, which that form shortens at the price of more instructions per block;
+// larger launches fill the chip and are paid per instruction.  X265GPU_FLOW_STAGED_JOBS overrides (0: never).
+static int flow_staged_jobs()
+{
+    const char* e = getenv("X265GPU_FLOW_STAGED_JOBS");      // read per launch: tests switch it between calls
+    return e ? atoi(e) : 112;
 }
 
 hipError_t launch_search_flow(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0, int method,
@@ -1322,10 +1461,15 @@ hipError_t launch_search_flow(hipStream_t s, const Geometry& g, int bpp, const S
     hipLaunchKernelGGL(search_flow_fill_kernel, dim3((blocks + 255) / 256, n), dim3(256), 0, s, dJobs, blocks);
     const int gx = gridPad > 1 ? (n + gridPad - 1) / gridPad * gridPad : n;
     const dim3 grid(gx, numChunks);
-    if (bpp == 1)
-        launch_flow_method<uint8_t>(method, s, grid, dJobs, n, g, level0, dChunkTab, costTab, maxMvd, dSync);
+    const bool staged = n <= flow_staged_jobs();
+    if (bpp == 1 && staged)
+        launch_flow_method<uint8_t, true>(method, s, grid, dJobs, n, g, level0, dChunkTab, costTab, maxMvd, dSync);
+    else if (bpp == 1)
+        launch_flow_method<uint8_t, false>(method, s, grid, dJobs, n, g, level0, dChunkTab, costTab, maxMvd, dSync);
+    else if (staged)
+        launch_flow_method<uint16_t, true>(method, s, grid, dJobs, n, g, level0, dChunkTab, costTab, maxMvd, dSync);
     else
-        launch_flow_method<uint16_t>(method, s, grid, dJobs, n, g, level0, dChunkTab, costTab, maxMvd, dSync);
+        launch_flow_method<uint16_t, false>(method, s, grid, dJobs, n, g, level0, dChunkTab, costTab, maxMvd, dSync);
     if (launches)
         (*launches) += 2;
     return hipGetLastError();

@@ -1,10 +1,11 @@
 """Where a flow search's dependency chain spends its time.  Diagnostic; run on the GPU box against the timing build
 (make -C x265_amd/csrc stamp): every block of the launch's first job leaves the 100 MHz clock at the ends of its
 stages, and this script walks the chain backwards from the last block to finish, always to the neighbour whose vector
-arrived last, and adds up the stages along it.
+arrived last, and adds up the steps along it: those whose search had run ahead on assumed vectors that agreed (a
+hand-over and a compare) and those that searched after the last vector came.
 
   PROBE_JOBS=10 python benchmarks/chain_probe.py        (searches in the launch; the stamps are the first one's)
-  X265GPU_SEARCH_LEAN_JOBS=64 ...                       (launches of at most that many searches take the lean kernel)"""
+  X265GPU_FLOW_STAGED_JOBS=0 ...                        (the one-wait form: every step searches after)"""
 import ctypes as C
 import json
 import os
@@ -64,52 +65,36 @@ def main():
                 out.append((x + 1, y + 1))
         return out
 
-    # stamps: 0 start, 1 early stage done (candidates of the early vectors, windows, their SATDs), 2 late vectors seen,
-    # 3 predictor picked, 4 integer search done, 5 sub-pel window staged, 6 result stored, 7 sub-pel window re-staged
-    names = ("handoff", "late-candidates+pick", "integer", "subpel-stage", "subpel", "early-stage-not-done")
-    tot = dict.fromkeys(names, 0)
+    # stamps: 0 start, 1 first stage done (what hangs on the vectors at hand at the first look), 2 last neighbour
+    # vector seen, 3 predictor picked, 4 integer search done, 5 sub-pel window staged, 6 result stored.  A block whose
+    # search ran ahead on assumed vectors that then agreed carries the moment of that agreement in 2..5.
+    names = ("ran-ahead", "searched-after")
+    tot = {k: 0 for k in names}
+    count = {k: 0 for k in names}
+    rows = {}
     x = y = 0                                               # the last block of the wavefront
     steps = 0
-    staged = 0
-    not_done = 0
-    early_lag = []                                          # early vectors stored -> early stage done, along the chain
     while True:
         i = x + y * W8
         s = st[i]
         nb = neighbours(x, y)
-        dep = max((store[a + b * W8] for a, b in nb), default=None)
-        if dep is not None:
-            early = [store[a + b * W8] for a, b in ((x, y + 1), (x + 1, y + 1)) if a < W8 and b < H8]
-            if early:
-                early_lag.append(int(s[1] - max(early)))
-            if s[1] > dep:                                  # the inputs were there before the early stage was through
-                not_done += 1
-                tot["early-stage-not-done"] += int(s[2] - dep)
-            else:
-                tot["handoff"] += int(s[2] - dep)
-        tot["late-candidates+pick"] += int(s[3] - s[2])
-        tot["integer"] += int(s[4] - s[3])
-        tot["subpel-stage"] += int(s[5] - s[4])
-        tot["subpel"] += int(s[6] - s[5])
-        staged += int(s[7] != s[0])
-        steps += 1
         if not nb:
             break
-        x, y = max(nb, key=lambda p: store[p[0] + p[1] * W8])
+        a, b = max(nb, key=lambda p: store[p[0] + p[1] * W8])
+        kind = "ran-ahead" if s[4] - s[3] < 50 else "searched-after"
+        tot[kind] += int(s[6] - store[a + b * W8])
+        count[kind] += 1
+        rows[y] = rows.get(y, 0) + 1
+        steps += 1
+        x, y = a, b
     span = int(store[0] - st[:, 0].min())
-    print(json.dumps({"jobs": jobs, "lean_jobs": os.environ.get("X265GPU_SEARCH_LEAN_JOBS", "0"), "call_ms": round(best * 1e3, 3), "first_job_span_us": span / 1e3, "chain_steps": steps,
-                      "subpel_windows_staged_on_chain": staged, "steps_early_stage_not_done": not_done,
-                      "early_vectors_to_early_stage_done_ns": {"mean": float(np.mean(early_lag)), "median": float(np.median(early_lag)),
-                                                               "p10": float(np.percentile(early_lag, 10)), "p90": float(np.percentile(early_lag, 90))},
-                      "chain_us": {k: round(v / 1e3, 1) for k, v in tot.items()},
-                      "per_step_ns": {k: round(v / steps) for k, v in tot.items()},
+    print(json.dumps({"jobs": jobs, "staged_jobs": os.environ.get("X265GPU_FLOW_STAGED_JOBS", "default"), "call_ms": round(best * 1e3, 3),
+                      "first_job_span_us": span / 1e3, "chain_steps": steps,
+                      "chain_steps_by_kind": count, "chain_us_by_kind": {k: round(v / 1e3, 1) for k, v in tot.items()},
+                      "mean_step_ns_by_kind": {k: round(tot[k] / count[k]) if count[k] else None for k in names},
+                      "chain_steps_in_bottom_row": rows.get(H8 - 1, 0),
                       "all_blocks_mean_ns": {"wave_life": float((st[:, 6] - st[:, 0]).mean()),
-                                             "early-stage": float((st[:, 1] - st[:, 0]).mean()),
-                                             "late-wait": float((st[:, 2] - st[:, 1]).mean()),
-                                             "late-candidates+pick": float((st[:, 3] - st[:, 2]).mean()),
-                                             "integer": float((st[:, 4] - st[:, 3]).mean()),
-                                             "subpel-stage": float((st[:, 5] - st[:, 4]).mean()),
-                                             "subpel": float((st[:, 6] - st[:, 5]).mean())}}))
+                                             "first-stage": float((st[:, 1] - st[:, 0]).mean())}}))
 
 
 if __name__ == "__main__":

@@ -1,5 +1,6 @@
 """Time of one search launch against the number of searches in it, for the two ways the single-launch search takes a
-block's neighbour vectors (X265GPU_FLOW_STAGED_JOBS = 0: one wait; large: as the dependent chain produces them).
+block's neighbour vectors (X265GPU_FLOW_STAGED_JOBS = 0: one wait; large: as the dependent chain produces them, the
+search run ahead on assumed ones).
 Diagnostic; run on the GPU box.  The crossover is where the library's default for that limit comes from.
 
   python benchmarks/launch_size_sweep.py [--cut]          (--cut: a clip with a scene cut, whose vector fields are rough)"""
@@ -22,7 +23,7 @@ def main():
     ctx.intra_estimate(list(range(F)))
     ctx.sync()
     pairs = [(b - d, b) for d in range(1, 6) for b in range(d, F)]
-    for n in (1, 4, 10, 20, 40, 80, 120, 160, 200, len(pairs)):
+    for n in (1, 4, 10, 20, 30, 40, 60, 80, 120, 160, len(pairs)):
         reqs = [(p0, b, b, p0, b, b, 1, 0) for p0, b in pairs[:n]]
         row = []
         for limit in ("0", "100000"):

@@ -888,12 +888,18 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     }
     int mvpx = 0, mvpy = 0, skipCost = 0x7fffffff;
     int zeroSad, zeroSatd, mvpSad, mv0cost;
+    int mx = 0, my = 0, fencCost = 0;
     {
         // one pass: groups 0..4 = the predictor candidates (SATD); group 5 = the
         // block at displacement (0,0) in the plane the closing zero-vector check
         // reads (SATD); group 6 = (0,0) in the searched full-pel plane (SAD)
-        const int off = (c.g == 0) ? 1 : (c.g == 1) ? W : (c.g == 2) ? W - 1 : W + 1;
-        const bool mine = (c.g == 0) ? v0 : (c.g == 1) ? v1 : (c.g == 2) ? v2 : (c.g == 3) ? v3 : false;
+        // STAGED, bottom row: a block there has one neighbour, and nothing to assume its vector from.  Group 1, idle
+        // in that row, stands in: it takes the vector of the block two to the right, which the chain produces one
+        // step before the neighbour's, and measures it like a candidate's; the predictor choice never looks at it.
+        const bool standIn = STAGED && lastRow;
+        const bool m1 = standIn ? cuX < W - 2 : v1;
+        const int off = (c.g == 0) ? 1 : (c.g == 1) ? (standIn ? 2 : W) : (c.g == 2) ? W - 1 : W + 1;
+        const bool mine = (c.g == 0) ? v0 : (c.g == 1) ? m1 : (c.g == 2) ? v2 : (c.g == 3) ? v3 : false;
         // STAGED (MODE_FLOW launches of few searches, which are paid in the length of the dependent chain): the
         // neighbour vectors are taken as they come.  The block below right finished three steps of the chain ago,
         // the block below two, and the blocks to the right and below left are the two this block is handed out
@@ -999,7 +1005,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         // predictor prices from.
         int sx = 0, sy = 0;
         if (v0 && AT_HAND(0)) { sx = group_value<0>(cx); sy = group_value<0>(cy); }
-        else if (v1 && AT_HAND(1)) { sx = group_value<1>(cx); sy = group_value<1>(cy); }
+        else if (m1 && AT_HAND(1)) { sx = group_value<1>(cx); sy = group_value<1>(cy); }
         else if (STAGED && v3 && AT_HAND(3)) { sx = group_value<3>(cx); sy = group_value<3>(cy); }
         else if (v4) { sx = group_value<4>(cx); sy = group_value<4>(cy); }
         sx = (clampi(sx, c.minx * 4, c.maxx * 4) + 2) >> 2;
@@ -1025,7 +1031,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
             }
             SAME_AS(3, v3 && AT_HAND(3))
             SAME_AS(2, v2 && AT_HAND(2))
-            SAME_AS(1, v1 && AT_HAND(1))
+            SAME_AS(1, m1 && AT_HAND(1))
             SAME_AS(0, v0 && AT_HAND(0))
 #undef SAME_AS
         }
@@ -1076,122 +1082,202 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         t0 += dpp<DPP_XOR1>(t0);
         STAMP(c, 1);
         STAMP(c, 2);
+        // ---- STAGED: the vectors that were still to come, in the order the chain produces them ----
+        // bit 8 G: group G holds figures it measured itself
+        unsigned long long measured = STAGED ? __builtin_amdgcn_ballot_w64(cand && !dup) : 0ull;
+        const int turn = c.g == 3 ? 0 : c.g == 1 ? 1 : 2;
+        bool tabAtZero = true;                  // the table windows are the ones staged above, around MVD 0
+        auto take_turn = [&](int k)
+        {
+            const bool want = later && turn == k;
+            if (!__builtin_amdgcn_ballot_w64(want))
+                return;
+            flow_wait(want, k > 0);
+            STAMP(c, 2);
+            if (want)
+            {
+                cx = (int)flowV;
+                cy = (int)(flowV >> 32);
+            }
+            {
+                // the lowest group that measured the same vector (a waiting group has measured nothing yet, so
+                // it never finds itself); of the last turn's two, which may carry the same new vector, the
+                // lower group fetches it
+                const int vec = (cx & 0xffff) | (int)((unsigned)cy << 16);
+                int found = c.g;
+#define SAME_AS(G)                                                                            \
+                {                                                                             \
+                    const bool same = (((measured >> (8 * G)) & 1) != 0) & (vec == group_value<G>(vec)); \
+                    found = same ? G : found;                                                 \
+                }
+                SAME_AS(4)
+                SAME_AS(3)
+                SAME_AS(2)
+                SAME_AS(1)
+                SAME_AS(0)
+#undef SAME_AS
+                const bool g0waits = (__builtin_amdgcn_ballot_w64(want) & 1) != 0;
+                const bool g0new = g0waits & (__builtin_amdgcn_readlane(found, 0) == 0);
+                const bool asG0 = g0new & (c.g == 2) & (found == 2) & (vec == group_value<0>(vec));
+                found = asG0 ? 0 : found;
+                origin = want ? found : origin;
+            }
+            const bool fetch = want && origin == c.g;
+            const unsigned long long fetching = __builtin_amdgcn_ballot_w64(fetch);
+            if (fetching)
+            {
+                // a vector that no group has measured yet: its block, and a pass for it
+                const Row<P> ref2 = cand_row<P>(c, cx, cy, fetch);
+                int t0b = 0;
+                // (a search that ran on the assumption below has moved the table windows)
+                const int t0d = c.r == 0 ? -cx : -cy;
+                const bool t0staged = (unsigned)(t0d + 4 * (TAB_N / 8)) < (unsigned)TAB_N && tabCovers && tabAtZero;
+                if (fetch && c.r < 2)
+                    t0b = t0staged ? (int)((const XG_LDS uint16_t*)c.tab)[(c.r & 1) * TAB_N + t0d - (c.r ? c.tabLoY : c.tabLoX)]
+                                   : (int)c.costBase[(unsigned)(clampi(t0d, -maxMvd, maxMvd) + maxMvd)];
+                const int cost2 = reduce_cost<P, EV_SATD>(c, ref2, 0);
+                const int sad2 = sad8x8<P>(c.fr, ref2);
+                t0b += dpp<DPP_XOR1>(t0b);
+                cost = fetch ? cost2 : cost;
+                sad = fetch ? sad2 : sad;
+                t0 = fetch ? t0b : t0;
+                measured |= fetching;
+            }
+        };
+        // While vectors are still out, the search runs on an assumption: that they will all equal the neighbour
+        // vector the chain produced last (below right, then below).  The vectors are then looked at turn by turn as
+        // they come: while they agree the result stands, and once the last turn's have agreed it is the block's
+        // result, since every figure that goes into it is a function of the vectors alone; a step of the chain is
+        // then a hand-over and a compare.  A vector that disagrees is taken the long way, and the search runs again
+        // on what is known by then (the vectors that are still out assumed as before).  The bottom row, which has
+        // only its right neighbour, waits.
+        const bool mayAssume = STAGED && m1;                                   // wave-uniform
+        int nextTurn = 0;                                                      // the turns before it have been taken
         if (STAGED && laterMask)
         {
-            // ---- the vectors that were still to come, in the order the chain produces them ----
-            // bit 8 G: group G holds figures it measured itself
-            unsigned long long measured = __builtin_amdgcn_ballot_w64(cand && !dup);
-            const int turn = c.g == 3 ? 0 : c.g == 1 ? 1 : 2;
+            const int upTo = mayAssume ? (v3 ? 1 : 2) : 3;
 #pragma unroll 1
-            for (int k = 0; k < 3; k++)
-            {
-                const bool want = later && turn == k;
-                if (!__builtin_amdgcn_ballot_w64(want))
-                    continue;
-                flow_wait(want, k > 0);
-                STAMP(c, 2);
-                if (want)
-                {
-                    cx = (int)flowV;
-                    cy = (int)(flowV >> 32);
-                }
-                {
-                    // the lowest group that measured the same vector (a waiting group has measured nothing yet, so
-                    // it never finds itself); of the last turn's two, which may carry the same new vector, the
-                    // lower group fetches it
-                    const int vec = (cx & 0xffff) | (int)((unsigned)cy << 16);
-                    int found = c.g;
-#define SAME_AS(G)                                                                            \
-                    {                                                                         \
-                        const bool same = (((measured >> (8 * G)) & 1) != 0) & (vec == group_value<G>(vec)); \
-                        found = same ? G : found;                                             \
-                    }
-                    SAME_AS(4)
-                    SAME_AS(3)
-                    SAME_AS(2)
-                    SAME_AS(1)
-                    SAME_AS(0)
-#undef SAME_AS
-                    const bool g0waits = ((__builtin_amdgcn_ballot_w64(want) >> 0) & 1) != 0;
-                    const bool g0new = g0waits & (__builtin_amdgcn_readlane(found, 0) == 0);
-                    const bool asG0 = g0new & (c.g == 2) & (found == 2) & (vec == group_value<0>(vec));
-                    found = asG0 ? 0 : found;
-                    origin = want ? found : origin;
-                }
-                const bool fetch = want && origin == c.g;
-                const unsigned long long fetching = __builtin_amdgcn_ballot_w64(fetch);
-                if (fetching)
-                {
-                    // a vector that no group has measured yet: its block, and a pass for it
-                    const Row<P> ref2 = cand_row<P>(c, cx, cy, fetch);
-                    int t0b = 0;
-                    const int t0d = c.r == 0 ? -cx : -cy;
-                    const bool t0staged = (unsigned)(t0d + 4 * (TAB_N / 8)) < (unsigned)TAB_N && tabCovers;
-                    if (fetch && c.r < 2)
-                        t0b = t0staged ? (int)((const XG_LDS uint16_t*)c.tab)[(c.r & 1) * TAB_N + t0d - (c.r ? c.tabLoY : c.tabLoX)]
-                                       : (int)c.costBase[(unsigned)(clampi(t0d, -maxMvd, maxMvd) + maxMvd)];
-                    const int cost2 = reduce_cost<P, EV_SATD>(c, ref2, 0);
-                    const int sad2 = sad8x8<P>(c.fr, ref2);
-                    t0b += dpp<DPP_XOR1>(t0b);
-                    cost = fetch ? cost2 : cost;
-                    sad = fetch ? sad2 : sad;
-                    t0 = fetch ? t0b : t0;
-                    measured |= fetching;
-                }
-            }
+            for (; nextTurn < upTo; nextTurn++)
+                take_turn(nextTurn);
         }
+        bool searched = false;                 // a search has run, from the start values in `was`
+        int was[7] = { 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll 1
+        for (;;)
         {
+            const bool assumed = STAGED && later && turn >= nextTurn;
+            const bool anyAssumed = mayAssume && __builtin_amdgcn_ballot_w64(assumed) != 0;
+            int ux = cx, uy = cy, uorigin = origin;
+            if (STAGED && anyAssumed)
+            {
+                const int from = (nextTurn >= 2 || !v3) ? 8 : 24;              // first lane of the group assumed from
+                const int ax = __builtin_amdgcn_readlane(cx, from), ay = __builtin_amdgcn_readlane(cy, from);
+                const int ao = __builtin_amdgcn_readlane(origin, from);
+                ux = assumed ? ax : cx;
+                uy = assumed ? ay : cy;
+                uorigin = assumed ? ao : origin;
+            }
             // groups whose vector another group measured take that group's figures (without STAGED such a group is
             // always the higher one, which the strict '<' below never picks: only its cost is looked at)
-            const bool copy = origin != c.g;
-            const int costO = __builtin_amdgcn_ds_bpermute(32 * origin, cost);
-            cost = copy ? costO : cost;
+            const bool copy = uorigin != c.g;
+            const int costO = __builtin_amdgcn_ds_bpermute(32 * uorigin, cost);
+            const int ucost = copy ? costO : cost;
+            int usad = sad, ut0 = t0;
             if (STAGED)
             {
-                const int sadO = __builtin_amdgcn_ds_bpermute(32 * origin, sad);
-                const int t0O = __builtin_amdgcn_ds_bpermute(32 * origin, t0);
-                sad = copy ? sadO : sad;
-                t0 = copy ? t0O : t0;
+                const int sadO = __builtin_amdgcn_ds_bpermute(32 * uorigin, sad);
+                const int t0O = __builtin_amdgcn_ds_bpermute(32 * uorigin, t0);
+                usad = copy ? sadO : sad;
+                ut0 = copy ? t0O : t0;
+            }
+            zeroSatd = group_value<5>(ucost);
+            zeroSad = group_value<6>(usad);
+            int mvpcost = COST_MAX;
+            int wg = 6;
+            mvpx = mvpy = 0;
+            skipCost = 0x7fffffff;
+#define TAKE(G, VALID)                                                                      \
+            if (VALID)                                                                      \
+            {                                                                               \
+                const int cg = group_value<G>(ucost);                                       \
+                if (cg < mvpcost)                                                           \
+                {                                                                           \
+                    mvpcost = cg;                                                           \
+                    mvpx = group_value<G>(ux);                                              \
+                    mvpy = group_value<G>(uy);                                              \
+                    wg = G;                                                                 \
+                }                                                                           \
+                /* tracks the latest candidate while the running best is the zero vector */\
+                if (!(mvpx | mvpy) && job.bBidir)                                           \
+                    skipCost = cg;                                                          \
+            }
+            TAKE(0, v0)
+            TAKE(1, v1)
+            TAKE(2, v2)
+            TAKE(3, v3)
+            TAKE(4, v4)
+#undef TAKE
+            mvpSad = __builtin_amdgcn_readlane(usad, wg * 8);
+            mv0cost = __builtin_amdgcn_readlane(ut0, wg * 8);
+
+            STAMP(c, 3);
+            // (a vector that disagreed with the assumption often loses to the assumed one all the same: the search
+            // then starts from what it started from before, and its result stands)
+            const bool sameStart = STAGED && searched && mvpx == was[0] && mvpy == was[1] && mvpSad == was[2] &&
+                                   mv0cost == was[3] && zeroSad == was[4] && zeroSatd == was[5] && skipCost == was[6];
+            if (!sameStart)
+            {
+                fencCost = motion_estimate_lowres<P, METHOD>(c, mvpx, mvpy, job.merange, zeroSad, zeroSatd, mvpSad, mv0cost, mx, my);
+                // bidir skip shortcut (slicetype.cpp:4485-4489)
+                if (skipCost < 64 && skipCost < fencCost && job.bBidir)
+                {
+                    fencCost = skipCost;
+                    mx = my = 0;
+                }
+            }
+            if (!STAGED || !anyAssumed)
+                break;
+            searched = true;
+            was[0] = mvpx;
+            was[1] = mvpy;
+            was[2] = mvpSad;
+            was[3] = mv0cost;
+            was[4] = zeroSad;
+            was[5] = zeroSatd;
+            was[6] = skipCost;
+            // the search left its own windows behind (the sub-pel steps' few table entries among them): whatever
+            // comes after it stages what it needs afresh
+            c.relX = c.relY = NOT_STAGED;
+            tabAtZero = false;
+            // the assumption's test, turn by turn
+            bool agreed = true;
+#pragma unroll 1
+            for (int k = nextTurn; k < 3; k++)
+            {
+                const bool lanes = assumed && turn == k;
+                if (!__builtin_amdgcn_ballot_w64(lanes))
+                    continue;
+                flow_wait(lanes, true);
+                if (__builtin_amdgcn_ballot_w64(lanes && ((int)flowV != ux || (int)(flowV >> 32) != uy)))
+                {
+                    agreed = false;
+#pragma unroll 1
+                    for (; nextTurn <= k; nextTurn++)
+                        take_turn(nextTurn);
+                    break;
+                }
+            }
+            if (agreed)
+            {
+                STAMP(c, 2);
+                STAMP(c, 3);
+                STAMP(c, 4);
+                STAMP(c, 5);
+                break;
             }
         }
-        zeroSatd = group_value<5>(cost);
-        zeroSad = group_value<6>(sad);
-        int mvpcost = COST_MAX;
-        int wg = 6;
-#define TAKE(G, VALID)                                                                      \
-        if (VALID)                                                                          \
-        {                                                                                   \
-            const int cg = group_value<G>(cost);                                            \
-            if (cg < mvpcost)                                                               \
-            {                                                                               \
-                mvpcost = cg;                                                               \
-                mvpx = group_value<G>(cx);                                                  \
-                mvpy = group_value<G>(cy);                                                  \
-                wg = G;                                                                     \
-            }                                                                               \
-            /* tracks the latest candidate while the running best is the zero vector */    \
-            if (!(mvpx | mvpy) && job.bBidir)                                               \
-                skipCost = cg;                                                              \
-        }
-        TAKE(0, v0)
-        TAKE(1, v1)
-        TAKE(2, v2)
-        TAKE(3, v3)
-        TAKE(4, v4)
-#undef TAKE
-        mvpSad = __builtin_amdgcn_readlane(sad, wg * 8);
-        mv0cost = __builtin_amdgcn_readlane(t0, wg * 8);
     }
 
-    int mx, my;
-    STAMP(c, 3);
-    int fencCost = motion_estimate_lowres<P, METHOD>(c, mvpx, mvpy, job.merange, zeroSad, zeroSatd, mvpSad, mv0cost, mx, my);
-    // bidir skip shortcut (slicetype.cpp:4485-4489)
-    if (skipCost < 64 && skipCost < fencCost && job.bBidir)
-    {
-        fencCost = skipCost;
-        mx = my = 0;
-    }
     if (MODE == MODE_ROWS)
     {
         // Announce the `done` blocks before this one: the previous block's vector was stored a
@@ -1381,8 +1467,10 @@ search_rows_kernel_wide(const SearchJob* jobs, int nJobs, Geometry g, int level0
 // job) fastest: a block only ever waits for blocks of lower chunks, i.e. of workgroups handed out before its own,
 // so the lowest unfinished workgroup can always run.  Should the hardware not hold to that, the bounded poll in
 // search_block ends the wait and the call fails.
+// (the STAGED form serves launches that are paid in the length of their dependent chain, not in resident waves: it
+// gets the registers its second look at the block needs)
 template <typename P, int METHOD, bool STAGED>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STAGED ? 4 : 8)))
 search_flow_kernel(const SearchJob* jobs, int nJobs, Geometry g, int level0, const uint32_t* chunkTab, const uint16_t* costTab,
                    int maxMvd, int* sync)
 {
@@ -1442,13 +1530,15 @@ static void launch_flow_method(int method, hipStream_t s, dim3 grid, const Searc
                            costTab, maxMvd, sync);
 }
 
-// Launches of up to this many searches take the neighbour vectors as they come (search_block's STAGED form): their
-// time is the length of the dependent chain, which that form shortens at the price of more instructions per block;
-// larger launches fill the chip and are paid per instruction.  X265GPU_FLOW_STAGED_JOBS overrides (0: never).
+// Launches of up to X265GPU_FLOW_STAGED_JOBS searches (default 48, 0: never) take search_block's STAGED form: the
+// neighbour vectors as they come, and the search run ahead on assumed ones.  Their time is the length of the dependent
+// chain, which that form shortens at the price of more instructions and registers per block; larger launches fill
+// the chip and are paid per instruction.  The default is the crossover on benchmarks/launch_size_sweep.py.  Read per
+// launch: tests switch it between calls.
 static int flow_staged_jobs()
 {
-    const char* e = getenv("X265GPU_FLOW_STAGED_JOBS");      // read per launch: tests switch it between calls
-    return e ? atoi(e) : 112;
+    const char* e = getenv("X265GPU_FLOW_STAGED_JOBS");
+    return e ? atoi(e) : 48;
 }
 
 hipError_t launch_search_flow(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0, int method,

@@ -135,7 +135,10 @@ template <typename P>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) intra_kernel(const IntraJob* jobs, Geometry g, int lambda, int pixelMax)
 {
     __shared__ int nbr[4][4][80];          // [wave][block][raw 0..32, smoothed 40..72]
-    __shared__ int extRef[4][8][32];       // [wave][group]: the angular reference array being used
+    // [wave][group]: the angular reference array being used (25 entries).  Groups 40 dwords apart: the eight lanes of
+    // a group read within eight consecutive entries, and the LDS serves 32 lanes (four groups) a cycle from 32 banks,
+    // so a spacing of 8 banks between groups keeps them out of each other's way (32 apart, all groups shared banks)
+    __shared__ int extRef[4][8][40];
     __shared__ long long red[4][3];
 
     const IntraJob job = jobs[blockIdx.y];

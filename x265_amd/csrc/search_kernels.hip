@@ -524,6 +524,35 @@ __device__ __forceinline__ void try_points(const BlockCtx<P>& c, int mx, int my,
     take_winner(wave_min(active ? make_key(cost, c.g + 1, c.g) : KEY_INVALID), mx, my, bmx, bmy, bcost);
 }
 
+// The horizontal arm of a long cross: its candidates all lie on the block's eight rows, two pixels apart, so the rows are
+// fetched once as a strip of STRIP_W pixels (16 pixels per lane, 40 lanes) into the sub-pel window's LDS, which nothing
+// uses before the sub-pel steps stage it, instead of one row per lane and candidate (the long-range steps are paid in
+// vector-L1 line accesses).  `x0`: the strip's first column in the padded plane.
+constexpr int STRIP_W = 80;
+template <typename P> struct StripT { static constexpr int S = STRIP_W * (int)sizeof(P) / 4; };
+template <typename P> __device__ __forceinline__ void stage_strip(const BlockCtx<P>& c, int x0, int oy)
+{
+    const int lane = c.g * 8 + c.r, row = lane / 5, chunk = lane - 5 * row;
+    const int Y0 = clampi(c.by + oy, c.minY, c.maxY);
+    Px16<P> px;
+    if (lane < 40)
+        px = load16_g<P>(c.base, c.padOffset + (Y0 + row) * c.stride + x0 + 16 * chunk);
+    lds_handover();
+    if (lane < 40)
+        store16_l<P>(c.sub + row * StripT<P>::S + chunk * (4 * (int)sizeof(P)), px);
+    lds_handover();
+}
+// try_points for candidates on the strip's rows
+template <typename P>
+__device__ __forceinline__ void try_strip_points(const BlockCtx<P>& c, int x0, int mx, int my, bool active, int& bmx, int& bmy,
+                                                 int& bcost)
+{
+    const int col = active ? clampi(c.bx + mx, c.minX, c.maxX) - x0 : 0;
+    const Row<P> ref = lds_row<P>(c.sub + c.r * StripT<P>::S, col);
+    const int cost = reduce_cost<P, EV_SAD>(c, ref, price_lanes_g<P>(c, mx * 4, my * 4, active));
+    take_winner(wave_min(active ? make_key(cost, c.g + 1, c.g) : KEY_INVALID), mx, my, bmx, bmy, bcost);
+}
+
 // COST_MV_X4 (motion.cpp:302-323) accepts each of its four points subject to the point's own row being inside
 // mvmin.y..mvmax.y: for a lane that is y_ok() of its own candidate.
 
@@ -538,6 +567,15 @@ __device__ __forceinline__ void umh_cross(const BlockCtx<P>& c, int ox, int oy, 
         const int lim = dirY ? y_max : x_max;
         const int room = dirY ? min(c.maxy - oy, oy - c.miny) : min(c.maxx - ox, ox - c.minx);
         int i = (short)start;
+        // the horizontal arm out of a strip when it is long enough to pay for one and the strip can hold it: every
+        // candidate's (clamped) block then starts within the strip's first STRIP_W - 8 columns
+        const bool strip = !dirY && lim - i > 8 && 2 * lim + 8 <= STRIP_W && c.maxX + 8 - c.minX >= STRIP_W;
+        int x0 = 0;
+        if (strip)
+        {
+            x0 = clampi(c.bx + ox - lim, c.minX, c.maxX + 8 - STRIP_W);
+            stage_strip<P>(c, x0, oy);
+        }
         if (lim <= room)
         {
             // x4 passes (i, -i, i+2, -i-2); two reference iterations per pass
@@ -548,7 +586,10 @@ __device__ __forceinline__ void umh_cross(const BlockCtx<P>& c, int ox, int oy, 
                 const int sel = c.g & 3;
                 const int d = (sel == 0) ? ii : (sel == 1) ? -ii : (sel == 2) ? ii + 2 : -ii - 2;
                 const int mx = dirY ? ox : ox + d, my = dirY ? oy + d : oy;
-                try_points<P>(c, mx, my, (c.g < 4 || two) && y_ok<P>(c, my), bmx, bmy, bcost);
+                if (strip)
+                    try_strip_points<P>(c, x0, mx, my, (c.g < 4 || two) && y_ok<P>(c, my), bmx, bmy, bcost);
+                else
+                    try_points<P>(c, mx, my, (c.g < 4 || two) && y_ok<P>(c, my), bmx, bmy, bcost);
                 i += two ? 8 : 4;
             }
         }
@@ -560,7 +601,10 @@ __device__ __forceinline__ void umh_cross(const BlockCtx<P>& c, int ox, int oy, 
             const int d = neg ? -ii : ii;
             const int at = (dirY ? oy : ox) + d;       // the coordinate that moves
             const bool ok = ii < lim && (neg ? at >= (dirY ? c.miny : c.minx) : at <= (dirY ? c.maxy : c.maxx));
-            try_points<P>(c, dirY ? ox : ox + d, dirY ? oy + d : oy, ok, bmx, bmy, bcost);
+            if (strip)
+                try_strip_points<P>(c, x0, ox + d, oy, ok, bmx, bmy, bcost);
+            else
+                try_points<P>(c, dirY ? ox : ox + d, dirY ? oy + d : oy, ok, bmx, bmy, bcost);
             i += 8;
         }
     }

@@ -68,14 +68,13 @@ struct BlockCtx
     // this wave's LDS slice and what it currently holds (all wave-uniform)
     XG_LDS uint32_t* win;          // full-pel window, WIN rows of LdsT<P>::WIN_S dwords
     XG_LDS uint32_t* sub;          // sub-pel window, 4 planes x SUB_ROWS rows of LdsT<P>::SUB_S dwords
-    XG_LDS uint32_t* tab;          // MV-cost windows, 2 axes x TAB_N entries of 16 bits
+    XG_LDS uint32_t* tab;          // MV-cost table entries of MVD -TAB_LO .. TAB_N - 1 - TAB_LO, 16 bits each
+    bool tabOk;                    // ... staged (the table is large enough to hold that window)
 #ifdef XG_STAMP
     unsigned long long st[8];
 #endif
     int relX, relY;                // block origin relative to the window's first pixel
     int subRelX, subRelY;          // the same for the sub-pel window
-    int tabLoX, tabLoY;            // MVD of entry 0 of each axis' staged table window
-    int tabBiasX, tabBiasY;        // quarter-pel component + bias = index into the 2 x TAB_N table entries
 };
 
 #ifdef XG_STAMP
@@ -91,7 +90,8 @@ __device__ unsigned long long xg_stamps[XG_STAMP_BLOCKS * 8];
 constexpr int WIN = 32;            // full-pel window side, pixels
 constexpr int WIN_PAD = 12;        // pixels between the window's edge and the centre block
 constexpr int SUB_ROWS = 10;       // sub-pel window: 10 rows x 16 pixels per plane
-constexpr int TAB_N = 200;         // MV-cost entries per axis
+constexpr int TAB_N = 400;         // MV-cost entries held in LDS: one window around MVD 0 for both axes, staged once per
+constexpr int TAB_LO = 199;        // block (+-49 pixels: what a search reaches from its predictor; beyond it, global memory)
 constexpr int NOT_STAGED = 1 << 24;
 
 // Row strides in dwords, chosen odd-ish so that the eight rows of a candidate
@@ -105,7 +105,7 @@ template <typename P> struct WaveLds
 {
     static constexpr int WIN_DW = WIN * LdsT<P>::WIN_S + 4;
     static constexpr int SUB_DW = 4 * SUB_ROWS * LdsT<P>::SUB_S + 4;
-    static constexpr int TAB_DW = TAB_N;            // 2 axes x 200 x 16 bit
+    static constexpr int TAB_DW = TAB_N / 2;        // 400 x 16 bit
     static constexpr int TOTAL = WIN_DW + SUB_DW + TAB_DW;
 };
 
@@ -201,27 +201,24 @@ template <typename P> __device__ __forceinline__ Row<P> cand_row(const BlockCtx<
 
 // The two MV-cost table reads of (qx,qy), BitCost::mvcost (source/encoder/bitcost.h:56):
 // lane 0 of the group takes the x term, lane 1 the y term, every other lane 0, so that
-// summing over the group adds mvcost.  This form reads the table in global memory.
-template <typename P> __device__ __forceinline__ int price_lanes_g(const BlockCtx<P>& c, int qx, int qy, bool priced)
+// summing over the group adds mvcost.
+// price_mvd: the entry for the MVD `d` of lane 0 (x) / lane 1 (y) of a group out of the staged table window; an MVD outside the
+// window (or a table too small to have one) goes to global memory, a wave-uniform branch that searches rarely take.
+template <typename P> __device__ __forceinline__ int price_mvd(const BlockCtx<P>& c, int d, bool priced)
 {
-    int t = 0;
-    if (priced && c.r < 2)
+    const bool want = priced && c.r < 2;
+    const bool in = c.tabOk && (unsigned)(d + TAB_LO) < (unsigned)TAB_N;
+    int t = (int)((const XG_LDS uint16_t*)c.tab)[in ? d + TAB_LO : 0];
+    if (__builtin_amdgcn_ballot_w64(want && !in))
     {
-        const int d = (c.r == 0) ? qx - c.mvpx : qy - c.mvpy;
-        t = (int)c.costBase[(unsigned)(clampi(d, -c.maxMvd, c.maxMvd) + c.maxMvd)];
+        if (want && !in)
+            t = (int)c.costBase[(unsigned)(clampi(d, -c.maxMvd, c.maxMvd) + c.maxMvd)];
     }
-    return t;
+    return want ? t : 0;
 }
-
-// The same out of the staged table windows.  Branch-free: every lane reads (odd
-// rows the y window, even rows the x window) and lanes 2..7 drop the value.  The
-// caller guarantees the vector lies within the staged windows (+-25 pixels of
-// the vector they were staged for).
-template <typename P> __device__ __forceinline__ int price_lanes(const BlockCtx<P>& c, int qx, int qy)
+template <typename P> __device__ __forceinline__ int price_lanes(const BlockCtx<P>& c, int qx, int qy, bool priced = true)
 {
-    const int idx = (c.r & 1) ? qy + c.tabBiasY : qx + c.tabBiasX;
-    const int t = (int)((const XG_LDS uint16_t*)c.tab)[idx];
-    return c.r < 2 ? t : 0;
+    return price_mvd<P>(c, (c.r & 1) ? qy - c.mvpy : qx - c.mvpx, priced);
 }
 
 template <typename P, int KIND> __device__ __forceinline__ int reduce_cost(const BlockCtx<P>& c, const Row<P>& ref, int t)
@@ -237,7 +234,7 @@ template <typename P, int KIND>
 __device__ __forceinline__ int eval(const BlockCtx<P>& c, int qx, int qy, bool active, bool priced)
 {
     const Row<P> ref = cand_row<P>(c, qx, qy, active);
-    const int t = price_lanes_g<P>(c, qx, qy, active && priced);
+    const int t = price_lanes<P>(c, qx, qy, active && priced);
     return reduce_cost<P, KIND>(c, ref, t);
 }
 
@@ -305,46 +302,32 @@ template <typename P> __device__ __forceinline__ int fpel_cost_g(const BlockCtx<
         const int X = clampi(c.bx + mx, c.minX, c.maxX), Y = clampi(c.by + my, c.minY, c.maxY) + c.r;
         ref = load_row_g<P>(c.base, c.padOffset + Y * c.stride + X);
     }
-    return reduce_cost<P, EV_SAD>(c, ref, price_lanes_g<P>(c, mx * 4, my * 4, active));
+    return reduce_cost<P, EV_SAD>(c, ref, price_lanes<P>(c, mx * 4, my * 4, active));
 }
 
-// 25 lanes x 8 entries per axis of the MV-cost table around the MVD (dcx,dcy);
-// load and store halves so that callers can put other loads in flight between them
-// CHUNKS lanes x 8 entries per axis, centred: TAB_N / 8 for a search, 1 (+-4 entries) for the sub-pel steps
-struct TabStage { u32x4_unaligned v; int lox, loy; };
-template <typename P, int CHUNKS = TAB_N / 8>
-__device__ __forceinline__ TabStage tab_load(const BlockCtx<P>& c, int dcx, int dcy)
+// The MV-cost window: 50 lanes x 8 entries; load and store halves so that callers can put other loads in flight
+// between them
+struct TabStage { u32x4_unaligned v; };
+template <typename P> __device__ __forceinline__ TabStage tab_load(const BlockCtx<P>& c)
 {
     TabStage t;
-    t.lox = clampi(dcx - 4 * CHUNKS, -c.maxMvd, c.maxMvd + 1 - 8 * CHUNKS);
-    t.loy = clampi(dcy - 4 * CHUNKS, -c.maxMvd, c.maxMvd + 1 - 8 * CHUNKS);
-    const int lane = c.g * 8 + c.r, axis = lane >> 5, k = lane & 31;
+    const int lane = c.g * 8 + c.r;
     t.v = u32x4_unaligned{ 0, 0, 0, 0 };
-    if (k < CHUNKS)
-        t.v = *(const XG_GLOBAL u32x4_unaligned*)(c.costBase + ((axis ? t.loy : t.lox) + c.maxMvd + 8 * k));
+    if (lane < TAB_N / 8 && c.tabOk)
+        t.v = *(const XG_GLOBAL u32x4_unaligned*)(c.costBase + (c.maxMvd - TAB_LO + 8 * lane));
     return t;
 }
-// point the table indices at the staged windows for the current predictor
-template <typename P> __device__ __forceinline__ void tab_bias(BlockCtx<P>& c)
+template <typename P> __device__ __forceinline__ void tab_store(BlockCtx<P>& c, const TabStage& t)
 {
-    c.tabBiasX = -c.mvpx - c.tabLoX;
-    c.tabBiasY = -c.mvpy - c.tabLoY + TAB_N;
-}
-template <typename P, int CHUNKS = TAB_N / 8>
-__device__ __forceinline__ void tab_store(BlockCtx<P>& c, const TabStage& t)
-{
-    const int lane = c.g * 8 + c.r, axis = lane >> 5, k = lane & 31;
-    if (k < CHUNKS)
+    const int lane = c.g * 8 + c.r;
+    if (lane < TAB_N / 8)
     {
-        XG_LDS uint32_t* d = c.tab + axis * (TAB_N / 2) + 4 * k;
+        XG_LDS uint32_t* d = c.tab + 4 * lane;
         d[0] = t.v.x;
         d[1] = t.v.y;
         d[2] = t.v.z;
         d[3] = t.v.w;
     }
-    c.tabLoX = t.lox;
-    c.tabLoY = t.loy;
-    tab_bias<P>(c);
 }
 
 // The full-pel window around the block displaced by (mx,my): one 16-pixel load per
@@ -368,27 +351,20 @@ template <typename P> __device__ __forceinline__ void win_store(BlockCtx<P>& c, 
     c.relY = c.by - w.wy;
 }
 
-// Stage the window around displacement (mx,my) and the MV-cost windows around that vector.
+// Stage the window around displacement (mx,my).
 template <typename P> __device__ __forceinline__ void stage_search(BlockCtx<P>& c, int mx, int my)
 {
     const WinStage<P> ws = win_load<P>(c, mx, my);
-    const TabStage ts = tab_load<P>(c, mx * 4 - c.mvpx, my * 4 - c.mvpy);
     lds_handover();
     win_store<P>(c, ws);
-    tab_store<P>(c, ts);
     lds_handover();
 }
 
-// Make sure every block within `ext` pixels of displacement (mx,my) lies in the staged window
-// and every such vector's MVD lies in the staged MV-cost windows.  The two are separate
-// conditions: the MV cost is relative to the unclipped predictor, so a window that still holds
-// the blocks says nothing about the table when the predictor was clipped or guessed.
+// Make sure every block within `ext` pixels of displacement (mx,my) lies in the staged window.
 template <typename P> __device__ __forceinline__ void ensure_window(BlockCtx<P>& c, int mx, int my, int ext)
 {
     const unsigned lim = (unsigned)(WIN - 8 - 2 * ext);
-    const unsigned tlim = (unsigned)(TAB_N - 1 - 8 * ext);
-    if ((unsigned)(c.relX + mx - ext) > lim || (unsigned)(c.relY + my - ext) > lim ||
-        (unsigned)(4 * (mx - ext) + c.tabBiasX) > tlim || (unsigned)(4 * (my - ext) + c.tabBiasY - TAB_N) > tlim)
+    if ((unsigned)(c.relX + mx - ext) > lim || (unsigned)(c.relY + my - ext) > lim)
         stage_search<P>(c, mx, my);
 }
 
@@ -424,11 +400,9 @@ template <typename P> __device__ __forceinline__ void stage_subpel(BlockCtx<P>& 
     Px16<P> px;
     if (lane < 4 * SUB_ROWS)
         px = load16_g<P>(c.base, c.padOffset + plane * c.planeSize + (sy + row) * c.stride + sx);
-    const TabStage ts = tab_load<P, 1>(c, bqx - c.mvpx, bqy - c.mvpy);
     lds_handover();
     if (lane < 4 * SUB_ROWS)
         store16_l<P>(c.sub + lane * LdsT<P>::SUB_S, px);
-    tab_store<P, 1>(c, ts);
     lds_handover();
     c.subRelX = c.bx - sx;
     c.subRelY = c.by - sy;
@@ -506,18 +480,14 @@ template <typename P>
 __device__ __forceinline__ void try_points(const BlockCtx<P>& c, int mx, int my, bool active, int& bmx, int& bmy,
                                            int& bcost)
 {
-    const bool staged = (unsigned)(c.relX + mx) <= (unsigned)(WIN - 8) && (unsigned)(c.relY + my) <= (unsigned)(WIN - 8) &&
-                        (unsigned)(4 * mx + c.tabBiasX) < (unsigned)TAB_N &&
-                        (unsigned)(4 * my + c.tabBiasY - TAB_N) < (unsigned)TAB_N;
+    const bool staged = (unsigned)(c.relX + mx) <= (unsigned)(WIN - 8) && (unsigned)(c.relY + my) <= (unsigned)(WIN - 8);
     int cost;
     if (__builtin_amdgcn_ballot_w64(active && !staged) == 0)
     {
         // idle groups read the window's first block: any address inside the slice will do
         const int wx = active ? mx : -c.relX, wy = active ? my : -c.relY;
         const Row<P> ref = win_row<P>(c, wx, wy);
-        const int idx = (c.r & 1) ? 4 * wy + c.tabBiasY : 4 * wx + c.tabBiasX;
-        const int t = (active && c.r < 2) ? (int)((const XG_LDS uint16_t*)c.tab)[idx] : 0;
-        cost = reduce_cost<P, EV_SAD>(c, ref, t);
+        cost = reduce_cost<P, EV_SAD>(c, ref, price_lanes<P>(c, 4 * mx, 4 * my, active));
     }
     else
         cost = fpel_cost_g<P>(c, mx, my, active);
@@ -549,7 +519,7 @@ __device__ __forceinline__ void try_strip_points(const BlockCtx<P>& c, int x0, i
 {
     const int col = active ? clampi(c.bx + mx, c.minX, c.maxX) - x0 : 0;
     const Row<P> ref = lds_row<P>(c.sub + c.r * StripT<P>::S, col);
-    const int cost = reduce_cost<P, EV_SAD>(c, ref, price_lanes_g<P>(c, mx * 4, my * 4, active));
+    const int cost = reduce_cost<P, EV_SAD>(c, ref, price_lanes<P>(c, mx * 4, my * 4, active));
     take_winner(wave_min(active ? make_key(cost, c.g + 1, c.g) : KEY_INVALID), mx, my, bmx, bmy, bcost);
 }
 
@@ -738,7 +708,6 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     int bcost, bprecost;
     int preKey, preX, preY;
     bool hexValid = METHOD == X265GPU_HEX;
-    tab_bias<P>(c);
     {
         const bool sub = ((pmvx | pmvy) & 3) != 0, nz = (pmvx | pmvy) != 0;
         // the start cost is the SAD (no MV cost) of the block the clipped predictor points at:
@@ -899,7 +868,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     lds_handover();
 #endif
     c.relX = c.relY = c.subRelX = c.subRelY = NOT_STAGED;
-    c.tabLoX = c.tabLoY = c.tabBiasX = c.tabBiasY = 0;
+    c.tabOk = maxMvd >= TAB_N;
     STAMP(c, 0);
     STAMP(c, 7);
     // search bounds that stay inside the extended frame (slicetype.cpp:4417-4420)
@@ -1085,28 +1054,15 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         Row<P> ref = cand_row<P>(c, cx, cy, (cand && !dup) || (c.g == 6 && !zeroShared));
         if (c.g == 5)
             ref = load_row_g<P>(as_global<P>(job.zeroRef), c.by * stride + c.bx + c.r * job.zeroStride);
-        // table entries of mvcost(0,0) should this group's vector become the predictor
-        // (group 6 stands in for the zero predictor of a block without neighbours)
-        int t0 = 0;
-        const bool tabCovers = maxMvd >= TAB_N;
-        {
-            const int t0d = c.r == 0 ? -cx : -cy;                // the MVD of the zero vector under this predictor
-            const bool t0staged = (unsigned)(t0d + 4 * (TAB_N / 8)) < (unsigned)TAB_N && tabCovers;
-            if ((cand || c.g == 6) && c.r < 2 && !dup && !t0staged)
-                t0 = (int)c.costBase[(unsigned)(clampi(t0d, -maxMvd, maxMvd) + maxMvd)];
-        }
         const WinStage<P> ws = win_load<P>(c, sx, sy);
-        const TabStage ts = tab_load<P>(c, 0, 0);
+        const TabStage ts = tab_load<P>(c);
         lds_handover();
         win_store<P>(c, ws);
         tab_store<P>(c, ts);
         lds_handover();
-        {
-            const int t0d = c.r == 0 ? -cx : -cy;
-            const bool t0staged = (unsigned)(t0d + 4 * (TAB_N / 8)) < (unsigned)TAB_N && tabCovers;
-            if ((cand || c.g == 6) && c.r < 2 && !dup && t0staged)
-                t0 = (int)((const XG_LDS uint16_t*)c.tab)[(c.r & 1) * TAB_N + t0d - (c.r ? c.tabLoY : c.tabLoX)];
-        }
+        // table entries of mvcost(0,0) should this group's vector become the predictor
+        // (group 6 stands in for the zero predictor of a block without neighbours)
+        int t0 = price_mvd<P>(c, c.r == 0 ? -cx : -cy, (cand || c.g == 6) && !dup);
 #pragma unroll
         for (int i = 0; i < PixT<P>::NW; i++)
             c.fr.w[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * c.r, (int)c.fr.w[i]);
@@ -1130,7 +1086,6 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
         // bit 8 G: group G holds figures it measured itself
         unsigned long long measured = STAGED ? __builtin_amdgcn_ballot_w64(cand && !dup) : 0ull;
         const int turn = c.g == 3 ? 0 : c.g == 1 ? 1 : 2;
-        bool tabAtZero = true;                  // the table windows are the ones staged above, around MVD 0
         auto take_turn = [&](int k)
         {
             const bool want = later && turn == k;
@@ -1172,13 +1127,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
             {
                 // a vector that no group has measured yet: its block, and a pass for it
                 const Row<P> ref2 = cand_row<P>(c, cx, cy, fetch);
-                int t0b = 0;
-                // (a search that ran on the assumption below has moved the table windows)
-                const int t0d = c.r == 0 ? -cx : -cy;
-                const bool t0staged = (unsigned)(t0d + 4 * (TAB_N / 8)) < (unsigned)TAB_N && tabCovers && tabAtZero;
-                if (fetch && c.r < 2)
-                    t0b = t0staged ? (int)((const XG_LDS uint16_t*)c.tab)[(c.r & 1) * TAB_N + t0d - (c.r ? c.tabLoY : c.tabLoX)]
-                                   : (int)c.costBase[(unsigned)(clampi(t0d, -maxMvd, maxMvd) + maxMvd)];
+                int t0b = price_mvd<P>(c, c.r == 0 ? -cx : -cy, fetch);
                 const int cost2 = reduce_cost<P, EV_SATD>(c, ref2, 0);
                 const int sad2 = sad8x8<P>(c.fr, ref2);
                 t0b += dpp<DPP_XOR1>(t0b);
@@ -1289,10 +1238,6 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
             was[4] = zeroSad;
             was[5] = zeroSatd;
             was[6] = skipCost;
-            // the search left its own windows behind (the sub-pel steps' few table entries among them): whatever
-            // comes after it stages what it needs afresh
-            c.relX = c.relY = NOT_STAGED;
-            tabAtZero = false;
             // the assumption's test, turn by turn
             bool agreed = true;
 #pragma unroll 1

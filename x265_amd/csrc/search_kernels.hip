@@ -1519,7 +1519,7 @@ static void launch_flow_method(int method, hipStream_t s, dim3 grid, const Searc
                            costTab, maxMvd, sync);
 }
 
-// Launches of up to X265GPU_FLOW_STAGED_JOBS searches (default 48, 0: never) take search_block's STAGED form: the
+// Launches of up to X265GPU_FLOW_STAGED_JOBS searches (default 64, 0: never) take search_block's STAGED form: the
 // neighbour vectors as they come, and the search run ahead on assumed ones.  Their time is the length of the dependent
 // chain, which that form shortens at the price of more instructions and registers per block; larger launches fill
 // the chip and are paid per instruction.  The default is the crossover on benchmarks/launch_size_sweep.py.  Read per
@@ -1527,7 +1527,7 @@ static void launch_flow_method(int method, hipStream_t s, dim3 grid, const Searc
 static int flow_staged_jobs()
 {
     const char* e = getenv("X265GPU_FLOW_STAGED_JOBS");
-    return e ? atoi(e) : 48;
+    return e ? atoi(e) : 64;
 }
 
 hipError_t launch_search_flow(hipStream_t s, const Geometry& g, int bpp, const SearchJob* dJobs, int n, int level0, int method,

@@ -157,7 +157,9 @@ int x265gpu_host_alloc(x265gpu_ctx* ctx, size_t bytes, void** out);
 int x265gpu_host_free(x265gpu_ctx* ctx, void* p);
 
 /* Uploads the host-built BitCost table (source/encoder/bitcost.cpp:31-56):
- * `centre` points at the MVD-0 entry, valid for [-maxMvd, +maxMvd]. */
+ * `centre` points at the MVD-0 entry, valid for [-maxMvd, +maxMvd]; maxMvd >= 1024 (x265's table spans +-2^17
+ * entries; the search kernels keep the entries around MVD 0 in LDS without testing for a shorter table), else
+ * X265GPU_ERR_ARG. */
 int x265gpu_set_mvcost(x265gpu_ctx* ctx, const uint16_t* centre, int32_t maxMvd);
 
 /* ---- pre-lookahead: PreLookaheadGroup::processTasks (slicetype.cpp:1836-1861) */

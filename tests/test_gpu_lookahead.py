@@ -319,36 +319,14 @@ def test_flow_search_both_ways_of_taking_neighbour_vectors(monkeypatch, staged_j
         ref.close()
 
 
-@pytest.mark.parametrize("search", [orc.HEX, orc.UMH])
-def test_mvcost_table_too_small_for_the_lds_window(search):
-    """The search keeps the table's entries for MVD -199..200 in LDS; a table that does not reach that far is read in
-    global memory throughout.  Cut down to +-320 entries (no MVD of this clip gets near that), the library must return
-    what it returns with the whole table."""
-    clip, ref, ctx, frames = _setup(384, 208, 4, 8, seed=91, search=search)
-    try:
-        est = CostEstimateGroup(ctx, frames)
-        want = []
-        for (p0, p1, b) in [(0, 1, 1), (0, 2, 1), (1, 3, 2)]:
-            est.single_cost(p0, p1, b)
-            _check_request(ref, ctx, frames, p0, p1, b)
-            want.append([np.array(a).copy() for a in ctx.get_mvs(frames[b].slot, 0, b - p0)])
-    finally:
-        ctx.close()
-    ctx = api.Context(384, 208, depth=8, bframes=4, num_slots=4, search=search)
-    try:
-        ctx.set_mvcost(ref.table[ref.centre - 320:ref.centre + 321], 320)
-        frames = [LowresState(i, i, ctx.D) for i in range(4)]
-        PreLookaheadGroup(ctx).process_tasks(frames, clip, None)
-        est = CostEstimateGroup(ctx, frames)
-        for k, (p0, p1, b) in enumerate([(0, 1, 1), (0, 2, 1), (1, 3, 2)]):
-            assert est.single_cost(p0, p1, b) == ref.frame_cost(p0, p1, b), (p0, p1, b)
-            mv, mc = ctx.get_mvs(frames[b].slot, 0, b - p0)
-            assert np.abs(np.array(mv)).max() < 4 * 60
-            np.testing.assert_array_equal(mv, want[k][0])
-            np.testing.assert_array_equal(mc, want[k][1])
-    finally:
-        ctx.close()
-        ref.close()
+def test_mvcost_table_must_reach_1024_entries_each_way():
+    """The search kernels keep the table's entries for MVD -199..200 in LDS and read further ones in place: the
+    library takes no table shorter than +-1024 entries (x265's spans +-2^17)."""
+    table, centre = api.bitcost_table(8)
+    with api.Context(256, 160, num_slots=2) as ctx:
+        with pytest.raises(api.X265GpuError):
+            ctx.set_mvcost(table[centre - 600:centre + 601], 600)
+        ctx.set_mvcost(table[centre - 1024:centre + 1025], 1024)
 
 
 @pytest.mark.parametrize("depth,methods,ranges", [

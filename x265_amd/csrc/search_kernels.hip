@@ -68,8 +68,8 @@ struct BlockCtx
     // this wave's LDS slice and what it currently holds (all wave-uniform)
     XG_LDS uint32_t* win;          // full-pel window, WIN rows of LdsT<P>::WIN_S dwords
     XG_LDS uint32_t* sub;          // sub-pel window, 4 planes x SUB_ROWS rows of LdsT<P>::SUB_S dwords
-    XG_LDS uint32_t* tab;          // MV-cost table entries of MVD -TAB_LO .. TAB_N - 1 - TAB_LO, 16 bits each
-    bool tabOk;                    // ... staged (the table is large enough to hold that window)
+    XG_LDS uint32_t* tab;          // MV-cost table entries of MVD -TAB_LO .. TAB_N - 1 - TAB_LO, 16 bits each (every table
+                                   // reaches that far: x265gpu_set_mvcost takes none below +-1024 entries)
 #ifdef XG_STAMP
     unsigned long long st[8];
 #endif
@@ -203,11 +203,11 @@ template <typename P> __device__ __forceinline__ Row<P> cand_row(const BlockCtx<
 // lane 0 of the group takes the x term, lane 1 the y term, every other lane 0, so that
 // summing over the group adds mvcost.
 // price_mvd: the entry for the MVD `d` of lane 0 (x) / lane 1 (y) of a group out of the staged table window; an MVD outside the
-// window (or a table too small to have one) goes to global memory, a wave-uniform branch that searches rarely take.
+// window goes to global memory, a wave-uniform branch that searches rarely take.
 template <typename P> __device__ __forceinline__ int price_mvd(const BlockCtx<P>& c, int d, bool priced)
 {
     const bool want = priced && c.r < 2;
-    const bool in = c.tabOk && (unsigned)(d + TAB_LO) < (unsigned)TAB_N;
+    const bool in = (unsigned)(d + TAB_LO) < (unsigned)TAB_N;
     int t = (int)((const XG_LDS uint16_t*)c.tab)[in ? d + TAB_LO : 0];
     if (__builtin_amdgcn_ballot_w64(want && !in))
     {
@@ -313,7 +313,7 @@ template <typename P> __device__ __forceinline__ TabStage tab_load(const BlockCt
     TabStage t;
     const int lane = c.g * 8 + c.r;
     t.v = u32x4_unaligned{ 0, 0, 0, 0 };
-    if (lane < TAB_N / 8 && c.tabOk)
+    if (lane < TAB_N / 8)
         t.v = *(const XG_GLOBAL u32x4_unaligned*)(c.costBase + (c.maxMvd - TAB_LO + 8 * lane));
     return t;
 }
@@ -868,7 +868,6 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     lds_handover();
 #endif
     c.relX = c.relY = c.subRelX = c.subRelY = NOT_STAGED;
-    c.tabOk = maxMvd >= TAB_N;
     STAMP(c, 0);
     STAMP(c, 7);
     // search bounds that stay inside the extended frame (slicetype.cpp:4417-4420)

@@ -70,6 +70,7 @@ struct BlockCtx
     XG_LDS uint32_t* sub;          // sub-pel window, 4 planes x SUB_ROWS rows of LdsT<P>::SUB_S dwords
     XG_LDS uint32_t* tab;          // MV-cost table entries of MVD -TAB_LO .. TAB_N - 1 - TAB_LO, 16 bits each (every table
                                    // reaches that far: x265gpu_set_mvcost takes none below +-1024 entries)
+    bool tabAll;                   // whatever this search can price lies inside that window (wave-uniform)
 #ifdef XG_STAMP
     unsigned long long st[8];
 #endif
@@ -207,6 +208,12 @@ template <typename P> __device__ __forceinline__ Row<P> cand_row(const BlockCtx<
 template <typename P> __device__ __forceinline__ int price_mvd(const BlockCtx<P>& c, int d, bool priced)
 {
     const bool want = priced && c.r < 2;
+    if (c.tabAll)
+    {
+        // (lanes that do not count may carry anything: their index is folded into the window)
+        const int t = (int)((const XG_LDS uint16_t*)c.tab)[min((unsigned)(d + TAB_LO), (unsigned)(TAB_N - 1))];
+        return want ? t : 0;
+    }
     const bool in = (unsigned)(d + TAB_LO) < (unsigned)TAB_N;
     int t = (int)((const XG_LDS uint16_t*)c.tab)[in ? d + TAB_LO : 0];
     if (__builtin_amdgcn_ballot_w64(want && !in))
@@ -364,7 +371,7 @@ template <typename P> __device__ __forceinline__ void stage_search(BlockCtx<P>& 
 template <typename P> __device__ __forceinline__ void ensure_window(BlockCtx<P>& c, int mx, int my, int ext)
 {
     const unsigned lim = (unsigned)(WIN - 8 - 2 * ext);
-    if ((unsigned)(c.relX + mx - ext) > lim || (unsigned)(c.relY + my - ext) > lim)
+    if (max((unsigned)(c.relX + mx - ext), (unsigned)(c.relY + my - ext)) > lim)       // one scalar compare
         stage_search<P>(c, mx, my);
 }
 
@@ -705,6 +712,14 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     const int pmvx = clampi(mvpx, qminx, qmaxx), pmvy = clampi(mvpy, qminy, qmaxy);
     int bmx = (pmvx + 2) >> 2, bmy = (pmvy + 2) >> 2;
     const int pfx = bmx, pfy = bmy;      // predictor rounded to full pel
+    {
+        // How far from the predictor this search can price a vector: it starts at the clipped predictor or at zero and
+        // walks at most merange pixels from there (the multi-hexagon search its patterns' reach and then a hexagon
+        // walk), plus the refinements.  Inside the staged table window, no pass needs to look.
+        const int walk = 4 * ((METHOD == X265GPU_UMH ? 2 : 1) * merange + 4);
+        const int off = max(max(abs(mvpx), abs(mvpy)), max(abs(pmvx - mvpx), abs(pmvy - mvpy)));
+        c.tabAll = off + walk <= TAB_LO;
+    }
     int bcost, bprecost;
     int preKey, preX, preY;
     bool hexValid = METHOD == X265GPU_HEX;
@@ -868,6 +883,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
     lds_handover();
 #endif
     c.relX = c.relY = c.subRelX = c.subRelY = NOT_STAGED;
+    c.tabAll = false;
     STAMP(c, 0);
     STAMP(c, 7);
     // search bounds that stay inside the extended frame (slicetype.cpp:4417-4420)
@@ -1220,6 +1236,7 @@ __device__ __forceinline__ void search_block(const SearchJob& job, const Geometr
             if (!sameStart)
             {
                 fencCost = motion_estimate_lowres<P, METHOD>(c, mvpx, mvpy, job.merange, zeroSad, zeroSatd, mvpSad, mv0cost, mx, my);
+                c.tabAll = false;           // what is priced outside a search (a late vector's zero entry) looks again
                 // bidir skip shortcut (slicetype.cpp:4485-4489)
                 if (skipCost < 64 && skipCost < fencCost && job.bBidir)
                 {

@@ -171,7 +171,9 @@ template <> __device__ __forceinline__ Row<uint16_t> lds_row<uint16_t>(const XG_
 template <typename P> __device__ __forceinline__ Row<P> fetch_plane_row(const BlockCtx<P>& c, int qx, int qy)
 {
     const int hp = (qy & 2) | ((qx & 2) >> 1);
-    const int off = c.padOffset + hp * c.planeSize + (c.by + (qy >> 2) + c.r) * c.stride + c.bx + (qx >> 2);
+    // (rows and strides are far below 2^23: the 24-bit multiply, which issues at full rate where the 32-bit one takes
+    // four slots, is exact for them; the plane offset is not multiplied that way, a plane can exceed 2^24 pixels)
+    const int off = c.padOffset + hp * c.planeSize + __mul24(c.by + (qy >> 2) + c.r, c.stride) + c.bx + (qx >> 2);
     return load_row_g<P>(c.base, clampi(off, 0, 4 * c.planeSize - 8));
 }
 
@@ -307,7 +309,7 @@ template <typename P> __device__ __forceinline__ int fpel_cost_g(const BlockCtx<
     if (active)
     {
         const int X = clampi(c.bx + mx, c.minX, c.maxX), Y = clampi(c.by + my, c.minY, c.maxY) + c.r;
-        ref = load_row_g<P>(c.base, c.padOffset + Y * c.stride + X);
+        ref = load_row_g<P>(c.base, c.padOffset + __mul24(Y, c.stride) + X);
     }
     return reduce_cost<P, EV_SAD>(c, ref, price_lanes<P>(c, mx * 4, my * 4, active));
 }
@@ -347,7 +349,7 @@ template <typename P> __device__ __forceinline__ WinStage<P> win_load(const Bloc
     w.wx = clampi(cx - WIN_PAD, c.minX, c.maxX + 8 - WIN);
     w.wy = clampi(cy - WIN_PAD, c.minY, c.maxY + 8 - WIN);
     const int lane = c.g * 8 + c.r, row = lane >> 1, half = lane & 1;
-    w.px = load16_g<P>(c.base, c.padOffset + (w.wy + row) * c.stride + w.wx + 16 * half);
+    w.px = load16_g<P>(c.base, c.padOffset + __mul24(w.wy + row, c.stride) + w.wx + 16 * half);
     return w;
 }
 template <typename P> __device__ __forceinline__ void win_store(BlockCtx<P>& c, const WinStage<P>& w)
@@ -378,7 +380,7 @@ template <typename P> __device__ __forceinline__ void ensure_window(BlockCtx<P>&
 // this lane's row of the block displaced by full-pel (mx,my), out of the staged window
 template <typename P> __device__ __forceinline__ Row<P> win_row(const BlockCtx<P>& c, int mx, int my)
 {
-    return lds_row<P>(c.win + (c.relY + my + c.r) * LdsT<P>::WIN_S, c.relX + mx);
+    return lds_row<P>(c.win + __mul24(c.relY + my + c.r, LdsT<P>::WIN_S), c.relX + mx);
 }
 
 // Key of this lane's group candidate at full-pel (mx,my) out of the staged window:
@@ -406,7 +408,7 @@ template <typename P> __device__ __forceinline__ void stage_subpel(BlockCtx<P>& 
     const int plane = lane / SUB_ROWS, row = lane - plane * SUB_ROWS;
     Px16<P> px;
     if (lane < 4 * SUB_ROWS)
-        px = load16_g<P>(c.base, c.padOffset + plane * c.planeSize + (sy + row) * c.stride + sx);
+        px = load16_g<P>(c.base, c.padOffset + plane * c.planeSize + __mul24(sy + row, c.stride) + sx);
     lds_handover();
     if (lane < 4 * SUB_ROWS)
         store16_l<P>(c.sub + lane * LdsT<P>::SUB_S, px);
@@ -418,7 +420,7 @@ template <typename P> __device__ __forceinline__ void stage_subpel(BlockCtx<P>& 
 template <typename P> __device__ __forceinline__ Row<P> sub_row(const BlockCtx<P>& c, int qx, int qy)
 {
     const int hp = (qy & 2) | ((qx & 2) >> 1);
-    return lds_row<P>(c.sub + (hp * SUB_ROWS + c.subRelY + (qy >> 2) + c.r) * LdsT<P>::SUB_S, c.subRelX + (qx >> 2));
+    return lds_row<P>(c.sub + __mul24(hp * SUB_ROWS + c.subRelY + (qy >> 2) + c.r, LdsT<P>::SUB_S), c.subRelX + (qx >> 2));
 }
 
 // cost at quarter-pel (qx,qy) out of the staged sub-pel window: ReferencePlanes::lowresQPelCost

@@ -319,6 +319,20 @@ def test_flow_search_both_ways_of_taking_neighbour_vectors(monkeypatch, staged_j
         ref.close()
 
 
+def test_multi_hexagon_search_moves_its_centre_three_times():
+    """A multi-hexagon search with a short range prices vectors up to three ranges from its start (the crosses move the
+    centre, the hexagon grid moves it again, the closing hexagon walk once more): a quarter-res level with range 8 whose
+    predictor lies ~30 pixels out reaches past the MV-cost entries the kernel keeps in LDS.  (Found by the randomised
+    sweep: one block's cost in 14 000 rounds.)"""
+    clip, ref, ctx, frames = _setup(616, 287, 4, 12, seed=995066814, bframes=3, hme=True,
+                                    hme_methods=(orc.UMH, orc.HEX, orc.HEX), hme_range=(8, 16, 48))
+    try:
+        _run_sequence(ref, ctx, frames, [(0, 3, 3), (0, 1, 1), (1, 3, 2), (0, 2, 2)])
+    finally:
+        ctx.close()
+        ref.close()
+
+
 def test_mvcost_table_must_reach_1024_entries_each_way():
     """The search kernels keep the table's entries for MVD -199..200 in LDS and read further ones in place: the
     library takes no table shorter than +-1024 entries (x265's spans +-2^17)."""

@@ -716,9 +716,10 @@ __device__ __forceinline__ int motion_estimate_lowres(BlockCtx<P>& c, int mvpx, 
     const int pfx = bmx, pfy = bmy;      // predictor rounded to full pel
     {
         // How far from the predictor this search can price a vector: it starts at the clipped predictor or at zero and
-        // walks at most merange pixels from there (the multi-hexagon search its patterns' reach and then a hexagon
-        // walk), plus the refinements.  Inside the staged table window, no pass needs to look.
-        const int walk = 4 * ((METHOD == X265GPU_UMH ? 2 : 1) * merange + 4);
+        // walks at most merange pixels from there, plus the refinements; the multi-hexagon search moves its centre by
+        // up to merange in the crosses, again in the hexagon grid, and then walks.  Inside the staged table window, no
+        // pass needs to look.
+        const int walk = METHOD == X265GPU_UMH ? 4 * (3 * merange + 8) : 4 * (merange + 4);
         const int off = max(max(abs(mvpx), abs(mvpy)), max(abs(pmvx - mvpx), abs(pmvy - mvpy)));
         c.tabAll = off + walk <= TAB_LO;
     }

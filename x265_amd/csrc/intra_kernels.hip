@@ -49,10 +49,10 @@ __device__ __forceinline__ void predict_row(const int* nb, int* ext, int mode, i
     const bool hor = mode < 18;
     const int angOff = hor ? 10 - mode : mode - 26;
     const int aabs = angOff < 0 ? -angOff : angOff;
-    // |angle| for offsets 0..8: 0,2,5,9,13,17,21,26,32 (angleTable, intrapred.cpp:136)
+    // |angle| for offsets 0..8: 0,2,5,9,13,17,21,26,32 (angleTable, intrapred.cpp:123)
     const int angMag = (int)((0x201A15110D090502ull >> (8 * ((aabs - 1) & 7))) & 0xff) & -(int)(aabs != 0);
     const int angle = angOff < 0 ? -angMag : angMag;
-    // inverse angles for offsets -1..-8: 4096,1638,910,630,482,390,315,256 (invAngleTable, :137)
+    // inverse angles for offsets -1..-8: 4096,1638,910,630,482,390,315,256 (invAngleTable, :124)
     const int inv = (aabs <= 4) ? ((aabs <= 2) ? (aabs <= 1 ? 4096 : 1638) : (aabs == 3 ? 910 : 630))
                                 : ((aabs <= 6) ? (aabs == 5 ? 482 : 390) : (aabs == 7 ? 315 : 256));
     const bool ang = !WITH_FLAT || mode >= 2;

@@ -6,6 +6,7 @@ the reference's sources where they lie (numbers only, no code):
   x265_lambda_tab at X265_LOOKAHEAD_QP, per bit depth    source/common/constants.cpp:30-130, common.h:217-221
   x265_exp2_lut                                          source/common/constants.cpp:552-558
   g_intraFilterFlags                                     source/common/constants.cpp:561-567
+  g_lumaFilter                                           source/common/constants.cpp:250-256
   angleTable, invAngleTable                              source/common/intrapred.cpp:123-124
   s_interpolationFilter                                  source/common/temporalfilter.h:36-54
 
@@ -66,6 +67,9 @@ def main():
 
     out["exp2_lut"] = ints(consts, "x265_exp2_lut[64]")
     out["intra_filter_flags"] = ints(consts, "g_intraFilterFlags[NUM_INTRA_MODE]")
+    luma = ints(consts, "g_lumaFilter[4][NTAPS_LUMA]")
+    assert len(luma) == 32
+    out["luma_filter"] = [luma[8 * k:8 * k + 8] for k in range(4)]
     out["angle_table"] = ints(intra, "angleTable[17]")
     out["inv_angle_table"] = ints(intra, "invAngleTable[8]")
     flt = ints(tf, "s_interpolationFilter[16][8]")

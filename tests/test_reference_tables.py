@@ -1,7 +1,7 @@
 """CPU: the constant tables of the lookahead path, in the oracle and in the shipped sources, against the reference's own
 data (tests/golden/reference_tables.json, read out of the reference's sources by tests/golden/make_reference_tables.py):
-search patterns, the lookahead lambda per bit depth, x265_exp2_lut, the intra filter flags, the angle tables and the
-temporal filter's interpolation taps.  The device code keeps several of these packed (biased nibbles, one byte per
+search patterns, the lookahead lambda per bit depth, x265_exp2_lut, the intra filter flags, the angle tables, the 8-tap
+luma filter and the temporal filter's interpolation taps.  The device code keeps several of these packed (biased nibbles, one byte per
 entry, a chain of selects); they are unpacked here from the text of the sources, the way the device unpacks them."""
 import json
 import os
@@ -137,3 +137,10 @@ def test_temporal_filter_taps():
     assert all(row[0] == 0 and row[7] == 0 for row in taps)
     dev = _initialiser(_text("x265_amd", "csrc", "mcstf_kernels.hip"), "kMcstfFilter[16][6]")
     assert dev == [v for row in taps for v in row[1:7]]
+
+
+def test_luma_filter_taps():
+    taps = [v for row in GOLDEN["luma_filter"] for v in row]
+    assert all(sum(row) == 64 for row in GOLDEN["luma_filter"])
+    assert _initialiser(_text("oracle", "orc_ipfilter.c"), "k_luma_taps[4][8]") == taps
+    assert _initialiser(_text("x265_amd", "csrc", "pu_kernels.hip"), "k_lumaTaps[4][8]") == taps
